@@ -1,0 +1,431 @@
+/*
+ * nasrec_hip.h — C-ABI of the MI355X (gfx950) NASRec supernet engine.
+ *
+ * This is the drop-in boundary for ONE hot path of facebookresearch/NasRec: the supernet
+ * forward / backward / optimizer step (reference: nasrec/supernet/{supernet,modules}.py and the step
+ * body nasrec/utils/train_utils.py:255-287).  The reference has no FFI of its own (it is 100 % Python
+ * on ATen); each entry point below replaces the ATen call sites named in its comment.  A maintainer
+ * binds these with ctypes; nasrec_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch / HIP types.  `stream` is a hipStream_t passed as void*.
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch owns all tensors).
+ *   - every function returns 0 on success, >0 = hipError_t, <0 = engine error; never throws, never
+ *     exits, never synchronises the device.  nasrec_last_error() returns the text of the last failure
+ *     on the calling thread.
+ *   - all arithmetic is fp32 (indices int64).  GEMMs run on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+ *   - "dense" tensors are [B, D] row-major with a row stride `ld` (floats);
+ *     "sparse" tensors are [B, N, 16] with a batch stride `ld` (floats) so that token sub-ranges of a
+ *     larger slab can be addressed without copies.
+ *   - concatenations (supernet.py:570-573, 635-638) are never materialised: consumers take up to
+ *     NASREC_MAX_SEGS segments.  A NULL segment pointer means "all zeros" (supernet.py:540-568).
+ */
+#ifndef NASREC_HIP_H
+#define NASREC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NASREC_MAX_SEGS 8
+#define NASREC_MAX_TABLES 32
+#define NASREC_EMB_DIM 16
+#define NASREC_MHA_PARAMS 1696 /* floats of parameter gradient produced per Transformer node */
+
+/* operand addressing modes of the GEMM family (see DESIGN.md "One GEMM, six bindings") */
+enum {
+  NASREC_AM_KC = 0,   /* P(r,k) = p[r*ld + k]                       k-contiguous rows              */
+  NASREC_AM_RC = 1,   /* P(r,k) = p[r + k*ld]                       r-contiguous                   */
+  NASREC_AM_TOKR = 2, /* P(r,k) = p[(r>>4)*ld + (r&15) + k*16]      r = (sample, e) of a [B,N,16]  */
+  NASREC_AM_TOKK = 3  /* P(r,k) = p[(k>>4)*ld + (k&15) + r*16]      k = (sample, e) of a [B,N,16]  */
+};
+enum { NASREC_CM_PLAIN = 0, /* C(i,j) = c[i*ldc + j] */
+       NASREC_CM_TOKJ = 1   /* C(i,j) = c[(j>>4)*ldc + (j&15) + i*16] */ };
+enum { NASREC_ACT_NONE = 0, NASREC_ACT_RELU = 1, NASREC_ACT_SILU = 2, NASREC_ACT_SIGMOID = 3 };
+
+/* op kinds (first int32 of every descriptor) */
+enum {
+  NASREC_OP_GEMM = 1,
+  NASREC_OP_EMBED_GATHER = 2,
+  NASREC_OP_DOT_TRI_FWD = 3,
+  NASREC_OP_DOT_TRI_BWD = 4,
+  NASREC_OP_FM_FWD = 5,
+  NASREC_OP_FM_BWD = 6,
+  NASREC_OP_MHA_FWD = 7,
+  NASREC_OP_MHA_BWD = 8,
+  NASREC_OP_REDUCE_ROWS = 9,
+  NASREC_OP_COPY_SEGS = 10,
+  NASREC_OP_GATE_BWD = 11,
+  NASREC_OP_ROWSUM = 12,
+  NASREC_OP_FINAL_FWD = 13,
+  NASREC_OP_BCE = 14,
+  NASREC_OP_FINAL_BWD = 15,
+  NASREC_OP_EMB_DEDUP = 16,
+  NASREC_OP_SUMSQ = 17,
+  NASREC_OP_CLIP_COEF = 18,
+  NASREC_OP_ADAGRAD_DENSE = 19,
+  NASREC_OP_ADAGRAD_ROWS = 20,
+  NASREC_OP_MEMSET = 21,
+  NASREC_OP_LAYERNORM_FWD = 22,
+  NASREC_OP_LAYERNORM_BWD = 23,
+  NASREC_OP_ADD_SEGS = 24,
+  NASREC_OP_SCALE = 25,
+  NASREC_OP_ACT_BWD = 26
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM family.  C(i,j) = epilogue( sum_k A(i,k) * B(j,k) ).   Replaces every nn.Linear / LazyLinear
+ * call site (modules.py:171,223,340,359,385,489,515,584,648,740; supernet.py:1140,1221) forward AND
+ * the three autograd products behind it (x·Wᵀ, dy·W, dyᵀ·x), for both dense [B,D] operands and
+ * token-axis operands ([B,N,16] transposed views, modules.py:222-234,358-361,648-650).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nasrec_gemm_seg {
+  const float* A;    /* NULL => this k-segment is all zeros (skipped) */
+  const float* B;
+  float* C;          /* used per z-problem (zmode=1); seg[0].C otherwise */
+  const float* Aaux; /* optional: A(r,k) is taken as 0 where Aaux(r,k) <= 0 (fused ReLU backward) */
+  const float* Baux; /* same for B */
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  int32_t Mvalid;    /* rows r >= Mvalid of A read as 0 (prefix mask on the row axis) */
+  int32_t accumulate;/* zmode: C += result */
+} nasrec_gemm_seg_t;
+
+typedef struct nasrec_gemm_desc {
+  int32_t kind;      /* NASREC_OP_GEMM */
+  int32_t amode, bmode, cmode;
+  int32_t nseg;
+  int32_t zmode;     /* 0: segments are K-ranges accumulated into seg[0].C (M,N from seg[0]);
+                        1: segments are independent problems (blockIdx.z) */
+  int32_t act;       /* NASREC_ACT_* applied to (acc + bias) */
+  int32_t bias_on_rows;  /* bias index = i (token-axis linear) instead of j */
+  int32_t mask_on_rows;  /* prefix mask index = i instead of j */
+  int32_t dims_in_use;   /* < 0: no mask; else entries with index >= dims_in_use are written as 0
+                            (CleverMaskGenerator, modules.py:57-96) */
+  int32_t beta;      /* zmode=0: C += result */
+  int32_t splitk;    /* zmode=0 only; >1: partial slabs in `workspace` + second pass */
+  const float* bias;
+  float* save_z;     /* optional store of (acc+bias), addressed like C */
+  float* save_act;   /* optional store of act(acc+bias), addressed like C */
+  /* optional elementwise multiplier R(i,j) given as column segments of dense tensors (SigmoidGating,
+     modules.py:576-582): out = act(z) * R, R = 0 outside every segment */
+  const float* mul_ptr[NASREC_MAX_SEGS];
+  int32_t mul_off[NASREC_MAX_SEGS], mul_width[NASREC_MAX_SEGS], mul_ld[NASREC_MAX_SEGS];
+  int32_t mul_nseg;
+  int32_t _pad;
+  float* workspace;  /* splitk slabs: splitk*M*N floats */
+  const float* pre_add; /* optional, addressed like C: added to the accumulator BEFORE bias/activation — lets a
+                           K-range longer than NASREC_MAX_SEGS segments be chained over several launches */
+  nasrec_gemm_seg_t seg[NASREC_MAX_SEGS];
+} nasrec_gemm_desc_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * Embedding stem.  out[b,f,:] = table_f[idx[b,f],:]  — replaces Fs × nn.Embedding + torch.stack
+ * (supernet.py:404-430).  Bit-exact copy.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nasrec_embed_desc {
+  int32_t kind; /* NASREC_OP_EMBED_GATHER */
+  int32_t B, Fs;
+  int32_t _pad;
+  const int64_t* idx;                      /* [B, Fs] */
+  const float* table[NASREC_MAX_TABLES];   /* table f: [rows_f, 16] */
+  int64_t rows[NASREC_MAX_TABLES];
+  float* out;                              /* [B, Fs, 16] */
+  int32_t* oob;                            /* optional: set to 1 if any index is out of range */
+} nasrec_embed_desc_t;
+
+/* Row-sparse embedding backward: per (b,f) decide whether b is the first occurrence ("leader") of its row
+ * within field f and, for leaders, sum the gradients of all occurrences in ascending b (deterministic).
+ * Mathematically identical to embedding_dense_backward + dense Adagrad when weight_decay == 0, because an
+ * untouched row has g = 0 and Adagrad(g=0) is a no-op (train_utils.py:283-286; SURVEY §7 hard parts). */
+typedef struct nasrec_emb_dedup_desc {
+  int32_t kind; /* NASREC_OP_EMB_DEDUP */
+  int32_t B, Fs;
+  int32_t _pad;
+  const int64_t* idx;   /* [B, Fs] */
+  const float* dout;    /* [B, Fs, 16] */
+  int32_t* leader;      /* [B, Fs] out: 1 if leader */
+  float* gsum;          /* [B, Fs, 16] out: summed gradient (valid where leader) */
+  float* sumsq_partial; /* [Fs * ceil(B/256)] out: sum of squares of leader gradients per workgroup */
+} nasrec_emb_dedup_desc_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * DotProduct core (modules.py:366-383): T[B,k1,16] -> out[B, k1(k1-1)/2], out[b, i(i-1)/2 + j] =
+ * <T[b,i,:], T[b,j,:]>, i>j  (== Z[:, li, lj] with torch.tril_indices(k1,k1,-1)).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nasrec_dot_tri_desc {
+  int32_t kind; /* NASREC_OP_DOT_TRI_FWD / _BWD */
+  int32_t B, k1;
+  int32_t ld_out;   /* row stride of out / dout */
+  const float* T;   /* [B,k1,16] contiguous */
+  float* out;       /* fwd: out */
+  const float* dout;/* bwd */
+  float* dT;        /* bwd: [B,k1,16] contiguous, overwritten */
+} nasrec_dot_tri_desc_t;
+
+/* FactorizationMachine3D core (modules.py:736-738): ix[b,e] = (sum_n x)^2 - sum_n x^2. */
+typedef struct nasrec_fm_desc {
+  int32_t kind; /* NASREC_OP_FM_FWD / _BWD */
+  int32_t B, N;
+  int32_t ldx;      /* batch stride of x / dx */
+  int32_t ld_ix;    /* row stride of ix / dix */
+  int32_t accumulate; /* fwd: ix += ; bwd: dx += */
+  const float* x;
+  float* ix;        /* fwd out [B,16] */
+  const float* dix; /* bwd in  [B,16] */
+  float* dx;        /* bwd out [B,N,16] */
+} nasrec_fm_desc_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * Transformer body after the token projection (modules.py:664-686): nn.MultiheadAttention(16, 8 heads,
+ * head_dim 2) + residual + LN + FC(16,16)+ReLU+FC(16,16) + residual + LN, optional token prefix mask on
+ * the output.  One wavefront per sample; everything between x and out stays in registers/LDS.
+ * `params` points to 10 parameter tensors in this order: in_proj_weight[48,16], in_proj_bias[48],
+ * out_proj.weight[16,16], out_proj.bias[16], attn_ln.weight[16], attn_ln.bias[16], fc1.weight[16,16],
+ * fc1.bias[16], fc2.weight[16,16], fc2.bias[16], fc_ln.weight[16], fc_ln.bias[16]  (12 pointers).
+ * Backward recomputes the forward from x, writes dx and per-sample parameter-gradient partials
+ * [B, NASREC_MHA_PARAMS] that NASREC_OP_REDUCE_ROWS sums in fixed order (deterministic).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nasrec_mha_desc {
+  int32_t kind; /* NASREC_OP_MHA_FWD / _BWD */
+  int32_t B, N;
+  int32_t ldx, ldo;     /* batch strides of x/dx and out/dout */
+  int32_t dims_in_use;  /* < 0 none; else output tokens >= dims_in_use are zero (modules.py:678-686) */
+  const float* x;
+  float* out;
+  const float* dout;
+  float* dx;            /* overwritten */
+  float* dparams_partial; /* [B, NASREC_MHA_PARAMS] */
+  const float* params[12];
+} nasrec_mha_desc_t;
+
+/* out[c] = sum_r in[r*ld + c], r < R, c < C, fixed order.  Optionally scattered to up to 16 destination
+ * tensors (parameter .grad buffers) by column ranges. */
+typedef struct nasrec_reduce_rows_desc {
+  int32_t kind; /* NASREC_OP_REDUCE_ROWS */
+  int32_t R, C, ld;
+  const float* in;
+  int32_t ndst;
+  int32_t _pad;
+  float* dst[16];
+  int32_t dst_off[16];   /* first column of each destination */
+  int32_t dst_len[16];
+} nasrec_reduce_rows_desc_t;
+
+/* Strided copy / accumulate of a segmented dense view:  dst[b, j] (=|+=) concat_j(seg)[b, j].
+ * Used where the reference reuses a tensor without a projection (modules.py:343,352,362,388; supernet.py
+ * 1145-1146) and for gradient fan-in of such aliases.  `reverse`=1 scatters dst-shaped gradient back:
+ * seg[b, j-off] += src[b, j]. */
+typedef struct nasrec_copy_segs_desc {
+  int32_t kind; /* NASREC_OP_COPY_SEGS */
+  int32_t B, nseg;
+  int32_t ld_dst;
+  int32_t accumulate;
+  int32_t reverse;
+  float* dst;                         /* forward: destination; reverse: source of gradients (read only) */
+  float* seg[NASREC_MAX_SEGS];        /* forward: sources (NULL = zeros); reverse: gradient destinations (NULL = skip) */
+  int32_t width[NASREC_MAX_SEGS], ld[NASREC_MAX_SEGS], off[NASREC_MAX_SEGS];
+  int32_t seg_accumulate[NASREC_MAX_SEGS]; /* reverse: += instead of = */
+} nasrec_copy_segs_desc_t;
+
+/* out[b,j] = (sum over segments covering j) — elementwise sum of two segmented dense views
+ * (Sum without projection, modules.py:487-491). Implemented through COPY_SEGS with accumulate. */
+
+/* SigmoidGating backward elementwise part (modules.py:578-582): given dout (grad of g*R), g = sigmoid(z)
+ * and R (segmented): dz = dout * R * g * (1-g)   (written to dz),  dR_seg += dout * g. */
+typedef struct nasrec_gate_bwd_desc {
+  int32_t kind; /* NASREC_OP_GATE_BWD */
+  int32_t B, D;
+  int32_t ld_dout, ld_g, ld_dz;
+  const float* dout;
+  const float* g;
+  float* dz;
+  int32_t nseg;
+  const float* r_ptr[NASREC_MAX_SEGS];
+  float* dr_ptr[NASREC_MAX_SEGS];        /* NULL = no gradient wanted */
+  int32_t r_off[NASREC_MAX_SEGS], r_width[NASREC_MAX_SEGS], r_ld[NASREC_MAX_SEGS];
+  int32_t dr_accumulate[NASREC_MAX_SEGS];
+} nasrec_gate_bwd_desc_t;
+
+/* Bias gradients: out[r] = sum_k P(r,k) with P addressed by `mode` (RC for dense dy[M,N] -> db[N];
+ * TOKK for token-axis dy[B,N',16] -> db[N']), optional fused ReLU mask (aux) and prefix mask (rvalid). */
+typedef struct nasrec_rowsum_desc {
+  int32_t kind; /* NASREC_OP_ROWSUM */
+  int32_t mode, R, K, ld;
+  int32_t rvalid;   /* rows >= rvalid produce 0 */
+  const float* p;
+  const float* aux;
+  float* out;
+} nasrec_rowsum_desc_t;
+
+/* Final logit (supernet.py:592-598 / 657-664): logits[b] = <feats[b,:], w> + bias, feats = segments. */
+typedef struct nasrec_final_desc {
+  int32_t kind; /* NASREC_OP_FINAL_FWD / _BWD */
+  int32_t B, nseg;
+  const float* w;      /* [1, K] */
+  const float* bias;   /* [1] */
+  float* logits;       /* [B] */
+  const float* dlogits;/* bwd in [B] */
+  float* dw;           /* bwd out [K], overwritten */
+  float* dbias;        /* bwd out [1] */
+  const float* seg[NASREC_MAX_SEGS];
+  float* dseg[NASREC_MAX_SEGS];  /* bwd: gradient destinations (NULL = skip) */
+  int32_t width[NASREC_MAX_SEGS], ld[NASREC_MAX_SEGS], off[NASREC_MAX_SEGS];
+  int32_t dseg_accumulate[NASREC_MAX_SEGS];
+} nasrec_final_desc_t;
+
+/* BCEWithLogitsLoss(mean) forward + dlogits (main_train.py:122; train_utils.py:266):
+ * loss = mean(max(z,0) - z*y + log1p(exp(-|z|))), dlogits[b] = (sigmoid(z_b) - y_b) * grad_scale. */
+typedef struct nasrec_bce_desc {
+  int32_t kind; /* NASREC_OP_BCE */
+  int32_t B;
+  float grad_scale;   /* 1/B for a single process, 1/(B*world) under data parallel */
+  int32_t _pad;
+  const float* logits;
+  const float* y;
+  float* loss;        /* [1] */
+  float* dlogits;     /* [B] */
+} nasrec_bce_desc_t;
+
+/* sum of squares of a flat fp32 buffer -> partial[nblocks] (deterministic two-stage). */
+typedef struct nasrec_sumsq_desc {
+  int32_t kind; /* NASREC_OP_SUMSQ */
+  int32_t nblocks;
+  int64_t n;
+  const float* x;
+  float* partial;
+} nasrec_sumsq_desc_t;
+
+/* clip_grad_norm_ coefficient (train_utils.py:285): total = sqrt(sum partials), coef = min(1, max_norm /
+ * (total + 1e-6)); out[0] = coef, out[1] = total.  max_norm <= 0 => coef = 1. */
+typedef struct nasrec_clip_coef_desc {
+  int32_t kind; /* NASREC_OP_CLIP_COEF */
+  int32_t n_a, n_b;
+  float max_norm;
+  const float* partial_a;
+  const float* partial_b;
+  float* out;
+} nasrec_clip_coef_desc_t;
+
+/* torch.optim.Adagrad(lr, eps, lr_decay=0, weight_decay=0) on a flat buffer (main_train.py:152-154):
+ * g' = g*coef; state += g'^2; p -= lr * g' / (sqrt(state) + eps).  lr and coef are read from device
+ * memory so a captured graph can be replayed with a new learning rate (lr_schedule.py). */
+typedef struct nasrec_adagrad_dense_desc {
+  int32_t kind; /* NASREC_OP_ADAGRAD_DENSE */
+  float eps;
+  int64_t n;
+  float* p;
+  const float* g;
+  float* state;
+  const float* lr;    /* device scalar */
+  const float* coef;  /* device scalar (clip) */
+} nasrec_adagrad_dense_desc_t;
+
+typedef struct nasrec_adagrad_rows_desc {
+  int32_t kind; /* NASREC_OP_ADAGRAD_ROWS */
+  int32_t B, Fs;
+  float eps;
+  const int64_t* idx;      /* [B,Fs] */
+  const int32_t* leader;   /* [B,Fs] */
+  const float* gsum;       /* [B,Fs,16] */
+  float* table[NASREC_MAX_TABLES];
+  float* state[NASREC_MAX_TABLES];
+  const float* lr;
+  const float* coef;
+} nasrec_adagrad_rows_desc_t;
+
+typedef struct nasrec_memset_desc {
+  int32_t kind; /* NASREC_OP_MEMSET */
+  int32_t _pad;
+  int64_t bytes;
+  void* ptr;
+} nasrec_memset_desc_t;
+
+/* LayerNorm over the last axis of a dense [R,D] view (mode KC) or over the token axis of a [B,N',16]
+ * tensor per (b,e) (mode TOKR: row r=(b,e), element i=n').  y = mask(act(LN(x)*w + b)) (modules.py:174-178,
+ * 226-230, 341, 360, 392, 493, 589, 649, 741; supernet.py:1141). Saves mean / rstd per row for backward. */
+typedef struct nasrec_layernorm_desc {
+  int32_t kind; /* NASREC_OP_LAYERNORM_FWD / _BWD */
+  int32_t mode, R, D;
+  int32_t ldx, ldy;
+  int32_t act, dims_in_use;
+  int32_t accumulate;  /* fwd: y += ; bwd: dx += */
+  float eps;
+  const float* x;
+  const float* w;
+  const float* b;
+  float* y;
+  float* stats;        /* [R,2] mean, rstd */
+  const float* dy;     /* bwd */
+  float* dx;           /* bwd */
+  float* dwb_partial;  /* bwd: [nblk, 2*D] partials of (dw, db); reduce with NASREC_OP_REDUCE_ROWS */
+  int32_t nblk;
+  int32_t _pad;
+} nasrec_layernorm_desc_t;
+
+/* y[i] = x[i] * s  */
+typedef struct nasrec_scale_desc {
+  int32_t kind; /* NASREC_OP_SCALE */
+  int32_t _pad;
+  int64_t n;
+  float s;
+  int32_t _pad2;
+  const float* x;
+  float* y;
+} nasrec_scale_desc_t;
+
+/* dz = dy * act'(z) * prefixmask, dense [R,D] views (SiLU path; ReLU is fused into the GEMM loads) */
+typedef struct nasrec_act_bwd_desc {
+  int32_t kind; /* NASREC_OP_ACT_BWD */
+  int32_t mode, R, D;
+  int32_t ld_dy, ld_z, ld_dz;
+  int32_t act, dims_in_use;
+  const float* dy;
+  const float* z;
+  float* dz;
+} nasrec_act_bwd_desc_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * Entry points
+ * ---------------------------------------------------------------------------------------------- */
+/* Launch one op (any descriptor above) on `stream`. */
+int nasrec_launch(void* stream, const void* desc);
+/* Launch a program: n descriptors in order on `stream` (one host call per training step). */
+int nasrec_program_run(void* stream, const void* const* descs, int n);
+
+/* hipGraph capture of a program: capture once, replay many times (launch-bound B=256 step). */
+int nasrec_graph_create(void* stream, const void* const* descs, int n, void** graph_out);
+int nasrec_graph_launch(void* graph, void* stream);
+int nasrec_graph_destroy(void* graph);
+
+/* Typed convenience wrappers == nasrec_launch with a kind check (one per reference call site). */
+int nasrec_gemm(void* stream, const nasrec_gemm_desc_t* d);
+int nasrec_embedding_gather(void* stream, const nasrec_embed_desc_t* d);
+int nasrec_embedding_dedup(void* stream, const nasrec_emb_dedup_desc_t* d);
+int nasrec_dot_tri(void* stream, const nasrec_dot_tri_desc_t* d);
+int nasrec_fm(void* stream, const nasrec_fm_desc_t* d);
+int nasrec_mha_ffn(void* stream, const nasrec_mha_desc_t* d);
+int nasrec_layernorm(void* stream, const nasrec_layernorm_desc_t* d);
+int nasrec_final_logit(void* stream, const nasrec_final_desc_t* d);
+int nasrec_bce_logits(void* stream, const nasrec_bce_desc_t* d);
+int nasrec_adagrad_dense(void* stream, const nasrec_adagrad_dense_desc_t* d);
+int nasrec_adagrad_rows(void* stream, const nasrec_adagrad_rows_desc_t* d);
+
+/* HIP-event timing on an arbitrary stream (bench.py measures kernels on the engine's own stream). */
+int nasrec_event_create(void** ev);
+int nasrec_event_record(void* ev, void* stream);
+int nasrec_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int nasrec_event_destroy(void* ev);
+
+const char* nasrec_last_error(void);
+int nasrec_abi_version(void);
+/* sizeof() of every descriptor, so a binding can verify its struct layout: fills out[0..n) in the
+ * order of the NASREC_OP_* enum (index = kind), returns number written. */
+int nasrec_desc_sizes(int32_t* out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NASREC_HIP_H */

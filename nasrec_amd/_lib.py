@@ -1,0 +1,203 @@
+"""ctypes binding of include/nasrec_hip.h (the C-ABI of the HIP engine).
+
+This is the reference-side binding a maintainer would add: plain structs, raw device pointers,
+a hipStream_t passed as void*.  There is NO CPU fallback: if the shared library is missing or a symbol / struct
+layout does not match, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnasrec_hip.so")
+
+MAX_SEGS = 8
+MAX_TABLES = 32
+EMB_DIM = 16
+MHA_PARAMS = 1696
+
+AM_KC, AM_RC, AM_TOKR, AM_TOKK = 0, 1, 2, 3
+CM_PLAIN, CM_TOKJ = 0, 1
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_BY_NAME = {"identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
+
+(OP_GEMM, OP_EMBED_GATHER, OP_DOT_TRI_FWD, OP_DOT_TRI_BWD, OP_FM_FWD, OP_FM_BWD, OP_MHA_FWD, OP_MHA_BWD, OP_REDUCE_ROWS,
+ OP_COPY_SEGS, OP_GATE_BWD, OP_ROWSUM, OP_FINAL_FWD, OP_BCE, OP_FINAL_BWD, OP_EMB_DEDUP, OP_SUMSQ, OP_CLIP_COEF,
+ OP_ADAGRAD_DENSE, OP_ADAGRAD_ROWS, OP_MEMSET, OP_LAYERNORM_FWD, OP_LAYERNORM_BWD, OP_ADD_SEGS, OP_SCALE,
+ OP_ACT_BWD) = range(1, 27)
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmSeg(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("Aaux", vp), ("Baux", vp), ("M", i32), ("N", i32), ("K", i32),
+                ("lda", i32), ("ldb", i32), ("ldc", i32), ("Mvalid", i32), ("accumulate", i32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("kind", i32), ("amode", i32), ("bmode", i32), ("cmode", i32), ("nseg", i32), ("zmode", i32), ("act", i32),
+                ("bias_on_rows", i32), ("mask_on_rows", i32), ("dims_in_use", i32), ("beta", i32), ("splitk", i32),
+                ("bias", vp), ("save_z", vp), ("save_act", vp), ("mul_ptr", vp * MAX_SEGS), ("mul_off", i32 * MAX_SEGS),
+                ("mul_width", i32 * MAX_SEGS), ("mul_ld", i32 * MAX_SEGS), ("mul_nseg", i32), ("_pad", i32),
+                ("workspace", vp), ("pre_add", vp), ("seg", GemmSeg * MAX_SEGS)]
+
+
+class EmbedDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("Fs", i32), ("_pad", i32), ("idx", vp), ("table", vp * MAX_TABLES),
+                ("rows", i64 * MAX_TABLES), ("out", vp), ("oob", vp)]
+
+
+class EmbDedupDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("Fs", i32), ("_pad", i32), ("idx", vp), ("dout", vp), ("leader", vp), ("gsum", vp),
+                ("sumsq_partial", vp)]
+
+
+class DotTriDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("k1", i32), ("ld_out", i32), ("T", vp), ("out", vp), ("dout", vp), ("dT", vp)]
+
+
+class FmDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("N", i32), ("ldx", i32), ("ld_ix", i32), ("accumulate", i32), ("x", vp), ("ix", vp),
+                ("dix", vp), ("dx", vp)]
+
+
+class MhaDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("N", i32), ("ldx", i32), ("ldo", i32), ("dims_in_use", i32), ("x", vp), ("out", vp),
+                ("dout", vp), ("dx", vp), ("dparams_partial", vp), ("params", vp * 12)]
+
+
+class ReduceRowsDesc(C.Structure):
+    _fields_ = [("kind", i32), ("R", i32), ("C", i32), ("ld", i32), ("in_", vp), ("ndst", i32), ("_pad", i32), ("dst", vp * 16),
+                ("dst_off", i32 * 16), ("dst_len", i32 * 16)]
+
+
+class CopySegsDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("nseg", i32), ("ld_dst", i32), ("accumulate", i32), ("reverse", i32), ("dst", vp),
+                ("seg", vp * MAX_SEGS), ("width", i32 * MAX_SEGS), ("ld", i32 * MAX_SEGS), ("off", i32 * MAX_SEGS),
+                ("seg_accumulate", i32 * MAX_SEGS)]
+
+
+class GateBwdDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("D", i32), ("ld_dout", i32), ("ld_g", i32), ("ld_dz", i32), ("dout", vp), ("g", vp),
+                ("dz", vp), ("nseg", i32), ("r_ptr", vp * MAX_SEGS), ("dr_ptr", vp * MAX_SEGS), ("r_off", i32 * MAX_SEGS),
+                ("r_width", i32 * MAX_SEGS), ("r_ld", i32 * MAX_SEGS), ("dr_accumulate", i32 * MAX_SEGS)]
+
+
+class RowsumDesc(C.Structure):
+    _fields_ = [("kind", i32), ("mode", i32), ("R", i32), ("K", i32), ("ld", i32), ("rvalid", i32), ("p", vp), ("aux", vp),
+                ("out", vp)]
+
+
+class FinalDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("nseg", i32), ("w", vp), ("bias", vp), ("logits", vp), ("dlogits", vp), ("dw", vp),
+                ("dbias", vp), ("seg", vp * MAX_SEGS), ("dseg", vp * MAX_SEGS), ("width", i32 * MAX_SEGS),
+                ("ld", i32 * MAX_SEGS), ("off", i32 * MAX_SEGS), ("dseg_accumulate", i32 * MAX_SEGS)]
+
+
+class BceDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("grad_scale", f32), ("_pad", i32), ("logits", vp), ("y", vp), ("loss", vp),
+                ("dlogits", vp)]
+
+
+class SumsqDesc(C.Structure):
+    _fields_ = [("kind", i32), ("nblocks", i32), ("n", i64), ("x", vp), ("partial", vp)]
+
+
+class ClipCoefDesc(C.Structure):
+    _fields_ = [("kind", i32), ("n_a", i32), ("n_b", i32), ("max_norm", f32), ("partial_a", vp), ("partial_b", vp), ("out", vp)]
+
+
+class AdagradDenseDesc(C.Structure):
+    _fields_ = [("kind", i32), ("eps", f32), ("n", i64), ("p", vp), ("g", vp), ("state", vp), ("lr", vp), ("coef", vp)]
+
+
+class AdagradRowsDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("Fs", i32), ("eps", f32), ("idx", vp), ("leader", vp), ("gsum", vp),
+                ("table", vp * MAX_TABLES), ("state", vp * MAX_TABLES), ("lr", vp), ("coef", vp)]
+
+
+class MemsetDesc(C.Structure):
+    _fields_ = [("kind", i32), ("_pad", i32), ("bytes", i64), ("ptr", vp)]
+
+
+class LayerNormDesc(C.Structure):
+    _fields_ = [("kind", i32), ("mode", i32), ("R", i32), ("D", i32), ("ldx", i32), ("ldy", i32), ("act", i32),
+                ("dims_in_use", i32), ("accumulate", i32), ("eps", f32), ("x", vp), ("w", vp), ("b", vp), ("y", vp), ("stats", vp),
+                ("dy", vp), ("dx", vp), ("dwb_partial", vp), ("nblk", i32), ("_pad", i32)]
+
+
+class ScaleDesc(C.Structure):
+    _fields_ = [("kind", i32), ("_pad", i32), ("n", i64), ("s", f32), ("_pad2", i32), ("x", vp), ("y", vp)]
+
+
+class ActBwdDesc(C.Structure):
+    _fields_ = [("kind", i32), ("mode", i32), ("R", i32), ("D", i32), ("ld_dy", i32), ("ld_z", i32), ("ld_dz", i32), ("act", i32),
+                ("dims_in_use", i32), ("dy", vp), ("z", vp), ("dz", vp)]
+
+
+DESC_BY_KIND = {
+    OP_GEMM: GemmDesc, OP_EMBED_GATHER: EmbedDesc, OP_DOT_TRI_FWD: DotTriDesc, OP_DOT_TRI_BWD: DotTriDesc, OP_FM_FWD: FmDesc,
+    OP_FM_BWD: FmDesc, OP_MHA_FWD: MhaDesc, OP_MHA_BWD: MhaDesc, OP_REDUCE_ROWS: ReduceRowsDesc, OP_COPY_SEGS: CopySegsDesc,
+    OP_GATE_BWD: GateBwdDesc, OP_ROWSUM: RowsumDesc, OP_FINAL_FWD: FinalDesc, OP_BCE: BceDesc, OP_FINAL_BWD: FinalDesc,
+    OP_EMB_DEDUP: EmbDedupDesc, OP_SUMSQ: SumsqDesc, OP_CLIP_COEF: ClipCoefDesc, OP_ADAGRAD_DENSE: AdagradDenseDesc,
+    OP_ADAGRAD_ROWS: AdagradRowsDesc, OP_MEMSET: MemsetDesc, OP_LAYERNORM_FWD: LayerNormDesc, OP_LAYERNORM_BWD: LayerNormDesc,
+    OP_SCALE: ScaleDesc, OP_ACT_BWD: ActBwdDesc,
+}
+
+# every symbol include/nasrec_hip.h declares
+SYMBOLS = [
+    "nasrec_launch", "nasrec_program_run", "nasrec_graph_create", "nasrec_graph_launch", "nasrec_graph_destroy", "nasrec_gemm",
+    "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm", "nasrec_mha_ffn", "nasrec_layernorm",
+    "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense", "nasrec_adagrad_rows", "nasrec_event_create",
+    "nasrec_event_record", "nasrec_event_elapsed_ms", "nasrec_event_destroy", "nasrec_last_error", "nasrec_abi_version",
+    "nasrec_desc_sizes",
+]
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the engine, verify every declared symbol exists and every struct layout matches. Raises on failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError("HIP engine library not found at %s — run `python __graft_entry__.py` (build()) first; "
+                          "there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise EngineError("libnasrec_hip.so does not export %s" % s)
+    lib.nasrec_last_error.restype = C.c_char_p
+    lib.nasrec_launch.argtypes = [vp, vp]
+    lib.nasrec_program_run.argtypes = [vp, C.POINTER(vp), C.c_int]
+    lib.nasrec_graph_create.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp)]
+    lib.nasrec_graph_launch.argtypes = [vp, vp]
+    lib.nasrec_graph_destroy.argtypes = [vp]
+    lib.nasrec_event_create.argtypes = [C.POINTER(vp)]
+    lib.nasrec_event_record.argtypes = [vp, vp]
+    lib.nasrec_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(f32)]
+    lib.nasrec_event_destroy.argtypes = [vp]
+    lib.nasrec_desc_sizes.argtypes = [C.POINTER(i32), C.c_int]
+    for name in ("nasrec_gemm", "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm",
+                 "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
+                 "nasrec_adagrad_rows"):
+        getattr(lib, name).argtypes = [vp, vp]
+    if lib.nasrec_abi_version() != 1:
+        raise EngineError("ABI version mismatch: library %d, binding 1" % lib.nasrec_abi_version())
+    sizes = (i32 * 32)()
+    n = lib.nasrec_desc_sizes(sizes, 32)
+    for kind, cls in DESC_BY_KIND.items():
+        if kind >= n or sizes[kind] != C.sizeof(cls):
+            raise EngineError("struct layout mismatch for op kind %d: library %d bytes, binding %d bytes"
+                              % (kind, sizes[kind] if kind < n else -1, C.sizeof(cls)))
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise EngineError("nasrec engine error %d: %s" % (rc, _lib.nasrec_last_error().decode(errors="replace")))

@@ -1,0 +1,64 @@
+// Shared device/host helpers for the gfx950 NASRec engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nasrec_hip.h"
+
+#define NASREC_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// address of element (r,k) of an operand under the four addressing modes of nasrec_hip.h
+template <int MODE>
+__device__ __forceinline__ long operand_offset(int r, int k, int ld) {
+  if (MODE == NASREC_AM_KC) return (long)r * ld + k;
+  if (MODE == NASREC_AM_RC) return (long)k * ld + r;
+  if (MODE == NASREC_AM_TOKR) return (long)(r >> 4) * ld + (r & 15) + (long)k * 16;
+  return (long)(k >> 4) * ld + (k & 15) + (long)r * 16;  // TOKK
+}
+
+template <int CMODE>
+__device__ __forceinline__ long c_offset(int i, int j, int ldc) {
+  if (CMODE == NASREC_CM_PLAIN) return (long)i * ldc + j;
+  return (long)(j >> 4) * ldc + (j & 15) + (long)i * 16;
+}
+
+__device__ __forceinline__ float act_apply(float z, int act) {
+  switch (act) {
+    case NASREC_ACT_RELU: return z > 0.f ? z : 0.f;
+    case NASREC_ACT_SILU: return z / (1.f + __expf(-z));
+    case NASREC_ACT_SIGMOID: return 1.f / (1.f + __expf(-z));
+    default: return z;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// host-side launch-error helper (defined in api.hip)
+int nasrec_set_error(int code, const char* fmt, ...);
+int nasrec_check_launch(const char* what);
+
+// per-kind launchers (each .hip file defines its own)
+int launch_gemm(hipStream_t s, const nasrec_gemm_desc_t* d);
+int launch_embed_gather(hipStream_t s, const nasrec_embed_desc_t* d);
+int launch_emb_dedup(hipStream_t s, const nasrec_emb_dedup_desc_t* d);
+int launch_dot_tri(hipStream_t s, const nasrec_dot_tri_desc_t* d);
+int launch_fm(hipStream_t s, const nasrec_fm_desc_t* d);
+int launch_mha(hipStream_t s, const nasrec_mha_desc_t* d);
+int launch_reduce_rows(hipStream_t s, const nasrec_reduce_rows_desc_t* d);
+int launch_copy_segs(hipStream_t s, const nasrec_copy_segs_desc_t* d);
+int launch_gate_bwd(hipStream_t s, const nasrec_gate_bwd_desc_t* d);
+int launch_rowsum(hipStream_t s, const nasrec_rowsum_desc_t* d);
+int launch_final(hipStream_t s, const nasrec_final_desc_t* d);
+int launch_bce(hipStream_t s, const nasrec_bce_desc_t* d);
+int launch_sumsq(hipStream_t s, const nasrec_sumsq_desc_t* d);
+int launch_clip_coef(hipStream_t s, const nasrec_clip_coef_desc_t* d);
+int launch_adagrad_dense(hipStream_t s, const nasrec_adagrad_dense_desc_t* d);
+int launch_adagrad_rows(hipStream_t s, const nasrec_adagrad_rows_desc_t* d);
+int launch_layernorm(hipStream_t s, const nasrec_layernorm_desc_t* d);
+int launch_scale(hipStream_t s, const nasrec_scale_desc_t* d);
+int launch_act_bwd(hipStream_t s, const nasrec_act_bwd_desc_t* d);

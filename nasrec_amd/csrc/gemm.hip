@@ -1,0 +1,255 @@
+// fp32 MFMA GEMM family for gfx950: C(i,j) = epilogue(sum_k A(i,k) * B(j,k)).
+//
+// One kernel template, six operand bindings (include/nasrec_hip.h "addressing modes"): it serves the dense
+// nn.Linear forward (modules.py:171 …), its two autograd products, and the token-axis Linear over
+// [B,N,16] tensors (modules.py:222-234, 358-361, 648-650) with its two autograd products — without ever
+// materialising a transpose or a concatenation (segments = K-ranges or independent z-problems).
+//
+// Tiling: 256 threads = 4 wavefronts (2x2), block tile 64x64x16, each wave 32x32 = 2x2
+// v_mfma_f32_16x16x4_f32 tiles (exact fp32 FMA chain, so results match an fp32 dot product bit-for-bit in
+// k order within a lane group).  Global -> registers -> LDS staging with one tile of register prefetch.
+// The k index inside a 16-deep tile is permuted (lane group g takes k = 4g..4g+3 as one ds_read_b128)
+// identically for A and B, which only reorders the fp32 summation.
+#include "common.h"
+
+#define BM 64
+#define BN 64
+#define BK 16
+#define LDS_LD 20  // 16 + 4 pad: 80-byte rows keep ds_read_b128 aligned and spread rows over banks
+
+template <int MODE>
+__device__ __forceinline__ float load_operand(const float* __restrict__ p, const float* __restrict__ aux, int r, int k,
+                                              int R, int K, int ld) {
+  if (r < R && k < K) {
+    long o = operand_offset<MODE>(r, k, ld);
+    float v = p[o];
+    if (aux != nullptr && !(aux[o] > 0.f)) v = 0.f;
+    return v;
+  }
+  return 0.f;
+}
+
+// thread -> (row, k) mapping of the staging loads: lanes run along the contiguous axis of the operand
+template <int MODE>
+__device__ __forceinline__ void stage_coords(int tid, int it, int& rr, int& kk) {
+  if (MODE == NASREC_AM_KC || MODE == NASREC_AM_TOKK) {
+    kk = tid & 15;
+    rr = (tid >> 4) + 16 * it;
+  } else {
+    rr = tid & 63;
+    kk = (tid >> 6) + 4 * it;
+  }
+}
+
+__device__ __forceinline__ float mul_lookup(const nasrec_gemm_desc_t& d, int i, int j) {
+  for (int q = 0; q < d.mul_nseg; ++q) {
+    int jj = j - d.mul_off[q];
+    if (jj >= 0 && jj < d.mul_width[q]) return d.mul_ptr[q] ? d.mul_ptr[q][(long)i * d.mul_ld[q] + jj] : 0.f;
+  }
+  return 0.f;
+}
+
+template <int CM>
+__device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, const nasrec_gemm_seg_t& sg, int i, int j,
+                                               float v) {
+  const long o = c_offset<CM>(i, j, sg.ldc);
+  if (d.pre_add) v += d.pre_add[o];
+  if (d.bias) v += d.bias_on_rows ? d.bias[i] : d.bias[j];
+  if (d.save_z) d.save_z[o] = v;
+  v = act_apply(v, d.act);
+  if (d.save_act) d.save_act[o] = v;
+  if (d.mul_nseg > 0) v *= mul_lookup(d, i, j);
+  if (d.dims_in_use >= 0) {
+    int idx = d.mask_on_rows ? i : j;
+    if (idx >= d.dims_in_use) v = 0.f;
+  }
+  if (d.zmode ? sg.accumulate : d.beta) v += sg.C[o];
+  sg.C[o] = v;
+}
+
+template <int AM, int BMODE, int CM>
+__global__ __launch_bounds__(256) void gemm_kernel(const nasrec_gemm_desc_t d, int Mmax, int Nmax) {
+  __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int S = d.splitk > 1 ? d.splitk : 1;
+  const int z = d.zmode ? (int)(blockIdx.z / S) : 0;
+  const int ks = (int)(blockIdx.z % S);
+  const nasrec_gemm_seg_t& s0 = d.seg[z];
+  const int M = s0.M, N = s0.N;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (m0 >= M || n0 >= N) return;
+
+  // live k-tiles of this problem and the range owned by this split
+  int T = 0;
+  if (d.zmode) {
+    T = s0.A ? (s0.K + BK - 1) / BK : 0;
+  } else {
+    for (int q = 0; q < d.nseg; ++q)
+      if (d.seg[q].A) T += (d.seg[q].K + BK - 1) / BK;
+  }
+  const int t0 = (int)((long)T * ks / S), t1 = (int)((long)T * (ks + 1) / S);
+  int s = z, kt = t0;
+  if (!d.zmode) {
+    s = 0;
+    int skip = t0;
+    while (s < d.nseg) {
+      int nt = d.seg[s].A ? (d.seg[s].K + BK - 1) / BK : 0;
+      if (skip < nt) break;
+      skip -= nt;
+      ++s;
+    }
+    kt = skip;
+  }
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float ra[4], rb[4];
+  auto fetch = [&](int sq, int ktq) {
+    const nasrec_gemm_seg_t& sg = d.seg[sq];
+    const int k0 = ktq * BK;
+    const int Ra = (sg.Mvalid > 0 && sg.Mvalid < M) ? sg.Mvalid : M;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      int rr, kk;
+      stage_coords<AM>(tid, it, rr, kk);
+      ra[it] = load_operand<AM>(sg.A, sg.Aaux, m0 + rr, k0 + kk, Ra, sg.K, sg.lda);
+      stage_coords<BMODE>(tid, it, rr, kk);
+      rb[it] = load_operand<BMODE>(sg.B, sg.Baux, n0 + rr, k0 + kk, N, sg.K, sg.ldb);
+    }
+  };
+
+  if (t0 < t1) fetch(s, kt);
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      int rr, kk;
+      stage_coords<AM>(tid, it, rr, kk);
+      As[rr * LDS_LD + kk] = ra[it];
+      stage_coords<BMODE>(tid, it, rr, kk);
+      Bs[rr * LDS_LD + kk] = rb[it];
+    }
+    __syncthreads();
+    // advance to the next live tile and prefetch it while the MFMAs run
+    ++kt;
+    if (!d.zmode) {
+      while (s < d.nseg && (!d.seg[s].A || kt * BK >= d.seg[s].K)) {
+        ++s;
+        kt = 0;
+      }
+    }
+    if (t + 1 < t1) fetch(s, kt);
+
+    f32x4 af[2], bf[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + a * 16 + fr) * LDS_LD + 4 * fg]);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 + b * 16 + fr) * LDS_LD + 4 * fg]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+  }
+
+  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
+  if (S > 1) {
+    float* slab = d.workspace + ((long)(z * S + ks)) * Mmax * Nmax;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int i = m0 + wm * 32 + a * 16 + 4 * fg + r, j = n0 + wn * 32 + b * 16 + fr;
+          if (i < M && j < N) slab[(long)i * N + j] = acc[a][b][r];
+        }
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = m0 + wm * 32 + a * 16 + 4 * fg + r, j = n0 + wn * 32 + b * 16 + fr;
+        if (i < M && j < N) epilogue_store<CM>(d, s0, i, j, acc[a][b][r]);
+      }
+}
+
+// second pass of split-K: fixed-order sum of the partial slabs, then the same epilogue
+template <int CM>
+__global__ __launch_bounds__(256) void gemm_splitk_epilogue(const nasrec_gemm_desc_t d, int Mmax, int Nmax) {
+  const int S = d.splitk;
+  const int z = blockIdx.z;
+  const nasrec_gemm_seg_t& sg = d.seg[d.zmode ? z : 0];
+  const int M = sg.M, N = sg.N;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)M * N) return;
+  // token-axis outputs: let consecutive threads walk e (=16 contiguous floats) then i
+  int i, j;
+  if (CM == NASREC_CM_TOKJ) {
+    int jb = (int)(e / ((long)M * 16));
+    int rem = (int)(e % ((long)M * 16));
+    i = rem >> 4;
+    j = jb * 16 + (rem & 15);
+  } else {
+    i = (int)(e / N);
+    j = (int)(e % N);
+  }
+  const float* slab = d.workspace + ((long)z * S) * Mmax * Nmax;
+  float v = 0.f;
+  for (int q = 0; q < S; ++q) v += slab[(long)q * Mmax * Nmax + (long)i * N + j];
+  epilogue_store<CM>(d, sg, i, j, v);
+}
+
+template <int AM, int BMODE, int CM>
+static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
+  int Mmax = 0, Nmax = 0;
+  const int nprob = d->zmode ? d->nseg : 1;
+  for (int q = 0; q < nprob; ++q) {
+    if (d->seg[q].M > Mmax) Mmax = d->seg[q].M;
+    if (d->seg[q].N > Nmax) Nmax = d->seg[q].N;
+  }
+  if (Mmax <= 0 || Nmax <= 0) return 0;
+  const int S = d->splitk > 1 ? d->splitk : 1;
+  if (S > 1 && d->workspace == nullptr) return nasrec_set_error(-3, "gemm: splitk=%d needs a workspace", S);
+  dim3 grid((Nmax + BN - 1) / BN, (Mmax + BM - 1) / BM, nprob * S);
+  hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM>), grid, dim3(256), 0, st, *d, Mmax, Nmax);
+  if (S > 1) {
+    long elems = (long)Mmax * Nmax;
+    dim3 g2((unsigned)((elems + 255) / 256), 1, nprob);
+    hipLaunchKernelGGL((gemm_splitk_epilogue<CM>), g2, dim3(256), 0, st, *d, Mmax, Nmax);
+  }
+  return nasrec_check_launch("gemm");
+}
+
+int launch_gemm(hipStream_t st, const nasrec_gemm_desc_t* d) {
+  if (d->nseg < 1 || d->nseg > NASREC_MAX_SEGS) return nasrec_set_error(-2, "gemm: nseg=%d out of range", d->nseg);
+  const int key = d->amode * 100 + d->bmode * 10 + d->cmode;
+  switch (key) {
+    case NASREC_AM_KC * 100 + NASREC_AM_KC * 10 + NASREC_CM_PLAIN:  // y = x Wᵀ
+      return launch_gemm_t<NASREC_AM_KC, NASREC_AM_KC, NASREC_CM_PLAIN>(st, d);
+    case NASREC_AM_KC * 100 + NASREC_AM_RC * 10 + NASREC_CM_PLAIN:  // dx = dy W
+      return launch_gemm_t<NASREC_AM_KC, NASREC_AM_RC, NASREC_CM_PLAIN>(st, d);
+    case NASREC_AM_RC * 100 + NASREC_AM_RC * 10 + NASREC_CM_PLAIN:  // dW = dyᵀ x
+      return launch_gemm_t<NASREC_AM_RC, NASREC_AM_RC, NASREC_CM_PLAIN>(st, d);
+    case NASREC_AM_KC * 100 + NASREC_AM_TOKR * 10 + NASREC_CM_TOKJ:  // token-axis y = W x
+      return launch_gemm_t<NASREC_AM_KC, NASREC_AM_TOKR, NASREC_CM_TOKJ>(st, d);
+    case NASREC_AM_RC * 100 + NASREC_AM_TOKR * 10 + NASREC_CM_TOKJ:  // token-axis dx = Wᵀ dy
+      return launch_gemm_t<NASREC_AM_RC, NASREC_AM_TOKR, NASREC_CM_TOKJ>(st, d);
+    case NASREC_AM_TOKK * 100 + NASREC_AM_TOKK * 10 + NASREC_CM_PLAIN:  // token-axis dW = dy xᵀ
+      return launch_gemm_t<NASREC_AM_TOKK, NASREC_AM_TOKK, NASREC_CM_PLAIN>(st, d);
+    default:
+      return nasrec_set_error(-2, "gemm: unsupported operand binding a=%d b=%d c=%d", d->amode, d->bmode, d->cmode);
+  }
+}

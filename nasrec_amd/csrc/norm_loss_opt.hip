@@ -1,0 +1,387 @@
+// Final logit + BCE loss, LayerNorm, and the optimizer tail (clip_grad_norm_ + Adagrad) of the training step
+// (reference: supernet.py:592-598/657-664, main_train.py:122, train_utils.py:262-286, main_train.py:152-154).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// final logit: one wavefront per sample, lanes stride the (segmented) feature axis
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void final_fwd_kernel(const nasrec_final_desc_t d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= d.B) return;
+  float s = 0.f;
+  for (int q = 0; q < d.nseg; ++q) {
+    if (!d.seg[q]) continue;
+    const float* x = d.seg[q] + (long)b * d.ld[q];
+    const float* w = d.w + d.off[q];
+    for (int j = lane; j < d.width[q]; j += 64) s = fmaf(x[j], w[j], s);
+  }
+  s = wave_sum(s);
+  if (lane == 0) d.logits[b] = s + d.bias[0];
+}
+
+// backward: part A (blocks [0, nA)): dseg[b,j] (+)= dlogits[b] * w[off+j]
+//           part B (blocks [nA, ..)): dw[k] = sum_b dlogits[b] * feat[b,k]; dbias = sum_b dlogits[b]
+__global__ __launch_bounds__(256) void final_bwd_kernel(const nasrec_final_desc_t d, int K, int nA) {
+  if ((int)blockIdx.x < nA) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)d.B * K) return;
+    const int b = (int)(t / K), k = (int)(t % K);
+    for (int q = 0; q < d.nseg; ++q) {
+      const int jj = k - d.off[q];
+      if (jj >= 0 && jj < d.width[q]) {
+        if (d.dseg[q]) {
+          float* p = d.dseg[q] + (long)b * d.ld[q] + jj;
+          const float v = d.dlogits[b] * d.w[k];
+          *p = d.dseg_accumulate[q] ? *p + v : v;
+        }
+        break;
+      }
+    }
+    return;
+  }
+  __shared__ float red[16][17];
+  const int kl = threadIdx.x & 15, bq = threadIdx.x >> 4;
+  const int k = ((int)blockIdx.x - nA) * 16 + kl;  // k == K is the bias column
+  float s = 0.f;
+  if (k <= K) {
+    const float* src = nullptr;
+    int ld = 0, jj = 0;
+    if (k < K) {
+      for (int q = 0; q < d.nseg; ++q) {
+        jj = k - d.off[q];
+        if (jj >= 0 && jj < d.width[q]) {
+          src = d.seg[q];
+          ld = d.ld[q];
+          break;
+        }
+      }
+    }
+    for (int b = bq; b < d.B; b += 16) {
+      float f = (k == K) ? 1.f : (src ? src[(long)b * ld + jj] : 0.f);
+      s = fmaf(d.dlogits[b], f, s);
+    }
+  }
+  red[bq][kl] = s;
+  __syncthreads();
+  if (bq == 0 && k <= K) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q][kl];
+    if (k < K)
+      d.dw[k] = tot;
+    else
+      d.dbias[0] = tot;
+  }
+}
+
+int launch_final(hipStream_t st, const nasrec_final_desc_t* d) {
+  if (d->B == 0) return 0;
+  if (d->kind == NASREC_OP_FINAL_FWD) {
+    hipLaunchKernelGGL(final_fwd_kernel, dim3((d->B + 3) / 4), dim3(256), 0, st, *d);
+  } else {
+    int K = 0;
+    for (int q = 0; q < d->nseg; ++q) K = max(K, d->off[q] + d->width[q]);
+    long tA = (long)d->B * K;
+    int nA = (int)((tA + 255) / 256);
+    int nB = (K + 1 + 15) / 16;
+    hipLaunchKernelGGL(final_bwd_kernel, dim3(nA + nB), dim3(256), 0, st, *d, K, nA);
+  }
+  return nasrec_check_launch("final");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BCE-with-logits (mean) + dlogits; one workgroup, fixed-order reduction
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bce_kernel(const nasrec_bce_desc_t d) {
+  __shared__ float red[1024];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < d.B; b += 1024) {
+    const float z = d.logits[b], y = d.y[b];
+    s += fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
+    const float sg = 1.f / (1.f + expf(-z));
+    d.dlogits[b] = (sg - y) * d.grad_scale;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) d.loss[0] = red[0] / (float)d.B;
+}
+
+int launch_bce(hipStream_t st, const nasrec_bce_desc_t* d) {
+  if (d->B == 0) return 0;
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, st, *d);
+  return nasrec_check_launch("bce");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// global-norm clip + Adagrad on the flat dense parameter arena
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const nasrec_sumsq_desc_t d) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long)gridDim.x * 256) {
+    const float v = d.x[i];
+    s = fmaf(v, v, s);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) d.partial[blockIdx.x] = red[0];
+}
+
+int launch_sumsq(hipStream_t st, const nasrec_sumsq_desc_t* d) {
+  if (d->nblocks < 1) return nasrec_set_error(-2, "sumsq: nblocks=%d", d->nblocks);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(d->nblocks), dim3(256), 0, st, *d);
+  return nasrec_check_launch("sumsq");
+}
+
+__global__ void clip_coef_kernel(const nasrec_clip_coef_desc_t d) {
+  if (threadIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < d.n_a; ++i) s += (double)d.partial_a[i];
+  for (int i = 0; i < d.n_b; ++i) s += (double)d.partial_b[i];
+  const float total = (float)sqrt(s);
+  float coef = 1.f;
+  if (d.max_norm > 0.f) coef = fminf(d.max_norm / (total + 1e-6f), 1.f);
+  d.out[0] = coef;
+  d.out[1] = total;
+}
+
+int launch_clip_coef(hipStream_t st, const nasrec_clip_coef_desc_t* d) {
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, st, *d);
+  return nasrec_check_launch("clip_coef");
+}
+
+__global__ __launch_bounds__(256) void adagrad_dense_kernel(const nasrec_adagrad_dense_desc_t d) {
+  const float lr = *d.lr, coef = *d.coef;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long)gridDim.x * 256) {
+    const float g = d.g[i] * coef;
+    const float s = fmaf(g, g, d.state[i]);
+    d.state[i] = s;
+    d.p[i] = d.p[i] - lr * (g / (sqrtf(s) + d.eps));
+  }
+}
+
+int launch_adagrad_dense(hipStream_t st, const nasrec_adagrad_dense_desc_t* d) {
+  if (d->n == 0) return 0;
+  long blocks = (d->n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adagrad_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, st, *d);
+  return nasrec_check_launch("adagrad_dense");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm (supernet mode: every projection is followed by LN -> activation -> prefix mask,
+// modules.py:174-178).  Row r, element i:  KC: x[r*ld + i];  TOKR: x[(r>>4)*ld + (r&15) + i*16].
+// ---------------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ long ln_off(int r, int i, int ld) {
+  if (MODE == NASREC_AM_KC) return (long)r * ld + i;
+  return (long)(r >> 4) * ld + (r & 15) + (long)i * 16;
+}
+
+__device__ __forceinline__ float act_grad(float u, int act) {
+  if (act == NASREC_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+  if (act == NASREC_ACT_SILU) {
+    const float s = 1.f / (1.f + __expf(-u));
+    return s * (1.f + u * (1.f - s));
+  }
+  if (act == NASREC_ACT_SIGMOID) {
+    const float s = 1.f / (1.f + __expf(-u));
+    return s * (1.f - s);
+  }
+  return 1.f;
+}
+
+// dense rows: one wavefront per row
+__global__ __launch_bounds__(256) void ln_fwd_kc_kernel(const nasrec_layernorm_desc_t d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= d.R) return;
+  const float* x = d.x + (long)r * d.ldx;
+  float s = 0.f;
+  for (int i = lane; i < d.D; i += 64) s += x[i];
+  const float mu = wave_sum(s) / (float)d.D;
+  float v = 0.f;
+  for (int i = lane; i < d.D; i += 64) {
+    const float c = x[i] - mu;
+    v = fmaf(c, c, v);
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(v) / (float)d.D + d.eps);
+  if (lane == 0) {
+    d.stats[2 * r] = mu;
+    d.stats[2 * r + 1] = rstd;
+  }
+  float* y = d.y + (long)r * d.ldy;
+  for (int i = lane; i < d.D; i += 64) {
+    float u = fmaf((x[i] - mu) * rstd, d.w[i], d.b[i]);
+    u = act_apply(u, d.act);
+    if (d.dims_in_use >= 0 && i >= d.dims_in_use) u = 0.f;
+    y[i] = d.accumulate ? y[i] + u : u;
+  }
+}
+
+// token-axis rows: one thread per (b,e) row, D = N' <= 64 elements strided by 16 floats
+__global__ __launch_bounds__(256) void ln_fwd_tokr_kernel(const nasrec_layernorm_desc_t d) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= d.R) return;
+  float s = 0.f;
+  for (int i = 0; i < d.D; ++i) s += d.x[ln_off<NASREC_AM_TOKR>(r, i, d.ldx)];
+  const float mu = s / (float)d.D;
+  float v = 0.f;
+  for (int i = 0; i < d.D; ++i) {
+    const float c = d.x[ln_off<NASREC_AM_TOKR>(r, i, d.ldx)] - mu;
+    v = fmaf(c, c, v);
+  }
+  const float rstd = 1.f / sqrtf(v / (float)d.D + d.eps);
+  d.stats[2 * r] = mu;
+  d.stats[2 * r + 1] = rstd;
+  for (int i = 0; i < d.D; ++i) {
+    float u = fmaf((d.x[ln_off<NASREC_AM_TOKR>(r, i, d.ldx)] - mu) * rstd, d.w[i], d.b[i]);
+    u = act_apply(u, d.act);
+    if (d.dims_in_use >= 0 && i >= d.dims_in_use) u = 0.f;
+    float* y = d.y + ln_off<NASREC_AM_TOKR>(r, i, d.ldy);
+    *y = d.accumulate ? *y + u : u;
+  }
+}
+
+// backward, dense rows: workgroup = 4 waves, grid-strided over rows; per-lane partial (dw, db) for its
+// columns, combined across the 4 waves in LDS -> dwb_partial[blk][2D].  D <= 1024.
+#define LN_MAXD 1024
+__global__ __launch_bounds__(256) void ln_bwd_kc_kernel(const nasrec_layernorm_desc_t d) {
+  __shared__ float sdw[4][LN_MAXD];
+  __shared__ float sdb[4][LN_MAXD];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float pdw[LN_MAXD / 64], pdb[LN_MAXD / 64];
+#pragma unroll
+  for (int c = 0; c < LN_MAXD / 64; ++c) pdw[c] = pdb[c] = 0.f;
+  for (int r = blockIdx.x * 4 + wave; r < d.R; r += gridDim.x * 4) {
+    const float* x = d.x + (long)r * d.ldx;
+    const float* dy = d.dy + (long)r * d.ldy;
+    const float mu = d.stats[2 * r], rstd = d.stats[2 * r + 1];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXD / 64; ++c) {
+      const int i = lane + 64 * c;
+      if (i < d.D) {
+        const float xh = (x[i] - mu) * rstd;
+        float g = dy[i];
+        if (d.dims_in_use >= 0 && i >= d.dims_in_use) g = 0.f;
+        if (d.act != NASREC_ACT_NONE) g *= act_grad(fmaf(xh, d.w[i], d.b[i]), d.act);
+        pdw[c] = fmaf(g, xh, pdw[c]);
+        pdb[c] += g;
+        const float gw = g * d.w[i];
+        c1 += gw;
+        c2 = fmaf(gw, xh, c2);
+      }
+    }
+    c1 = wave_sum(c1) / (float)d.D;
+    c2 = wave_sum(c2) / (float)d.D;
+    float* dx = d.dx + (long)r * d.ldx;
+#pragma unroll
+    for (int c = 0; c < LN_MAXD / 64; ++c) {
+      const int i = lane + 64 * c;
+      if (i < d.D) {
+        const float xh = (x[i] - mu) * rstd;
+        float g = dy[i];
+        if (d.dims_in_use >= 0 && i >= d.dims_in_use) g = 0.f;
+        if (d.act != NASREC_ACT_NONE) g *= act_grad(fmaf(xh, d.w[i], d.b[i]), d.act);
+        const float v = rstd * (g * d.w[i] - c1 - xh * c2);
+        dx[i] = d.accumulate ? dx[i] + v : v;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < LN_MAXD / 64; ++c) {
+    const int i = lane + 64 * c;
+    if (i < d.D) {
+      sdw[wave][i] = pdw[c];
+      sdb[wave][i] = pdb[c];
+    }
+  }
+  __syncthreads();
+  float* out = d.dwb_partial + (long)blockIdx.x * 2 * d.D;
+  for (int i = threadIdx.x; i < d.D; i += 256) {
+    out[i] = (sdw[0][i] + sdw[1][i]) + (sdw[2][i] + sdw[3][i]);
+    out[d.D + i] = (sdb[0][i] + sdb[1][i]) + (sdb[2][i] + sdb[3][i]);
+  }
+}
+
+// backward, token-axis rows: thread = (b,e) row; dw/db reduced over the workgroup's 256 rows per element i
+__global__ __launch_bounds__(256) void ln_bwd_tokr_kernel(const nasrec_layernorm_desc_t d) {
+  __shared__ float red[4][2][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const bool live = r < d.R;
+  const float mu = live ? d.stats[2 * r] : 0.f, rstd = live ? d.stats[2 * r + 1] : 0.f;
+  float c1 = 0.f, c2 = 0.f;
+  if (live) {
+    for (int i = 0; i < d.D; ++i) {
+      const float xh = (d.x[ln_off<NASREC_AM_TOKR>(r, i, d.ldx)] - mu) * rstd;
+      float g = d.dy[ln_off<NASREC_AM_TOKR>(r, i, d.ldy)];
+      if (d.dims_in_use >= 0 && i >= d.dims_in_use) g = 0.f;
+      if (d.act != NASREC_ACT_NONE) g *= act_grad(fmaf(xh, d.w[i], d.b[i]), d.act);
+      const float gw = g * d.w[i];
+      c1 += gw;
+      c2 = fmaf(gw, xh, c2);
+    }
+    c1 /= (float)d.D;
+    c2 /= (float)d.D;
+  }
+  for (int i = 0; i < d.D; ++i) {
+    float g = 0.f, xh = 0.f;
+    if (live) {
+      xh = (d.x[ln_off<NASREC_AM_TOKR>(r, i, d.ldx)] - mu) * rstd;
+      g = d.dy[ln_off<NASREC_AM_TOKR>(r, i, d.ldy)];
+      if (d.dims_in_use >= 0 && i >= d.dims_in_use) g = 0.f;
+      if (d.act != NASREC_ACT_NONE) g *= act_grad(fmaf(xh, d.w[i], d.b[i]), d.act);
+      const float v = rstd * (g * d.w[i] - c1 - xh * c2);
+      float* dx = d.dx + ln_off<NASREC_AM_TOKR>(r, i, d.ldx);
+      *dx = d.accumulate ? *dx + v : v;
+    }
+    const float sw = wave_sum(g * xh), sb = wave_sum(g);
+    if (lane == 0) {
+      red[wave][0][i] = sw;
+      red[wave][1][i] = sb;
+    }
+  }
+  __syncthreads();
+  float* out = d.dwb_partial + (long)blockIdx.x * 2 * d.D;
+  for (int i = threadIdx.x; i < d.D; i += 256) {
+    out[i] = (red[0][0][i] + red[1][0][i]) + (red[2][0][i] + red[3][0][i]);
+    out[d.D + i] = (red[0][1][i] + red[1][1][i]) + (red[2][1][i] + red[3][1][i]);
+  }
+}
+
+int launch_layernorm(hipStream_t st, const nasrec_layernorm_desc_t* d) {
+  if (d->R == 0) return 0;
+  const bool fwd = d->kind == NASREC_OP_LAYERNORM_FWD;
+  if (d->mode == NASREC_AM_KC) {
+    if (d->D > LN_MAXD) return nasrec_set_error(-2, "layernorm: D=%d > %d", d->D, LN_MAXD);
+    if (fwd) {
+      hipLaunchKernelGGL(ln_fwd_kc_kernel, dim3((d->R + 3) / 4), dim3(256), 0, st, *d);
+    } else {
+      if (d->nblk < 1) return nasrec_set_error(-2, "layernorm bwd: nblk=%d", d->nblk);
+      hipLaunchKernelGGL(ln_bwd_kc_kernel, dim3(d->nblk), dim3(256), 0, st, *d);
+    }
+  } else if (d->mode == NASREC_AM_TOKR) {
+    if (d->D > 64) return nasrec_set_error(-2, "layernorm(tok): D=%d > 64", d->D);
+    const int nb = (d->R + 255) / 256;
+    if (fwd) {
+      hipLaunchKernelGGL(ln_fwd_tokr_kernel, dim3(nb), dim3(256), 0, st, *d);
+    } else {
+      if (d->nblk != nb) return nasrec_set_error(-2, "layernorm(tok) bwd: nblk=%d, want %d", d->nblk, nb);
+      hipLaunchKernelGGL(ln_bwd_tokr_kernel, dim3(nb), dim3(256), 0, st, *d);
+    }
+  } else {
+    return nasrec_set_error(-2, "layernorm: unsupported mode %d", d->mode);
+  }
+  return nasrec_check_launch("layernorm");
+}

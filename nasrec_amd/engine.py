@@ -1,0 +1,341 @@
+"""SupernetEngine — executes compiled plans (nasrec_amd/plan.py) on one MI355X through the C-ABI.
+
+Ownership: PyTorch owns every byte of device memory (parameters, gradients, optimizer state, activations);
+the engine owns launch plans, a HIP stream and captured hipGraphs.  Dense parameters live in ONE flat fp32 buffer
+(gradients and Adagrad state in two more of the same layout) so that the global-norm clip, the optimizer and the
+data-parallel all-reduce are single passes; the embedding tables stay separate [rows,16] tensors and are updated
+row-sparsely (identical to the dense reference update when weight_decay == 0).
+
+There is no CPU path here: everything below needs the HIP library and a GPU.
+"""
+import ctypes as C
+import json
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import plan as P
+
+E = 16
+
+
+def _ptr_array(descs):
+    arr = (C.c_void_p * len(descs))()
+    for i, d in enumerate(descs):
+        arr[i] = C.addressof(d)
+    return arr
+
+
+class Program:
+    """An ordered list of descriptors; runs with one host call (nasrec_program_run) or as a captured hipGraph."""
+
+    def __init__(self, descs: List):
+        self.descs = list(descs)
+        self.arr = _ptr_array(self.descs)
+        self.n = len(self.descs)
+        self.graph = None
+
+    def run(self, stream_ptr):
+        lib = L.load()
+        L.check(lib.nasrec_program_run(stream_ptr, self.arr, self.n))
+
+    def capture(self, stream_ptr):
+        lib = L.load()
+        g = C.c_void_p()
+        L.check(lib.nasrec_graph_create(stream_ptr, self.arr, self.n, C.byref(g)))
+        self.graph = g
+
+    def replay(self, stream_ptr):
+        L.check(L.load().nasrec_graph_launch(self.graph, stream_ptr))
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                L.load().nasrec_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+
+class CompiledPlan:
+    pass
+
+
+class SupernetEngine:
+    def __init__(self, cfg: P.NetConfig, Fd: int, Fs: int, num_embeddings: List[int], device="cuda:0", warm_choice=None,
+                 world_size: int = 1):
+        L.load()
+        if not torch.cuda.is_available():
+            raise L.EngineError("SupernetEngine needs a GPU: there is no CPU fallback")
+        self.cfg, self.Fd, self.Fs = cfg, Fd, Fs
+        self.num_embeddings = [int(n) for n in num_embeddings[:Fs]]
+        self.device = torch.device(device)
+        self.world_size = world_size
+        self.stream = torch.cuda.Stream(device=self.device)
+        if cfg.fixed:
+            assert warm_choice is not None, "fixed mode needs the fixed choice"
+            self.warm_choice = warm_choice
+        else:
+            self.warm_choice = P.full_path_choice(cfg)
+        self.shapes = P.infer_param_shapes(cfg, self.warm_choice, Fd, Fs, self.num_embeddings)
+        self.dense_names = [n for n in self.shapes if not n.startswith("_embedding.")]
+        # flat dense arena, every parameter 16-byte aligned
+        self.offsets, off = {}, 0
+        for n in self.dense_names:
+            self.offsets[n] = off
+            numel = 1
+            for s in self.shapes[n]:
+                numel *= s
+            off += (numel + 3) // 4 * 4
+        self.flat_numel = off
+        with torch.cuda.stream(self.stream):
+            self.flat_p = torch.zeros(off, dtype=torch.float32, device=self.device)
+            self.flat_g = torch.zeros(off, dtype=torch.float32, device=self.device)
+            self.flat_s = torch.zeros(off, dtype=torch.float32, device=self.device)
+            self.tables = [torch.zeros(n, E, dtype=torch.float32, device=self.device) for n in self.num_embeddings]
+            self.table_state: Optional[List[torch.Tensor]] = None
+            self.lr_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self.clip_out = torch.ones(2, dtype=torch.float32, device=self.device)  # [coef, total_norm]
+            self.oob = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.params: Dict[str, torch.Tensor] = {}
+        self.grads: Dict[str, torch.Tensor] = {}
+        self.state: Dict[str, torch.Tensor] = {}
+        for n in self.dense_names:
+            shp = self.shapes[n]
+            numel = 1
+            for s in shp:
+                numel *= s
+            o = self.offsets[n]
+            self.params[n] = self.flat_p[o:o + numel].view(shp)
+            self.grads[n] = self.flat_g[o:o + numel].view(shp)
+            self.state[n] = self.flat_s[o:o + numel].view(shp)
+        for f in range(Fs):
+            self.params["_embedding.%d.weight" % f] = self.tables[f]
+        self._plans: Dict[str, CompiledPlan] = {}
+        self.stream.synchronize()
+
+    # -------------------------------------------------------------------------------------------------------
+    def load_params(self, src: Dict[str, torch.Tensor]):
+        """copy values (any device/dtype) into the engine's storage; keys = reference state_dict names"""
+        with torch.cuda.stream(self.stream):
+            for k, v in src.items():
+                if k not in self.params:
+                    raise KeyError("unexpected parameter %s" % k)
+                self.params[k].copy_(torch.as_tensor(v).to(torch.float32).reshape(self.params[k].shape))
+        missing = [k for k in self.params if k not in src]
+        self.stream.synchronize()
+        return missing
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        self.stream.synchronize()
+        return {k: v.detach().cpu().clone() for k, v in self.params.items()}
+
+    def _ensure_table_state(self):
+        if self.table_state is None:
+            with torch.cuda.stream(self.stream):
+                self.table_state = [torch.zeros_like(t) for t in self.tables]
+
+    # -------------------------------------------------------------------------------------------------------
+    def compile(self, choice, B: int, train: bool, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = False,
+                grad_scale: Optional[float] = None) -> CompiledPlan:
+        key = json.dumps([choice, B, train, clip, eps, graph, grad_scale], sort_keys=True, default=_jsonable)
+        if key in self._plans:
+            return self._plans[key]
+        cfg = self.cfg
+        with torch.cuda.stream(self.stream):
+            cp = CompiledPlan()
+            ctx = P.Ctx(B, self.device, self.params, self.grads, shape_only=False, train=train)
+            cp.ctx = ctx
+            cp.int_x = torch.zeros(B, self.Fd, dtype=torch.float32, device=self.device)
+            cp.cat_x = torch.zeros(B, self.Fs, dtype=torch.int64, device=self.device)
+            cp.y = torch.zeros(B, dtype=torch.float32, device=self.device)
+            cp.logits = torch.zeros(B, dtype=torch.float32, device=self.device)
+            cp.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+            cp.dlogits = torch.zeros(B, dtype=torch.float32, device=self.device)
+            int_buf = P.Buf(ctx, B * self.Fd, need_grad=False, tensor=cp.int_x)
+            dense0 = P.DV(int_buf, 0, self.Fd, self.Fd)
+            sbuf = ctx.buf(B * self.Fs * E)
+            sparse0 = P.SV(sbuf, 0, self.Fs, self.Fs * E)
+            cp.sparse0 = sbuf
+            g = L.EmbedDesc()
+            g.kind = L.OP_EMBED_GATHER
+            g.B, g.Fs = B, self.Fs
+            g.idx = cp.cat_x.data_ptr()
+            for f in range(self.Fs):
+                g.table[f] = self.tables[f].data_ptr()
+                g.rows[f] = self.num_embeddings[f]
+            g.out = sbuf.t.data_ptr()
+            g.oob = self.oob.data_ptr()
+            ctx.emit(g)
+            d_last, s_last = P.network_walk(ctx, cfg, choice, dense0, sparse0)
+            # final logit (supernet.py:592-598 / 657-664)
+            K = d_last.width + s_last.N * E
+            w = ctx.param("_final.weight", (1, K))
+            bptr = ctx.param("_final.bias", (1,))
+            fsegs = [P.Seg(d_last, 0, d_last.width), P.Seg(s_last.dense(), d_last.width, s_last.N * E)]
+            fd = L.FinalDesc()
+            fd.kind = L.OP_FINAL_FWD
+            fd.B, fd.nseg = B, 2
+            fd.w, fd.bias, fd.logits = w, bptr, cp.logits.data_ptr()
+            for q, s in enumerate(fsegs):
+                fd.seg[q], fd.width[q], fd.ld[q], fd.off[q] = s.view.ptr, s.width, s.view.ld, s.koff
+            ctx.emit(fd)
+            if cfg.use_final_sigmoid:
+                raise NotImplementedError("use_final_sigmoid is never enabled by the reference CLIs")
+            cp.fwd = Program(ctx.fwd)
+            cp.used_params = list(ctx.used_params)
+            if train:
+                self._ensure_table_state()
+                bd = L.BceDesc()
+                bd.kind = L.OP_BCE
+                bd.B = B
+                bd.grad_scale = grad_scale if grad_scale is not None else 1.0 / B
+                bd.logits, bd.y, bd.loss, bd.dlogits = cp.logits.data_ptr(), cp.y.data_ptr(), cp.loss.data_ptr(), cp.dlogits.data_ptr()
+                pre = [bd]
+                if not cfg.fixed:
+                    # paths differ from step to step: parameters outside this path must see g = 0 (Adagrad no-op ==
+                    # torch skipping grad=None parameters)
+                    pre.append(P.memset_desc(self.flat_g))
+
+                def final_bwd():
+                    e = L.FinalDesc()
+                    e.kind = L.OP_FINAL_BWD
+                    e.B, e.nseg = B, 2
+                    e.w, e.bias, e.dlogits = w, bptr, cp.dlogits.data_ptr()
+                    e.dw, e.dbias = self.grads["_final.weight"].data_ptr(), self.grads["_final.bias"].data_ptr()
+                    for q, s in enumerate(fsegs):
+                        gp, acc = ctx.gtarget(s.view)
+                        e.seg[q], e.dseg[q], e.width[q], e.ld[q], e.off[q], e.dseg_accumulate[q] = s.view.ptr, gp, s.width, s.view.ld, s.koff, acc
+                    ctx.emit(e)
+
+                ctx.on_backward(final_bwd)
+                ctx.build_backward()
+                cp.bwd = Program(pre + ctx.bwd)
+                cp.opt = Program(self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if sbuf.grad_written else None, clip, eps))
+                if graph:
+                    cp.step = Program(cp.fwd.descs + cp.bwd.descs + cp.opt.descs)
+                    cp.step.capture(self.stream.cuda_stream)
+            elif graph:
+                cp.fwd.capture(self.stream.cuda_stream)
+        self._plans[key] = cp
+        return cp
+
+    def _optimizer_descs(self, cp, Bg, cat_x, sparse_grad, clip, eps):
+        """clip_grad_norm_ + Adagrad (train_utils.py:285-286): row-sparse on the tables, flat on the dense arena."""
+        descs = []
+        nb = (Bg + 255) // 256
+        cp.leader = torch.zeros(Bg * self.Fs, dtype=torch.int32, device=self.device)
+        cp.gsum = torch.zeros(Bg * self.Fs * E, dtype=torch.float32, device=self.device)
+        cp.emb_partial = torch.zeros(self.Fs * nb, dtype=torch.float32, device=self.device)
+        nblk = max(1, min(1024, (self.flat_numel + 256 * 8 - 1) // (256 * 8)))
+        cp.dense_partial = torch.zeros(nblk, dtype=torch.float32, device=self.device)
+        if sparse_grad is not None:
+            dd = L.EmbDedupDesc()
+            dd.kind = L.OP_EMB_DEDUP
+            dd.B, dd.Fs = Bg, self.Fs
+            dd.idx, dd.dout = cat_x.data_ptr(), sparse_grad.data_ptr()
+            dd.leader, dd.gsum, dd.sumsq_partial = cp.leader.data_ptr(), cp.gsum.data_ptr(), cp.emb_partial.data_ptr()
+            descs.append(dd)
+        sq = L.SumsqDesc()
+        sq.kind = L.OP_SUMSQ
+        sq.nblocks, sq.n = nblk, self.flat_numel
+        sq.x, sq.partial = self.flat_g.data_ptr(), cp.dense_partial.data_ptr()
+        descs.append(sq)
+        cc = L.ClipCoefDesc()
+        cc.kind = L.OP_CLIP_COEF
+        cc.n_a, cc.n_b = nblk, (self.Fs * nb if sparse_grad is not None else 0)
+        cc.max_norm = float(clip) if clip is not None else 0.0
+        cc.partial_a, cc.partial_b, cc.out = cp.dense_partial.data_ptr(), cp.emb_partial.data_ptr(), self.clip_out.data_ptr()
+        descs.append(cc)
+        ad = L.AdagradDenseDesc()
+        ad.kind = L.OP_ADAGRAD_DENSE
+        ad.eps, ad.n = eps, self.flat_numel
+        ad.p, ad.g, ad.state = self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_s.data_ptr()
+        ad.lr, ad.coef = self.lr_dev.data_ptr(), self.clip_out.data_ptr()
+        descs.append(ad)
+        if sparse_grad is not None:
+            ar = L.AdagradRowsDesc()
+            ar.kind = L.OP_ADAGRAD_ROWS
+            ar.B, ar.Fs, ar.eps = Bg, self.Fs, eps
+            ar.idx, ar.leader, ar.gsum = cat_x.data_ptr(), cp.leader.data_ptr(), cp.gsum.data_ptr()
+            for f in range(self.Fs):
+                ar.table[f] = self.tables[f].data_ptr()
+                ar.state[f] = self.table_state[f].data_ptr()
+            ar.lr, ar.coef = self.lr_dev.data_ptr(), self.clip_out.data_ptr()
+            descs.append(ar)
+        return descs
+
+    # -------------------------------------------------------------------------------------------------------
+    def _stage_inputs(self, cp, int_x, cat_x, y=None):
+        cp.int_x.copy_(int_x.reshape(cp.int_x.shape), non_blocking=True)
+        cp.cat_x.copy_(cat_x.reshape(cp.cat_x.shape), non_blocking=True)
+        if y is not None:
+            cp.y.copy_(y.reshape(cp.y.shape), non_blocking=True)
+
+    def forward(self, int_x, cat_x, choice=None, graph=False):
+        """logits [B,1] for the given choice (fixed mode: the fixed choice)."""
+        choice = choice if choice is not None else self.warm_choice
+        B = int(int_x.shape[0])
+        cp = self.compile(choice, B, train=False, graph=graph)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._stage_inputs(cp, int_x, cat_x)
+            if graph:
+                cp.fwd.replay(self.stream.cuda_stream)
+            else:
+                cp.fwd.run(self.stream.cuda_stream)
+        cur.wait_stream(self.stream)
+        return cp.logits.view(B, 1)
+
+    def train_step(self, int_x, cat_x, y, lr: float, choice=None, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = False,
+                   staged: bool = False):
+        """zero_grad -> forward -> BCE -> backward -> clip_grad_norm_ -> Adagrad (train_utils.py:262-286).
+        Returns the (device) loss tensor of this step.  `staged`: inputs are already in the plan's static buffers."""
+        choice = choice if choice is not None else self.warm_choice
+        B = int(int_x.shape[0]) if int_x is not None else None
+        cp = self.compile(choice, B, train=True, clip=clip, eps=eps, graph=graph)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            if not staged:
+                self._stage_inputs(cp, int_x, cat_x, y)
+            self.lr_dev.fill_(float(lr))
+            sp = self.stream.cuda_stream
+            if graph:
+                cp.step.replay(sp)
+            else:
+                cp.fwd.run(sp)
+                cp.bwd.run(sp)
+                cp.opt.run(sp)
+        cur.wait_stream(self.stream)
+        return cp.loss
+
+    def forward_backward(self, int_x, cat_x, y, choice=None, grad_scale=None):
+        """forward + BCE + backward only (gradients left in self.grads / plan.sparse0 gradient); used by the data-parallel
+        wrapper and by the parity tests."""
+        choice = choice if choice is not None else self.warm_choice
+        B = int(int_x.shape[0])
+        cp = self.compile(choice, B, train=True, grad_scale=grad_scale)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._stage_inputs(cp, int_x, cat_x, y)
+            cp.fwd.run(self.stream.cuda_stream)
+            cp.bwd.run(self.stream.cuda_stream)
+        cur.wait_stream(self.stream)
+        return cp
+
+    def check_indices(self):
+        """raise IndexError if any embedding id seen so far was out of range (torch raises at lookup time)"""
+        self.stream.synchronize()
+        if int(self.oob.item()) != 0:
+            raise IndexError("index out of range in embedding lookup")
+
+
+def _jsonable(o):
+    if hasattr(o, "tolist"):
+        return o.tolist()
+    if hasattr(o, "item"):
+        return o.item()
+    raise TypeError(type(o))

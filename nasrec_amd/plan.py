@@ -1,0 +1,1060 @@
+"""Plan compiler: (network description, choice, batch size) -> launch program for the HIP engine.
+
+One walk over the choice (macro wiring supernet.py:513-668, block wiring :1067-1242, operators modules.py) is used
+three ways:
+  * shape inference  — which parameters exist and their shapes (LazyLinear semantics + the "delete the projection if
+    the input already has the target width" rules, modules.py:344-364,389,491,586,743; supernet.py:1144,1225);
+  * forward program  — a list of C-ABI descriptors (include/nasrec_hip.h) executed by nasrec_program_run;
+  * backward program — emitted by replaying per-op closures in reverse, with liveness (dead branches are skipped, as
+    autograd would) and write-vs-accumulate tracking per gradient buffer.
+
+Concatenations are never materialised: every consumer takes a list of segments.  In supernet mode an un-chosen input
+is a zero segment (supernet.py:536-568): it is dropped from the segment list while its width still advances the K
+offset, so the arithmetic is identical to multiplying by zeros.
+"""
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+
+NUM_MHA_HEADS = 8  # modules.py:26
+DS_INTERACT_NUM_SPLITS = 8  # supernet.py:882
+E = 16
+
+DENSE_UNARY = ("linear-2d", "zeros-2d")
+DENSE_BINARY = ("sum", "sigmoid-gating")
+DENSE_SPARSE = ("dot-product",)
+SPARSE_NODES = ("zeros-3d", "transformer", "linear-3d")
+
+MHA_LEAVES = ["_mha.in_proj_weight", "_mha.in_proj_bias", "_mha.out_proj.weight", "_mha.out_proj.bias", "_attn_ln.weight",
+              "_attn_ln.bias", "attn_fc1.weight", "attn_fc1.bias", "attn_fc2.weight", "attn_fc2.bias", "_attn_fc_ln.weight",
+              "_attn_fc_ln.bias"]
+MHA_SHAPES = [(48, 16), (48,), (16, 16), (16,), (16,), (16,), (16, 16), (16,), (16, 16), (16,), (16,), (16,)]
+MHA_OFFS = [0, 768, 816, 1072, 1088, 1104, 1120, 1376, 1392, 1648, 1664, 1680]
+
+
+class NetConfig:
+    """The SuperNet constructor arguments that shape the computation (supernet.py:214-236)."""
+
+    def __init__(self, num_blocks, ops_config, use_layernorm, activation="relu", embedding_dim=16, fixed=False,
+                 last_n_blocks_out=1, use_final_sigmoid=False):
+        assert embedding_dim == E, "the engine is specialised for embedding_dim == 16 (supernet.py:224)"
+        assert last_n_blocks_out == 1, "last_n_blocks_out != 1 is not used by any reference script"
+        self.num_blocks = num_blocks
+        self.ops_config = ops_config
+        self.use_layernorm = bool(use_layernorm)
+        self.activation = activation
+        self.fixed = fixed
+        self.use_final_sigmoid = use_final_sigmoid
+
+    def block_ops(self, i):
+        return self.ops_config[i] if isinstance(self.ops_config, list) else self.ops_config
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# buffers and views
+# ----------------------------------------------------------------------------------------------------------------
+class Buf:
+    def __init__(self, ctx, numel, need_grad=True, tensor=None):
+        self.ctx = ctx
+        self.numel = numel
+        self.t = tensor if tensor is not None else ctx.alloc(numel)
+        self.g = None
+        self.need_grad = need_grad
+        self.written = []  # column intervals [c0, c1) of each row whose gradient has been written
+
+    @property
+    def grad_written(self):
+        return bool(self.written)
+
+    def mark(self, c0=0, c1=1 << 30):
+        self.written.append((c0, c1))
+
+    def overlaps(self, c0, c1):
+        return any(a < c1 and c0 < b for a, b in self.written)
+
+    def grad_tensor(self):
+        if self.g is None:
+            self.g = self.ctx.alloc(self.numel)
+        return self.g
+
+
+class DV:
+    """dense view [B, width], row stride ld, starting `off` floats into buf"""
+
+    def __init__(self, buf, off, width, ld):
+        self.buf, self.off, self.width, self.ld = buf, off, width, ld
+
+    @property
+    def ptr(self):
+        return self.buf.t.data_ptr() + 4 * self.off
+
+    @property
+    def gptr(self):
+        return self.buf.grad_tensor().data_ptr() + 4 * self.off
+
+    def full(self, B):
+        return self.off == 0 and self.width == self.ld and self.width * B == self.buf.numel
+
+    def cols(self):
+        c0 = self.off % self.ld
+        return c0, c0 + self.width
+
+
+class SV:
+    """sparse view [B, N, 16] = tokens of a [B, Ntot, 16] slab; batch stride ld"""
+
+    def __init__(self, buf, off, N, ld):
+        self.buf, self.off, self.N, self.ld = buf, off, N, ld
+
+    @property
+    def ptr(self):
+        return self.buf.t.data_ptr() + 4 * self.off
+
+    @property
+    def gptr(self):
+        return self.buf.grad_tensor().data_ptr() + 4 * self.off
+
+    def dense(self):
+        return DV(self.buf, self.off, self.N * E, self.ld)
+
+    def rows(self, n0, n):
+        return SV(self.buf, self.off + n0 * E, n, self.ld)
+
+    def full(self, B):
+        return self.off == 0 and self.N * E == self.ld and self.N * E * B == self.buf.numel
+
+    def cols(self):
+        c0 = self.off % self.ld
+        return c0, c0 + self.N * E
+
+
+class Seg:
+    """one segment of a virtual concatenation: view (or None = zeros) placed at offset koff of the consumer's K axis"""
+
+    def __init__(self, view, koff, width):
+        self.view, self.koff, self.width = view, koff, width
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# compile context
+# ----------------------------------------------------------------------------------------------------------------
+class Ctx:
+    def __init__(self, B, device, params: Optional[Dict[str, torch.Tensor]], grads: Optional[Dict[str, torch.Tensor]],
+                 shape_only=False, train=True):
+        self.B = B
+        self.device = device
+        self.params = params
+        self.grads = grads
+        self.shape_only = shape_only
+        self.train = train
+        self.shapes: Dict[str, tuple] = {}
+        self.fwd: List = []
+        self.bwd: List = []
+        self.closures: List = []
+        self.keep: List = []  # tensors kept alive for the lifetime of the plan
+        self.used_params: List[str] = []
+        self.grad_params: List[str] = []  # parameters whose gradient the backward program writes
+        self.out = self.fwd  # current emission target
+
+    # -- memory -----------------------------------------------------------------------------------------------
+    def alloc(self, numel):
+        if self.shape_only:
+            return _FakeTensor()
+        t = torch.empty(int(numel), dtype=torch.float32, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def buf(self, numel, need_grad=True):
+        return Buf(self, int(numel), need_grad)
+
+    # -- parameters -------------------------------------------------------------------------------------------
+    def param(self, name, shape, used=True):
+        shape = tuple(int(s) for s in shape)
+        if name in self.shapes:
+            assert self.shapes[name] == shape, (name, self.shapes[name], shape)
+        self.shapes[name] = shape
+        if self.shape_only:
+            return 0
+        p = self.params[name]
+        assert tuple(p.shape) == shape, "parameter %s has shape %s, the path needs %s" % (name, tuple(p.shape), shape)
+        if used and name not in self.used_params:
+            self.used_params.append(name)
+        return p.data_ptr()
+
+    def gparam(self, name):
+        if name not in self.grad_params:
+            self.grad_params.append(name)
+        return self.grads[name].data_ptr()
+
+    # -- emission ---------------------------------------------------------------------------------------------
+    def emit(self, desc):
+        if not self.shape_only:
+            self.out.append(desc)
+
+    def on_backward(self, fn):
+        if self.train and not self.shape_only:
+            self.closures.append(fn)
+
+    def build_backward(self):
+        self.out = self.bwd
+        for fn in reversed(self.closures):
+            fn()
+        self.out = self.fwd
+
+    # gradient destination of a view: returns (ptr, accumulate) or (None, 0) if no gradient is wanted
+    def gtarget(self, view):
+        buf = view.buf
+        if not buf.need_grad:
+            return None, 0
+        acc = buf.grad_written
+        if not acc and not view.full(self.B):
+            self.emit(memset_desc(buf.grad_tensor()))
+            acc = True
+        buf.mark(*view.cols())
+        return view.gptr, int(acc)
+
+    def live(self, view):
+        """does any gradient reach this view? (column-interval granularity: e.g. the dense->sparse projection rows of
+        a block output are dead when only the block's own DeepFM touched the slab's gradient)"""
+        return view.buf.overlaps(*view.cols())
+
+
+class _FakeTensor:
+    def data_ptr(self):
+        return 0
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# descriptor builders
+# ----------------------------------------------------------------------------------------------------------------
+def memset_desc(t):
+    d = L.MemsetDesc()
+    d.kind = L.OP_MEMSET
+    d.bytes = t.numel() * 4
+    d.ptr = t.data_ptr()
+    return d
+
+
+def _splitk_for(tiles_mn, ktiles, nprob=1):
+    """pick a split-K factor so that the launch has a few hundred workgroups and >= 4 k-tiles per split"""
+    if tiles_mn * nprob >= 192 or ktiles < 8:
+        return 1
+    s = min(ktiles // 4, max(1, 256 // max(1, tiles_mn * nprob)))
+    return max(1, min(s, 32))
+
+
+def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, **kw):
+    """One GEMM launch descriptor for <= MAX_SEGS segments (list of dicts with nasrec_gemm_seg_t fields)."""
+    if not segs:
+        return []
+    assert len(segs) <= L.MAX_SEGS
+    d = L.GemmDesc()
+    d.kind = L.OP_GEMM
+    d.amode, d.bmode, d.cmode = amode, bmode, cmode
+    d.nseg = len(segs)
+    d.zmode = zmode
+    d.act = kw.get("act", 0)
+    d.bias_on_rows = kw.get("bias_on_rows", 0)
+    d.mask_on_rows = kw.get("mask_on_rows", 0)
+    d.dims_in_use = kw.get("dims", -1)
+    d.beta = kw.get("beta", 0)
+    d.bias = kw.get("bias", None)
+    d.save_z = kw.get("save_z", None)
+    d.save_act = kw.get("save_act", None)
+    mul = kw.get("mul", None)
+    if mul:
+        assert len(mul) <= L.MAX_SEGS
+        d.mul_nseg = len(mul)
+        for q, (ptr, off, width, ld) in enumerate(mul):
+            d.mul_ptr[q], d.mul_off[q], d.mul_width[q], d.mul_ld[q] = ptr, off, width, ld
+    for q, sdict in enumerate(segs):
+        s = d.seg[q]
+        for k, v in sdict.items():
+            setattr(s, k, v)
+        if "Mvalid" not in sdict:
+            s.Mvalid = sdict["M"]
+    M = max(sd["M"] for sd in segs)
+    N = max(sd["N"] for sd in segs)
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if zmode:
+        kt = max((sd["K"] + 15) // 16 for sd in segs)
+        S = _splitk_for(tiles, kt, len(segs))
+    else:
+        kt = sum((sd["K"] + 15) // 16 for sd in segs)
+        S = _splitk_for(tiles, kt)
+    S = kw.get("splitk", S)
+    d.splitk = 1
+    if S > 1:
+        d.splitk = S
+        ws = ctx.alloc(S * M * N * (len(segs) if zmode else 1))
+        d.workspace = ws.data_ptr()
+    return [d]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# emitters (forward descriptor(s) + backward closure)
+# ----------------------------------------------------------------------------------------------------------------
+def _live_segs(segs: List[Seg]):
+    return [s for s in segs if s.view is not None]
+
+
+def emit_layernorm(ctx, mode, x_ptr, ldx, R, D, wname, out_ptr, ldy, act, dims, accumulate, out_view, x_grad_cb):
+    """LN forward + closure. x_grad_cb(dx_tensor) is called in backward with the tensor holding dL/dx
+    (same layout as x) and must emit the producer's backward."""
+    w = ctx.param(wname + ".weight", (D,))
+    b = ctx.param(wname + ".bias", (D,))
+    if ctx.shape_only:
+        return
+    stats = ctx.alloc(R * 2)
+    d = L.LayerNormDesc()
+    d.kind = L.OP_LAYERNORM_FWD
+    d.mode, d.R, d.D, d.ldx, d.ldy = mode, R, D, ldx, ldy
+    d.act, d.dims_in_use, d.accumulate, d.eps = act, dims, accumulate, 1e-5
+    d.x, d.w, d.b, d.y, d.stats = x_ptr, w, b, out_ptr, stats.data_ptr()
+    ctx.emit(d)
+
+    def bwd():
+        if not ctx.live(out_view):
+            return
+        nblk = min((R + 3) // 4, 256) if mode == L.AM_KC else (R + 255) // 256
+        part = ctx.alloc(nblk * 2 * D)
+        dx = ctx.alloc(_ln_numel(mode, R, D, ldx))
+        e = L.LayerNormDesc()
+        e.kind = L.OP_LAYERNORM_BWD
+        e.mode, e.R, e.D, e.ldx, e.ldy = mode, R, D, ldx, ldy
+        e.act, e.dims_in_use, e.accumulate, e.eps = act, dims, 0, 1e-5
+        e.x, e.w, e.b, e.stats = x_ptr, w, b, stats.data_ptr()
+        e.dy = out_view.gptr
+        e.dx = dx.data_ptr()
+        e.dwb_partial = part.data_ptr()
+        e.nblk = nblk
+        ctx.emit(e)
+        r = L.ReduceRowsDesc()
+        r.kind = L.OP_REDUCE_ROWS
+        r.R, r.C, r.ld = nblk, 2 * D, 2 * D
+        r.in_ = part.data_ptr()
+        r.ndst = 2
+        r.dst[0], r.dst_off[0], r.dst_len[0] = ctx.gparam(wname + ".weight"), 0, D
+        r.dst[1], r.dst_off[1], r.dst_len[1] = ctx.gparam(wname + ".bias"), D, D
+        ctx.emit(r)
+        x_grad_cb(dx)
+
+    ctx.on_backward(bwd)
+
+
+def _ln_numel(mode, R, D, ld):
+    if mode == L.AM_KC:
+        return R * ld
+    return (R // 16) * ld
+
+
+def linear_dense(ctx, segs: List[Seg], Ktot, wname, nout, bias: bool, out: DV, act=L.ACT_NONE, dims=-1, beta=0, ln=None,
+                 mul=None, save_act: Optional[DV] = None, pre_dz_cb=None):
+    """y = epilogue(concat(segs) · Wᵀ + b).  `ln`: parameter prefix of a LayerNorm applied after the product
+    (then act/mask/beta move to the LN kernel).  `mul`/`save_act`: SigmoidGating epilogue.  Returns nothing;
+    registers the backward closure.  pre_dz_cb: if given, called in backward to obtain (dz_ptr, ld) instead of
+    using out.grad (gating)."""
+    B = ctx.B
+    W = ctx.param(wname + ".weight", (nout, Ktot))
+    bptr = ctx.param(wname + ".bias", (nout,)) if bias else None
+    if ctx.shape_only:
+        if ln:
+            ctx.param(ln + ".weight", (nout,))
+            ctx.param(ln + ".bias", (nout,))
+        return
+    live = _live_segs(segs)
+    if len(live) > L.MAX_SEGS and not ln and (act != L.ACT_NONE or mul is not None):
+        raise NotImplementedError("more than %d live input segments for the activated product %s" % (L.MAX_SEGS, wname))
+    need_z = act == L.ACT_SILU and not ln  # SiLU backward needs the pre-activation
+    zbuf = None
+    if ln:
+        zbuf = ctx.alloc(B * nout)
+        tgt_ptr, tgt_ld = zbuf.data_ptr(), nout
+        g_act, g_dims, g_beta = L.ACT_NONE, -1, 0
+    else:
+        tgt_ptr, tgt_ld = out.ptr, out.ld
+        g_act, g_dims, g_beta = act, dims, beta
+    savez = ctx.alloc(B * nout) if need_z else None
+    sd = [dict(A=s.view.ptr, B=W + 4 * s.koff, C=tgt_ptr, M=B, N=nout, K=s.width, lda=s.view.ld, ldb=Ktot, ldc=tgt_ld) for s in live]
+    if not sd:  # every input is a zero segment: the product is 0
+        sd = [dict(A=None, B=W, C=tgt_ptr, M=B, N=nout, K=0, lda=1, ldb=Ktot, ldc=tgt_ld)]
+    mul_list = None
+    if mul is not None:
+        mul_list = [(m.view.ptr, m.koff, m.width, m.view.ld) for m in mul if m.view is not None]
+        if not mul_list:
+            mul_list = [(None, 0, 1, 1)]
+    # a K range of more than MAX_SEGS live segments (Sum on the full path) is a sum of products: chain with beta
+    for c0 in range(0, len(sd), L.MAX_SEGS):
+        for d in gemm_descs(ctx, L.AM_KC, L.AM_KC, L.CM_PLAIN, sd[c0:c0 + L.MAX_SEGS], 0, act=g_act, dims=g_dims,
+                            beta=g_beta if c0 == 0 else 1, bias=bptr if c0 == 0 else None,
+                            save_z=savez.data_ptr() if need_z else None, save_act=save_act.ptr if save_act is not None else None,
+                            mul=mul_list):
+            ctx.emit(d)
+
+    def backward_products(dz_ptr, dz_ld, aux_ptr, kdims):
+        """dz: [B, nout] with row stride dz_ld; aux: optional ReLU mask source (same layout); kdims: number of
+        leading output columns that can carry gradient (prefix mask)."""
+        kd = nout if kdims < 0 else min(kdims, nout)
+        # dX per live segment that wants a gradient
+        zs = []
+        for s in live:
+            gp, acc = ctx.gtarget(s.view)
+            if gp is None:
+                continue
+            zs.append(dict(A=dz_ptr, Aaux=aux_ptr, B=W + 4 * s.koff, C=gp, M=B, N=s.width, K=kd, lda=dz_ld, ldb=Ktot, ldc=s.view.ld,
+                           accumulate=acc))
+        for i in range(0, len(zs), L.MAX_SEGS):
+            for d in gemm_descs(ctx, L.AM_KC, L.AM_RC, L.CM_PLAIN, zs[i:i + L.MAX_SEGS], 1):
+                ctx.emit(d)
+        # dW per live segment (columns of zero segments keep the zero the flat gradient buffer was reset to)
+        gW = ctx.gparam(wname + ".weight")
+        ws = [dict(A=dz_ptr, Aaux=aux_ptr, B=s.view.ptr, C=gW + 4 * s.koff, M=nout, N=s.width, K=B, lda=dz_ld, ldb=s.view.ld, ldc=Ktot,
+                   Mvalid=kd, accumulate=0) for s in live]
+        for i in range(0, len(ws), L.MAX_SEGS):
+            for d in gemm_descs(ctx, L.AM_RC, L.AM_RC, L.CM_PLAIN, ws[i:i + L.MAX_SEGS], 1):
+                ctx.emit(d)
+        if bias:
+            r = L.RowsumDesc()
+            r.kind = L.OP_ROWSUM
+            r.mode, r.R, r.K, r.ld, r.rvalid = L.AM_RC, nout, B, dz_ld, kd
+            r.p, r.aux, r.out = dz_ptr, aux_ptr, ctx.gparam(wname + ".bias")
+            ctx.emit(r)
+
+    if ln:
+        emit_layernorm(ctx, L.AM_KC, zbuf.data_ptr(), nout, B, nout, ln, out.ptr, out.ld, act, dims, beta, out,
+                       lambda dx: backward_products(dx.data_ptr(), nout, None, -1))
+        return
+
+    def bwd():
+        if pre_dz_cb is not None:
+            r = pre_dz_cb()
+            if r is None:
+                return
+            dz_ptr, dz_ld = r
+            backward_products(dz_ptr, dz_ld, None, -1)
+            return
+        if not ctx.live(out):
+            return
+        if act == L.ACT_RELU:
+            backward_products(out.gptr, out.ld, out.ptr, dims)
+        elif act == L.ACT_SILU:
+            dz = ctx.alloc(B * nout)
+            a = L.ActBwdDesc()
+            a.kind = L.OP_ACT_BWD
+            a.mode, a.R, a.D = L.AM_KC, B, nout
+            a.ld_dy, a.ld_z, a.ld_dz = out.ld, nout, nout
+            a.act, a.dims_in_use = act, dims
+            a.dy, a.z, a.dz = out.gptr, savez.data_ptr(), dz.data_ptr()
+            ctx.emit(a)
+            backward_products(dz.data_ptr(), nout, None, -1)
+        else:
+            backward_products(out.gptr, out.ld, None, dims)
+
+    ctx.on_backward(bwd)
+
+
+def linear_tokens(ctx, segs: List[Seg], Ntot, wname, nout, bias: bool, out: SV, act=L.ACT_NONE, dims=-1, ln=None):
+    """Token-axis Linear (modules.py:222-234, 358-361, 648-650): out[b,n',e] = sum_n W[n',n] x[b,n,e] (+ b[n']),
+    optional LayerNorm over n', activation, prefix mask over n'."""
+    B = ctx.B
+    W = ctx.param(wname + ".weight", (nout, Ntot))
+    bptr = ctx.param(wname + ".bias", (nout,)) if bias else None
+    if ctx.shape_only:
+        if ln:
+            ctx.param(ln + ".weight", (nout,))
+            ctx.param(ln + ".bias", (nout,))
+        return
+    live = _live_segs(segs)
+    if len(live) > L.MAX_SEGS:
+        raise NotImplementedError("more than %d live input segments for %s" % (L.MAX_SEGS, wname))
+    need_z = act == L.ACT_SILU and not ln
+    if ln:
+        zbuf = ctx.alloc(B * nout * E)
+        tgt_ptr, tgt_ld = zbuf.data_ptr(), nout * E
+        g_act, g_dims = L.ACT_NONE, -1
+    else:
+        tgt_ptr, tgt_ld = out.ptr, out.ld
+        g_act, g_dims = act, dims
+    savez = ctx.alloc(B * nout * E) if need_z else None
+    sd = [dict(A=W + 4 * s.koff, B=s.view.ptr, C=tgt_ptr, M=nout, N=B * E, K=s.width, lda=Ntot, ldb=s.view.ld, ldc=tgt_ld) for s in live]
+    if not sd:
+        sd = [dict(A=None, B=W, C=tgt_ptr, M=nout, N=B * E, K=0, lda=Ntot, ldb=1, ldc=tgt_ld)]
+    for d in gemm_descs(ctx, L.AM_KC, L.AM_TOKR, L.CM_TOKJ, sd, 0, act=g_act, dims=g_dims, bias=bptr, bias_on_rows=1, mask_on_rows=1,
+                        save_z=savez.data_ptr() if need_z else None):
+        ctx.emit(d)
+
+    def backward_products(dz_ptr, dz_ld, aux_ptr, kdims):
+        kd = nout if kdims < 0 else min(kdims, nout)
+        zs = []
+        for s in live:
+            gp, acc = ctx.gtarget(s.view)
+            if gp is None:
+                continue
+            zs.append(dict(A=W + 4 * s.koff, B=dz_ptr, Baux=aux_ptr, C=gp, M=s.width, N=B * E, K=kd, lda=Ntot, ldb=dz_ld, ldc=s.view.ld,
+                           accumulate=acc))
+        for i in range(0, len(zs), L.MAX_SEGS):
+            for d in gemm_descs(ctx, L.AM_RC, L.AM_TOKR, L.CM_TOKJ, zs[i:i + L.MAX_SEGS], 1):
+                ctx.emit(d)
+        gW = ctx.gparam(wname + ".weight")
+        ws = [dict(A=dz_ptr, Aaux=aux_ptr, B=s.view.ptr, C=gW + 4 * s.koff, M=nout, N=s.width, K=B * E, lda=dz_ld, ldb=s.view.ld, ldc=Ntot,
+                   Mvalid=kd, accumulate=0) for s in live]
+        for i in range(0, len(ws), L.MAX_SEGS):
+            for d in gemm_descs(ctx, L.AM_TOKK, L.AM_TOKK, L.CM_PLAIN, ws[i:i + L.MAX_SEGS], 1):
+                ctx.emit(d)
+        if bias:
+            r = L.RowsumDesc()
+            r.kind = L.OP_ROWSUM
+            r.mode, r.R, r.K, r.ld, r.rvalid = L.AM_TOKK, nout, B * E, dz_ld, kd
+            r.p, r.aux, r.out = dz_ptr, aux_ptr, ctx.gparam(wname + ".bias")
+            ctx.emit(r)
+
+    if ln:
+        emit_layernorm(ctx, L.AM_TOKR, zbuf.data_ptr(), nout * E, B * E, nout, ln, out.ptr, out.ld, act, dims, 0, out,
+                       lambda dx: backward_products(dx.data_ptr(), nout * E, None, -1))
+        return
+
+    def bwd():
+        if not ctx.live(out):
+            return
+        if act == L.ACT_RELU:
+            backward_products(out.gptr, out.ld, out.ptr, dims)
+        elif act == L.ACT_SILU:
+            dz = ctx.alloc(B * nout * E)
+            a = L.ActBwdDesc()
+            a.kind = L.OP_ACT_BWD
+            a.mode, a.R, a.D = L.AM_TOKR, B * E, nout
+            a.ld_dy, a.ld_z, a.ld_dz = out.ld, nout * E, nout * E
+            a.act, a.dims_in_use = act, dims
+            a.dy, a.z, a.dz = out.gptr, savez.data_ptr(), dz.data_ptr()
+            ctx.emit(a)
+            backward_products(dz.data_ptr(), nout * E, None, -1)
+        else:
+            backward_products(out.gptr, out.ld, None, dims)
+
+    ctx.on_backward(bwd)
+
+
+def copy_into(ctx, segs: List[Seg], dst: DV, accumulate=0):
+    """dst[b, koff+j] (+)= seg[b, j]; backward: seg.grad += dst.grad slice."""
+    if ctx.shape_only:
+        return
+    live = _live_segs(segs)
+    for i in range(0, max(len(live), 1), L.MAX_SEGS):
+        chunk = live[i:i + L.MAX_SEGS]
+        d = L.CopySegsDesc()
+        d.kind = L.OP_COPY_SEGS
+        d.B, d.nseg, d.ld_dst, d.accumulate, d.reverse = ctx.B, len(chunk), dst.ld, accumulate, 0
+        d.dst = dst.ptr
+        for q, s in enumerate(chunk):
+            d.seg[q], d.width[q], d.ld[q], d.off[q] = s.view.ptr, s.width, s.view.ld, s.koff
+        if chunk:
+            ctx.emit(d)
+
+    def bwd():
+        if not ctx.live(dst):
+            return
+        for i in range(0, len(live), L.MAX_SEGS):
+            chunk = live[i:i + L.MAX_SEGS]
+            d = L.CopySegsDesc()
+            d.kind = L.OP_COPY_SEGS
+            d.B, d.ld_dst, d.reverse = ctx.B, dst.ld, 1
+            d.dst = dst.gptr
+            n = 0
+            for s in chunk:
+                gp, acc = ctx.gtarget(s.view)
+                if gp is None:
+                    continue
+                d.seg[n], d.width[n], d.ld[n], d.off[n], d.seg_accumulate[n] = gp, s.width, s.view.ld, s.koff, acc
+                n += 1
+            d.nseg = n
+            if n:
+                ctx.emit(d)
+
+    ctx.on_backward(bwd)
+
+
+def zero_fill(ctx, view_dense: DV):
+    """write zeros into a dense view (copy of a single zero segment)"""
+    if ctx.shape_only:
+        return
+    d = L.CopySegsDesc()
+    d.kind = L.OP_COPY_SEGS
+    d.B, d.nseg, d.ld_dst, d.accumulate, d.reverse = ctx.B, 1, view_dense.ld, 0, 0
+    d.dst = view_dense.ptr
+    d.seg[0], d.width[0], d.ld[0], d.off[0] = None, view_dense.width, 1, 0
+    ctx.emit(d)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# operators
+# ----------------------------------------------------------------------------------------------------------------
+class Target:
+    """where a node writes its [B, width] (dense) or [B, N, 16] (sparse) result, and whether it must add to it"""
+
+    def __init__(self, view, accumulate):
+        self.view, self.accumulate = view, accumulate
+
+
+def op_elastic_linear(ctx, cfg, pre, segs, Ktot, max_dims, dims, tgt: Target):
+    """ElasticLinear modules.py:134-181"""
+    act = L.ACT_BY_NAME[cfg.activation]
+    use_ln = cfg.use_layernorm
+    mask = -1 if cfg.fixed else dims
+    if use_ln:
+        linear_dense(ctx, segs, Ktot, pre + "._linear", max_dims, False, tgt.view, act, mask, tgt.accumulate, ln=pre + "._layernorm")
+    else:
+        assert not (tgt.accumulate and act != L.ACT_NONE), "activated node output needs a private buffer"
+        linear_dense(ctx, segs, Ktot, pre + "._linear", max_dims, True, tgt.view, act, mask, tgt.accumulate)
+
+
+def op_elastic_linear3d(ctx, cfg, pre, segs, Ntot, max_dims, dims, out: SV):
+    """ElasticLinear3D modules.py:184-235"""
+    act = L.ACT_BY_NAME[cfg.activation]
+    mask = -1 if cfg.fixed else dims
+    if cfg.use_layernorm:
+        linear_tokens(ctx, segs, Ntot, pre + "._linear", max_dims, False, out, act, mask, ln=pre + "._layernorm")
+    else:
+        linear_tokens(ctx, segs, Ntot, pre + "._linear", max_dims, True, out, act, mask)
+
+
+def op_dot_product(ctx, cfg, pre, dsegs, Dtot, ssegs, Ntot, max_dims, dims, tgt: Target):
+    """DotProduct modules.py:273-401"""
+    B = ctx.B
+    use_ln = cfg.use_layernorm
+    k = round(math.sqrt(2 * max_dims))  # modules.py:298
+    k1 = k + 1
+    P = k1 * k // 2
+    Tbuf = ctx.buf(B * k1 * E)
+    Tx = DV(Tbuf, 0, E, k1 * E)  # row 0
+    Ty = SV(Tbuf, E, k, k1 * E)  # rows 1..k
+    # dense side
+    if Dtot != E:
+        linear_dense(ctx, dsegs, Dtot, pre + "._dense_proj", E, not use_ln, Tx, L.ACT_NONE, -1, 0,
+                     ln=(pre + "._dense_layernorm") if use_ln else None)
+    else:
+        copy_into(ctx, dsegs, Tx)
+    # sparse side (E is always 16, so _sparse_proj is always dropped, modules.py:347-354)
+    if Ntot != k:
+        linear_tokens(ctx, ssegs, Ntot, pre + "._sparse_inp_proj", k, not use_ln, Ty, L.ACT_NONE, -1,
+                      ln=(pre + "._sparse_inp_proj_layernorm") if use_ln else None)
+    else:
+        copy_into(ctx, [Seg(s.view.dense() if s.view is not None else None, s.koff * E, s.width * E) for s in ssegs], Ty.dense())
+    if P == max_dims:
+        raise NotImplementedError("DotProduct without _linear_proj (triangle size == dims) never occurs for the reference dims")
+    tri = ctx.buf(B * P)
+    triv = DV(tri, 0, P, P)
+    if not ctx.shape_only:
+        d = L.DotTriDesc()
+        d.kind = L.OP_DOT_TRI_FWD
+        d.B, d.k1, d.ld_out = B, k1, P
+        d.T, d.out = Tbuf.t.data_ptr(), tri.t.data_ptr()
+        ctx.emit(d)
+
+        def bwd():
+            if not ctx.live(triv):
+                return
+            e = L.DotTriDesc()
+            e.kind = L.OP_DOT_TRI_BWD
+            e.B, e.k1, e.ld_out = B, k1, P
+            e.T, e.dout, e.dT = Tbuf.t.data_ptr(), tri.grad_tensor().data_ptr(), Tbuf.grad_tensor().data_ptr()
+            Tbuf.mark()
+            ctx.emit(e)
+
+        ctx.on_backward(bwd)
+    mask = -1 if cfg.fixed else dims
+    linear_dense(ctx, [Seg(triv, 0, P)], P, pre + "._linear_proj", max_dims, not use_ln, tgt.view, L.ACT_NONE, mask, tgt.accumulate,
+                 ln=(pre + "._linear_layernorm") if use_ln else None)
+
+
+def _pad_width(lsegs, Ltot, rsegs, Rtot):
+    return max(Ltot, Rtot)
+
+
+def op_sum(ctx, cfg, pre, lsegs, Ltot, rsegs, Rtot, max_dims, dims, tgt: Target):
+    """Sum modules.py:432-501 (+ zero padding :403-430).  Linear(left+right) == one GEMM over both segment lists."""
+    D = _pad_width(lsegs, Ltot, rsegs, Rtot)
+    use_ln = cfg.use_layernorm
+    mask = -1 if cfg.fixed else dims
+    both = list(lsegs) + list(rsegs)
+    if D != max_dims:
+        linear_dense(ctx, both, D, pre + "._linear_proj", max_dims, not use_ln, tgt.view, L.ACT_NONE, mask, tgt.accumulate,
+                     ln=(pre + "._layernorm") if use_ln else None)
+        return
+    # no projection: out = left + right (then LN / mask)
+    if use_ln:
+        tmp = ctx.buf(ctx.B * D)
+        tv = DV(tmp, 0, D, D)
+        _sum_into(ctx, lsegs, rsegs, tv, 0)
+        emit_ln_dense(ctx, tv, D, pre + "._layernorm", tgt, L.ACT_NONE, mask)
+    else:
+        if mask >= 0 and mask < D:
+            raise NotImplementedError("Sum without projection/LayerNorm under a prefix mask")
+        _sum_into(ctx, lsegs, rsegs, tgt.view, tgt.accumulate)
+
+
+def _sum_into(ctx, lsegs, rsegs, dst: DV, accumulate):
+    if not accumulate:
+        zero_fill(ctx, dst)
+    copy_into(ctx, lsegs, dst, 1)
+    copy_into(ctx, rsegs, dst, 1)
+    # make the zero_fill/copies visible as a producer of dst for liveness: nothing else to do
+
+
+def emit_ln_dense(ctx, x: DV, D, lnname, tgt: Target, act, mask):
+    """standalone LayerNorm of a dense buffer (operators that skipped their projection)"""
+    def xgrad(dx):
+        # dx holds dL/dx for the whole [B, D] buffer: hand it to the producers of x through x.grad
+        if ctx.shape_only:
+            return
+        gp, acc = ctx.gtarget(x)
+        d = L.CopySegsDesc()
+        d.kind = L.OP_COPY_SEGS
+        d.B, d.nseg, d.ld_dst, d.accumulate, d.reverse = ctx.B, 1, x.ld, acc, 0
+        d.dst = gp
+        d.seg[0], d.width[0], d.ld[0], d.off[0] = dx.data_ptr(), D, D, 0
+        ctx.emit(d)
+
+    emit_layernorm(ctx, L.AM_KC, x.ptr, x.ld, ctx.B, D, lnname, tgt.view.ptr, tgt.view.ld, act, mask, tgt.accumulate, tgt.view, xgrad)
+
+
+def op_sigmoid_gating(ctx, cfg, pre, lsegs, Ltot, rsegs, Rtot, max_dims, dims, tgt: Target):
+    """SigmoidGating modules.py:521-595: out = LN?(Linear(sigmoid(Linear_DxD(left)) * right)) * mask"""
+    B = ctx.B
+    D = _pad_width(lsegs, Ltot, rsegs, Rtot)
+    use_ln = cfg.use_layernorm
+    mask = -1 if cfg.fixed else dims
+    sl = pre + "._left_self_linear._linear"
+    need_proj = D != max_dims
+    gbuf = ctx.buf(B * D, need_grad=False)
+    g = DV(gbuf, 0, D, D)
+    if need_proj or use_ln:
+        pbuf = ctx.buf(B * D)
+        prod = DV(pbuf, 0, D, D)
+        ptgt = Target(prod, 0)
+    else:
+        prod = tgt.view
+        ptgt = tgt
+        if mask >= 0 and mask < D:
+            raise NotImplementedError("SigmoidGating without projection/LayerNorm under a prefix mask")
+    dzbuf = {}
+
+    def pre_dz():
+        if not ctx.live(prod):
+            return None
+        dz = ctx.alloc(B * D)
+        e = L.GateBwdDesc()
+        e.kind = L.OP_GATE_BWD
+        e.B, e.D = B, D
+        e.ld_dout, e.ld_g, e.ld_dz = prod.ld, D, D
+        e.dout, e.g, e.dz = prod.gptr, g.ptr, dz.data_ptr()
+        n = 0
+        for s in _live_segs(rsegs):
+            gp, acc = ctx.gtarget(s.view)
+            e.r_ptr[n], e.dr_ptr[n] = s.view.ptr, gp
+            e.r_off[n], e.r_width[n], e.r_ld[n], e.dr_accumulate[n] = s.koff, s.width, s.view.ld, acc
+            n += 1
+        e.nseg = n
+        ctx.emit(e)
+        return dz.data_ptr(), D
+
+    # the D x D self-linear consumes the zero-padded left operand: K range = Ltot (padding contributes nothing)
+    linear_dense(ctx, lsegs, D, sl, D, True, prod, L.ACT_SIGMOID, -1, ptgt.accumulate, mul=rsegs, save_act=g, pre_dz_cb=pre_dz)
+    if need_proj:
+        linear_dense(ctx, [Seg(prod, 0, D)], D, pre + "._linear_proj", max_dims, True, tgt.view, L.ACT_NONE, mask, tgt.accumulate,
+                     ln=(pre + "._layernorm") if use_ln else None)
+    elif use_ln:
+        emit_ln_dense(ctx, prod, D, pre + "._layernorm", tgt, L.ACT_NONE, mask)
+
+
+def op_transformer(ctx, cfg, pre, ssegs, Ntot, max_dims, dims, out: SV):
+    """Transformer modules.py:599-688"""
+    B = ctx.B
+    use_ln = cfg.use_layernorm
+    mask = -1 if cfg.fixed else dims
+    xbuf = ctx.buf(B * max_dims * E)
+    x = SV(xbuf, 0, max_dims, max_dims * E)
+    linear_tokens(ctx, ssegs, Ntot, pre + "._linear_proj", max_dims, not use_ln, x, L.ACT_NONE, mask,
+                  ln=(pre + "._proj_ln") if use_ln else None)
+    pp = [ctx.param(pre + "." + leaf, shp) for leaf, shp in zip(MHA_LEAVES, MHA_SHAPES)]
+    if ctx.shape_only:
+        return
+    d = L.MhaDesc()
+    d.kind = L.OP_MHA_FWD
+    d.B, d.N, d.ldx, d.ldo, d.dims_in_use = B, max_dims, x.ld, out.ld, mask
+    d.x, d.out = x.ptr, out.ptr
+    for q in range(12):
+        d.params[q] = pp[q]
+    ctx.emit(d)
+
+    def bwd():
+        if not ctx.live(out):
+            return
+        part = ctx.alloc(B * L.MHA_PARAMS)
+        e = L.MhaDesc()
+        e.kind = L.OP_MHA_BWD
+        e.B, e.N, e.ldx, e.ldo, e.dims_in_use = B, max_dims, x.ld, out.ld, mask
+        e.x, e.dout = x.ptr, out.gptr
+        e.dx = xbuf.grad_tensor().data_ptr()
+        xbuf.mark()
+        e.dparams_partial = part.data_ptr()
+        for q in range(12):
+            e.params[q] = pp[q]
+        ctx.emit(e)
+        r = L.ReduceRowsDesc()
+        r.kind = L.OP_REDUCE_ROWS
+        r.R, r.C, r.ld = B, L.MHA_PARAMS, L.MHA_PARAMS
+        r.in_ = part.data_ptr()
+        r.ndst = 12
+        for q, leaf in enumerate(MHA_LEAVES):
+            r.dst[q] = ctx.gparam(pre + "." + leaf)
+            r.dst_off[q] = MHA_OFFS[q]
+            r.dst_len[q] = int(torch.Size(MHA_SHAPES[q]).numel())
+        ctx.emit(r)
+
+    ctx.on_backward(bwd)
+
+
+def op_fm(ctx, cfg, pre, x: SV, fm_dims, dims, dense_out: DV):
+    """FactorizationMachine3D modules.py:720-750, added into dense_out (supernet.py:1154-1157)."""
+    B = ctx.B
+    use_ln = cfg.use_layernorm
+    mask = -1 if cfg.fixed else dims
+    direct = fm_dims == E
+    if direct:
+        ix = dense_out
+        if use_ln:  # the LayerNorm module stays registered but unused (modules.py:743)
+            ctx.param(pre + "._linear_layernorm.weight", (fm_dims,), used=False)
+            ctx.param(pre + "._linear_layernorm.bias", (fm_dims,), used=False)
+    else:
+        ixbuf = ctx.buf(B * E)
+        ix = DV(ixbuf, 0, E, E)
+    if not ctx.shape_only:
+        d = L.FmDesc()
+        d.kind = L.OP_FM_FWD
+        d.B, d.N, d.ldx, d.ld_ix, d.accumulate = B, x.N, x.ld, ix.ld, 1 if direct else 0
+        d.x, d.ix = x.ptr, ix.ptr
+        ctx.emit(d)
+
+        def bwd():
+            if not ctx.live(ix):
+                return
+            gp, acc = ctx.gtarget(x)
+            if gp is None:
+                return
+            e = L.FmDesc()
+            e.kind = L.OP_FM_BWD
+            e.B, e.N, e.ldx, e.ld_ix, e.accumulate = B, x.N, x.ld, ix.ld, acc
+            e.x, e.dix, e.dx = x.ptr, ix.gptr, gp
+            ctx.emit(e)
+
+        ctx.on_backward(bwd)
+    if not direct:
+        linear_dense(ctx, [Seg(ix, 0, E)], E, pre + "._linear_proj", fm_dims, not use_ln, dense_out, L.ACT_NONE, mask, 1,
+                     ln=(pre + "._linear_layernorm") if use_ln else None)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# block and network walks
+# ----------------------------------------------------------------------------------------------------------------
+def _as_set(v):
+    return set(int(x) for x in (v.tolist() if hasattr(v, "tolist") else v))
+
+
+def _mk_segs(views, widths, selected, fixed):
+    """ascending-j concatenation (supernet.py:536-568 / 625-633) -> (segments, total width)"""
+    segs, off = [], 0
+    for j, (v, w) in enumerate(zip(views, widths)):
+        if j in selected:
+            segs.append(Seg(v, off, w))
+            off += w
+        elif not fixed:
+            segs.append(Seg(None, off, w))
+            off += w
+    return segs, off
+
+
+def block_walk(ctx, cfg: NetConfig, i, ops, choice, d_in, Dtot, s_in, Ntot, l_in, Ltot, r_in, Rtot):
+    """SuperNetBlock.forward supernet.py:1067-1162 / fixed_forward :1185-1242.  Returns (dense DV, sparse SV)."""
+    B = ctx.B
+    pre = "_blocks.%d" % i
+    fixed = cfg.fixed
+    dd, sdm = int(choice["dense_in_dims"]), int(choice["sparse_in_dims"])
+    max_dense = dd if fixed else int(max(ops["dense_node_dims"]))
+    max_sparse = sdm if fixed else int(max(ops["sparse_node_dims"]))
+    active = [int(a) for a in choice["active_nodes"]]
+    dsi = int(choice["dense_sparse_interact"])
+    deep_fm = int(choice["deep_fm"])
+    names = ops["node_names"]
+    dense_nodes = [n for n in range(ops["num_nodes"]) if n in active and names[n] in DENSE_UNARY + DENSE_BINARY + DENSE_SPARSE]
+    sparse_nodes = [n for n in range(ops["num_nodes"]) if n in active and names[n] in SPARSE_NODES]
+    if not fixed:
+        assert dense_nodes and sparse_nodes or True
+    extra = DS_INTERACT_NUM_SPLITS if (dsi == 1 or not fixed) else 0
+    dbuf = ctx.buf(B * max_dense)
+    dense_out = DV(dbuf, 0, max_dense, max_dense)
+    sbuf = ctx.buf(B * (max_sparse + extra) * E)
+    sparse_all = SV(sbuf, 0, max_sparse + extra, (max_sparse + extra) * E)
+    sparse_nodes_out = sparse_all.rows(0, max_sparse)
+    act = L.ACT_BY_NAME[cfg.activation]
+
+    # ---- dense nodes: sum of node outputs (supernet.py:1133 / 1215) --------------------------------------------
+    real_dense = [n for n in dense_nodes if names[n] != "zeros-2d"]
+    n_contrib = len(real_dense) + (1 if deep_fm else 0)
+    wrote = False
+    for n in range(ops["num_nodes"]):
+        if n not in dense_nodes:
+            continue
+        name = names[n]
+        npre = "%s._nodes.%d" % (pre, n)
+        if name == "zeros-2d":
+            continue
+        has_act = name == "linear-2d" and act != L.ACT_NONE and not cfg.use_layernorm
+        if has_act and n_contrib > 1:
+            # activated output needs its own buffer for the ReLU/SiLU backward; its gradient is dense_out's gradient
+            tb = ctx.buf(B * max_dense)
+            tb_view = DV(tb, 0, max_dense, max_dense)
+            tgt = Target(tb_view, 0)
+        else:
+            tgt = Target(dense_out, 1 if wrote else 0)
+        if name == "linear-2d":
+            op_elastic_linear(ctx, cfg, npre, d_in, Dtot, max_dense, dd, tgt)
+        elif name == "dot-product":
+            op_dot_product(ctx, cfg, npre, d_in, Dtot, s_in, Ntot, max_dense, dd, tgt)
+        elif name == "sum":
+            op_sum(ctx, cfg, npre, l_in, Ltot, r_in, Rtot, max_dense, dd, tgt)
+        elif name == "sigmoid-gating":
+            op_sigmoid_gating(ctx, cfg, npre, l_in, Ltot, r_in, Rtot, max_dense, dd, tgt)
+        else:
+            raise NotImplementedError(name)
+        if tgt.view is not dense_out:
+            _alias_add(ctx, tgt.view, dense_out, 1 if wrote else 0)
+        wrote = True
+    if not wrote:
+        zero_fill(ctx, dense_out)
+
+    # ---- sparse nodes ------------------------------------------------------------------------------------------
+    real_sparse = [n for n in sparse_nodes if names[n] != "zeros-3d"]
+    wrote_s = False
+    for n in range(ops["num_nodes"]):
+        if n not in real_sparse:
+            continue
+        name = names[n]
+        npre = "%s._nodes.%d" % (pre, n)
+        if len(real_sparse) > 1:
+            tb = ctx.buf(B * max_sparse * E)
+            tv = SV(tb, 0, max_sparse, max_sparse * E)
+        else:
+            tv = sparse_nodes_out
+        if name == "transformer":
+            op_transformer(ctx, cfg, npre, s_in, Ntot, max_sparse, sdm, tv)
+        elif name == "linear-3d":
+            op_elastic_linear3d(ctx, cfg, npre, s_in, Ntot, max_sparse, sdm, tv)
+        else:
+            raise NotImplementedError(name)
+        if tv is not sparse_nodes_out:
+            _alias_add(ctx, tv.dense(), sparse_nodes_out.dense(), 1 if wrote_s else 0)
+        wrote_s = True
+    if not wrote_s:
+        zero_fill(ctx, sparse_nodes_out.dense())
+
+    # ---- dense -> sparse merge (supernet.py:1137-1150 / 1218-1231) --------------------------------------------
+    if extra:
+        proj_rows = sparse_all.rows(max_sparse, DS_INTERACT_NUM_SPLITS).dense()  # [B,128] view into the sparse slab
+        if dsi == 1:
+            if max_dense != E * DS_INTERACT_NUM_SPLITS:
+                linear_dense(ctx, [Seg(dense_out, 0, max_dense)], max_dense, pre + ".project_emb_dim", E * DS_INTERACT_NUM_SPLITS,
+                             not cfg.use_layernorm, proj_rows, L.ACT_NONE, -1, 0,
+                             ln=(pre + ".project_emb_dim_layernorm") if cfg.use_layernorm else None)
+            else:
+                copy_into(ctx, [Seg(dense_out, 0, max_dense)], proj_rows)
+        else:
+            zero_fill(ctx, proj_rows)
+
+    # ---- sparse -> dense merge: DeepFM on the node outputs only (supernet.py:1154-1157 / 1233-1236) -----------
+    if deep_fm == 1:
+        fm_dims = max_dense if fixed else int(max(ops["dense_node_dims"]))
+        op_fm(ctx, cfg, pre + ".deep_fm", sparse_nodes_out, fm_dims, dd, dense_out)
+    return dense_out, sparse_all
+
+
+def _alias_add(ctx, src: DV, dst: DV, accumulate):
+    """dst (+)= src where src is a private copy of a node output; in backward the node reads dst's gradient through
+    src.grad := dst.grad (no copy: d dst / d src = I)."""
+    if ctx.shape_only:
+        return
+    d = L.CopySegsDesc()
+    d.kind = L.OP_COPY_SEGS
+    d.B, d.nseg, d.ld_dst, d.accumulate, d.reverse = ctx.B, 1, dst.ld, accumulate, 0
+    d.dst = dst.ptr
+    d.seg[0], d.width[0], d.ld[0], d.off[0] = src.ptr, src.width, src.ld, 0
+    ctx.emit(d)
+
+    def bwd():
+        if not ctx.live(dst):
+            return
+        # share the gradient storage: src's gradient view aliases dst's
+        sb, db = src.buf, dst.buf
+        if src.off == 0 and dst.off == 0 and src.ld == dst.ld and sb.numel == db.numel:
+            sb.g = db.grad_tensor()
+            sb.mark()
+        else:
+            gp, acc = ctx.gtarget(src)
+            e = L.CopySegsDesc()
+            e.kind = L.OP_COPY_SEGS
+            e.B, e.nseg, e.ld_dst, e.reverse = ctx.B, 1, dst.ld, 1
+            e.dst = dst.gptr
+            e.seg[0], e.width[0], e.ld[0], e.off[0], e.seg_accumulate[0] = gp, src.width, src.ld, 0, acc
+            ctx.emit(e)
+
+    ctx.on_backward(bwd)
+
+
+class Plan:
+    """Result of compiling one (choice, B): buffers for inputs/outputs and the launch programs."""
+    pass
+
+
+def network_walk(ctx, cfg: NetConfig, choice, int_x: DV, sparse0: SV):
+    """SuperNet.forward / fixed_forward wiring (supernet.py:513-668). Returns (dense_last, sparse_last)."""
+    dlist, slist = [int_x], [sparse0]
+    for i in range(cfg.num_blocks):
+        mac = choice["macro"][i]
+        dviews, dwidths = dlist, [v.width for v in dlist]
+        sviews, swidths = slist, [v.N for v in slist]
+        d_in, Dtot = _mk_segs(dviews, dwidths, _as_set(mac["dense_idx"]), cfg.fixed)
+        s_in, Ntot = _mk_segs(sviews, swidths, _as_set(mac["sparse_idx"]), cfg.fixed)
+        l_in, Ltot = _mk_segs(dviews, dwidths, _as_set(mac["dense_left_idx"]), cfg.fixed)
+        r_in, Rtot = _mk_segs(dviews, dwidths, _as_set(mac["dense_right_idx"]), cfg.fixed)
+        d_out, s_out = block_walk(ctx, cfg, i, cfg.block_ops(i), choice["micro"][i], d_in, Dtot, s_in, Ntot, l_in, Ltot, r_in, Rtot)
+        dlist.append(d_out)
+        slist.append(s_out)
+    return dlist[-1], slist[-1]
+
+
+def infer_param_shapes(cfg: NetConfig, choice, Fd, Fs, num_embeddings) -> Dict[str, tuple]:
+    """Names and shapes of every parameter the reference would hold after its warm-up forward
+    (train_utils.py:392-433): fixed mode walks the fixed choice, supernet mode walks the full path."""
+    ctx = Ctx(B=2, device=None, params=None, grads=None, shape_only=True)
+    for f in range(Fs):
+        ctx.param("_embedding.%d.weight" % f, (int(num_embeddings[f]), E))
+    d_last, s_last = network_walk(ctx, cfg, choice, DV(Buf(ctx, 2 * Fd, False), 0, Fd, Fd), SV(Buf(ctx, 2 * Fs * E, False), 0, Fs, Fs * E))
+    K = d_last.width + s_last.N * E
+    ctx.param("_final.weight", (1, K))
+    ctx.param("_final.bias", (1,))
+    return ctx.shapes
+
+
+def full_path_choice(cfg: NetConfig):
+    """supernet.py:814-824 + :1265-1276"""
+    macro, micro = [], []
+    for i in range(cfg.num_blocks):
+        n = i + 1
+        macro.append({k: list(range(n)) for k in ("dense_idx", "sparse_idx", "dense_left_idx", "dense_right_idx")})
+        ops = cfg.block_ops(i)
+        micro.append({"active_nodes": list(range(ops["num_nodes"])), "dense_in_dims": int(max(ops["dense_node_dims"])),
+                      "sparse_in_dims": int(max(ops["sparse_node_dims"])), "dense_sparse_interact": 1, "deep_fm": 1})
+    return {"macro": macro, "micro": micro}

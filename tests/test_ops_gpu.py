@@ -1,0 +1,501 @@
+"""Per-kernel parity tests of the HIP engine through the C-ABI (run with `-m gpu` on an MI355X).
+Each test compares one descriptor launch against plain torch fp64 math of the same operator on the same seeded inputs.
+Integer/index work must be bit-exact; fp32 work within 2e-5 relative to the operand scale (stated per test)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from nasrec_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return L.load()
+
+
+def dev(t):
+    return t.to("cuda").contiguous()
+
+
+def launch(lib, d):
+    L.check(lib.nasrec_launch(None, C.addressof(d)))
+    torch.cuda.synchronize()
+
+
+def close(a, b, tol=2e-5):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, "max err %.3e (scale %.3e)" % (err, scale)
+
+
+def gemm_desc(am, bm, cm, segs, zmode, **kw):
+    d = L.GemmDesc()
+    d.kind = L.OP_GEMM
+    d.amode, d.bmode, d.cmode, d.nseg, d.zmode = am, bm, cm, len(segs), zmode
+    d.dims_in_use = kw.get("dims", -1)
+    d.act = kw.get("act", 0)
+    d.bias = kw.get("bias", None)
+    d.bias_on_rows = kw.get("bias_on_rows", 0)
+    d.mask_on_rows = kw.get("mask_on_rows", 0)
+    d.beta = kw.get("beta", 0)
+    d.splitk = kw.get("splitk", 1)
+    d.workspace = kw.get("workspace", None)
+    for q, sd in enumerate(segs):
+        for k, v in sd.items():
+            setattr(d.seg[q], k, v)
+        if "Mvalid" not in sd:
+            d.seg[q].Mvalid = sd["M"]
+    return d
+
+
+@pytest.mark.parametrize("splitk", [1, 3])
+@pytest.mark.parametrize("act,dims", [(L.ACT_NONE, -1), (L.ACT_RELU, 40)])
+def test_gemm_dense_forward_segments(lib, splitk, act, dims):
+    """y = act(cat(x0, 0, x2) Wᵀ + b) * mask — ragged widths (13, 7, 781) exercise the tile edges."""
+    torch.manual_seed(0)
+    B, N = 70, 77
+    w0, w1, w2 = 13, 7, 781
+    x0 = torch.randn(B, w0)
+    x2s = torch.randn(B, w2 + 5)  # x2 has a row stride != width
+    x2 = x2s[:, :w2]
+    W, b = torch.randn(N, w0 + w1 + w2) * 0.1, torch.randn(N)
+    y0 = torch.randn(B, N)
+    gx0, gx2s, gW, gb, gy = dev(x0), dev(x2s), dev(W), dev(b), dev(y0)
+    K = w0 + w1 + w2
+    segs = [dict(A=gx0.data_ptr(), B=gW.data_ptr(), C=gy.data_ptr(), M=B, N=N, K=w0, lda=w0, ldb=K, ldc=N),
+            dict(A=None, B=gW.data_ptr() + 4 * w0, C=gy.data_ptr(), M=B, N=N, K=w1, lda=1, ldb=K, ldc=N),
+            dict(A=gx2s.data_ptr(), B=gW.data_ptr() + 4 * (w0 + w1), C=gy.data_ptr(), M=B, N=N, K=w2, lda=w2 + 5, ldb=K, ldc=N)]
+    ws = dev(torch.zeros(splitk * B * N))
+    d = gemm_desc(L.AM_KC, L.AM_KC, L.CM_PLAIN, segs, 0, act=act, dims=dims, bias=gb.data_ptr(), beta=1, splitk=splitk,
+                  workspace=ws.data_ptr())
+    launch(lib, d)
+    xcat = torch.cat([x0, torch.zeros(B, w1), x2], 1).double()
+    ref = xcat @ W.double().t() + b.double()
+    if act == L.ACT_RELU:
+        ref = ref.clamp_min(0)
+    if dims >= 0:
+        ref[:, dims:] = 0
+    ref = ref + y0.double()
+    close(gy, ref)
+
+
+def test_gemm_dense_backward_products(lib):
+    """dx_seg (+)= (dy ⊙ [y>0])[:, :dims] W[:dims, seg];  dW[:, seg] = (dy ⊙ [y>0])ᵀ x_seg with rows >= dims zero."""
+    torch.manual_seed(1)
+    B, N, dims = 66, 50, 33
+    w0, w1 = 21, 100
+    K = w0 + w1
+    x0, x1, W = torch.randn(B, w0), torch.randn(B, w1), torch.randn(N, K) * 0.1
+    y = torch.randn(B, N)
+    y[:, dims:] = 0
+    dy = torch.randn(B, N)
+    dx0_init = torch.randn(B, w0)
+    g = {k: dev(v) for k, v in dict(x0=x0, x1=x1, W=W, y=y, dy=dy, dx0=dx0_init.clone(), dx1=torch.zeros(B, w1), dW=torch.full((N, K), 7.0)).items()}
+    zs = [dict(A=g["dy"].data_ptr(), Aaux=g["y"].data_ptr(), B=g["W"].data_ptr(), C=g["dx0"].data_ptr(), M=B, N=w0, K=dims, lda=N, ldb=K, ldc=w0, accumulate=1),
+          dict(A=g["dy"].data_ptr(), Aaux=g["y"].data_ptr(), B=g["W"].data_ptr() + 4 * w0, C=g["dx1"].data_ptr(), M=B, N=w1, K=dims, lda=N, ldb=K, ldc=w1, accumulate=0)]
+    launch(lib, gemm_desc(L.AM_KC, L.AM_RC, L.CM_PLAIN, zs, 1))
+    dz = (dy * (y > 0)).double()
+    dz[:, dims:] = 0
+    close(g["dx0"], dx0_init.double() + dz @ W.double()[:, :w0])
+    close(g["dx1"], dz @ W.double()[:, w0:])
+    ws_ = [dict(A=g["dy"].data_ptr(), Aaux=g["y"].data_ptr(), B=g["x0"].data_ptr(), C=g["dW"].data_ptr(), M=N, N=w0, K=B, lda=N, ldb=w0, ldc=K, Mvalid=dims),
+           dict(A=g["dy"].data_ptr(), Aaux=g["y"].data_ptr(), B=g["x1"].data_ptr(), C=g["dW"].data_ptr() + 4 * w0, M=N, N=w1, K=B, lda=N, ldb=w1, ldc=K, Mvalid=dims)]
+    launch(lib, gemm_desc(L.AM_RC, L.AM_RC, L.CM_PLAIN, ws_, 1))
+    close(g["dW"], dz.t() @ torch.cat([x0, x1], 1).double())
+    # bias gradient
+    db = dev(torch.zeros(N))
+    r = L.RowsumDesc()
+    r.kind, r.mode, r.R, r.K, r.ld, r.rvalid = L.OP_ROWSUM, L.AM_RC, N, B, N, dims
+    r.p, r.aux, r.out = g["dy"].data_ptr(), g["y"].data_ptr(), db.data_ptr()
+    launch(lib, r)
+    close(db, dz.sum(0))
+
+
+@pytest.mark.parametrize("splitk", [1, 4])
+def test_gemm_token_axis_all_products(lib, splitk):
+    """token-axis Linear over [B,N,16] with two token segments living inside larger slabs, + both gradients."""
+    torch.manual_seed(2)
+    B, n0, n1, Np, dims = 9, 26, 45, 40, 24
+    slab0, slab1 = torch.randn(B, n0 + 3, 16), torch.randn(B, n1, 16)
+    x0, x1 = slab0[:, 3:, :], slab1
+    Nt = n0 + n1
+    W, bias = torch.randn(Np, Nt) * 0.2, torch.randn(Np)
+    g0, g1, gW, gb = dev(slab0), dev(slab1), dev(W), dev(bias)
+    out = dev(torch.zeros(B, Np + 8, 16))  # output rows live in a bigger slab too
+    segs = [dict(A=gW.data_ptr(), B=g0.data_ptr() + 4 * 3 * 16, C=out.data_ptr(), M=Np, N=B * 16, K=n0, lda=Nt, ldb=(n0 + 3) * 16, ldc=(Np + 8) * 16),
+            dict(A=gW.data_ptr() + 4 * n0, B=g1.data_ptr(), C=out.data_ptr(), M=Np, N=B * 16, K=n1, lda=Nt, ldb=n1 * 16, ldc=(Np + 8) * 16)]
+    ws = dev(torch.zeros(splitk * Np * B * 16))
+    launch(lib, gemm_desc(L.AM_KC, L.AM_TOKR, L.CM_TOKJ, segs, 0, act=L.ACT_RELU, dims=dims, bias=gb.data_ptr(), bias_on_rows=1, mask_on_rows=1,
+                          splitk=splitk, workspace=ws.data_ptr()))
+    x = torch.cat([x0, x1], 1).double()
+    z = torch.einsum("pn,bne->bpe", W.double(), x) + bias.double()[None, :, None]
+    y = z.clamp_min(0)
+    y[:, dims:, :] = 0
+    close(out[:, :Np, :], y)
+    assert float(out[:, Np:, :].abs().max()) == 0.0
+    # backward: dz = dy ⊙ [y>0], rows >= dims are zero
+    dy = torch.randn(B, Np, 16)
+    gdy, gy = dev(dy), out[:, :Np, :].contiguous()
+    dz = (dy.double() * (y > 0))
+    dx0, dx1 = dev(torch.zeros(B, n0, 16)), dev(torch.full((B, n1, 16), 1.0))
+    zs = [dict(A=gW.data_ptr(), B=gdy.data_ptr(), Baux=gy.data_ptr(), C=dx0.data_ptr(), M=n0, N=B * 16, K=dims, lda=Nt, ldb=Np * 16, ldc=n0 * 16, accumulate=0),
+          dict(A=gW.data_ptr() + 4 * n0, B=gdy.data_ptr(), Baux=gy.data_ptr(), C=dx1.data_ptr(), M=n1, N=B * 16, K=dims, lda=Nt, ldb=Np * 16, ldc=n1 * 16, accumulate=1)]
+    launch(lib, gemm_desc(L.AM_RC, L.AM_TOKR, L.CM_TOKJ, zs, 1))
+    dx = torch.einsum("pn,bpe->bne", W.double(), dz)
+    close(dx0, dx[:, :n0])
+    close(dx1, dx[:, n0:] + 1.0)
+    dW = dev(torch.zeros(Np, Nt))
+    ws2 = dev(torch.zeros(2 * splitk * Np * max(n0, n1)))
+    wsd = [dict(A=gdy.data_ptr(), Aaux=gy.data_ptr(), B=g0.data_ptr() + 4 * 3 * 16, C=dW.data_ptr(), M=Np, N=n0, K=B * 16, lda=Np * 16, ldb=(n0 + 3) * 16, ldc=Nt, Mvalid=dims),
+           dict(A=gdy.data_ptr(), Aaux=gy.data_ptr(), B=g1.data_ptr(), C=dW.data_ptr() + 4 * n0, M=Np, N=n1, K=B * 16, lda=Np * 16, ldb=n1 * 16, ldc=Nt, Mvalid=dims)]
+    launch(lib, gemm_desc(L.AM_TOKK, L.AM_TOKK, L.CM_PLAIN, wsd, 1, splitk=splitk, workspace=ws2.data_ptr()))
+    close(dW, torch.einsum("bpe,bne->pn", dz, x))
+    db = dev(torch.zeros(Np))
+    r = L.RowsumDesc()
+    r.kind, r.mode, r.R, r.K, r.ld, r.rvalid = L.OP_ROWSUM, L.AM_TOKK, Np, B * 16, Np * 16, dims
+    r.p, r.aux, r.out = gdy.data_ptr(), gy.data_ptr(), db.data_ptr()
+    launch(lib, r)
+    close(db, dz.sum((0, 2)))
+
+
+def test_embedding_gather_bit_exact_and_oob(lib):
+    torch.manual_seed(3)
+    rows = [5, 1000, 1, 77777]
+    Fs, B = len(rows), 300
+    tables = [torch.randn(n, 16) for n in rows]
+    idx = torch.stack([torch.randint(0, n, (B,)) for n in rows], 1)
+    idx[0] = 0
+    idx[1] = torch.tensor(rows) - 1
+    idx[2] = idx[3]
+    gt, gi = [dev(t) for t in tables], dev(idx)
+    out, oob = dev(torch.zeros(B, Fs, 16)), dev(torch.zeros(1, dtype=torch.int32))
+    d = L.EmbedDesc()
+    d.kind, d.B, d.Fs = L.OP_EMBED_GATHER, B, Fs
+    d.idx, d.out, d.oob = gi.data_ptr(), out.data_ptr(), oob.data_ptr()
+    for f in range(Fs):
+        d.table[f], d.rows[f] = gt[f].data_ptr(), rows[f]
+    launch(lib, d)
+    ref = torch.stack([tables[f][idx[:, f]] for f in range(Fs)], 1)
+    assert torch.equal(out.cpu(), ref)  # bit-exact
+    assert int(oob.item()) == 0
+    gi[5, 1] = 1000  # one past the end
+    launch(lib, d)
+    assert int(oob.item()) == 1
+
+
+def test_rowsparse_adagrad_equals_dense_reference(lib):
+    """dedup + row-sparse clip·Adagrad == embedding_dense_backward + clip_grad_norm_ + torch.optim.Adagrad (dense)."""
+    torch.manual_seed(4)
+    rows = [4, 50, 3000]
+    Fs, B = 3, 600  # field 0 has ~150 duplicates per row, B > 512 exercises two row-blocks and LDS chunking
+    tables = [torch.randn(n, 16) for n in rows]
+    idx = torch.stack([torch.randint(0, n, (B,)) for n in rows], 1)
+    dout = torch.randn(B, Fs, 16) * 0.1
+    lr, eps, clip = 0.16, 1e-2, 0.05
+    # dense reference in fp64, two steps (state carries over)
+    ref_t = [torch.nn.Parameter(t.double().clone()) for t in tables]
+    opt = torch.optim.Adagrad(ref_t, lr=lr, eps=eps)
+    gt, gs = [dev(t.clone()) for t in tables], [dev(torch.zeros_like(t)) for t in tables]
+    gi, gd = dev(idx), dev(dout)
+    leader, gsum = dev(torch.zeros(B * Fs, dtype=torch.int32)), dev(torch.zeros(B * Fs * 16))
+    nb = (B + 255) // 256
+    part = dev(torch.zeros(Fs * nb))
+    lr_d, coef = dev(torch.tensor([lr])), dev(torch.zeros(2))
+    for step in range(2):
+        for f in range(Fs):
+            ref_t[f].grad = torch.zeros_like(ref_t[f]).index_add_(0, idx[:, f], dout[:, f].double())
+        total = torch.nn.utils.clip_grad_norm_(ref_t, clip)
+        opt.step()
+        dd = L.EmbDedupDesc()
+        dd.kind, dd.B, dd.Fs = L.OP_EMB_DEDUP, B, Fs
+        dd.idx, dd.dout, dd.leader, dd.gsum, dd.sumsq_partial = gi.data_ptr(), gd.data_ptr(), leader.data_ptr(), gsum.data_ptr(), part.data_ptr()
+        launch(lib, dd)
+        cc = L.ClipCoefDesc()
+        cc.kind, cc.n_a, cc.n_b, cc.max_norm = L.OP_CLIP_COEF, Fs * nb, 0, clip
+        cc.partial_a, cc.partial_b, cc.out = part.data_ptr(), part.data_ptr(), coef.data_ptr()
+        launch(lib, cc)
+        assert abs(float(coef[1]) - float(total)) <= 1e-5 * float(total)
+        ar = L.AdagradRowsDesc()
+        ar.kind, ar.B, ar.Fs, ar.eps = L.OP_ADAGRAD_ROWS, B, Fs, eps
+        ar.idx, ar.leader, ar.gsum, ar.lr, ar.coef = gi.data_ptr(), leader.data_ptr(), gsum.data_ptr(), lr_d.data_ptr(), coef.data_ptr()
+        for f in range(Fs):
+            ar.table[f], ar.state[f] = gt[f].data_ptr(), gs[f].data_ptr()
+        launch(lib, ar)
+        for f in range(Fs):
+            close(gt[f], ref_t[f].data, 1e-5)
+    # leaders are exactly the first occurrences
+    lead = leader.cpu().view(B, Fs)
+    for f in range(Fs):
+        first = {}
+        for b in range(B):
+            first.setdefault(int(idx[b, f]), b)
+        want = torch.zeros(B, dtype=torch.int32)
+        want[list(first.values())] = 1
+        assert torch.equal(lead[:, f], want)
+
+
+@pytest.mark.parametrize("k1", [2, 9, 40, 46])
+def test_dot_tri(lib, k1):
+    torch.manual_seed(5)
+    B = 11
+    T = torch.randn(B, k1, 16)
+    P = k1 * (k1 - 1) // 2
+    gT, out = dev(T), dev(torch.zeros(B, P + 3))
+    d = L.DotTriDesc()
+    d.kind, d.B, d.k1, d.ld_out = L.OP_DOT_TRI_FWD, B, k1, P + 3
+    d.T, d.out = gT.data_ptr(), out.data_ptr()
+    launch(lib, d)
+    Td = T.double().requires_grad_(True)
+    Z = Td @ Td.transpose(1, 2)
+    li, lj = torch.tril_indices(k1, k1, offset=-1)
+    ref = Z[:, li, lj]
+    close(out[:, :P], ref)
+    dout = torch.randn(B, P + 3)
+    ref.backward(dout[:, :P].double())
+    gdo, dT = dev(dout), dev(torch.zeros(B, k1, 16))
+    e = L.DotTriDesc()
+    e.kind, e.B, e.k1, e.ld_out = L.OP_DOT_TRI_BWD, B, k1, P + 3
+    e.T, e.dout, e.dT = gT.data_ptr(), gdo.data_ptr(), dT.data_ptr()
+    launch(lib, e)
+    close(dT, Td.grad)
+
+
+def test_fm(lib):
+    torch.manual_seed(6)
+    B, N, Ntot = 37, 48, 56
+    slab = torch.randn(B, Ntot, 16)
+    x = slab[:, :N]
+    base = torch.randn(B, 20)
+    gx, ix = dev(slab), dev(base.clone())
+    d = L.FmDesc()
+    d.kind, d.B, d.N, d.ldx, d.ld_ix, d.accumulate = L.OP_FM_FWD, B, N, Ntot * 16, 20, 1
+    d.x, d.ix = gx.data_ptr(), ix.data_ptr()
+    launch(lib, d)
+    xd = x.double().requires_grad_(True)
+    ref = xd.sum(1) ** 2 - (xd ** 2).sum(1)
+    close(ix[:, :16], base[:, :16].double() + ref)
+    dix = torch.randn(B, 20)
+    ref.backward(dix[:, :16].double())
+    gdix, dx = dev(dix), dev(torch.ones(B, Ntot, 16))
+    e = L.FmDesc()
+    e.kind, e.B, e.N, e.ldx, e.ld_ix, e.accumulate = L.OP_FM_BWD, B, N, Ntot * 16, 20, 1
+    e.x, e.dix, e.dx = gx.data_ptr(), gdix.data_ptr(), dx.data_ptr()
+    launch(lib, e)
+    close(dx[:, :N], xd.grad + 1.0)
+    assert float((dx[:, N:] - 1.0).abs().max()) == 0.0
+
+
+def _mha_ref(x, p, dims):
+    """modules.py:664-686 in fp64"""
+    Win, bin_, Wout, bout, l1w, l1b, W1, c1, W2, c2, l2w, l2b = p
+    B, N, E = x.shape
+    qkv = x @ Win.t() + bin_
+    q, k, v = [t.reshape(B, N, 8, 2).permute(0, 2, 1, 3) for t in (qkv[..., :16], qkv[..., 16:32], qkv[..., 32:])]
+    a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(2), -1) @ v
+    a = a.permute(0, 2, 1, 3).reshape(B, N, E) @ Wout.t() + bout
+    h = torch.nn.functional.layer_norm(a + x, (16,), l1w, l1b, 1e-5)
+    f = torch.relu(h @ W1.t() + c1) @ W2.t() + c2
+    out = torch.nn.functional.layer_norm(h + f, (16,), l2w, l2b, 1e-5)
+    if dims >= 0:
+        out = out * (torch.arange(N) < dims).double()[None, :, None]
+    return out
+
+
+@pytest.mark.parametrize("N,dims", [(16, -1), (64, -1), (48, 32), (7, -1)])
+def test_mha_ffn(lib, N, dims):
+    torch.manual_seed(7 + N)
+    B = 13
+    shapes = [(48, 16), (48,), (16, 16), (16,), (16,), (16,), (16, 16), (16,), (16, 16), (16,), (16,), (16,)]
+    p = [torch.randn(s) * (0.3 if len(s) == 2 else 0.1) for s in shapes]
+    p[4] = 0.17 + 0.02 * torch.randn(16)
+    p[10] = 0.17 + 0.02 * torch.randn(16)
+    x = torch.randn(B, N, 16)
+    if dims >= 0:
+        x[:, dims:] = 0  # supernet mode zeroes masked tokens before attention (modules.py:653-662)
+    gp, gx, out = [dev(t) for t in p], dev(x), dev(torch.zeros(B, N, 16))
+    d = L.MhaDesc()
+    d.kind, d.B, d.N, d.ldx, d.ldo, d.dims_in_use = L.OP_MHA_FWD, B, N, N * 16, N * 16, dims
+    d.x, d.out = gx.data_ptr(), out.data_ptr()
+    for q in range(12):
+        d.params[q] = gp[q].data_ptr()
+    launch(lib, d)
+    pd = [t.double().requires_grad_(True) for t in p]
+    xd = x.double().requires_grad_(True)
+    ref = _mha_ref(xd, pd, dims)
+    close(out, ref, 1e-5)
+    dout = torch.randn(B, N, 16)
+    ref.backward(dout.double())
+    gdo, dx, part = dev(dout), dev(torch.zeros(B, N, 16)), dev(torch.zeros(B, L.MHA_PARAMS))
+    e = L.MhaDesc()
+    e.kind, e.B, e.N, e.ldx, e.ldo, e.dims_in_use = L.OP_MHA_BWD, B, N, N * 16, N * 16, dims
+    e.x, e.dout, e.dx, e.dparams_partial = gx.data_ptr(), gdo.data_ptr(), dx.data_ptr(), part.data_ptr()
+    for q in range(12):
+        e.params[q] = gp[q].data_ptr()
+    launch(lib, e)
+    close(dx, xd.grad, 2e-5)
+    grads = [dev(torch.zeros(s)) for s in shapes]
+    r = L.ReduceRowsDesc()
+    r.kind, r.R, r.C, r.ld, r.ndst = L.OP_REDUCE_ROWS, B, L.MHA_PARAMS, L.MHA_PARAMS, 12
+    r.in_ = part.data_ptr()
+    off = 0
+    for q, s in enumerate(shapes):
+        n = int(np.prod(s))
+        r.dst[q], r.dst_off[q], r.dst_len[q] = grads[q].data_ptr(), off, n
+        off += n
+    launch(lib, r)
+    for q in range(12):
+        close(grads[q], pd[q].grad, 2e-5)
+
+
+@pytest.mark.parametrize("mode", ["dense", "token"])
+@pytest.mark.parametrize("act", [L.ACT_NONE, L.ACT_RELU, L.ACT_SILU])
+def test_layernorm(lib, mode, act):
+    torch.manual_seed(8)
+    if mode == "dense":
+        R, D, dims = 37, 300, 200
+        x = torch.randn(R, D) * 2 + 0.5
+    else:
+        B, D, dims = 5, 45, 30
+        x3 = torch.randn(B, D, 16) * 2 + 0.5  # [B, N', 16]; LN over N' per (b,e)
+        R = B * 16
+        x = x3.permute(0, 2, 1).reshape(R, D)
+    w, b = 1 + 0.1 * torch.randn(D), 0.1 * torch.randn(D)
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    u = torch.nn.functional.layer_norm(xd, (D,), wd, bd, 1e-5)
+    u = {L.ACT_NONE: u, L.ACT_RELU: u.clamp_min(0), L.ACT_SILU: u * torch.sigmoid(u)}[act]
+    ref = u * (torch.arange(D) < dims).double()
+    dy = torch.randn(R, D)
+    ref.backward(dy.double())
+
+    def to_dev_layout(t):
+        if mode == "dense":
+            return dev(t)
+        return dev(t.reshape(-1, 16, D).permute(0, 2, 1))  # back to [B, N', 16]
+
+    gx, gw, gb, gdy = to_dev_layout(x), dev(w), dev(b), to_dev_layout(dy)
+    y, stats, dx = torch.zeros_like(gx), dev(torch.zeros(R * 2)), torch.zeros_like(gx)
+    d = L.LayerNormDesc()
+    d.kind = L.OP_LAYERNORM_FWD
+    d.mode = L.AM_KC if mode == "dense" else L.AM_TOKR
+    d.R, d.D = R, D
+    d.ldx = d.ldy = D if mode == "dense" else D * 16
+    d.act, d.dims_in_use, d.accumulate, d.eps = act, dims, 0, 1e-5
+    d.x, d.w, d.b, d.y, d.stats = gx.data_ptr(), gw.data_ptr(), gb.data_ptr(), y.data_ptr(), stats.data_ptr()
+    launch(lib, d)
+
+    def from_dev_layout(t):
+        if mode == "dense":
+            return t
+        return t.permute(0, 2, 1).reshape(R, D)
+
+    close(from_dev_layout(y), ref, 1e-5)
+    nblk = min((R + 3) // 4, 256) if mode == "dense" else (R + 255) // 256
+    part = dev(torch.zeros(nblk * 2 * D))
+    d.kind = L.OP_LAYERNORM_BWD
+    d.dy, d.dx, d.dwb_partial, d.nblk = gdy.data_ptr(), dx.data_ptr(), part.data_ptr(), nblk
+    launch(lib, d)
+    close(from_dev_layout(dx), xd.grad, 2e-5)
+    pw = part.view(nblk, 2 * D).sum(0).cpu()
+    close(pw[:D], wd.grad, 2e-5)
+    close(pw[D:], bd.grad, 2e-5)
+
+
+def test_final_bce_and_dense_optimizer(lib):
+    torch.manual_seed(9)
+    B, D, N = 300, 128, 48
+    dl, sl = torch.randn(B, D), torch.randn(B, N, 16)
+    K = D + N * 16
+    w, bias = torch.randn(1, K) * 0.05, torch.randn(1)
+    y = (torch.rand(B) < 0.25).float()
+    g = {k: dev(v) for k, v in dict(dl=dl, sl=sl, w=w, bias=bias, y=y).items()}
+    logits, loss, dlog = dev(torch.zeros(B)), dev(torch.zeros(1)), dev(torch.zeros(B))
+    f = L.FinalDesc()
+    f.kind, f.B, f.nseg = L.OP_FINAL_FWD, B, 2
+    f.w, f.bias, f.logits = g["w"].data_ptr(), g["bias"].data_ptr(), logits.data_ptr()
+    f.seg[0], f.width[0], f.ld[0], f.off[0] = g["dl"].data_ptr(), D, D, 0
+    f.seg[1], f.width[1], f.ld[1], f.off[1] = g["sl"].data_ptr(), N * 16, N * 16, D
+    launch(lib, f)
+    feats = torch.cat([dl, sl.reshape(B, -1)], 1).double().requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    z = feats @ wd.t() + bd
+    close(logits, z[:, 0])
+    bd_ = L.BceDesc()
+    bd_.kind, bd_.B, bd_.grad_scale = L.OP_BCE, B, 1.0 / B
+    bd_.logits, bd_.y, bd_.loss, bd_.dlogits = logits.data_ptr(), g["y"].data_ptr(), loss.data_ptr(), dlog.data_ptr()
+    launch(lib, bd_)
+    ref_loss = torch.nn.functional.binary_cross_entropy_with_logits(z[:, 0], y.double())
+    close(loss, ref_loss.reshape(1), 1e-6)
+    ref_loss.backward()
+    ddl, dsl, dw, db = dev(torch.zeros(B, D)), dev(torch.ones(B, N, 16)), dev(torch.zeros(K)), dev(torch.zeros(1))
+    f.kind = L.OP_FINAL_BWD
+    f.dlogits, f.dw, f.dbias = dlog.data_ptr(), dw.data_ptr(), db.data_ptr()
+    f.dseg[0], f.dseg_accumulate[0] = ddl.data_ptr(), 0
+    f.dseg[1], f.dseg_accumulate[1] = dsl.data_ptr(), 1
+    launch(lib, f)
+    close(ddl, feats.grad[:, :D], 1e-5)
+    close(dsl.reshape(B, -1), feats.grad[:, D:] + 1.0, 1e-5)
+    close(dw, wd.grad[0], 1e-5)
+    close(db, bd.grad, 1e-5)
+    # flat clip + Adagrad vs torch
+    n = 100003
+    p0, gr = torch.randn(n), torch.randn(n) * 0.01
+    P = torch.nn.Parameter(p0.double().clone())
+    opt = torch.optim.Adagrad([P], lr=0.16, eps=1e-2)
+    gp, gg, gs = dev(p0.clone()), dev(gr), dev(torch.zeros(n))
+    part, coef, lr = dev(torch.zeros(64)), dev(torch.zeros(2)), dev(torch.tensor([0.16]))
+    for step in range(2):
+        P.grad = gr.double().clone()
+        total = torch.nn.utils.clip_grad_norm_([P], 0.5)
+        opt.step()
+        sq = L.SumsqDesc()
+        sq.kind, sq.nblocks, sq.n, sq.x, sq.partial = L.OP_SUMSQ, 64, n, gg.data_ptr(), part.data_ptr()
+        launch(lib, sq)
+        cc = L.ClipCoefDesc()
+        cc.kind, cc.n_a, cc.n_b, cc.max_norm = L.OP_CLIP_COEF, 64, 0, 0.5
+        cc.partial_a, cc.partial_b, cc.out = part.data_ptr(), part.data_ptr(), coef.data_ptr()
+        launch(lib, cc)
+        assert abs(float(coef[1]) - float(total)) <= 1e-5 * float(total)
+        ad = L.AdagradDenseDesc()
+        ad.kind, ad.eps, ad.n = L.OP_ADAGRAD_DENSE, 1e-2, n
+        ad.p, ad.g, ad.state, ad.lr, ad.coef = gp.data_ptr(), gg.data_ptr(), gs.data_ptr(), lr.data_ptr(), coef.data_ptr()
+        launch(lib, ad)
+        close(gp, P.data, 1e-5)
+
+
+def test_gate_backward_and_copy_segments(lib):
+    torch.manual_seed(10)
+    B, D, wr = 21, 32, 13
+    dout, gate, R = torch.randn(B, D), torch.rand(B, D), torch.randn(B, wr)
+    g = {k: dev(v) for k, v in dict(dout=dout, g=gate, R=R).items()}
+    dz, dR = dev(torch.zeros(B, D)), dev(torch.ones(B, wr))
+    e = L.GateBwdDesc()
+    e.kind, e.B, e.D, e.ld_dout, e.ld_g, e.ld_dz = L.OP_GATE_BWD, B, D, D, D, D
+    e.dout, e.g, e.dz, e.nseg = g["dout"].data_ptr(), g["g"].data_ptr(), dz.data_ptr(), 1
+    e.r_ptr[0], e.dr_ptr[0], e.r_off[0], e.r_width[0], e.r_ld[0], e.dr_accumulate[0] = g["R"].data_ptr(), dR.data_ptr(), 0, wr, wr, 1
+    launch(lib, e)
+    Rp = torch.cat([R, torch.zeros(B, D - wr)], 1).double()
+    close(dz, dout.double() * Rp * gate.double() * (1 - gate.double()))
+    close(dR, 1.0 + (dout.double() * gate.double())[:, :wr])
+    # copy / reverse-copy
+    a, b2 = torch.randn(B, 5), torch.randn(B, 9, 16)
+    ga, gb = dev(a), dev(b2)
+    dst = dev(torch.zeros(B, 5 + 7 + 9 * 16))
+    c = L.CopySegsDesc()
+    c.kind, c.B, c.nseg, c.ld_dst, c.accumulate, c.reverse = L.OP_COPY_SEGS, B, 2, dst.shape[1], 0, 0
+    c.dst = dst.data_ptr()
+    c.seg[0], c.width[0], c.ld[0], c.off[0] = ga.data_ptr(), 5, 5, 0
+    c.seg[1], c.width[1], c.ld[1], c.off[1] = gb.data_ptr(), 9 * 16, 9 * 16, 12
+    launch(lib, c)
+    ref = torch.cat([a, torch.zeros(B, 7), b2.reshape(B, -1)], 1)
+    assert torch.equal(dst.cpu(), ref)
+    c.reverse = 1
+    c.seg_accumulate[0], c.seg_accumulate[1] = 1, 0
+    launch(lib, c)
+    assert torch.equal(ga.cpu(), a + a) and torch.equal(gb.cpu(), b2)
