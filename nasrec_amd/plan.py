@@ -302,6 +302,48 @@ def _live_segs(segs: List[Seg]):
     return [s for s in segs if s.view is not None]
 
 
+def _cover_pieces(live: List[Seg]):
+    """Split the K-axis footprints of the segments into disjoint pieces.  Returns [(seg, a, b, rank)]: columns
+    [a, b) of the consumer's K axis are covered by `seg` as the rank-th writer.  Sum feeds two segment lists into the
+    same K range (modules.py:487), so dW[:, a:b] receives one product per covering segment: rank 0 overwrites, later
+    ranks accumulate in later launches."""
+    cuts = sorted({s.koff for s in live} | {s.koff + s.width for s in live})
+    out = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        rank = 0
+        for s in live:
+            if s.koff <= a and b <= s.koff + s.width:
+                if out and out[-1][0] is s and out[-1][2] == a and out[-1][3] == rank:
+                    out[-1] = (s, out[-1][1], b, rank)
+                else:
+                    out.append((s, a, b, rank))
+                rank += 1
+    return out
+
+
+def _emit_z_groups(ctx, am, bm, cm, items):
+    """items: [(group_index, seg_dict)] -> one launch per group (in order), <= MAX_SEGS problems per launch"""
+    for gi in sorted({g for g, _ in items}):
+        grp = [d for g, d in items if g == gi]
+        for i in range(0, len(grp), L.MAX_SEGS):
+            for d in gemm_descs(ctx, am, bm, cm, grp[i:i + L.MAX_SEGS], 1):
+                ctx.emit(d)
+
+
+def _dx_groups(ctx, live, mk):
+    """gradient products towards the input segments; two segments that alias the same buffer (Sum/gating with
+    left == right) must not race inside one launch -> they go to consecutive launches."""
+    items, seen = [], {}
+    for s in live:
+        gp, acc = ctx.gtarget(s.view)
+        if gp is None:
+            continue
+        g = seen.get(id(s.view.buf), 0)
+        seen[id(s.view.buf)] = g + 1
+        items.append((g, mk(s, gp, acc)))
+    return items
+
+
 def emit_layernorm(ctx, mode, x_ptr, ldx, R, D, wname, out_ptr, ldy, act, dims, accumulate, out_view, x_grad_cb):
     """LN forward + closure. x_grad_cb(dx_tensor) is called in backward with the tensor holding dL/dx
     (same layout as x) and must emit the producer's backward."""
@@ -400,23 +442,13 @@ def linear_dense(ctx, segs: List[Seg], Ktot, wname, nout, bias: bool, out: DV, a
         leading output columns that can carry gradient (prefix mask)."""
         kd = nout if kdims < 0 else min(kdims, nout)
         # dX per live segment that wants a gradient
-        zs = []
-        for s in live:
-            gp, acc = ctx.gtarget(s.view)
-            if gp is None:
-                continue
-            zs.append(dict(A=dz_ptr, Aaux=aux_ptr, B=W + 4 * s.koff, C=gp, M=B, N=s.width, K=kd, lda=dz_ld, ldb=Ktot, ldc=s.view.ld,
-                           accumulate=acc))
-        for i in range(0, len(zs), L.MAX_SEGS):
-            for d in gemm_descs(ctx, L.AM_KC, L.AM_RC, L.CM_PLAIN, zs[i:i + L.MAX_SEGS], 1):
-                ctx.emit(d)
-        # dW per live segment (columns of zero segments keep the zero the flat gradient buffer was reset to)
+        _emit_z_groups(ctx, L.AM_KC, L.AM_RC, L.CM_PLAIN, _dx_groups(ctx, live, lambda s, gp, acc: dict(
+            A=dz_ptr, Aaux=aux_ptr, B=W + 4 * s.koff, C=gp, M=B, N=s.width, K=kd, lda=dz_ld, ldb=Ktot, ldc=s.view.ld, accumulate=acc)))
+        # dW per covered piece of the K axis (columns of zero segments keep the zero the flat gradient buffer was reset to)
         gW = ctx.gparam(wname + ".weight")
-        ws = [dict(A=dz_ptr, Aaux=aux_ptr, B=s.view.ptr, C=gW + 4 * s.koff, M=nout, N=s.width, K=B, lda=dz_ld, ldb=s.view.ld, ldc=Ktot,
-                   Mvalid=kd, accumulate=0) for s in live]
-        for i in range(0, len(ws), L.MAX_SEGS):
-            for d in gemm_descs(ctx, L.AM_RC, L.AM_RC, L.CM_PLAIN, ws[i:i + L.MAX_SEGS], 1):
-                ctx.emit(d)
+        _emit_z_groups(ctx, L.AM_RC, L.AM_RC, L.CM_PLAIN, [(rank, dict(
+            A=dz_ptr, Aaux=aux_ptr, B=s.view.ptr + 4 * (a - s.koff), C=gW + 4 * a, M=nout, N=b - a, K=B, lda=dz_ld, ldb=s.view.ld, ldc=Ktot,
+            Mvalid=kd, accumulate=int(rank > 0))) for s, a, b, rank in _cover_pieces(live)])
         if bias:
             r = L.RowsumDesc()
             r.kind = L.OP_ROWSUM
@@ -489,22 +521,12 @@ def linear_tokens(ctx, segs: List[Seg], Ntot, wname, nout, bias: bool, out: SV, 
 
     def backward_products(dz_ptr, dz_ld, aux_ptr, kdims):
         kd = nout if kdims < 0 else min(kdims, nout)
-        zs = []
-        for s in live:
-            gp, acc = ctx.gtarget(s.view)
-            if gp is None:
-                continue
-            zs.append(dict(A=W + 4 * s.koff, B=dz_ptr, Baux=aux_ptr, C=gp, M=s.width, N=B * E, K=kd, lda=Ntot, ldb=dz_ld, ldc=s.view.ld,
-                           accumulate=acc))
-        for i in range(0, len(zs), L.MAX_SEGS):
-            for d in gemm_descs(ctx, L.AM_RC, L.AM_TOKR, L.CM_TOKJ, zs[i:i + L.MAX_SEGS], 1):
-                ctx.emit(d)
+        _emit_z_groups(ctx, L.AM_RC, L.AM_TOKR, L.CM_TOKJ, _dx_groups(ctx, live, lambda s, gp, acc: dict(
+            A=W + 4 * s.koff, B=dz_ptr, Baux=aux_ptr, C=gp, M=s.width, N=B * E, K=kd, lda=Ntot, ldb=dz_ld, ldc=s.view.ld, accumulate=acc)))
         gW = ctx.gparam(wname + ".weight")
-        ws = [dict(A=dz_ptr, Aaux=aux_ptr, B=s.view.ptr, C=gW + 4 * s.koff, M=nout, N=s.width, K=B * E, lda=dz_ld, ldb=s.view.ld, ldc=Ntot,
-                   Mvalid=kd, accumulate=0) for s in live]
-        for i in range(0, len(ws), L.MAX_SEGS):
-            for d in gemm_descs(ctx, L.AM_TOKK, L.AM_TOKK, L.CM_PLAIN, ws[i:i + L.MAX_SEGS], 1):
-                ctx.emit(d)
+        _emit_z_groups(ctx, L.AM_TOKK, L.AM_TOKK, L.CM_PLAIN, [(rank, dict(
+            A=dz_ptr, Aaux=aux_ptr, B=s.view.ptr + 4 * (a - s.koff) * E, C=gW + 4 * a, M=nout, N=b - a, K=B * E, lda=dz_ld, ldb=s.view.ld,
+            ldc=Ntot, Mvalid=kd, accumulate=int(rank > 0))) for s, a, b, rank in _cover_pieces(live)])
         if bias:
             r = L.RowsumDesc()
             r.kind = L.OP_ROWSUM
@@ -977,6 +999,13 @@ def block_walk(ctx, cfg: NetConfig, i, ops, choice, d_in, Dtot, s_in, Ntot, l_in
     # ---- sparse -> dense merge: DeepFM on the node outputs only (supernet.py:1154-1157 / 1233-1236) -----------
     if deep_fm == 1:
         fm_dims = max_dense if fixed else int(max(ops["dense_node_dims"]))
+        if dsi == 1 and max_dense != E * DS_INTERACT_NUM_SPLITS:
+            # the projection above read dense_out *before* the FM term is added (dense_t_2d_out.clone(), supernet.py:1139)
+            # and its weight gradient needs that value again: keep it, add the FM term into a copy
+            fbuf = ctx.buf(B * max_dense)
+            dense_final = DV(fbuf, 0, max_dense, max_dense)
+            _alias_add(ctx, dense_out, dense_final, 0)
+            dense_out = dense_final
         op_fm(ctx, cfg, pre + ".deep_fm", sparse_nodes_out, fm_dims, dd, dense_out)
     return dense_out, sparse_all
 

@@ -36,6 +36,6 @@ def oracle_params(meta, dtype=torch.float64):
 
 
 def proj_checksum(name, t):
-    a = t.detach().double().numpy().reshape(-1)
+    a = t.detach().double().cpu().numpy().reshape(-1)
     r = O.seeded_array("chk:" + name, a.shape)
     return float(np.dot(a, r)), float(np.linalg.norm(a))
