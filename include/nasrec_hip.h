@@ -72,7 +72,8 @@ enum {
   NASREC_OP_LAYERNORM_BWD = 23,
   NASREC_OP_ADD_SEGS = 24,
   NASREC_OP_SCALE = 25,
-  NASREC_OP_ACT_BWD = 26
+  NASREC_OP_ACT_BWD = 26,
+  NASREC_OP_STAGE_INPUTS = 27
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -386,6 +387,20 @@ typedef struct nasrec_act_bwd_desc {
   const float* z;
   float* dz;
 } nasrec_act_bwd_desc_t;
+
+/* Per-step input staging (train_utils.py:257-259 does three .to(gpu) copies): one launch copies the dense features,
+ * the ids and the labels into the plan's static buffers and stores the step's learning rate into device memory
+ * (lr_scheduler.step(), train_utils.py:386) so that the captured step graph can be replayed unchanged. */
+typedef struct nasrec_stage_desc {
+  int32_t kind; /* NASREC_OP_STAGE_INPUTS */
+  int32_t B, Fd, Fs;
+  float lr;
+  int32_t _pad;
+  const float* int_src;   float* int_dst;     /* [B, Fd] */
+  const int64_t* cat_src; int64_t* cat_dst;   /* [B, Fs] */
+  const float* y_src;     float* y_dst;       /* [B] (may be NULL) */
+  float* lr_dst;                              /* device scalar (may be NULL) */
+} nasrec_stage_desc_t;
 
 /* ------------------------------------------------------------------------------------------------
  * Entry points

@@ -7,6 +7,11 @@ layout does not match, loading fails loudly.
 import ctypes as C
 import os
 
+# torch must be imported BEFORE the engine is dlopen'ed: PyTorch-ROCm bundles its own libamdhip64, and the engine has
+# to bind to that same HIP runtime instance (device pointers and streams are shared with torch).  Loading the engine
+# first would pull in the system runtime as a second, separate HIP instance ("no ROCm-capable device").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnasrec_hip.so")
 
@@ -23,7 +28,7 @@ ACT_BY_NAME = {"identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
 (OP_GEMM, OP_EMBED_GATHER, OP_DOT_TRI_FWD, OP_DOT_TRI_BWD, OP_FM_FWD, OP_FM_BWD, OP_MHA_FWD, OP_MHA_BWD, OP_REDUCE_ROWS,
  OP_COPY_SEGS, OP_GATE_BWD, OP_ROWSUM, OP_FINAL_FWD, OP_BCE, OP_FINAL_BWD, OP_EMB_DEDUP, OP_SUMSQ, OP_CLIP_COEF,
  OP_ADAGRAD_DENSE, OP_ADAGRAD_ROWS, OP_MEMSET, OP_LAYERNORM_FWD, OP_LAYERNORM_BWD, OP_ADD_SEGS, OP_SCALE,
- OP_ACT_BWD) = range(1, 27)
+ OP_ACT_BWD, OP_STAGE_INPUTS) = range(1, 28)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -134,13 +139,18 @@ class ActBwdDesc(C.Structure):
                 ("dims_in_use", i32), ("dy", vp), ("z", vp), ("dz", vp)]
 
 
+class StageDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("Fd", i32), ("Fs", i32), ("lr", f32), ("_pad", i32), ("int_src", vp), ("int_dst", vp),
+                ("cat_src", vp), ("cat_dst", vp), ("y_src", vp), ("y_dst", vp), ("lr_dst", vp)]
+
+
 DESC_BY_KIND = {
     OP_GEMM: GemmDesc, OP_EMBED_GATHER: EmbedDesc, OP_DOT_TRI_FWD: DotTriDesc, OP_DOT_TRI_BWD: DotTriDesc, OP_FM_FWD: FmDesc,
     OP_FM_BWD: FmDesc, OP_MHA_FWD: MhaDesc, OP_MHA_BWD: MhaDesc, OP_REDUCE_ROWS: ReduceRowsDesc, OP_COPY_SEGS: CopySegsDesc,
     OP_GATE_BWD: GateBwdDesc, OP_ROWSUM: RowsumDesc, OP_FINAL_FWD: FinalDesc, OP_BCE: BceDesc, OP_FINAL_BWD: FinalDesc,
     OP_EMB_DEDUP: EmbDedupDesc, OP_SUMSQ: SumsqDesc, OP_CLIP_COEF: ClipCoefDesc, OP_ADAGRAD_DENSE: AdagradDenseDesc,
     OP_ADAGRAD_ROWS: AdagradRowsDesc, OP_MEMSET: MemsetDesc, OP_LAYERNORM_FWD: LayerNormDesc, OP_LAYERNORM_BWD: LayerNormDesc,
-    OP_SCALE: ScaleDesc, OP_ACT_BWD: ActBwdDesc,
+    OP_SCALE: ScaleDesc, OP_ACT_BWD: ActBwdDesc, OP_STAGE_INPUTS: StageDesc,
 }
 
 # every symbol include/nasrec_hip.h declares

@@ -57,6 +57,7 @@ static int dispatch(hipStream_t st, const void* desc) {
     case NASREC_OP_LAYERNORM_BWD: return launch_layernorm(st, (const nasrec_layernorm_desc_t*)desc);
     case NASREC_OP_SCALE: return launch_scale(st, (const nasrec_scale_desc_t*)desc);
     case NASREC_OP_ACT_BWD: return launch_act_bwd(st, (const nasrec_act_bwd_desc_t*)desc);
+    case NASREC_OP_STAGE_INPUTS: return launch_stage(st, (const nasrec_stage_desc_t*)desc);
     default: return nasrec_set_error(-1, "unknown op kind %d", kind);
   }
 }
@@ -204,6 +205,7 @@ int nasrec_desc_sizes(int32_t* out, int n) {
       0,                                            // 24 (ADD_SEGS: served by COPY_SEGS)
       (int32_t)sizeof(nasrec_scale_desc_t),         // 25
       (int32_t)sizeof(nasrec_act_bwd_desc_t),       // 26
+      (int32_t)sizeof(nasrec_stage_desc_t),         // 27
   };
   const int total = (int)(sizeof(sizes) / sizeof(sizes[0]));
   int w = 0;

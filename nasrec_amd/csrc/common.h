@@ -62,3 +62,4 @@ int launch_adagrad_rows(hipStream_t s, const nasrec_adagrad_rows_desc_t* d);
 int launch_layernorm(hipStream_t s, const nasrec_layernorm_desc_t* d);
 int launch_scale(hipStream_t s, const nasrec_scale_desc_t* d);
 int launch_act_bwd(hipStream_t s, const nasrec_act_bwd_desc_t* d);
+int launch_stage(hipStream_t s, const nasrec_stage_desc_t* d);

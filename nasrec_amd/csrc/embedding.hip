@@ -53,7 +53,17 @@ __global__ __launch_bounds__(256) void emb_dedup_kernel(const nasrec_emb_dedup_d
     for (int q = threadIdx.x; q < cn; q += 256) sidx[q] = d.idx[(long)(c0 + q) * d.Fs + f];
     __syncthreads();
     if (live) {
-      for (int q = 0; q < cn; ++q) {
+      // 8 ids per trip: the LDS broadcast reads are issued back to back, the (rare) match branch comes after
+      for (int q8 = 0; q8 < cn; q8 += 8) {
+        long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (q8 + u < cn) ? sidx[q8 + u] : -2;
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) any |= (v[u] == my);
+        if (!any) continue;
+#pragma unroll 1
+        for (int q = q8; q < min(q8 + 8, cn); ++q) {
         if (sidx[q] == my) {
           const int bp = c0 + q;
           if (bp < b) {
@@ -69,6 +79,7 @@ __global__ __launch_bounds__(256) void emb_dedup_kernel(const nasrec_emb_dedup_d
               g[4 * v + 3] += x.w;
             }
           }
+        }
         }
       }
     }

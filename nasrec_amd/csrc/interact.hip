@@ -100,41 +100,52 @@ int launch_dot_tri(hipStream_t st, const nasrec_dot_tri_desc_t* d) {
 // ---------------------------------------------------------------------------------------------------
 // FactorizationMachine3D core (modules.py:736-738): thread = (b, e); 16 lanes read one 64-byte token row.
 // ---------------------------------------------------------------------------------------------------
+// one wavefront per sample: lane = (token group g = lane>>4, e = lane&15); 4 token rows (256 B) per load instruction,
+// then the 4 groups are folded with two xor-shuffles.
 __global__ __launch_bounds__(256) void fm_fwd_kernel(const nasrec_fm_desc_t d) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  const int b = (int)(t >> 4), e = (int)(t & 15);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
   if (b >= d.B) return;
+  const int g = lane >> 4, e = lane & 15;
   const float* x = d.x + (long)b * d.ldx + e;
   float s = 0.f, q = 0.f;
-  for (int n = 0; n < d.N; ++n) {
+  for (int n = g; n < d.N; n += 4) {
     float v = x[n * 16];
     s += v;
     q = fmaf(v, v, q);
   }
-  float r = s * s - q;
-  float* o = d.ix + (long)b * d.ld_ix + e;
-  *o = d.accumulate ? *o + r : r;
+  s += __shfl_xor(s, 16, 64);
+  q += __shfl_xor(q, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  q += __shfl_xor(q, 32, 64);
+  if (g == 0) {
+    float r = s * s - q;
+    float* o = d.ix + (long)b * d.ld_ix + e;
+    *o = d.accumulate ? *o + r : r;
+  }
 }
 
 __global__ __launch_bounds__(256) void fm_bwd_kernel(const nasrec_fm_desc_t d) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  const int b = (int)(t >> 4), e = (int)(t & 15);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
   if (b >= d.B) return;
+  const int g = lane >> 4, e = lane & 15;
   const float* x = d.x + (long)b * d.ldx + e;
   float* dx = d.dx + (long)b * d.ldx + e;
   float s = 0.f;
-  for (int n = 0; n < d.N; ++n) s += x[n * 16];
+  for (int n = g; n < d.N; n += 4) s += x[n * 16];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
   const float g2 = 2.f * d.dix[(long)b * d.ld_ix + e];
-  for (int n = 0; n < d.N; ++n) {
+  for (int n = g; n < d.N; n += 4) {
     float r = g2 * (s - x[n * 16]);
     dx[n * 16] = d.accumulate ? dx[n * 16] + r : r;
   }
 }
 
 int launch_fm(hipStream_t st, const nasrec_fm_desc_t* d) {
-  long threads = (long)d->B * 16;
-  if (threads == 0) return 0;
-  dim3 grid((unsigned)((threads + 255) / 256));
+  if (d->B == 0) return 0;
+  dim3 grid((unsigned)((d->B + 3) / 4));
   if (d->kind == NASREC_OP_FM_FWD)
     hipLaunchKernelGGL(fm_fwd_kernel, grid, dim3(256), 0, st, *d);
   else

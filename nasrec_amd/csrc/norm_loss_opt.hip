@@ -142,16 +142,21 @@ int launch_sumsq(hipStream_t st, const nasrec_sumsq_desc_t* d) {
   return nasrec_check_launch("sumsq");
 }
 
-__global__ void clip_coef_kernel(const nasrec_clip_coef_desc_t d) {
-  if (threadIdx.x != 0) return;
+// one wavefront: lanes take the partials round-robin (fixed assignment), fp64 butterfly -> same value in every lane
+__global__ __launch_bounds__(64) void clip_coef_kernel(const nasrec_clip_coef_desc_t d) {
+  const int lane = threadIdx.x;
   double s = 0.0;
-  for (int i = 0; i < d.n_a; ++i) s += (double)d.partial_a[i];
-  for (int i = 0; i < d.n_b; ++i) s += (double)d.partial_b[i];
-  const float total = (float)sqrt(s);
-  float coef = 1.f;
-  if (d.max_norm > 0.f) coef = fminf(d.max_norm / (total + 1e-6f), 1.f);
-  d.out[0] = coef;
-  d.out[1] = total;
+  for (int i = lane; i < d.n_a; i += 64) s += (double)d.partial_a[i];
+  for (int i = lane; i < d.n_b; i += 64) s += (double)d.partial_b[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) {
+    const float total = (float)sqrt(s);
+    float coef = 1.f;
+    if (d.max_norm > 0.f) coef = fminf(d.max_norm / (total + 1e-6f), 1.f);
+    d.out[0] = coef;
+    d.out[1] = total;
+  }
 }
 
 int launch_clip_coef(hipStream_t st, const nasrec_clip_coef_desc_t* d) {
@@ -384,4 +389,23 @@ int launch_layernorm(hipStream_t st, const nasrec_layernorm_desc_t* d) {
     return nasrec_set_error(-2, "layernorm: unsupported mode %d", d->mode);
   }
   return nasrec_check_launch("layernorm");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-step input staging + learning-rate store (one launch instead of three copies and a fill)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stage_inputs_kernel(const nasrec_stage_desc_t d) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int n_int = d.B * d.Fd, n_cat = d.B * d.Fs;
+  if (t < n_int) d.int_dst[t] = d.int_src[t];
+  if (t < n_cat) d.cat_dst[t] = d.cat_src[t];
+  if (d.y_src != nullptr && t < d.B) d.y_dst[t] = d.y_src[t];
+  if (t == 0 && d.lr_dst != nullptr) d.lr_dst[0] = d.lr;
+}
+
+int launch_stage(hipStream_t st, const nasrec_stage_desc_t* d) {
+  int n = d->B * (d->Fd > d->Fs ? d->Fd : d->Fs);
+  if (n < 1) n = 1;
+  hipLaunchKernelGGL(stage_inputs_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *d);
+  return nasrec_check_launch("stage_inputs");
 }

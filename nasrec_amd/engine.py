@@ -126,6 +126,34 @@ class SupernetEngine:
         self.stream.synchronize()
         return missing
 
+    def init_weights(self, seed: int = 0):
+        """train_utils.py:70-89 applied to this parameter set: xavier_normal_ tables, xavier_uniform_ 2-D weights
+        (nn.Linear and the MultiheadAttention projections alike), zero biases; LayerNorm stays at its constructor
+        value (1, or LN_INIT = 0.17 for the two Transformer norms, modules.py:598,636-640) with zero bias."""
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed)
+        with torch.cuda.stream(self.stream):
+            for name, p in self.params.items():
+                is_ln = ("_ln" in name) or ("layernorm" in name)
+                if name.startswith("_embedding."):
+                    std = (2.0 / (p.shape[0] + p.shape[1])) ** 0.5
+                    p.normal_(0.0, std, generator=g)
+                elif is_ln:
+                    if name.endswith(".weight"):
+                        p.fill_(0.17 if ("_attn_ln" in name or "_attn_fc_ln" in name) else 1.0)
+                    else:
+                        p.zero_()
+                elif p.dim() == 2:
+                    bound = (6.0 / (p.shape[0] + p.shape[1])) ** 0.5
+                    p.uniform_(-bound, bound, generator=g)
+                else:
+                    p.zero_()
+            self.flat_s.zero_()
+            if self.table_state is not None:
+                for t in self.table_state:
+                    t.zero_()
+        self.stream.synchronize()
+
     def state_dict(self) -> Dict[str, torch.Tensor]:
         self.stream.synchronize()
         return {k: v.detach().cpu().clone() for k, v in self.params.items()}
@@ -266,11 +294,29 @@ class SupernetEngine:
         return descs
 
     # -------------------------------------------------------------------------------------------------------
-    def _stage_inputs(self, cp, int_x, cat_x, y=None):
-        cp.int_x.copy_(int_x.reshape(cp.int_x.shape), non_blocking=True)
-        cp.cat_x.copy_(cat_x.reshape(cp.cat_x.shape), non_blocking=True)
+    def _stage_inputs(self, cp, int_x, cat_x, y=None, lr=None):
+        """one launch: batch -> the plan's static buffers (+ this step's learning rate -> device scalar)"""
+        ok = (int_x.is_cuda and cat_x.is_cuda and int_x.dtype == torch.float32 and cat_x.dtype == torch.int64
+              and int_x.is_contiguous() and cat_x.is_contiguous()
+              and (y is None or (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous())))
+        if not ok:  # host tensors / other dtypes: let torch convert and copy
+            cp.int_x.copy_(int_x.reshape(cp.int_x.shape), non_blocking=True)
+            cp.cat_x.copy_(cat_x.reshape(cp.cat_x.shape), non_blocking=True)
+            if y is not None:
+                cp.y.copy_(y.reshape(cp.y.shape), non_blocking=True)
+            if lr is not None:
+                self.lr_dev.fill_(float(lr))
+            return
+        d = L.StageDesc()
+        d.kind = L.OP_STAGE_INPUTS
+        d.B, d.Fd, d.Fs = cp.int_x.shape[0], self.Fd, self.Fs
+        d.int_src, d.int_dst = int_x.data_ptr(), cp.int_x.data_ptr()
+        d.cat_src, d.cat_dst = cat_x.data_ptr(), cp.cat_x.data_ptr()
         if y is not None:
-            cp.y.copy_(y.reshape(cp.y.shape), non_blocking=True)
+            d.y_src, d.y_dst = y.data_ptr(), cp.y.data_ptr()
+        if lr is not None:
+            d.lr, d.lr_dst = float(lr), self.lr_dev.data_ptr()
+        L.check(L.load().nasrec_launch(self.stream.cuda_stream, C.addressof(d)))
 
     def forward(self, int_x, cat_x, choice=None, graph=False):
         """logits [B,1] for the given choice (fixed mode: the fixed choice)."""
@@ -299,8 +345,9 @@ class SupernetEngine:
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             if not staged:
-                self._stage_inputs(cp, int_x, cat_x, y)
-            self.lr_dev.fill_(float(lr))
+                self._stage_inputs(cp, int_x, cat_x, y, lr)
+            else:
+                self.lr_dev.fill_(float(lr))
             sp = self.stream.cuda_stream
             if graph:
                 cp.step.replay(sp)

@@ -1,0 +1,84 @@
+"""Data-parallel training step: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI).
+
+The path shards over the batch (samples are independent; LayerNorm is per row — SURVEY §8e).  Per step, after the
+local forward/backward:
+  * dense gradients: ONE all-reduce (sum) of the flat gradient arena; the 1/(B·world) factor is already folded into
+    dlogits, so the sum equals the gradient of the mean loss over the global batch;
+  * embedding gradients: all-gather of (ids [B,Fs] int64, per-sample row gradients [B,Fs,16]) — B_global·Fs·72 bytes,
+    instead of all-reducing 2.16 GB of dense table gradient — then every rank runs the same row-sparse
+    dedup + clip + Adagrad over the global batch, so the replicated tables stay bit-identical across ranks;
+  * the global-norm clip coefficient comes out identical on every rank because it is computed from identical data.
+The reference has no distributed code at all; equivalence target = a single process at the global batch.
+"""
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .engine import Program, SupernetEngine
+
+
+def all_gather_rows(out: torch.Tensor, local: torch.Tensor):
+    """out[r*n:(r+1)*n] = local of rank r (n = local.numel()); works on nccl and gloo."""
+    try:
+        dist.all_gather_into_tensor(out.view(-1), local.reshape(-1))
+    except (RuntimeError, NotImplementedError):
+        n = local.numel()
+        chunks = [out.view(-1)[r * n:(r + 1) * n] for r in range(dist.get_world_size())]
+        dist.all_gather(chunks, local.reshape(-1))
+
+
+def exchange_gradients(flat_g: torch.Tensor, cat_local: torch.Tensor, sg_local: torch.Tensor, cat_all: torch.Tensor, sg_all: torch.Tensor):
+    """the only cross-rank traffic of a step (see module docstring)"""
+    dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+    all_gather_rows(cat_all, cat_local)
+    all_gather_rows(sg_all, sg_local)
+
+
+class _Holder:
+    pass
+
+
+class DataParallelStep:
+    def __init__(self, engine: SupernetEngine, choice, B_local: int, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = True):
+        self.engine = engine
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.B = B_local
+        self.graph = graph and engine.cfg.fixed
+        if self.world == 1:
+            self.cp = engine.compile(choice, B_local, True, clip, eps, graph=self.graph)
+            self.choice = choice
+            self.clip, self.eps = clip, eps
+            return
+        self.cp = engine.compile(choice, B_local, True, clip, eps, graph=False, grad_scale=1.0 / (B_local * self.world))
+        with torch.cuda.stream(engine.stream):
+            Bg = B_local * self.world
+            self.cat_all = torch.zeros(Bg, engine.Fs, dtype=torch.int64, device=engine.device)
+            self.sg_all = torch.zeros(Bg * engine.Fs * 16, dtype=torch.float32, device=engine.device)
+            self.holder = _Holder()
+            self.opt = Program(engine._optimizer_descs(self.holder, Bg, self.cat_all, self.sg_all, clip, eps))
+            self.fb = Program(self.cp.fwd.descs + self.cp.bwd.descs)
+            if self.graph:
+                self.fb.capture(engine.stream.cuda_stream)
+                self.opt.capture(engine.stream.cuda_stream)
+
+    def step(self, int_x, cat_x, y, lr: float):
+        eng = self.engine
+        if self.world == 1:
+            return eng.train_step(int_x, cat_x, y, lr, self.choice, self.clip, self.eps, graph=self.graph)
+        cur = torch.cuda.current_stream(eng.device)
+        eng.stream.wait_stream(cur)
+        with torch.cuda.stream(eng.stream):
+            eng._stage_inputs(self.cp, int_x, cat_x, y, lr)
+            sp = eng.stream.cuda_stream
+            if self.graph:
+                self.fb.replay(sp)
+            else:
+                self.fb.run(sp)
+            exchange_gradients(eng.flat_g, self.cp.cat_x, self.cp.sparse0.grad_tensor(), self.cat_all, self.sg_all)
+            if self.graph:
+                self.opt.replay(sp)
+            else:
+                self.opt.run(sp)
+        cur.wait_stream(eng.stream)
+        return self.cp.loss

@@ -1,0 +1,53 @@
+"""Learning-rate schedules of the reference (nasrec/utils/lr_schedule.py) as closed-form functions of the optimizer
+step index t (the lr the optimizer uses at its t-th step); the engine keeps lr in a device scalar, so no
+torch.optim.lr_scheduler object is involved."""
+import math
+
+
+class CosineAnnealingWarmupRestarts:
+    """lr_schedule.py:47-164.  Step 0 runs at min_lr (init_lr() overrides the constructor's first step, :88-95)."""
+
+    def __init__(self, first_cycle_steps, cycle_mult=1.0, max_lr=0.1, min_lr=0.001, warmup_steps=0, gamma=1.0):
+        assert warmup_steps < first_cycle_steps
+        self.first_cycle_steps, self.cycle_mult, self.base_max_lr = first_cycle_steps, cycle_mult, max_lr
+        self.min_lr, self.warmup_steps, self.gamma = min_lr, warmup_steps, gamma
+        self.cur_cycle_steps, self.cycle, self.step_in_cycle, self.max_lr = first_cycle_steps, 0, 0, max_lr
+        self.lr = min_lr
+
+    def get_lr(self):
+        return self.lr
+
+    def step(self):
+        self.step_in_cycle += 1
+        if self.step_in_cycle >= self.cur_cycle_steps:
+            self.cycle += 1
+            self.step_in_cycle -= self.cur_cycle_steps
+            self.cur_cycle_steps = int((self.cur_cycle_steps - self.warmup_steps) * self.cycle_mult) + self.warmup_steps
+        self.max_lr = self.base_max_lr * (self.gamma ** self.cycle)
+        if self.step_in_cycle < self.warmup_steps:
+            self.lr = (self.max_lr - self.min_lr) * self.step_in_cycle / self.warmup_steps + self.min_lr
+        else:
+            self.lr = self.min_lr + (self.max_lr - self.min_lr) * (
+                1 + math.cos(math.pi * (self.step_in_cycle - self.warmup_steps) / (self.cur_cycle_steps - self.warmup_steps))) / 2
+        return self.lr
+
+
+class ConstantWithWarmup:
+    """lr_schedule.py:21-43: linear ramp over num_warmup_steps (first step at base/num_warmup_steps), then constant."""
+
+    def __init__(self, base_lr, num_warmup_steps):
+        self.base_lr, self.num_warmup_steps, self.count = base_lr, num_warmup_steps, 1
+        self.lr = self._at(1)
+
+    def _at(self, c):
+        if c <= self.num_warmup_steps:
+            return self.base_lr * (1.0 - (self.num_warmup_steps - c) / self.num_warmup_steps)
+        return self.base_lr
+
+    def get_lr(self):
+        return self.lr
+
+    def step(self):
+        self.count += 1
+        self.lr = self._at(self.count)
+        return self.lr
