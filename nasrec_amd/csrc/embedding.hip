@@ -30,82 +30,103 @@ int launch_embed_gather(hipStream_t st, const nasrec_embed_desc_t* d) {
   return nasrec_check_launch("embed_gather");
 }
 
-// Row-sparse backward: leader election + ordered duplicate summation, per field.
-// grid = (Fs, ceil(B/256)); thread = one (b, f).  The B ids of the field are streamed through LDS in
-// chunks; every lane compares against the same id at a time (LDS broadcast).  Leaders (first occurrence)
-// add up the 64-byte gradient rows of all their occurrences in ascending b, so the result is
-// reproducible run to run.
-#define DEDUP_CHUNK 1024
+// Row-sparse backward: leader election + duplicate summation, per field.
+// grid = (Fs, ceil(B/256)); all B ids of the field are staged once in LDS as int32 (rows < 2^31).
+//   phase 1 (thread = one (b,f)): scan the ids four at a time (ds_read_b128 broadcast): first occurrence + count.
+//            Unique rows (the common case on the big tables) just copy their 64-byte gradient row.
+//   phase 2 (wavefront = one duplicated row at a time): ballot the matching samples 64 at a time and add their
+//            gradient rows four per round (lane group g takes the g-th match), so a 64-fold duplicate on a 4-row table
+//            costs 16 load rounds instead of a 64-long dependent chain in one lane.
+// The summation order is a fixed function of the ids, so results are reproducible run to run.
+#define DEDUP_MAXB 8192
 __global__ __launch_bounds__(256) void emb_dedup_kernel(const nasrec_emb_dedup_desc_t d) {
-  __shared__ long sidx[DEDUP_CHUNK];
+  __shared__ __attribute__((aligned(16))) int sidx[DEDUP_MAXB];
   __shared__ float red[256];
+  __shared__ int multi[256];
+  __shared__ int nmulti;
   const int f = blockIdx.x;
-  const int b = blockIdx.y * 256 + threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.y * 256 + tid;
+  const int Bp = (d.B + 3) & ~3;
+  if (tid == 0) nmulti = 0;
+  for (int q = tid; q < Bp; q += 256) sidx[q] = q < d.B ? (int)d.idx[(long)q * d.Fs + f] : -1;
+  __syncthreads();
   const bool live = b < d.B;
-  const long my = live ? d.idx[(long)b * d.Fs + f] : -1;
-  int lead = live ? 1 : 0;
-  float g[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) g[e] = 0.f;
-  for (int c0 = 0; c0 < d.B; c0 += DEDUP_CHUNK) {
-    const int cn = min(DEDUP_CHUNK, d.B - c0);
-    __syncthreads();
-    for (int q = threadIdx.x; q < cn; q += 256) sidx[q] = d.idx[(long)(c0 + q) * d.Fs + f];
-    __syncthreads();
-    if (live) {
-      // 8 ids per trip: the LDS broadcast reads are issued back to back, the (rare) match branch comes after
-      for (int q8 = 0; q8 < cn; q8 += 8) {
-        long v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (q8 + u < cn) ? sidx[q8 + u] : -2;
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) any |= (v[u] == my);
-        if (!any) continue;
-#pragma unroll 1
-        for (int q = q8; q < min(q8 + 8, cn); ++q) {
-        if (sidx[q] == my) {
-          const int bp = c0 + q;
-          if (bp < b) {
-            lead = 0;
-          } else if (lead) {
-            const float4* src = reinterpret_cast<const float4*>(d.dout + ((long)bp * d.Fs + f) * 16);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              float4 x = src[v];
-              g[4 * v + 0] += x.x;
-              g[4 * v + 1] += x.y;
-              g[4 * v + 2] += x.z;
-              g[4 * v + 3] += x.w;
-            }
-          }
-        }
-        }
+  const int my = live ? sidx[b] : -2;
+  int first = b, count = 0;
+  if (live) {
+    first = 1 << 30;
+    const int4* s4 = reinterpret_cast<const int4*>(sidx);
+    for (int q = 0; q < Bp / 4; ++q) {
+      const int4 v = s4[q];
+      const int m0 = v.x == my, m1 = v.y == my, m2 = v.z == my, m3 = v.w == my;
+      count += m0 + m1 + m2 + m3;
+      if (m0 | m1 | m2 | m3) {
+        const int p = 4 * q + (m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3)));
+        first = min(first, p);
       }
     }
   }
+  const bool lead = live && first == b;
   float ss = 0.f;
-  if (live) {
-    d.leader[(long)b * d.Fs + f] = lead;
-    if (lead) {
-      float4* dst = reinterpret_cast<float4*>(d.gsum + ((long)b * d.Fs + f) * 16);
+  if (live) d.leader[(long)b * d.Fs + f] = lead ? 1 : 0;
+  if (lead && count == 1) {
+    const float4* src = reinterpret_cast<const float4*>(d.dout + ((long)b * d.Fs + f) * 16);
+    float4* dst = reinterpret_cast<float4*>(d.gsum + ((long)b * d.Fs + f) * 16);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) dst[v] = make_float4(g[4 * v], g[4 * v + 1], g[4 * v + 2], g[4 * v + 3]);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) ss += g[e] * g[e];
+    for (int v = 0; v < 4; ++v) {
+      const float4 x = src[v];
+      dst[v] = x;
+      ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
     }
+  } else if (lead) {
+    multi[atomicAdd(&nmulti, 1)] = tid;
   }
-  red[threadIdx.x] = ss;
+  red[tid] = ss;
+  __syncthreads();
+  const int nm = nmulti;
+  const int g = lane >> 4, e = lane & 15;
+  for (int i = wave; i < nm; i += 4) {
+    const int tl = multi[i];
+    const int v = sidx[blockIdx.y * 256 + tl];
+    float acc = 0.f;
+    for (int c0 = 0; c0 < d.B; c0 += 64) {
+      const bool m = (c0 + lane < d.B) && (sidx[c0 + lane] == v);
+      unsigned long long mask = __ballot(m);
+      while (mask) {
+        int mypos = -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (mask) {
+            const int pos = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            if (g == r) mypos = pos;
+          }
+        }
+        if (mypos >= 0) acc += d.dout[((long)(c0 + mypos) * d.Fs + f) * 16 + e];
+      }
+    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    float sq = acc * acc;
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    sq += __shfl_xor(sq, 4, 64);
+    sq += __shfl_xor(sq, 8, 64);
+    if (g == 0) d.gsum[((long)(blockIdx.y * 256 + tl) * d.Fs + f) * 16 + e] = acc;
+    if (lane == 0) red[tl] = sq;
+  }
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    if (tid < o) red[tid] += red[tid + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) d.sumsq_partial[(long)f * gridDim.y + blockIdx.y] = red[0];
+  if (tid == 0) d.sumsq_partial[(long)f * gridDim.y + blockIdx.y] = red[0];
 }
 
 int launch_emb_dedup(hipStream_t st, const nasrec_emb_dedup_desc_t* d) {
   if (d->B == 0) return 0;
+  if (d->B > DEDUP_MAXB) return nasrec_set_error(-2, "emb_dedup: B=%d > %d", d->B, DEDUP_MAXB);
   dim3 grid(d->Fs, (d->B + 255) / 256);
   hipLaunchKernelGGL(emb_dedup_kernel, grid, dim3(256), 0, st, *d);
   return nasrec_check_launch("emb_dedup");
