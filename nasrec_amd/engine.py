@@ -63,7 +63,7 @@ class CompiledPlan:
 
 class SupernetEngine:
     def __init__(self, cfg: P.NetConfig, Fd: int, Fs: int, num_embeddings: List[int], device="cuda:0", warm_choice=None,
-                 world_size: int = 1):
+                 world_size: int = 1, tables: Optional[List[torch.Tensor]] = None):
         L.load()
         if not torch.cuda.is_available():
             raise L.EngineError("SupernetEngine needs a GPU: there is no CPU fallback")
@@ -92,7 +92,12 @@ class SupernetEngine:
             self.flat_p = torch.zeros(off, dtype=torch.float32, device=self.device)
             self.flat_g = torch.zeros(off, dtype=torch.float32, device=self.device)
             self.flat_s = torch.zeros(off, dtype=torch.float32, device=self.device)
-            self.tables = [torch.zeros(n, E, dtype=torch.float32, device=self.device) for n in self.num_embeddings]
+            if tables is not None:  # adopt the caller's nn.Embedding storage (no copy; PyTorch keeps ownership)
+                for t, n in zip(tables, self.num_embeddings):
+                    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (n, E)
+                self.tables = list(tables)
+            else:
+                self.tables = [torch.zeros(n, E, dtype=torch.float32, device=self.device) for n in self.num_embeddings]
             self.table_state: Optional[List[torch.Tensor]] = None
             self.lr_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
             self.clip_out = torch.ones(2, dtype=torch.float32, device=self.device)  # [coef, total_norm]
@@ -169,6 +174,9 @@ class SupernetEngine:
         key = json.dumps([choice, B, train, clip, eps, graph, grad_scale], sort_keys=True, default=_jsonable)
         if key in self._plans:
             return self._plans[key]
+        if not self.cfg.fixed and len(self._plans) >= 4:  # sampled paths rarely repeat: keep the cache small
+            self.stream.synchronize()
+            self._plans.pop(next(iter(self._plans)))
         cfg = self.cfg
         with torch.cuda.stream(self.stream):
             cp = CompiledPlan()
@@ -239,6 +247,7 @@ class SupernetEngine:
                 ctx.on_backward(final_bwd)
                 ctx.build_backward()
                 cp.bwd = Program(pre + ctx.bwd)
+                cp.bwd_core = Program(pre[1:] + ctx.bwd)  # dlogits supplied by the caller (autograd path)
                 cp.opt = Program(self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if sbuf.grad_written else None, clip, eps))
                 if graph:
                     cp.step = Program(cp.fwd.descs + cp.bwd.descs + cp.opt.descs)
@@ -357,6 +366,24 @@ class SupernetEngine:
                 cp.opt.run(sp)
         cur.wait_stream(self.stream)
         return cp.loss
+
+    def run_forward(self, cp, int_x, cat_x):
+        """forward program of an already compiled (training) plan; logits land in cp.logits"""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._stage_inputs(cp, int_x, cat_x)
+            cp.fwd.run(self.stream.cuda_stream)
+        cur.wait_stream(self.stream)
+
+    def run_backward(self, cp, dlogits):
+        """backward program with an externally supplied d(loss)/d(logits) [B,1] (torch.autograd entry)"""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            cp.dlogits.copy_(dlogits.reshape(-1), non_blocking=True)
+            cp.bwd_core.run(self.stream.cuda_stream)
+        cur.wait_stream(self.stream)
 
     def forward_backward(self, int_x, cat_x, y, choice=None, grad_scale=None):
         """forward + BCE + backward only (gradients left in self.grads / plan.sparse0 gradient); used by the data-parallel

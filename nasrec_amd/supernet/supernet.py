@@ -1,0 +1,575 @@
+"""SuperNet / SuperNetBlock — the reference's model API (nasrec/supernet/supernet.py) on top of the HIP engine.
+
+Drop-in surface: constructor signature, `forward(int_feats, cat_feats, choices=None) -> logits [B,1]`,
+`.choice`, path-sampling configuration and the global-`np.random` sampling order, mode setters, parameter getters,
+`state_dict()` keys and `parameters()` order, lazy shapes fixed by the first forward (warm-up).  What differs is
+*how* a forward runs: the whole choice is compiled into one launch plan (nasrec_amd/plan.py) and executed by
+hand-written HIP kernels through the C-ABI; autograd sees one node for the whole network.
+
+Gradient semantics of this `nn.Module` path are the reference's (dense `.grad` for every `nn.Embedding`, so the
+unchanged `clip_grad_norm_` + `torch.optim.Adagrad` harness works).  The fast path used by `bench.py` is
+`SuperNet.engine_train_step`, whose row-sparse table update is mathematically identical for weight_decay == 0.
+"""
+import copy
+from itertools import combinations
+from typing import Any, List, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import plan as P
+from ..search_space import ops_config_lib, path_sampling_strategy_lib  # noqa: F401  (re-exported, supernet.py:134-207)
+from ..utils.config import NUM_EMBEDDINGS_CRITEO
+from .modules import (CleverMaskGenerator, CleverZeroTensorGenerator, DotProduct, ElasticLinear, ElasticLinear3D,  # noqa: F401
+                      FactorizationMachine3D, SigmoidGating, Sum, Transformer, Zeros2D, Zeros3D)
+from .utils import anypath_choice_fn, assert_valid_ops_config
+
+_dense_unary_nodes = ["linear-2d", "zeros-2d"]
+_dense_binary_nodes = ["sum", "sigmoid-gating"]
+_dense_sparse_nodes = ["dot-product"]
+_sparse_nodes = ["zeros-3d", "transformer", "linear-3d"]
+
+assert_valid_ops_config(ops_config_lib)
+
+DS_INTERACT_NUM_SPLITS = 8  # supernet.py:882
+
+# LayerNorm siblings that disappear together with a dropped projection (modules.py:344-345,353-354,363-364; supernet.py:1144,1225)
+_LN_SIBLING = {"_dense_proj": "_dense_layernorm", "_sparse_proj": "_sparse_layernorm",
+               "_sparse_inp_proj": "_sparse_inp_proj_layernorm", "project_emb_dim": "project_emb_dim_layernorm"}
+
+
+def _make_node(name, use_layernorm, dims, activation, embedding_dim, fixed):
+    """supernet.py:53-113"""
+    if name == "linear-2d":
+        return ElasticLinear(use_layernorm=use_layernorm, max_dims_or_dims=dims, activation=activation, fixed=fixed)
+    if name == "zeros-2d":
+        return Zeros2D(use_layernorm=use_layernorm, max_dims_or_dims=dims, activation=activation, fixed=fixed)
+    if name == "sigmoid-gating":
+        return SigmoidGating(use_layernorm=use_layernorm, max_dims_or_dims=dims, activation=activation, fixed=fixed)
+    if name == "sum":
+        return Sum(use_layernorm=use_layernorm, max_dims_or_dims=dims, activation=activation, fixed=fixed)
+    if name == "dot-product":
+        return DotProduct(use_layernorm=use_layernorm, max_dims_or_dims=dims, embedding_dim=embedding_dim, fixed=fixed)
+    if name == "zeros-3d":
+        return Zeros3D(use_layernorm=use_layernorm, max_dims_or_dims=dims, fixed=fixed, embedding_dim=embedding_dim, activation=activation)
+    if name == "transformer":
+        return Transformer(use_layernorm=use_layernorm, max_dims_or_dims=dims, fixed=fixed, embedding_dim=embedding_dim, activation=activation)
+    if name == "linear-3d":
+        return ElasticLinear3D(use_layernorm=use_layernorm, max_dims_or_dims=dims, activation=activation, embedding_dim=embedding_dim, fixed=fixed)
+    raise NotImplementedError("Block name {} is not supported in supernet!".format(name))
+
+
+class _SupernetFunction(torch.autograd.Function):
+    """One autograd node for the whole network: forward = forward program, backward = backward program."""
+
+    @staticmethod
+    def forward(ctx, model, choice, int_x, cat_x, *params):
+        eng = model._engine
+        B = int(int_x.shape[0])
+        cp = eng.compile(choice, B, train=True)
+        eng.run_forward(cp, int_x, cat_x)
+        ctx.model, ctx.cp, ctx.cat_x = model, cp, cat_x
+        return cp.logits.view(B, 1).clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model, cp = ctx.model, ctx.cp
+        eng = model._engine
+        eng.run_backward(cp, dlogits)
+        written = set(cp.ctx.grad_params) | {"_final.weight", "_final.bias"}
+        grads = []
+        sg = cp.sparse0.grad_tensor().view(dlogits.shape[0], eng.Fs, 16) if cp.sparse0.grad_written else None
+        for name, p in model._param_names:
+            if not p.requires_grad:
+                grads.append(None)
+            elif name.startswith("_embedding."):
+                f = int(name.split(".")[1])
+                if sg is None:
+                    grads.append(None)
+                else:  # dense gradient, exactly like nn.Embedding(sparse=False) (supernet.py:407)
+                    grads.append(torch.zeros_like(p).index_add_(0, ctx.cat_x[:, f], sg[:, f]))
+            elif name in written:
+                grads.append(eng.grads[name].clone())
+            else:
+                grads.append(None)  # dead branch or unused parameter: autograd leaves .grad = None
+        return (None, None, None, None) + tuple(grads)
+
+
+class SuperNet(nn.Module):
+    """Top-level supernet (supernet.py:210-880)."""
+
+    def __init__(self, num_blocks: int, ops_config: Any, use_layernorm: bool, activation: str = "relu",
+                 num_embeddings: List[int] = NUM_EMBEDDINGS_CRITEO, sparse_input_size: int = 26, embedding_dim: int = 16,
+                 last_n_blocks_out: int = 1, path_sampling_strategy: str = "default", fixed: bool = False, fixed_choice: Any = None,
+                 place_embedding_on_cpu: bool = False, anypath_choice: str = "uniform", supernet_training_steps: int = 0,
+                 candidate_choices: Optional[List] = None, use_final_sigmoid: bool = False):
+        super().__init__()
+        assert num_blocks >= 1, ValueError("Supernet must contain a minimum of 1 block, but found {}!".format(num_blocks))
+        if place_embedding_on_cpu:
+            raise NotImplementedError("place_embedding_on_cpu is a memory-saving fallback of the reference that no script "
+                                      "uses (supernet.py:253-254); 288 GB of HBM hold every table")
+        self._num_blocks = num_blocks
+        self._ops_config = ops_config
+        self._use_layernorm = use_layernorm
+        self._activation = activation
+        self._last_n_blocks_out = last_n_blocks_out
+        self._sparse_input_size = sparse_input_size
+        self._num_embeddings = num_embeddings
+        self._embedding_dim = embedding_dim
+        self._path_sampling_strategy = path_sampling_strategy
+        self._macro_path_sampling_strategy = path_sampling_strategy_lib[path_sampling_strategy]["macro"]
+        self._candidate_choices = candidate_choices
+        self._fixed = fixed
+        self._embedding = self._embedding_layers(sparse_input_size, num_embeddings, embedding_dim)
+        self._final = nn.LazyLinear(1)
+        self._final_sigmoid = nn.Sigmoid() if use_final_sigmoid else None
+        self._place_embedding_on_cpu = place_embedding_on_cpu
+        self._supernet_training_steps = supernet_training_steps
+        self._anypath_choice_fn = anypath_choice_fn[anypath_choice]
+        self._supernet_train_steps_counter = -1
+        self._device_args = None
+        if self._fixed and fixed_choice is not None:
+            self.choice = fixed_choice
+            self.macro_last_choice = fixed_choice["macro"]
+        else:
+            self.choice = []
+            self.macro_last_choice = None
+        if self._fixed:
+            assert self._macro_path_sampling_strategy == "fixed-path", ValueError(
+                "'fixed_path_strategy' should be explicitly specified when 'fixed' option is True.")
+        blocks = []
+        for idx in range(num_blocks):
+            oc = ops_config[idx] if isinstance(ops_config, list) else ops_config
+            blocks.append(SuperNetBlock(
+                oc, use_layernorm, int(max(oc["dense_node_dims"])), int(max(oc["sparse_node_dims"])), embedding_dim, activation,
+                path_sampling_strategy=path_sampling_strategy_lib[path_sampling_strategy]["micro"], fixed=fixed,
+                fixed_micro_choice=None if (fixed_choice is None) or (not fixed) else fixed_choice["micro"][idx],
+                anypath_choice=anypath_choice, supernet_training_steps=supernet_training_steps, sparse_input_size=sparse_input_size))
+        self._blocks = nn.ModuleList(blocks)
+        # engine state (not part of the reference API)
+        self._engine = None
+        self._materialized = False
+        self._param_names = []
+
+    # ------------------------------------------------------------------------------------------------ parameters
+    def get_dense_parameters(self):
+        return list(self._blocks.parameters()) + list(self._final.parameters())
+
+    def get_sparse_parameters(self):
+        return list(self._embedding.parameters())
+
+    def load_embeddings_from_dlrm(self, dlrm_ckpt_path=None):
+        """supernet.py:368-383"""
+        if dlrm_ckpt_path is not None:
+            checkpoint = torch.load(dlrm_ckpt_path, map_location=torch.device("cpu"))
+            assert "model_state_dict" in checkpoint.keys(), "Please use the DLRM checkpoint to load!"
+            checkpoint = checkpoint["model_state_dict"]
+            with torch.no_grad():
+                for idx in range(len(self._embedding)):
+                    w = self._embedding[idx].weight
+                    w.copy_(checkpoint["embedding_layers.{}.weight".format(idx)].to(w.device))
+
+    def _embedding_layers(self, sparse_input_size, num_embeddings, embedding_dim):
+        return nn.ModuleList([nn.Embedding(num_embeddings[i], embedding_dim) for i in range(sparse_input_size)])
+
+    # ------------------------------------------------------------------------------------------------ sampling
+    def configure_path_sampling_strategy(self, strategy):
+        assert strategy in ["full-path", "single-path", "any-path", "fixed-path", "evo-2shot-path", "default"], \
+            "Strategy {} is not found!".format(strategy)
+        self._path_sampling_strategy = strategy
+        self._macro_path_sampling_strategy = path_sampling_strategy_lib[strategy]["macro"]
+        for block in self._blocks:
+            block._micro_path_sampling_strategy = path_sampling_strategy_lib[strategy]["micro"]
+
+    def _thresh(self):
+        c, n = self._supernet_train_steps_counter, self._supernet_training_steps
+        return 1.0 - c / (n + 1e-10) if (c < n and c > 0) else 0  # supernet.py:446-453
+
+    def _get_choice(self):
+        """supernet.py:432-511 — draws from the global np.random stream in the reference's order."""
+        nb = self._num_blocks
+        s = self._macro_path_sampling_strategy
+        thresh = self._thresh()
+        if s == "single-path":
+            choice = ([self._get_full_path_choice(1 + i) for i in range(nb)] if np.random.random() < thresh
+                      else [self._get_single_path_choice(1 + i) for i in range(nb)])
+        elif s == "full-path":
+            choice = [self._get_full_path_choice(1 + i) for i in range(nb)]
+        elif s == "any-path":
+            choice = ([self._get_full_path_choice(1 + i) for i in range(nb)] if np.random.random() < thresh
+                      else [self._get_any_path_choice(1 + i) for i in range(nb)])
+        elif s == "fixed-path" and self.macro_last_choice is None:
+            if getattr(self, "_fixed_path_called", False):
+                raise ValueError("Error! fixed-path choice should be generated only once for each supernet!")
+            self._fixed_path_called = True
+            choice = [self._get_fixed_path_choice(1 + i) for i in range(nb)]
+        elif s == "fixed-path":
+            choice = self.macro_last_choice
+        elif s == "evo-2shot-path":
+            assert self._candidate_choices is not None, "You must specify self._candidate_choices before using 'evo-2shot-path'!"
+            cand = self._candidate_choices[np.random.randint(len(self._candidate_choices))]["choice"]
+            for i in range(nb):
+                self._blocks[i].configure_choice(cand["micro"][i])
+            choice = cand["macro"]
+        else:
+            raise NotImplementedError("Path strategy {} is not supported!".format(s))
+        if s != "full-path":
+            self.macro_last_choice = choice
+        return choice
+
+    def _get_single_path_choice(self, n: int):
+        """supernet.py:723-736 (the pair of gating inputs is drawn first)"""
+        bi = np.random.choice(n, 2)
+        return {"dense_idx": [np.random.choice(n)], "sparse_idx": [np.random.choice(n)],
+                "dense_left_idx": [bi[0]], "dense_right_idx": [bi[1]]}
+
+    def _any_like(self, n: int, fn):
+        nd, ns = fn(n), fn(n)
+        bi = np.random.choice(n, 2)
+        return {"dense_idx": np.random.choice(n, nd, replace=False).reshape(-1).tolist(),
+                "sparse_idx": np.random.choice(n, ns, replace=False).reshape(-1).tolist(),
+                "dense_left_idx": bi[:1].reshape(-1).tolist(), "dense_right_idx": bi[1:].reshape(-1).tolist()}
+
+    def _get_any_path_choice(self, n: int):
+        """supernet.py:738-770"""
+        return self._any_like(n, self._anypath_choice_fn)
+
+    def _get_fixed_path_choice(self, n: int):
+        """supernet.py:772-812 (always the uniform count sampler)"""
+        return self._any_like(n, anypath_choice_fn["uniform"])
+
+    def _get_full_path_choice(self, n: int):
+        """supernet.py:814-824"""
+        return {k: np.arange(n) for k in ("dense_idx", "sparse_idx", "dense_left_idx", "dense_right_idx")}
+
+    def get_all_subnet_macro_choices(self, block_idx: int):
+        """supernet.py:670-712"""
+        m = 1 + block_idx
+        out = {"dense_left_idx": [], "dense_right_idx": [], "dense_idx": [], "sparse_idx": []}
+        for k in range(1, m + 1):
+            out["dense_idx"] += list(combinations(list(range(m)), k))
+        for k in range(1, m + 1):
+            out["sparse_idx"] += list(combinations(list(range(m)), k))
+        for k in range(1, min(2, m + 1)):
+            out["dense_left_idx"] += list(combinations(list(range(m)), k))
+            out["dense_right_idx"] += list(combinations(list(range(m)), k))
+        return out
+
+    def get_all_subnet_choices(self):
+        """supernet.py:714-721"""
+        out = {"macro": [], "micro": []}
+        for i in range(self._num_blocks):
+            out["macro"].append(self.get_all_subnet_macro_choices(i))
+            out["micro"].append(self._blocks[i].get_all_subnet_micro_choices())
+        return out
+
+    def configure_choice(self, choice: Any):
+        """supernet.py:842-848"""
+        self.choice = copy.deepcopy(choice)
+        self.macro_last_choice = copy.deepcopy(choice["macro"])
+        for idx in range(self._num_blocks):
+            self._blocks[idx].configure_choice(choice["micro"][idx])
+
+    # ------------------------------------------------------------------------------------------------ modes
+    def set_mode_to_finelune_last_only(self):
+        self._embedding.requires_grad_(False)
+        self._blocks.requires_grad_(False)
+        self._final.requires_grad_(True)
+
+    def set_mode_to_normal_mode(self):
+        self._embedding.requires_grad_(True)
+        self._blocks.requires_grad_(True)
+        self._final.requires_grad_(True)
+
+    def set_mode_to_layernorm_calibrate(self):
+        self._embedding.requires_grad_(False)
+        self._blocks.requires_grad_(False)
+        self._final.requires_grad_(False)
+        for _, m in self._blocks.named_modules():
+            if isinstance(m, nn.LayerNorm):
+                m.requires_grad_(True)
+
+    def set_mode_to_finetune_no_embedding(self):
+        self._embedding.requires_grad_(False)
+        self._blocks.requires_grad_(True)
+        self._final.requires_grad_(True)
+
+    # ------------------------------------------------------------------------------------------------ engine glue
+    def _net_config(self):
+        return P.NetConfig(self._num_blocks, self._ops_config, self._use_layernorm, self._activation, self._embedding_dim,
+                           fixed=self._fixed, last_n_blocks_out=self._last_n_blocks_out,
+                           use_final_sigmoid=self._final_sigmoid is not None)
+
+    def _warm_choice(self):
+        if self._fixed:
+            return {"macro": self.macro_last_choice, "micro": [b._fixed_micro_choice for b in self._blocks]}
+        return P.full_path_choice(self._net_config())
+
+    def _materialize(self, Fd: int):
+        """Fix every lazy shape exactly as the reference's warm-up forward does (train_utils.py:392-433): LazyLinear ->
+        nn.Linear with the inferred in_features (created in forward order, so the RNG stream is consumed in the
+        reference's order), projections whose input already has the target width are dropped."""
+        if self._materialized:
+            return
+        cfg = self._net_config()
+        shapes = P.infer_param_shapes(cfg, self._warm_choice(), Fd, self._sparse_input_size, self._num_embeddings)
+        self._shapes = shapes
+        for name, shp in shapes.items():
+            if not name.endswith(".weight") or len(shp) != 2 or name.startswith("_embedding."):
+                continue
+            path = name[:-len(".weight")].split(".")
+            parent = self
+            for a in path[:-1]:
+                parent = getattr(parent, a) if not a.isdigit() else parent[int(a)]
+            attr = path[-1]
+            cur = getattr(parent, attr, None)
+            if isinstance(cur, nn.LazyLinear) or cur is None:
+                dev = self._embedding[0].weight.device
+                lin = nn.Linear(shp[1], shp[0], bias=(name[:-len("weight")] + "bias") in shapes).to(dev)
+                setattr(parent, attr, lin)
+                if type(parent).__name__ == "LazySelfLinear":
+                    parent._linear_size = shp[1]
+        # anything still lazy was skipped by the reference's forward and is deleted there
+        for mod in list(self.modules()):
+            for attr, child in list(mod._modules.items()):
+                if isinstance(child, nn.LazyLinear):
+                    setattr(mod, attr, None)
+                    sib = _LN_SIBLING.get(attr)
+                    if sib is not None and hasattr(mod, sib):
+                        setattr(mod, sib, None)
+                    if isinstance(mod, FactorizationMachine3D):
+                        mod._use_layernorm = None  # modules.py:743
+        got = {k: tuple(v.shape) for k, v in self.state_dict().items()}
+        assert got == {k: tuple(v) for k, v in shapes.items()}, "materialised module tree does not match the inferred parameter set"
+        self._materialized = True
+
+    def _bind_engine(self, device):
+        from ..engine import SupernetEngine
+        params = dict(self.named_parameters())
+        Fd = self._Fd
+        eng = SupernetEngine(self._net_config(), Fd, self._sparse_input_size, self._num_embeddings, device=device,
+                             warm_choice=self._warm_choice(), tables=[params["_embedding.%d.weight" % f].data
+                                                                      for f in range(self._sparse_input_size)])
+        eng.load_params({k: v.data for k, v in params.items() if not k.startswith("_embedding.")})
+        # re-point every dense nn.Parameter at the engine's flat arena (optimizers update in place; kernels read the
+        # same bytes each step — SURVEY §8b "no engine-side copy of weights may go stale")
+        for name, p in params.items():
+            if not name.startswith("_embedding."):
+                p.data = eng.params[name]
+        self._engine = eng
+        self._param_names = list(self.named_parameters())
+
+    def _ensure_engine(self, int_feats):
+        if not self._materialized:
+            self._Fd = int(int_feats.shape[1])
+            self._materialize(self._Fd)
+        dev = int_feats.device
+        if dev.type != "cuda":
+            from .._lib import EngineError
+            raise EngineError("SuperNet.forward runs on the HIP engine: move the model and its inputs to a GPU "
+                              "(there is no CPU fallback)")
+        if self._engine is None or self._engine.device != dev:
+            if next(self.parameters()).device != dev:
+                super().to(dev)
+            self._bind_engine(dev)
+
+    def __deepcopy__(self, memo):
+        eng, names = self._engine, self._param_names
+        self._engine, self._param_names = None, []
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        finally:
+            self._engine, self._param_names = eng, names
+        return new  # the copy re-binds its own engine at its next forward
+
+    def to(self, *args, **kwargs):
+        out = super().to(*args, **kwargs)
+        self._engine = None  # storage moved: re-bind lazily
+        return out
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def _resolve_choice(self, choices):
+        """choice bookkeeping of supernet.py:513-529,585 / 605-618,650 without running anything"""
+        if not self._fixed:
+            self._supernet_train_steps_counter += 1
+        self.choice = {"micro": [], "macro": []}
+        macro = self._get_choice() if choices is None else choices["macro"]
+        self.choice["macro"] = macro
+        for i, blk in enumerate(self._blocks):
+            # the reference hands the *whole* micro list to every block (supernet.py:574,583), which cannot work;
+            # an explicit `choices` is honoured per block here
+            self.choice["micro"].append(blk._resolve_choice(None if choices is None else choices["micro"][i]))
+        return self.choice
+
+    def forward(self, int_feats: torch.Tensor, cat_feats: torch.Tensor, choices=None):
+        choice = self._resolve_choice(choices)  # host-side bookkeeping first: a fixed net may sample its path here
+        self._ensure_engine(int_feats)
+        eng = self._engine
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for _, p in self._param_names)
+        if needs_grad:
+            out = _SupernetFunction.apply(self, choice, int_feats, cat_feats, *[p for _, p in self._param_names])
+        else:
+            out = eng.forward(int_feats, cat_feats, choice).clone()
+        if self._final_sigmoid is not None:
+            out = self._final_sigmoid(out)
+        return out
+
+    def fixed_forward(self, int_feats: torch.Tensor, cat_feats: torch.Tensor, choices: Any):
+        return self.forward(int_feats, cat_feats, choices)
+
+    def engine_train_step(self, int_feats, cat_feats, y, lr: float, clip: Optional[float] = 5.0, eps: float = 1e-2, graph=None):
+        """Fused step on the engine (forward, BCE, backward, clip_grad_norm_, Adagrad with row-sparse table update):
+        the counterpart of train_utils.py:262-286 for optimizer == Adagrad, weight_decay == 0."""
+        choice = self._resolve_choice(None)
+        self._ensure_engine(int_feats)
+        graph = self._fixed if graph is None else graph
+        return self._engine.train_step(int_feats, cat_feats, y, lr, choice, clip, eps, graph=graph)
+
+
+class SuperNetBlock(nn.Module):
+    """One choice block (supernet.py:884-1381)."""
+
+    def __init__(self, ops_config: Any, use_layernorm: bool, max_dims_or_dims_dense: int, max_dims_or_dims_sparse: int,
+                 embedding_dim: int, activation: str = "relu", path_sampling_strategy: str = "single-path", fixed: bool = False,
+                 fixed_micro_choice=None, anypath_choice: str = "uniform", supernet_training_steps: int = 0,
+                 sparse_input_size: int = 26):
+        super().__init__()
+        self._num_nodes = ops_config["num_nodes"]
+        self._dense_nodes = ops_config["dense_nodes"]
+        self._sparse_nodes = ops_config["sparse_nodes"]
+        self._node_names = ops_config["node_names"]
+        self._dense_node_dims = ops_config["dense_node_dims"]
+        self._sparse_node_dims = ops_config["sparse_node_dims"]
+        self._zero_nodes = ops_config["zero_nodes"]
+        self._sparse_input_size = sparse_input_size
+        self._use_layernorm = use_layernorm
+        self._max_dims_or_dims_dense = max_dims_or_dims_dense
+        self._max_dims_or_dims_sparse = max_dims_or_dims_sparse
+        self._embedding_dim = embedding_dim
+        self._activation = activation
+        self._micro_path_sampling_strategy = path_sampling_strategy
+        self._fixed = fixed
+        self._fixed_micro_choice = fixed_micro_choice
+        self._anypath_choice_fn = anypath_choice_fn[anypath_choice]
+        self._supernet_training_steps = supernet_training_steps
+        self._device_args = None
+        self._supernet_train_steps_counter = -1
+        self._nodes = nn.ModuleList()
+        self.micro_last_choice = self._fixed_micro_choice if self._fixed else None
+        if self._fixed:
+            choice = self._get_choice()
+            self._fixed_micro_choice = choice
+            choice_nodes = choice["active_nodes"]
+        else:
+            choice, choice_nodes = None, list(range(self._num_nodes))
+        for i in range(self._num_nodes):
+            if i not in choice_nodes:
+                self._nodes.append(nn.ModuleList([]))
+                continue
+            name = self._node_names[i]
+            if name in _dense_binary_nodes + _dense_unary_nodes + _dense_sparse_nodes:
+                dims = choice["dense_in_dims"] if self._fixed else self._max_dims_or_dims_dense
+            elif name in _sparse_nodes:
+                dims = choice["sparse_in_dims"] if self._fixed else self._max_dims_or_dims_sparse
+            else:
+                raise NotImplementedError("Block name {} is not supported in supernet!".format(name))
+            self._nodes.append(_make_node(name, use_layernorm, int(dims), activation, embedding_dim, fixed))
+        if self._fixed and choice["dense_sparse_interact"] == 0:
+            self.project_emb_dim, self.project_emb_dim_layernorm = None, None
+        else:
+            self.ds_interact_expanded_dim = DS_INTERACT_NUM_SPLITS * self._embedding_dim
+            self.project_emb_dim = nn.LazyLinear(self.ds_interact_expanded_dim, bias=not use_layernorm)
+            self.project_emb_dim_layernorm = nn.LayerNorm(self.ds_interact_expanded_dim, eps=1e-5) if use_layernorm else None
+        if self._fixed and choice["deep_fm"] == 0:
+            self.deep_fm, self.deep_fm_output_ln = None, None
+        else:
+            self.deep_fm_dims = max(self._dense_node_dims) if not self._fixed else choice["dense_in_dims"]
+            self.deep_fm = FactorizationMachine3D(fixed=self._fixed, use_layernorm=self._use_layernorm, max_dims_or_dims=int(self.deep_fm_dims))
+        self.choice = []
+
+    def forward(self, tensors, choices=None):
+        raise NotImplementedError("a SuperNetBlock is executed as part of its SuperNet's launch plan; call SuperNet.forward")
+
+    def _get_choice(self):
+        """supernet.py:1009-1061"""
+        c, n = self._supernet_train_steps_counter, self._supernet_training_steps
+        thresh = 1.0 - c / (n + 1e-10) if (c < n and c > 0) else 0
+        s = self._micro_path_sampling_strategy
+        if s == "single-path":
+            choice = self._get_full_path_choice() if np.random.random() < thresh else self._get_single_path_choice()
+        elif s == "full-path":
+            choice = self._get_full_path_choice()
+        elif s == "any-path":
+            choice = self._get_full_path_choice() if np.random.random() < thresh else self._get_any_path_choice()
+        elif s == "fixed-path" and self.micro_last_choice is None:
+            if getattr(self, "_fixed_path_called", False):
+                raise ValueError("Error! fixed-path choice should be generated only once for each supernet!")
+            self._fixed_path_called = True
+            choice = self._get_fixed_path_choice()
+        elif s in ("fixed-path", "evo-2shot-path"):
+            choice = self.micro_last_choice
+        else:
+            raise NotImplementedError("Path strategy {} is not supported!".format(s))
+        if s != "full-path":
+            self.micro_last_choice = choice
+        return choice
+
+    def _resolve_choice(self, choices):
+        """supernet.py:1067-1076: draw (or take) the micro choice, then advance the block's own step counter"""
+        choice = self._get_choice() if choices is None else choices
+        self.choice = choice
+        if not self._fixed:
+            self._supernet_train_steps_counter += 1
+        return choice
+
+    def get_all_subnet_micro_choices(self):
+        """supernet.py:1164-1183"""
+        out = {"active_nodes": [], "dense_in_dims": [], "sparse_in_dims": [], "dense_sparse_interact": [0, 1]}
+        for s in self._sparse_nodes:
+            for d in self._dense_nodes:
+                out["active_nodes"].append((d, s))
+        out["dense_in_dims"] = [(x,) for x in self._dense_node_dims]
+        out["sparse_in_dims"] = [(x,) for x in self._sparse_node_dims]
+        return out
+
+    def _get_single_path_choice(self):
+        """supernet.py:1244-1263"""
+        while True:
+            choice = {"active_nodes": sorted([np.random.choice(self._dense_nodes)] + [np.random.choice(self._sparse_nodes)]),
+                      "dense_in_dims": np.random.choice(self._dense_node_dims),
+                      "sparse_in_dims": np.random.choice(self._sparse_node_dims),
+                      "dense_sparse_interact": np.random.choice([0, 1]), "deep_fm": np.random.choice([0, 1])}
+            if choice["active_nodes"] != self._zero_nodes:
+                return choice
+
+    def _get_full_path_choice(self):
+        """supernet.py:1265-1276"""
+        return {"active_nodes": np.arange(self._num_nodes), "dense_in_dims": np.max(self._dense_node_dims),
+                "sparse_in_dims": np.max(self._sparse_node_dims), "dense_sparse_interact": 1, "deep_fm": 1}
+
+    def _get_any_path_choice(self):
+        """supernet.py:1278-1303"""
+        while True:
+            nd = self._anypath_choice_fn(len(self._dense_nodes))
+            ns = self._anypath_choice_fn(len(self._sparse_nodes))
+            dn = np.random.choice(self._dense_nodes, nd, replace=False).tolist()
+            sn = np.random.choice(self._sparse_nodes, ns, replace=False).tolist()
+            choice = {"active_nodes": sorted(dn + sn), "dense_in_dims": np.random.choice(self._dense_node_dims),
+                      "sparse_in_dims": np.random.choice(self._sparse_node_dims),
+                      "dense_sparse_interact": np.random.choice([0, 1]), "deep_fm": np.random.choice([0, 1])}
+            if choice["active_nodes"] != self._zero_nodes:
+                return choice
+
+    def _get_fixed_path_choice(self):
+        """supernet.py:1305-1313"""
+        return self._get_single_path_choice()
+
+    def configure_choice(self, choice):
+        """supernet.py:1316-1318"""
+        self.choice = copy.deepcopy(choice)
+        self.micro_last_choice = copy.deepcopy(choice)

@@ -1,0 +1,89 @@
+"""CPU tests of the drop-in nn.Module surface: module tree / state_dict keys / parameters() order against what the real
+reference produced (stored in the golden fixtures), sampling order against the reference's traces, C-ABI symbols."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, golden_files, load_golden
+from nasrec_amd import _lib as L
+from nasrec_amd.search_space import ops_config_lib
+from nasrec_amd.supernet.supernet import SuperNet
+
+NPZ = golden_files("fixed_*.npz") + golden_files("supernet_*.npz")
+
+
+def build(meta, Fs):
+    fixed = meta["mode"] == "fixed"
+    return SuperNet(num_blocks=meta["num_blocks"], ops_config=ops_config_lib[meta["config"]], use_layernorm=meta["use_layernorm"],
+                    activation=meta["activation"], num_embeddings=meta["tables"], sparse_input_size=Fs,
+                    path_sampling_strategy="fixed-path" if fixed else "full-path", fixed=fixed,
+                    fixed_choice=meta["choice"] if fixed else None)
+
+
+@pytest.mark.parametrize("path", NPZ, ids=[os.path.basename(p)[:-4] for p in NPZ])
+def test_state_dict_keys_and_parameter_order_match_reference(path):
+    z, meta = load_golden(path)
+    m = build(meta, z["cat_x"].shape[1])
+    m._materialize(z["int_x"].shape[1])
+    sd = m.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == meta["param_shapes"]
+    assert list(sd.keys()) == list(meta["param_shapes"].keys())  # state_dict order
+    assert [n for n, _ in m.named_parameters()] == meta["param_order"]  # optimizer / clip order
+    # init_weights dispatches on exact types (train_utils.py:76-87)
+    kinds = {type(x) for x in m.modules()}
+    assert torch.nn.Linear in kinds and torch.nn.Embedding in kinds
+    assert not any(isinstance(x, torch.nn.LazyLinear) for x in m.modules())
+
+
+def test_sampling_order_matches_reference_traces():
+    traces = json.load(open(os.path.join(GOLDEN, "samplers.json")))
+    for tr in traces:
+        m = SuperNet(num_blocks=tr["num_blocks"], ops_config=ops_config_lib[tr["space"]], use_layernorm=True,
+                     num_embeddings=[50] * 10, sparse_input_size=10, path_sampling_strategy="full-path", fixed=False,
+                     anypath_choice=tr["anypath_choice"], supernet_training_steps=tr["supernet_training_steps"])
+        for _ in range(tr["warmup_forwards"]):
+            m._resolve_choice(None)  # the full-path warm-up forward advances every counter
+        m.configure_path_sampling_strategy(tr["strategy"])
+        np.random.seed(tr["seed"])
+        for want in tr["choices"]:
+            got = m._resolve_choice(None)
+            got = json.loads(json.dumps(got, default=lambda o: o.tolist() if hasattr(o, "tolist") else int(o)))
+            assert got == want, (tr["strategy"], tr["anypath_choice"], tr["supernet_training_steps"])
+
+
+def test_cpu_forward_fails_loudly():
+    z, meta = load_golden(os.path.join(GOLDEN, "fixed_criteo_xlarge.npz"))
+    m = build(meta, 26)
+    with pytest.raises(L.EngineError):
+        m(torch.tensor(z["int_x"]), torch.tensor(z["cat_x"]))
+
+
+def test_c_abi_exports_every_declared_symbol_and_struct_layouts():
+    lib = L.load()  # verifies symbols + sizeof of every descriptor against the header's structs
+    hdr = open(os.path.join(os.path.dirname(GOLDEN), "..", "include", "nasrec_hip.h")).read()
+    import re
+    declared = set(re.findall(r"\n(?:int|const char\*)\s+(nasrec_\w+)\(", hdr))
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s)
+    assert lib.nasrec_abi_version() == 1
+    assert lib.nasrec_launch(None, None) != 0  # null descriptor: error code + message, no crash
+    assert b"null descriptor" in lib.nasrec_last_error()
+
+
+def test_deepcopy_and_modes():
+    import copy
+    z, meta = load_golden(os.path.join(GOLDEN, "fixed_kdd_autoctr.npz"))
+    m = build(meta, 10)
+    m._materialize(3)
+    m2 = copy.deepcopy(m)
+    assert list(m2.state_dict().keys()) == list(m.state_dict().keys())
+    m.set_mode_to_finelune_last_only()
+    assert all(p.requires_grad == n.startswith("_final") for n, p in m.named_parameters())
+    m.set_mode_to_normal_mode()
+    assert all(p.requires_grad for p in m.parameters())
+    assert len(m.get_sparse_parameters()) == 10 and len(m.get_dense_parameters()) == len(list(m.parameters())) - 10

@@ -105,3 +105,76 @@ def test_three_adagrad_steps(path, graph):
         for k, (dot, nrm) in meta["params_after"].items():
             d, n = proj_checksum(k, sd[k])
             assert abs(n - nrm) <= 2e-3 * max(nrm, 1e-6), (k, n, nrm)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the drop-in nn.Module path: reference-style harness (torch BCE loss, clip_grad_norm_, torch.optim.Adagrad) on top of
+# nasrec_amd.supernet.SuperNet, compared with what the real reference produced with the same harness
+# ---------------------------------------------------------------------------------------------------------------
+MODULE_CASES = ["fixed_criteo_xlarge", "fixed_avazu_xlarge", "supernet_xlarge_any", "supernet_autoctr_single"]
+
+
+@pytest.mark.parametrize("case", MODULE_CASES)
+def test_module_dropin_with_unchanged_torch_harness(case):
+    from nasrec_amd.supernet.supernet import SuperNet
+    from helpers import GOLDEN
+    z, meta = load_golden(os.path.join(GOLDEN, case + ".npz"))
+    fixed = meta["mode"] == "fixed"
+    Fs = z["cat_x"].shape[1]
+    model = SuperNet(num_blocks=meta["num_blocks"], ops_config=ops_config_lib[meta["config"]], use_layernorm=meta["use_layernorm"],
+                     activation=meta["activation"], num_embeddings=meta["tables"], sparse_input_size=Fs,
+                     path_sampling_strategy="fixed-path" if fixed else "full-path", fixed=fixed,
+                     fixed_choice=meta["choice"] if fixed else None).to("cuda")
+    int_x, cat_x, y = torch.tensor(z["int_x"]).cuda(), torch.tensor(z["cat_x"]).cuda(), torch.tensor(z["y"]).cuda()
+    with torch.no_grad():
+        model(int_x, cat_x)  # warm-up (train_utils.py:392-433)
+    if not fixed:  # pin the path like eval_subnet_from_supernet.py:101-103 / searcher_utils.py:71
+        model.configure_path_sampling_strategy("fixed-path")
+        model.configure_choice(meta["choice"])
+    assert [n for n, _ in model.named_parameters()] == meta["param_order"]
+    model.load_state_dict({k: torch.tensor(O.seeded_param(k, s), dtype=torch.float32) for k, s in meta["param_shapes"].items()}, strict=True)
+    model.train()
+    out = model(int_x, cat_x)
+    ref = z["logits_f64"]
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(out.detach().cpu().numpy().astype(np.float64) - ref).max()) <= 1e-5 * scale
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out, y)
+    loss.backward()
+    none = sorted(n for n, p in model.named_parameters() if p.grad is None)
+    assert none == sorted(meta["grad_none"])
+    for k, (dot, nrm) in meta["grads"].items():
+        d, n = proj_checksum(k, dict(model.named_parameters())[k].grad)
+        assert abs(n - nrm) <= 2e-5 * max(nrm, 1e-6), (k, n, nrm)
+    # unchanged harness: zero_grad -> forward -> loss -> backward -> clip -> Adagrad
+    opt = torch.optim.Adagrad(model.parameters(), lr=meta["lr"], eps=1e-2)
+    losses = []
+    for _ in range(meta["n_steps"]):
+        opt.zero_grad()
+        l = torch.nn.functional.binary_cross_entropy_with_logits(model(int_x, cat_x), y)
+        l.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+        losses.append(float(l))
+    assert np.allclose(losses, z["step_losses"], rtol=2e-3, atol=2e-4), (losses, z["step_losses"])
+    sd = model.state_dict()
+    for k, (dot, nrm) in meta["params_after"].items():
+        d, n = proj_checksum(k, sd[k])
+        assert abs(n - nrm) <= 2e-3 * max(nrm, 1e-6), (k, n, nrm)
+    # the engine's fused step (row-sparse tables) lands on the same parameters as the dense-gradient harness
+    model2 = SuperNet(num_blocks=meta["num_blocks"], ops_config=ops_config_lib[meta["config"]], use_layernorm=meta["use_layernorm"],
+                      activation=meta["activation"], num_embeddings=meta["tables"], sparse_input_size=Fs,
+                      path_sampling_strategy="fixed-path" if fixed else "full-path", fixed=fixed,
+                      fixed_choice=meta["choice"] if fixed else None).to("cuda")
+    with torch.no_grad():
+        model2(int_x, cat_x)
+    if not fixed:
+        model2.configure_path_sampling_strategy("fixed-path")
+        model2.configure_choice(meta["choice"])
+    model2.load_state_dict({k: torch.tensor(O.seeded_param(k, s), dtype=torch.float32) for k, s in meta["param_shapes"].items()}, strict=True)
+    for _ in range(meta["n_steps"]):
+        model2.engine_train_step(int_x, cat_x, y.view(-1), lr=meta["lr"])
+    torch.cuda.synchronize()
+    sd2 = model2.state_dict()
+    for k in sd:
+        a, b = sd[k].double().cpu(), sd2[k].double().cpu()
+        assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(a.abs().max())), k
