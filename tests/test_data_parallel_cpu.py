@@ -1,0 +1,97 @@
+"""world_size-2 gloo test (CPU) of the data-parallel exchange used for N > 1 GPUs (nasrec_amd/parallel.py):
+after the exchange every rank holds (a) the SUM of the flat dense gradients, (b) the ids and per-sample embedding-row
+gradients of the GLOBAL batch in rank order; a row-sparse clip + Adagrad over (b) then equals the dense reference update
+(clip_grad_norm_ + torch.optim.Adagrad) of a single process at the global batch — on every rank identically."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nasrec_amd.parallel import exchange_gradients
+
+WORLD, B, FS, ROWS = 2, 6, 3, [4, 50, 7]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rowsparse_update(tables, state, idx, g, coef, lr, eps):
+    """what emb_dedup + adagrad_rows compute: first occurrence leads, duplicates summed, touched rows updated"""
+    for f in range(idx.shape[1]):
+        seen = {}
+        for b in range(idx.shape[0]):
+            seen.setdefault(int(idx[b, f]), []).append(b)
+        for row, bs in seen.items():
+            gs = sum(g[b, f] for b in bs) * coef
+            state[f][row] += gs * gs
+            tables[f][row] -= lr * gs / (state[f][row].sqrt() + eps)
+
+
+def _worker(rank, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    g = torch.Generator().manual_seed(100 + rank)
+    flat_g = torch.randn(37, generator=g, dtype=torch.float64)
+    cat = torch.stack([torch.randint(0, n, (B,), generator=g) for n in ROWS], 1)
+    sg = torch.randn(B, FS, 16, generator=g, dtype=torch.float64) * 0.1
+    cat_all = torch.zeros(WORLD * B, FS, dtype=torch.int64)
+    sg_all = torch.zeros(WORLD * B * FS * 16, dtype=torch.float64)
+    local_flat = flat_g.clone()
+    exchange_gradients(flat_g, cat, sg, cat_all, sg_all)
+    out[rank] = dict(local_flat=local_flat, flat=flat_g, cat=cat, sg=sg, cat_all=cat_all, sg_all=sg_all.view(WORLD * B, FS, 16))
+    dist.destroy_process_group()
+
+
+def test_exchange_and_rowsparse_equivalence():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(port, out), nprocs=WORLD, join=True)
+    r0, r1 = out[0], out[1]
+    # (a) all-reduce: both ranks hold the same sum
+    assert torch.equal(r0["flat"], r1["flat"])
+    assert torch.allclose(r0["flat"], r0["local_flat"] + r1["local_flat"])
+    # (b) all-gather in rank order, identical everywhere
+    for r in (r0, r1):
+        assert torch.equal(r["cat_all"], torch.cat([r0["cat"], r1["cat"]], 0))
+        assert torch.equal(r["sg_all"], torch.cat([r0["sg"], r1["sg"]], 0))
+    # (c) row-sparse update over the gathered rows == dense single-process reference at the global batch
+    idx, g = r0["cat_all"], r0["sg_all"]
+    tables = [torch.nn.Parameter(torch.randn(n, 16, dtype=torch.float64, generator=torch.Generator().manual_seed(5 + i)))
+              for i, n in enumerate(ROWS)]
+    dense = torch.nn.Parameter(torch.randn(37, dtype=torch.float64, generator=torch.Generator().manual_seed(9)))
+    mine_t = [t.detach().clone() for t in tables]
+    mine_s = [torch.zeros_like(t) for t in mine_t]
+    mine_d, mine_ds = dense.detach().clone(), torch.zeros(37, dtype=torch.float64)
+    opt = torch.optim.Adagrad(tables + [dense], lr=0.16, eps=1e-2)
+    for step in range(2):
+        for f in range(FS):
+            tables[f].grad = torch.zeros_like(tables[f]).index_add_(0, idx[:, f], g[:, f])
+        dense.grad = r0["flat"].clone()
+        total = torch.nn.utils.clip_grad_norm_(tables + [dense], 0.3)
+        opt.step()
+        # engine-side arithmetic
+        ss = float((r0["flat"] ** 2).sum())
+        for f in range(FS):
+            seen = {}
+            for b in range(idx.shape[0]):
+                seen.setdefault(int(idx[b, f]), []).append(b)
+            for bs in seen.values():
+                ss += float((sum(g[b, f] for b in bs) ** 2).sum())
+        assert abs(ss ** 0.5 - float(total)) < 1e-12
+        coef = min(1.0, 0.3 / (ss ** 0.5 + 1e-6))
+        _rowsparse_update(mine_t, mine_s, idx, g, coef, 0.16, 1e-2)
+        gd = r0["flat"] * coef
+        mine_ds += gd * gd
+        mine_d -= 0.16 * gd / (mine_ds.sqrt() + 1e-2)
+    for f in range(FS):
+        assert torch.allclose(mine_t[f], tables[f].data, rtol=0, atol=1e-12)
+    assert torch.allclose(mine_d, dense.data, rtol=0, atol=1e-12)
