@@ -92,6 +92,9 @@ typedef struct nasrec_gemm_seg {
   int32_t lda, ldb, ldc;
   int32_t Mvalid;    /* rows r >= Mvalid of A read as 0 (prefix mask on the row axis) */
   int32_t accumulate;/* zmode: C += result */
+  int32_t ones_col;  /* 1: this problem's last column j = N-1 is virtual: B(N-1,k) = 1, and C(i,N-1) = sum_k A(i,k) is
+                        written to desc.rowsum_out[i] instead of C (bias gradient fused into the weight-gradient product) */
+  int32_t _pad;
 } nasrec_gemm_seg_t;
 
 typedef struct nasrec_gemm_desc {
@@ -106,7 +109,8 @@ typedef struct nasrec_gemm_desc {
   int32_t dims_in_use;   /* < 0: no mask; else entries with index >= dims_in_use are written as 0
                             (CleverMaskGenerator, modules.py:57-96) */
   int32_t beta;      /* zmode=0: C += result */
-  int32_t splitk;    /* zmode=0 only; >1: partial slabs in `workspace` + second pass */
+  int32_t splitk;    /* >1: K is split over `splitk` workgroups per tile; partial slabs go to `workspace`, a second
+                        pass sums them in fixed order and runs the epilogue */
   const float* bias;
   float* save_z;     /* optional store of (acc+bias), addressed like C */
   float* save_act;   /* optional store of act(acc+bias), addressed like C */
@@ -117,6 +121,8 @@ typedef struct nasrec_gemm_desc {
   int32_t mul_nseg;
   int32_t _pad;
   float* workspace;  /* splitk slabs: splitk*M*N floats */
+  int32_t* counters; /* reserved (must be NULL) */
+  float* rowsum_out; /* destination of the ones_col row sums */
   const float* pre_add; /* optional, addressed like C: added to the accumulator BEFORE bias/activation — lets a
                            K-range longer than NASREC_MAX_SEGS segments be chained over several launches */
   nasrec_gemm_seg_t seg[NASREC_MAX_SEGS];

@@ -35,7 +35,7 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 class GemmSeg(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("Aaux", vp), ("Baux", vp), ("M", i32), ("N", i32), ("K", i32),
-                ("lda", i32), ("ldb", i32), ("ldc", i32), ("Mvalid", i32), ("accumulate", i32)]
+                ("lda", i32), ("ldb", i32), ("ldc", i32), ("Mvalid", i32), ("accumulate", i32), ("ones_col", i32), ("_pad", i32)]
 
 
 class GemmDesc(C.Structure):
@@ -43,7 +43,7 @@ class GemmDesc(C.Structure):
                 ("bias_on_rows", i32), ("mask_on_rows", i32), ("dims_in_use", i32), ("beta", i32), ("splitk", i32),
                 ("bias", vp), ("save_z", vp), ("save_act", vp), ("mul_ptr", vp * MAX_SEGS), ("mul_off", i32 * MAX_SEGS),
                 ("mul_width", i32 * MAX_SEGS), ("mul_ld", i32 * MAX_SEGS), ("mul_nseg", i32), ("_pad", i32),
-                ("workspace", vp), ("pre_add", vp), ("seg", GemmSeg * MAX_SEGS)]
+                ("workspace", vp), ("counters", vp), ("rowsum_out", vp), ("pre_add", vp), ("seg", GemmSeg * MAX_SEGS)]
 
 
 class EmbedDesc(C.Structure):

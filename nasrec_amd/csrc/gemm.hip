@@ -5,7 +5,7 @@
 // [B,N,16] tensors (modules.py:222-234, 358-361, 648-650) with its two autograd products — without ever
 // materialising a transpose or a concatenation (segments = K-ranges or independent z-problems).
 //
-// Tiling: 256 threads = 4 wavefronts (2x2), block tile 64x64x16, each wave 32x32 = 2x2
+// Tiling: 256 threads = 4 wavefronts (2x2), block tile 64x64x32, each wave 32x32 = 2x2
 // v_mfma_f32_16x16x4_f32 tiles (exact fp32 FMA chain, so results match an fp32 dot product bit-for-bit in
 // k order within a lane group).  Global -> registers -> LDS staging with one tile of register prefetch.
 // The k index inside a 16-deep tile is permuted (lane group g takes k = 4g..4g+3 as one ds_read_b128)
@@ -14,8 +14,9 @@
 
 #define BM 64
 #define BN 64
-#define BK 16
-#define LDS_LD 20  // 16 + 4 pad: 80-byte rows keep ds_read_b128 aligned and spread rows over banks
+#define BK 32
+#define NIT (BK / 4)       // staging loads per thread and operand: 64 rows x BK / 256 threads
+#define LDS_LD (BK + 4)    // +4 pad: rows stay 16-byte aligned for ds_read_b128 and spread over banks
 
 template <int MODE>
 __device__ __forceinline__ float load_operand(const float* __restrict__ p, const float* __restrict__ aux, int r, int k,
@@ -33,8 +34,8 @@ __device__ __forceinline__ float load_operand(const float* __restrict__ p, const
 template <int MODE>
 __device__ __forceinline__ void stage_coords(int tid, int it, int& rr, int& kk) {
   if (MODE == NASREC_AM_KC || MODE == NASREC_AM_TOKK) {
-    kk = tid & 15;
-    rr = (tid >> 4) + 16 * it;
+    kk = tid & (BK - 1);
+    rr = tid / BK + (256 / BK) * it;
   } else {
     rr = tid & 63;
     kk = (tid >> 6) + 4 * it;
@@ -49,9 +50,18 @@ __device__ __forceinline__ float mul_lookup(const nasrec_gemm_desc_t& d, int i, 
   return 0.f;
 }
 
+// leading dimension of operand A (which = 0) or B (1) of segment sq; only needed on the partial-k-tile path
+__device__ __forceinline__ int seg_ld(const nasrec_gemm_desc_t& d, int sq, int which) {
+  return which ? d.seg[sq].ldb : d.seg[sq].lda;
+}
+
 template <int CM>
 __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, const nasrec_gemm_seg_t& sg, int i, int j,
                                                float v) {
+  if (sg.ones_col && j == sg.N - 1) {  // virtual column: row sums of A (bias gradient)
+    d.rowsum_out[i] = v;
+    return;
+  }
   const long o = c_offset<CM>(i, j, sg.ldc);
   if (d.pre_add) v += d.pre_add[o];
   if (d.bias) v += d.bias_on_rows ? d.bias[i] : d.bias[j];
@@ -111,32 +121,124 @@ __global__ __launch_bounds__(256) void gemm_kernel(const nasrec_gemm_desc_t d, i
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float ra[4], rb[4];
-  auto fetch = [&](int sq, int ktq) {
+  // Staging loads.  The per-iteration instruction budget decides this kernel at small batch (one wave per SIMD: every
+  // VALU instruction costs >= 4 cycles), so everything loop-invariant is hoisted to segment entry:
+  //   * per slot: a 32-bit BYTE offset of (row, kk) relative to the segment base (rows outside the operand are
+  //     redirected to row 0 and zeroed at commit), the LDS slot, the row-valid predicate;
+  //   * per k-tile only the UNIFORM base pointer advances (scalar adds), so a load is `global_load_dword v, voff, s[base]`
+  //     with no vector address arithmetic at all;
+  //   * k bounds matter only in the last tile of a segment -> uniform branch to a checked path;
+  //   * the ReLU-mask operand and the virtual ones-column sit behind uniform branches.
+  const char* cA = nullptr;
+  const char* cB = nullptr;
+  const char* cAaux = nullptr;
+  const char* cBaux = nullptr;
+  int cK = 0, cOnes = 0, cur = -1;
+  long stepA = 0, stepB = 0;          // bytes per k-tile
+  unsigned voffA[NIT], voffB[NIT];   // byte offset of (row, kk) at k-tile 0
+  bool rvA[NIT], rvB[NIT], oneB[NIT];
+  bool edgeA = false, edgeB = false;  // any row of this tile outside the operand?
+  auto load_seg = [&](int sq) {
     const nasrec_gemm_seg_t& sg = d.seg[sq];
-    const int k0 = ktq * BK;
+    cA = reinterpret_cast<const char*>(sg.A);
+    cB = reinterpret_cast<const char*>(sg.B);
+    cAaux = reinterpret_cast<const char*>(sg.Aaux);
+    cBaux = reinterpret_cast<const char*>(sg.Baux);
+    cK = sg.K;
+    cOnes = sg.ones_col;
+    const int lda = sg.lda, ldb = sg.ldb;
     const int Ra = (sg.Mvalid > 0 && sg.Mvalid < M) ? sg.Mvalid : M;
+    const int Rb = cOnes ? N - 1 : N;
+    // every addressing mode is linear in k across k-tiles (BK is a multiple of 16)
+    stepA = 4 * operand_offset<AM>(0, BK, lda);
+    stepB = 4 * operand_offset<BMODE>(0, BK, ldb);
+    edgeA = (m0 + BM > Ra);
+    edgeB = (n0 + BN > Rb);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       int rr, kk;
       stage_coords<AM>(tid, it, rr, kk);
-      ra[it] = load_operand<AM>(sg.A, sg.Aaux, m0 + rr, k0 + kk, Ra, sg.K, sg.lda);
+      rvA[it] = (m0 + rr) < Ra;
+      voffA[it] = 4u * (unsigned)operand_offset<AM>(rvA[it] ? m0 + rr : 0, kk, lda);
       stage_coords<BMODE>(tid, it, rr, kk);
-      rb[it] = load_operand<BMODE>(sg.B, sg.Baux, n0 + rr, k0 + kk, N, sg.K, sg.ldb);
+      rvB[it] = (n0 + rr) < Rb;
+      oneB[it] = cOnes && (n0 + rr == N - 1);
+      voffB[it] = 4u * (unsigned)operand_offset<BMODE>(rvB[it] ? n0 + rr : 0, kk, ldb);
+    }
+    cur = sq;
+  };
+  // fetch() only ISSUES loads; commit() applies predicates and parks the tile in LDS one iteration later.
+  float ra[NIT], rb[NIT], xa[NIT], xb[NIT];
+  bool hasAaux = false, hasBaux = false, ktail = false;
+  int tailK = 0;  // valid k in a tail tile
+  auto fetch = [&](int ktq) {
+    const int k0 = ktq * BK;
+    const char* pa = cA + (long)ktq * stepA;
+    const char* pb = cB + (long)ktq * stepB;
+    ktail = (k0 + BK > cK);
+    tailK = cK - k0;
+    hasAaux = cAaux != nullptr;
+    hasBaux = cBaux != nullptr;
+    if (!ktail) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        ra[it] = *reinterpret_cast<const float*>(pa + voffA[it]);
+        rb[it] = *reinterpret_cast<const float*>(pb + voffB[it]);
+      }
+      if (hasAaux) {
+        const char* xp = cAaux + (long)ktq * stepA;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) xa[it] = *reinterpret_cast<const float*>(xp + voffA[it]);
+      }
+      if (hasBaux) {
+        const char* xp = cBaux + (long)ktq * stepB;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) xb[it] = *reinterpret_cast<const float*>(xp + voffB[it]);
+      }
+    } else {
+      // last (partial) k-tile of the segment: k beyond K is redirected to kk = 0 of the slot's row and zeroed at commit
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        int rr, kk;
+        stage_coords<AM>(tid, it, rr, kk);
+        const unsigned oa = (kk < tailK) ? voffA[it] : voffA[it] - 4u * (unsigned)operand_offset<AM>(0, kk, seg_ld(d, cur, 0));
+        stage_coords<BMODE>(tid, it, rr, kk);
+        const unsigned ob = (kk < tailK) ? voffB[it] : voffB[it] - 4u * (unsigned)operand_offset<BMODE>(0, kk, seg_ld(d, cur, 1));
+        ra[it] = *reinterpret_cast<const float*>(pa + oa);
+        rb[it] = *reinterpret_cast<const float*>(pb + ob);
+        if (hasAaux) xa[it] = *reinterpret_cast<const float*>(cAaux + (long)ktq * stepA + oa);
+        if (hasBaux) xb[it] = *reinterpret_cast<const float*>(cBaux + (long)ktq * stepB + ob);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      float a = ra[it], b = rb[it];
+      if (hasAaux) a = (xa[it] > 0.f) ? a : 0.f;
+      if (hasBaux) b = (xb[it] > 0.f) ? b : 0.f;
+      if (edgeA) a = rvA[it] ? a : 0.f;
+      if (edgeB) b = rvB[it] ? b : 0.f;
+      int rrA, kkA, rrB, kkB;
+      stage_coords<AM>(tid, it, rrA, kkA);
+      stage_coords<BMODE>(tid, it, rrB, kkB);
+      if (ktail) {
+        a = (kkA < tailK) ? a : 0.f;
+        b = (kkB < tailK) ? b : 0.f;
+      }
+      if (cOnes && oneB[it]) b = (!ktail || kkB < tailK) ? 1.f : 0.f;
+      As[rrA * LDS_LD + kkA] = a;
+      Bs[rrB * LDS_LD + kkB] = b;
     }
   };
 
-  if (t0 < t1) fetch(s, kt);
+  if (t0 < t1) {
+    load_seg(s);
+    fetch(kt);
+  }
   for (int t = t0; t < t1; ++t) {
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      int rr, kk;
-      stage_coords<AM>(tid, it, rr, kk);
-      As[rr * LDS_LD + kk] = ra[it];
-      stage_coords<BMODE>(tid, it, rr, kk);
-      Bs[rr * LDS_LD + kk] = rb[it];
-    }
+    commit();
     __syncthreads();
     // advance to the next live tile and prefetch it while the MFMAs run
     ++kt;
@@ -146,23 +248,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(const nasrec_gemm_desc_t d, i
         kt = 0;
       }
     }
-    if (t + 1 < t1) fetch(s, kt);
+    if (t + 1 < t1) {
+      if (s != cur) load_seg(s);
+      fetch(kt);
+    }
 
-    f32x4 af[2], bf[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + a * 16 + fr) * LDS_LD + 4 * fg]);
+    for (int kb = 0; kb < BK / 16; ++kb) {
+      f32x4 af[2], bf[2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 + b * 16 + fr) * LDS_LD + 4 * fg]);
+      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + a * 16 + fr) * LDS_LD + kb * 16 + 4 * fg]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 + b * 16 + fr) * LDS_LD + kb * 16 + 4 * fg]);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+    }
   }
 
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
   if (S > 1) {
+    // split-K: park the partial tile in this split's slab; gemm_splitk_epilogue sums the slabs in fixed order
+    // (deterministic) with one thread per output element.  An in-kernel "last arriver reduces" variant (agent-scope
+    // release/acquire, or sc1 write-through slabs) was measured 1.3-2x slower at these sizes: the serial tail of one
+    // workgroup reading S slabs costs more than the extra ~5 us launch of a fully parallel second pass.
     float* slab = d.workspace + ((long)(z * S + ks)) * Mmax * Nmax;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -195,9 +307,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue(const nasrec_gemm_de
   const int M = sg.M, N = sg.N;
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long)M * N) return;
-  // token-axis outputs: let consecutive threads walk e (=16 contiguous floats) then i
   int i, j;
-  if (CM == NASREC_CM_TOKJ) {
+  if (CM == NASREC_CM_TOKJ) {  // token-axis outputs: consecutive threads walk e (16 contiguous floats), then i
     int jb = (int)(e / ((long)M * 16));
     int rem = (int)(e % ((long)M * 16));
     i = rem >> 4;

@@ -168,6 +168,13 @@ class Ctx:
         self.keep.append(t)
         return t
 
+    def zeros_i32(self, n):
+        if self.shape_only:
+            return _FakeTensor()
+        t = torch.zeros(int(n), dtype=torch.int32, device=self.device)
+        self.keep.append(t)
+        return t
+
     def buf(self, numel, need_grad=True):
         return Buf(self, int(numel), need_grad)
 
@@ -281,17 +288,20 @@ def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, **kw):
     N = max(sd["N"] for sd in segs)
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     if zmode:
-        kt = max((sd["K"] + 15) // 16 for sd in segs)
+        kt = max((sd["K"] + 31) // 32 for sd in segs)
         S = _splitk_for(tiles, kt, len(segs))
     else:
-        kt = sum((sd["K"] + 15) // 16 for sd in segs)
+        kt = sum((sd["K"] + 31) // 32 for sd in segs)
         S = _splitk_for(tiles, kt)
     S = kw.get("splitk", S)
     d.splitk = 1
     if S > 1:
         d.splitk = S
-        ws = ctx.alloc(S * M * N * (len(segs) if zmode else 1))
+        nprob = len(segs) if zmode else 1
+        ws = ctx.alloc(S * M * N * nprob)
         d.workspace = ws.data_ptr()
+    if kw.get("rowsum_out") is not None:
+        d.rowsum_out = kw["rowsum_out"]
     return [d]
 
 
@@ -321,12 +331,20 @@ def _cover_pieces(live: List[Seg]):
     return out
 
 
-def _emit_z_groups(ctx, am, bm, cm, items):
-    """items: [(group_index, seg_dict)] -> one launch per group (in order), <= MAX_SEGS problems per launch"""
+def _emit_z_groups(ctx, am, bm, cm, items, rowsum_out=None):
+    """items: [(group_index, seg_dict)] -> one launch per group (in order), <= MAX_SEGS problems per launch.
+    rowsum_out: fuse the bias gradient into the first problem as a virtual ones-column (B(N-1,k) = 1)."""
+    first = True
     for gi in sorted({g for g, _ in items}):
         grp = [d for g, d in items if g == gi]
         for i in range(0, len(grp), L.MAX_SEGS):
-            for d in gemm_descs(ctx, am, bm, cm, grp[i:i + L.MAX_SEGS], 1):
+            chunk = grp[i:i + L.MAX_SEGS]
+            ro = None
+            if first and rowsum_out is not None:
+                chunk[0] = dict(chunk[0], N=chunk[0]["N"] + 1, ones_col=1)
+                ro = rowsum_out
+            first = False
+            for d in gemm_descs(ctx, am, bm, cm, chunk, 1, rowsum_out=ro):
                 ctx.emit(d)
 
 
@@ -448,8 +466,9 @@ def linear_dense(ctx, segs: List[Seg], Ktot, wname, nout, bias: bool, out: DV, a
         gW = ctx.gparam(wname + ".weight")
         _emit_z_groups(ctx, L.AM_RC, L.AM_RC, L.CM_PLAIN, [(rank, dict(
             A=dz_ptr, Aaux=aux_ptr, B=s.view.ptr + 4 * (a - s.koff), C=gW + 4 * a, M=nout, N=b - a, K=B, lda=dz_ld, ldb=s.view.ld, ldc=Ktot,
-            Mvalid=kd, accumulate=int(rank > 0))) for s, a, b, rank in _cover_pieces(live)])
-        if bias:
+            Mvalid=kd, accumulate=int(rank > 0))) for s, a, b, rank in _cover_pieces(live)],
+            rowsum_out=ctx.gparam(wname + ".bias") if (bias and live) else None)
+        if bias and not live:
             r = L.RowsumDesc()
             r.kind = L.OP_ROWSUM
             r.mode, r.R, r.K, r.ld, r.rvalid = L.AM_RC, nout, B, dz_ld, kd
@@ -526,8 +545,9 @@ def linear_tokens(ctx, segs: List[Seg], Ntot, wname, nout, bias: bool, out: SV, 
         gW = ctx.gparam(wname + ".weight")
         _emit_z_groups(ctx, L.AM_TOKK, L.AM_TOKK, L.CM_PLAIN, [(rank, dict(
             A=dz_ptr, Aaux=aux_ptr, B=s.view.ptr + 4 * (a - s.koff) * E, C=gW + 4 * a, M=nout, N=b - a, K=B * E, lda=dz_ld, ldb=s.view.ld,
-            ldc=Ntot, Mvalid=kd, accumulate=int(rank > 0))) for s, a, b, rank in _cover_pieces(live)])
-        if bias:
+            ldc=Ntot, Mvalid=kd, accumulate=int(rank > 0))) for s, a, b, rank in _cover_pieces(live)],
+            rowsum_out=ctx.gparam(wname + ".bias") if (bias and live) else None)
+        if bias and not live:
             r = L.RowsumDesc()
             r.kind = L.OP_ROWSUM
             r.mode, r.R, r.K, r.ld, r.rvalid = L.AM_TOKK, nout, B * E, dz_ld, kd
