@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--force-dp-path", action="store_true", help="run the N>1 exchange code path on a single rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,8 +114,9 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dp_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from nasrec_amd import _lib as L
@@ -136,7 +138,7 @@ def main():
     batches = synthetic_batches(16, 13, tables, device, 1234 + rank)
     steps_per_epoch = TRAIN_LIMIT // B
     sched = CosineAnnealingWarmupRestarts(steps_per_epoch, max_lr=LR_MAX, min_lr=LR_MIN, warmup_steps=steps_per_epoch // 10)
-    dp = DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=not args.no_graph)
+    dp = DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=not args.no_graph, force_exchange=args.force_dp_path)
 
     def run(n, start):
         for i in range(n):
@@ -216,7 +218,7 @@ def main():
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -40,12 +40,16 @@ class _Holder:
 
 
 class DataParallelStep:
-    def __init__(self, engine: SupernetEngine, choice, B_local: int, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = True):
+    def __init__(self, engine: SupernetEngine, choice, B_local: int, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = True,
+                 force_exchange: bool = False):
+        """force_exchange: take the multi-rank code path (all-reduce + all-gather + global-batch optimizer) even in a
+        single-rank process group — lets one GPU exercise exactly what N GPUs run."""
         self.engine = engine
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.B = B_local
         self.graph = graph and engine.cfg.fixed
-        if self.world == 1:
+        self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
+        if not self.exchange:
             self.cp = engine.compile(choice, B_local, True, clip, eps, graph=self.graph)
             self.choice = choice
             self.clip, self.eps = clip, eps
@@ -64,7 +68,7 @@ class DataParallelStep:
 
     def step(self, int_x, cat_x, y, lr: float):
         eng = self.engine
-        if self.world == 1:
+        if not self.exchange:
             return eng.train_step(int_x, cat_x, y, lr, self.choice, self.clip, self.eps, graph=self.graph)
         cur = torch.cuda.current_stream(eng.device)
         eng.stream.wait_stream(cur)

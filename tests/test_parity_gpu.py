@@ -178,3 +178,31 @@ def test_module_dropin_with_unchanged_torch_harness(case):
     for k in sd:
         a, b = sd[k].double().cpu(), sd2[k].double().cpu()
         assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(a.abs().max())), k
+
+
+def test_data_parallel_code_path_single_rank():
+    """The N>1 step (all-reduce of the flat gradient arena, all-gather of ids + embedding-row gradients, optimizer over
+    the gathered global batch) run in a single-rank RCCL group must land on the same parameters as the plain step."""
+    import torch.distributed as dist
+    from helpers import GOLDEN
+    from nasrec_amd.parallel import DataParallelStep
+    z, meta = load_golden(os.path.join(GOLDEN, "fixed_criteo_xlarge.npz"))
+    int_x, cat_x, y = torch.tensor(z["int_x"]).cuda(), torch.tensor(z["cat_x"]).cuda(), torch.tensor(z["y"]).cuda().view(-1)
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        outs = []
+        for force in (False, True):
+            eng = build_engine(z, meta)
+            dp = DataParallelStep(eng, meta["choice"], int_x.shape[0], clip=5.0, eps=1e-2, graph=True, force_exchange=force)
+            assert dp.exchange == force
+            for _ in range(3):
+                dp.step(int_x, cat_x, y, lr=0.05)
+            torch.cuda.synchronize()
+            outs.append(eng.state_dict())
+        for k in outs[0]:
+            assert torch.allclose(outs[0][k], outs[1][k], rtol=0, atol=1e-6), k
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
