@@ -5,7 +5,7 @@
 // [B,N,16] tensors (modules.py:222-234, 358-361, 648-650) with its two autograd products — without ever
 // materialising a transpose or a concatenation (segments = K-ranges or independent z-problems).
 //
-// Tiling: 256 threads = 4 wavefronts (2x2), block tile 64x64x32, each wave 32x32 = 2x2
+// Tiling: block tile 64x64x32 on 4 or 8 wavefronts (see NT below), each wave 32x32 (or 32x16) =
 // v_mfma_f32_16x16x4_f32 tiles (exact fp32 FMA chain, so results match an fp32 dot product bit-for-bit in
 // k order within a lane group).  Global -> registers -> LDS staging with one tile of register prefetch.
 // The k index inside a 16-deep tile is permuted (lane group g takes k = 4g..4g+3 as one ds_read_b128)
@@ -15,7 +15,11 @@
 #define BM 64
 #define BN 64
 #define BK 32
-#define NIT (BK / 4)       // staging loads per thread and operand: 64 rows x BK / 256 threads
+// The kernel is instantiated for 256 threads (4 waves, 2x2, 32x32 each: large products, throughput regime) and for
+// 512 threads (8 waves, 2x4, 32x16 each: two waves per SIMD, so one wave's waits hide under the other's MFMAs; 10-15 %
+// faster in the latency regime of batch 256 where a launch has fewer workgroups than the chip has CUs).
+#define NIT (BM * BK / NT)  // staging loads per thread and operand
+#define NB (128 * 64 / NT)  // output columns per wave: waves are laid out 2 (m) x NT/128 (n), each 32 x NB
 #define LDS_LD (BK + 4)    // +4 pad: rows stay 16-byte aligned for ds_read_b128 and spread over banks
 
 template <int MODE>
@@ -31,14 +35,14 @@ __device__ __forceinline__ float load_operand(const float* __restrict__ p, const
 }
 
 // thread -> (row, k) mapping of the staging loads: lanes run along the contiguous axis of the operand
-template <int MODE>
+template <int MODE, int NT>
 __device__ __forceinline__ void stage_coords(int tid, int it, int& rr, int& kk) {
   if (MODE == NASREC_AM_KC || MODE == NASREC_AM_TOKK) {
     kk = tid & (BK - 1);
-    rr = tid / BK + (256 / BK) * it;
+    rr = tid / BK + (NT / BK) * it;
   } else {
     rr = tid & 63;
-    kk = (tid >> 6) + 4 * it;
+    kk = (tid >> 6) + (NT / 64) * it;
   }
 }
 
@@ -77,13 +81,13 @@ __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, cons
   sg.C[o] = v;
 }
 
-template <int AM, int BMODE, int CM>
-__global__ __launch_bounds__(256) void gemm_kernel(const nasrec_gemm_desc_t d, int Mmax, int Nmax) {
+template <int AM, int BMODE, int CM, int NT>
+__global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, int Mmax, int Nmax) {
   __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / (64 / NB), wn = wave % (64 / NB);
   const int fr = lane & 15, fg = lane >> 4;
   const int S = d.splitk > 1 ? d.splitk : 1;
   const int z = d.zmode ? (int)(blockIdx.z / S) : 0;
@@ -115,11 +119,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const nasrec_gemm_desc_t d, i
     kt = skip;
   }
 
-  f32x4 acc[2][2];
+  f32x4 acc[2][NB / 16];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NB / 16; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // Staging loads.  The per-iteration instruction budget decides this kernel at small batch (one wave per SIMD: every
   // VALU instruction costs >= 4 cycles), so everything loop-invariant is hoisted to segment entry:
@@ -157,10 +161,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const nasrec_gemm_desc_t d, i
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int rr, kk;
-      stage_coords<AM>(tid, it, rr, kk);
+      stage_coords<AM, NT>(tid, it, rr, kk);
       rvA[it] = (m0 + rr) < Ra;
       voffA[it] = 4u * (unsigned)operand_offset<AM>(rvA[it] ? m0 + rr : 0, kk, lda);
-      stage_coords<BMODE>(tid, it, rr, kk);
+      stage_coords<BMODE, NT>(tid, it, rr, kk);
       rvB[it] = (n0 + rr) < Rb;
       oneB[it] = cOnes && (n0 + rr == N - 1);
       voffB[it] = 4u * (unsigned)operand_offset<BMODE>(rvB[it] ? n0 + rr : 0, kk, ldb);
@@ -200,9 +204,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const nasrec_gemm_desc_t d, i
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         int rr, kk;
-        stage_coords<AM>(tid, it, rr, kk);
+        stage_coords<AM, NT>(tid, it, rr, kk);
         const unsigned oa = (kk < tailK) ? voffA[it] : voffA[it] - 4u * (unsigned)operand_offset<AM>(0, kk, seg_ld(d, cur, 0));
-        stage_coords<BMODE>(tid, it, rr, kk);
+        stage_coords<BMODE, NT>(tid, it, rr, kk);
         const unsigned ob = (kk < tailK) ? voffB[it] : voffB[it] - 4u * (unsigned)operand_offset<BMODE>(0, kk, seg_ld(d, cur, 1));
         ra[it] = *reinterpret_cast<const float*>(pa + oa);
         rb[it] = *reinterpret_cast<const float*>(pb + ob);
@@ -220,8 +224,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const nasrec_gemm_desc_t d, i
       if (edgeA) a = rvA[it] ? a : 0.f;
       if (edgeB) b = rvB[it] ? b : 0.f;
       int rrA, kkA, rrB, kkB;
-      stage_coords<AM>(tid, it, rrA, kkA);
-      stage_coords<BMODE>(tid, it, rrB, kkB);
+      stage_coords<AM, NT>(tid, it, rrA, kkA);
+      stage_coords<BMODE, NT>(tid, it, rrB, kkB);
       if (ktail) {
         a = (kkA < tailK) ? a : 0.f;
         b = (kkB < tailK) ? b : 0.f;
@@ -255,17 +259,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const nasrec_gemm_desc_t d, i
 
 #pragma unroll
     for (int kb = 0; kb < BK / 16; ++kb) {
-      f32x4 af[2], bf[2];
+      f32x4 af[2], bf[NB / 16];
 #pragma unroll
       for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + a * 16 + fr) * LDS_LD + kb * 16 + 4 * fg]);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 + b * 16 + fr) * LDS_LD + kb * 16 + 4 * fg]);
+      for (int b = 0; b < NB / 16; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&Bs[(wn * NB + b * 16 + fr) * LDS_LD + kb * 16 + 4 * fg]);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < NB / 16; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
     }
   }
 
@@ -279,10 +283,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const nasrec_gemm_desc_t d, i
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NB / 16; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int i = m0 + wm * 32 + a * 16 + 4 * fg + r, j = n0 + wn * 32 + b * 16 + fr;
+          int i = m0 + wm * 32 + a * 16 + 4 * fg + r, j = n0 + wn * NB + b * 16 + fr;
           if (i < M && j < N) slab[(long)i * N + j] = acc[a][b][r];
         }
     return;
@@ -290,10 +294,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const nasrec_gemm_desc_t d, i
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB / 16; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int i = m0 + wm * 32 + a * 16 + 4 * fg + r, j = n0 + wn * 32 + b * 16 + fr;
+        int i = m0 + wm * 32 + a * 16 + 4 * fg + r, j = n0 + wn * NB + b * 16 + fr;
         if (i < M && j < N) epilogue_store<CM>(d, s0, i, j, acc[a][b][r]);
       }
 }
@@ -335,7 +339,10 @@ static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
   const int S = d->splitk > 1 ? d->splitk : 1;
   if (S > 1 && d->workspace == nullptr) return nasrec_set_error(-3, "gemm: splitk=%d needs a workspace", S);
   dim3 grid((Nmax + BN - 1) / BN, (Mmax + BM - 1) / BM, nprob * S);
-  hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM>), grid, dim3(256), 0, st, *d, Mmax, Nmax);
+  if ((long)grid.x * grid.y * grid.z < 1024)  // fewer than ~4 workgroups per CU: latency regime
+    hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM, 512>), grid, dim3(512), 0, st, *d, Mmax, Nmax);
+  else
+    hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM, 256>), grid, dim3(256), 0, st, *d, Mmax, Nmax);
   if (S > 1) {
     long elems = (long)Mmax * Nmax;
     dim3 g2((unsigned)((elems + 255) / 256), 1, nprob);
