@@ -33,6 +33,7 @@ extern "C" {
 #define NASREC_MAX_TABLES 32
 #define NASREC_EMB_DIM 16
 #define NASREC_MHA_PARAMS 1696 /* floats of parameter gradient produced per Transformer node */
+#define NASREC_MHA_SAVED 148   /* floats of forward state kept per token for the Transformer backward */
 
 /* operand addressing modes of the GEMM family (see DESIGN.md "One GEMM, six bindings") */
 enum {
@@ -206,6 +207,9 @@ typedef struct nasrec_mha_desc {
   float* dx;            /* overwritten */
   float* dparams_partial; /* [B, NASREC_MHA_PARAMS] */
   const float* params[12];
+  float* saved;         /* optional [B, N, NASREC_MHA_SAVED]: forward intermediates per token (scaled q, k, v, attention
+                           output, softmax max / 1/sum per head, both LayerNorm x-hats and 1/std, FFN hidden) written by the
+                           forward launch and read by the backward launch instead of recomputing the forward */
 } nasrec_mha_desc_t;
 
 /* out[c] = sum_r in[r*ld + c], r < R, c < C, fixed order.  Optionally scattered to up to 16 destination

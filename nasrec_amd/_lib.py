@@ -19,6 +19,7 @@ MAX_SEGS = 8
 MAX_TABLES = 32
 EMB_DIM = 16
 MHA_PARAMS = 1696
+MHA_SAVED = 148
 
 AM_KC, AM_RC, AM_TOKR, AM_TOKK = 0, 1, 2, 3
 CM_PLAIN, CM_TOKJ = 0, 1
@@ -67,7 +68,7 @@ class FmDesc(C.Structure):
 
 class MhaDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("N", i32), ("ldx", i32), ("ldo", i32), ("dims_in_use", i32), ("x", vp), ("out", vp),
-                ("dout", vp), ("dx", vp), ("dparams_partial", vp), ("params", vp * 12)]
+                ("dout", vp), ("dx", vp), ("dparams_partial", vp), ("params", vp * 12), ("saved", vp)]
 
 
 class ReduceRowsDesc(C.Structure):

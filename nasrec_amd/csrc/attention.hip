@@ -29,6 +29,18 @@
 #define OFF_L2W 1664
 #define OFF_L2B 1680
 
+// layout of the per-token forward state kept for the backward (NASREC_MHA_SAVED floats)
+#define SV_Q 0      // scaled query
+#define SV_K 16
+#define SV_V 32
+#define SV_O 48     // attention output (before the out-projection)
+#define SV_H1 64    // LayerNorm-1 output
+#define SV_XH1 80   // LayerNorm-1 x-hat
+#define SV_F1 96    // FFN hidden (post-ReLU)
+#define SV_XH2 112  // LayerNorm-2 x-hat
+#define SV_M 128    // per-head softmax max (8) and 1/sum (8)
+#define SV_RSTD 144 // 1/std of both LayerNorms
+
 // All 1696 parameters of the node are staged once per workgroup into LDS (6.8 KB) and read back with
 // wave-uniform (broadcast) ds_reads: keeping them in SGPRs instead blows the scalar register file.
 static __device__ const int kParamOff[12] = {OFF_WIN, OFF_BIN, OFF_WOUT, OFF_BOUT, OFF_L1W, OFF_L1B,
@@ -223,8 +235,8 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const nasrec_mha_desc_t d) 
   matvec16(Wsh + OFF_WOUT, Wsh + OFF_BOUT, o, a, scr);
 #pragma unroll
   for (int e = 0; e < 16; ++e) a[e] += x[e];
-  float h1[16], xh[16], rstd;
-  ln16_fwd(a, Wsh + OFF_L1W, Wsh + OFF_L1B, h1, xh, rstd);
+  float h1[16], xh1[16], rstd1;
+  ln16_fwd(a, Wsh + OFF_L1W, Wsh + OFF_L1B, h1, xh1, rstd1);
   float f1[16], f2[16];
   matvec16(Wsh + OFF_W1, Wsh + OFF_C1, h1, f1, scr);
 #pragma unroll
@@ -232,13 +244,32 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const nasrec_mha_desc_t d) 
   matvec16(Wsh + OFF_W2, Wsh + OFF_C2, f1, f2, scr);
 #pragma unroll
   for (int e = 0; e < 16; ++e) f2[e] += h1[e];
-  float out[16];
-  ln16_fwd(f2, Wsh + OFF_L2W, Wsh + OFF_L2B, out, xh, rstd);
+  float out[16], xh2[16], rstd2;
+  ln16_fwd(f2, Wsh + OFF_L2W, Wsh + OFF_L2B, out, xh2, rstd2);
   if (d.dims_in_use >= 0 && lane >= d.dims_in_use) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) out[e] = 0.f;
   }
   if (active) store_row16(d.out + (long)b * d.ldo + lane * 16, out);
+  if (d.saved != nullptr && active) {  // training: keep what the backward needs instead of recomputing it there
+    float* sv = d.saved + ((long)b * N + lane) * NASREC_MHA_SAVED;
+    store_row16(sv + SV_Q, q);
+    store_row16(sv + SV_K, k);
+    store_row16(sv + SV_V, v);
+    store_row16(sv + SV_O, o);
+    store_row16(sv + SV_H1, h1);
+    store_row16(sv + SV_XH1, xh1);
+    store_row16(sv + SV_F1, f1);
+    store_row16(sv + SV_XH2, xh2);
+    float ml[16];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      ml[h] = m[h];
+      ml[8 + h] = linv[h];
+    }
+    store_row16(sv + SV_M, ml);
+    *reinterpret_cast<f32x4*>(sv + SV_RSTD) = (f32x4){rstd1, rstd2, 0.f, 0.f};
+  }
 }
 
 // LDS outer-product stage: entry(o,i) = sum_tok L[tok][o] * R[tok][i], i in [0,16]; R[tok][16] == 1 gives the
@@ -304,7 +335,7 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const nasrec_mha_desc_t d) 
   const float* l2w = Wsh + OFF_L2W;
   float* gp = d.dparams_partial + (long)b * NASREC_MHA_PARAMS;
 
-  // ---------------- recompute forward ----------------
+  // ---------------- forward state: saved by the forward launch, or recomputed from x ----------------
   float x[16];
   if (active) {
     load_row16(d.x + (long)b * d.ldx + lane * 16, x);
@@ -313,33 +344,67 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const nasrec_mha_desc_t d) 
     for (int e = 0; e < 16; ++e) x[e] = 0.f;
   }
   __syncthreads();
-  float qs[16], k[16], v[16];
-  matvec16(Win, bin, x, qs, scr);
-  matvec16(Win + 256, bin + 16, x, k, scr);
-  matvec16(Win + 512, bin + 32, x, v, scr);
+  float qs[16], k[16], v[16], o[16], m[8], linv[8], h1[16], xhat1[16], rstd1, f1[16], xhat2[16], rstd2;
+  if (d.saved != nullptr) {
+    if (active) {
+      const float* sv = d.saved + ((long)b * N + lane) * NASREC_MHA_SAVED;
+      load_row16(sv + SV_Q, qs);
+      load_row16(sv + SV_K, k);
+      load_row16(sv + SV_V, v);
+      load_row16(sv + SV_O, o);
+      load_row16(sv + SV_H1, h1);
+      load_row16(sv + SV_XH1, xhat1);
+      load_row16(sv + SV_F1, f1);
+      load_row16(sv + SV_XH2, xhat2);
+      float ml[16];
+      load_row16(sv + SV_M, ml);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) qs[e] *= MHA_SCALE;
-  store_row16(Ks + lane * 16, k);
-  store_row16(Vs + lane * 16, v);
-  store_row16(Qs + lane * 16, qs);
-  __syncthreads();
-  float o[16], m[8], linv[8];
-  attn_fwd_lane(qs, Ks, Vs, N, o, m, linv);
-  float r1[16];
-  matvec16(Wout, Wsh + OFF_BOUT, o, r1, scr);
+      for (int h = 0; h < 8; ++h) {
+        m[h] = ml[h];
+        linv[h] = ml[8 + h];
+      }
+      const f32x4 rs = *reinterpret_cast<const f32x4*>(sv + SV_RSTD);
+      rstd1 = rs[0];
+      rstd2 = rs[1];
+    } else {
 #pragma unroll
-  for (int e = 0; e < 16; ++e) r1[e] += x[e];
-  float h1[16], xhat1[16], rstd1;
-  ln16_fwd(r1, l1w, Wsh + OFF_L1B, h1, xhat1, rstd1);
-  float f1[16], r2[16];
-  matvec16(W1, Wsh + OFF_C1, h1, f1, scr);
+      for (int e = 0; e < 16; ++e) qs[e] = k[e] = v[e] = o[e] = h1[e] = xhat1[e] = f1[e] = xhat2[e] = 0.f;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) f1[e] = fmaxf(f1[e], 0.f);
-  matvec16(W2, Wsh + OFF_C2, f1, r2, scr);
+      for (int h = 0; h < 8; ++h) {
+        m[h] = 0.f;
+        linv[h] = 1.f;
+      }
+      rstd1 = rstd2 = 1.f;
+    }
+    store_row16(Ks + lane * 16, k);
+    store_row16(Vs + lane * 16, v);
+    store_row16(Qs + lane * 16, qs);
+    __syncthreads();
+  } else {
+    matvec16(Win, bin, x, qs, scr);
+    matvec16(Win + 256, bin + 16, x, k, scr);
+    matvec16(Win + 512, bin + 32, x, v, scr);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) r2[e] += h1[e];
-  float y2[16], xhat2[16], rstd2;
-  ln16_fwd(r2, l2w, Wsh + OFF_L2B, y2, xhat2, rstd2);
+    for (int e = 0; e < 16; ++e) qs[e] *= MHA_SCALE;
+    store_row16(Ks + lane * 16, k);
+    store_row16(Vs + lane * 16, v);
+    store_row16(Qs + lane * 16, qs);
+    __syncthreads();
+    attn_fwd_lane(qs, Ks, Vs, N, o, m, linv);
+    float r1[16];
+    matvec16(Wout, Wsh + OFF_BOUT, o, r1, scr);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) r1[e] += x[e];
+    ln16_fwd(r1, l1w, Wsh + OFF_L1B, h1, xhat1, rstd1);
+    float r2[16], y2[16];
+    matvec16(W1, Wsh + OFF_C1, h1, f1, scr);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) f1[e] = fmaxf(f1[e], 0.f);
+    matvec16(W2, Wsh + OFF_C2, f1, r2, scr);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) r2[e] += h1[e];
+    ln16_fwd(r2, l2w, Wsh + OFF_L2B, y2, xhat2, rstd2);
+  }
 
   // ---------------- backward ----------------
   float dout[16];

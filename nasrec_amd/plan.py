@@ -824,10 +824,12 @@ def op_transformer(ctx, cfg, pre, ssegs, Ntot, max_dims, dims, out: SV):
     pp = [ctx.param(pre + "." + leaf, shp) for leaf, shp in zip(MHA_LEAVES, MHA_SHAPES)]
     if ctx.shape_only:
         return
+    saved = ctx.alloc(B * max_dims * L.MHA_SAVED) if ctx.train else None
     d = L.MhaDesc()
     d.kind = L.OP_MHA_FWD
     d.B, d.N, d.ldx, d.ldo, d.dims_in_use = B, max_dims, x.ld, out.ld, mask
     d.x, d.out = x.ptr, out.ptr
+    d.saved = saved.data_ptr() if saved is not None else None
     for q in range(12):
         d.params[q] = pp[q]
     ctx.emit(d)
@@ -843,6 +845,7 @@ def op_transformer(ctx, cfg, pre, ssegs, Ntot, max_dims, dims, out: SV):
         e.dx = xbuf.grad_tensor().data_ptr()
         xbuf.mark()
         e.dparams_partial = part.data_ptr()
+        e.saved = saved.data_ptr() if saved is not None else None
         for q in range(12):
             e.params[q] = pp[q]
         ctx.emit(e)
