@@ -2,14 +2,18 @@
 // batch_first, no dropout/mask) + residual + LayerNorm(16) + Linear(16,16) + ReLU + Linear(16,16) + residual +
 // LayerNorm(16) (+ supernet token prefix mask).
 //
-// Mapping: one wavefront = one sample, lane = token (N <= 64).  A token row is 16 fp32 = 16 VGPRs, so the
-// in/out projections, both LayerNorms and the FFN are pure in-lane math with wave-uniform weights (scalar
-// loads).  Attention at head_dim 2 has nothing for MFMA to chew on (K = 2): K/V rows are parked in LDS and
-// every lane walks the keys with LDS broadcast reads (2 FMA + 1 exp per key and head).
-// The backward kernel recomputes the forward from x (nothing but x is saved), runs the flash-style
-// two-phase attention backward (lane = query for dq, lane = key for dk/dv), and reduces the 1696 parameter
-// gradients of the node over the sample's tokens through LDS outer-product stages; per-sample partials are
-// summed across the batch in fixed order by NASREC_OP_REDUCE_ROWS (deterministic).
+// Mapping: one workgroup (4 wavefronts) = one sample; lane = token (N <= 64), wave w owns the 4-column slice
+// [4w, 4w+4) of every 16-wide vector — i.e. heads 2w and 2w+1 of the attention, rows 4w..4w+3 of every projection.
+// Full 16-vectors that a slice computation needs (the other waves' columns) go through LDS rows [token][16].
+// With one sample per wavefront only 256 of the chip's 1024 SIMDs had work at batch 256; this layout gives every
+// SIMD one wave and cuts the serial instruction stream per wave by ~4x.
+// Attention at head_dim 2 has nothing for MFMA to chew on (K = 2): K/V slices are parked in LDS and every lane walks
+// the keys (one ds_read_b128 per key for K, one for V; 2 FMA + 1 exp per key and head).
+// The forward launch saves per-token state (NASREC_MHA_SAVED floats); the backward launch reads it, runs the
+// flash-style two-phase attention backward (lane = query for dq, lane = key for dk/dv), and reduces the 1696
+// parameter gradients of the node over the sample's tokens: weight gradients as LDS outer products (lane = one
+// (row, column) entry of the wave's 4x16 slice), bias / LayerNorm gradients as wave reductions; per-sample
+// partials are summed across the batch in fixed order by NASREC_OP_REDUCE_ROWS (deterministic).
 #include "common.h"
 
 #define MHA_N 64
@@ -47,106 +51,21 @@ static __device__ const int kParamOff[12] = {OFF_WIN, OFF_BIN, OFF_WOUT, OFF_BOU
                                              OFF_W1,  OFF_C1,  OFF_W2,   OFF_C2,   OFF_L2W, OFF_L2B};
 static __device__ const int kParamLen[12] = {768, 48, 256, 16, 16, 16, 256, 16, 256, 16, 16, 16};
 
-__device__ __forceinline__ void stage_params(const nasrec_mha_desc_t& d, float* Wsh, int lane) {
+__device__ __forceinline__ void stage_params(const nasrec_mha_desc_t& d, float* Wsh, int tid) {
 #pragma unroll
   for (int q = 0; q < 12; ++q) {
     const float* src = d.params[q];
-    for (int i = lane; i < kParamLen[q]; i += 64) Wsh[kParamOff[q] + i] = src[i];
+    for (int i = tid; i < kParamLen[q]; i += 256) Wsh[kParamOff[q] + i] = src[i];
   }
 }
 
-// y = W x + b for one token row held in registers.  The output loop is deliberately NOT unrolled and the
-// result goes through the lane's private LDS scratch row: with full unrolling hipcc hoists all 256 weight loads
-// of a matvec (and of its neighbours) and spills hundreds of VGPRs.
-#define SCR_LD 20
-__device__ __forceinline__ void matvec16(const float* W, const float* b, const float* x, float* y, float* scr) {
-#pragma unroll 1
-  for (int o = 0; o < 16; ++o) {
-    const f32x4* wr = reinterpret_cast<const f32x4*>(W + o * 16);
-    float s = b[o];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      f32x4 w = wr[v];
-      s = fmaf(w[0], x[4 * v], s);
-      s = fmaf(w[1], x[4 * v + 1], s);
-      s = fmaf(w[2], x[4 * v + 2], s);
-      s = fmaf(w[3], x[4 * v + 3], s);
-    }
-    scr[o] = s;
-  }
-  const f32x4* sr = reinterpret_cast<const f32x4*>(scr);
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+__device__ __forceinline__ void ld_row(const float* p, float* x) {
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
-    f32x4 t = sr[v];
-    y[4 * v] = t[0];
-    y[4 * v + 1] = t[1];
-    y[4 * v + 2] = t[2];
-    y[4 * v + 3] = t[3];
-  }
-}
-
-// y[i] += sum_o W[o*16+i] * g[o]
-__device__ __forceinline__ void matvec16_t_acc(const float* W, const float* g, float* y, float* scr) {
-  f32x4* sw = reinterpret_cast<f32x4*>(scr);
-#pragma unroll
-  for (int v = 0; v < 4; ++v) sw[v] = (f32x4){g[4 * v], g[4 * v + 1], g[4 * v + 2], g[4 * v + 3]};
-#pragma unroll 1
-  for (int o = 0; o < 16; ++o) {
-    const f32x4* wr = reinterpret_cast<const f32x4*>(W + o * 16);
-    const float go = scr[o];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      f32x4 w = wr[v];
-      y[4 * v] = fmaf(w[0], go, y[4 * v]);
-      y[4 * v + 1] = fmaf(w[1], go, y[4 * v + 1]);
-      y[4 * v + 2] = fmaf(w[2], go, y[4 * v + 2]);
-      y[4 * v + 3] = fmaf(w[3], go, y[4 * v + 3]);
-    }
-  }
-}
-
-__device__ __forceinline__ void ln16_fwd(const float* r, const float* __restrict__ w, const float* __restrict__ b, float* y,
-                                         float* xhat, float& rstd) {
-  float mu = 0.f;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) mu += r[e];
-  mu *= (1.f / 16.f);
-  float var = 0.f;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    float c = r[e] - mu;
-    var = fmaf(c, c, var);
-  }
-  var *= (1.f / 16.f);
-  rstd = 1.f / sqrtf(var + 1e-5f);
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    xhat[e] = (r[e] - mu) * rstd;
-    y[e] = fmaf(xhat[e], w[e], b[e]);
-  }
-}
-
-// dx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat))
-__device__ __forceinline__ void ln16_bwd(const float* g, const float* __restrict__ w, const float* xhat, float rstd, float* dx) {
-  float c1 = 0.f, c2 = 0.f;
-  float gw[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    gw[e] = g[e] * w[e];
-    c1 += gw[e];
-    c2 = fmaf(gw[e], xhat[e], c2);
-  }
-  c1 *= (1.f / 16.f);
-  c2 *= (1.f / 16.f);
-#pragma unroll
-  for (int e = 0; e < 16; ++e) dx[e] = rstd * (gw[e] - c1 - xhat[e] * c2);
-}
-
-__device__ __forceinline__ void load_row16(const float* p, float* x) {
-  const f32x4* s = reinterpret_cast<const f32x4*>(p);
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    f32x4 t = s[v];
+    f32x4 t = ld4(p + 4 * v);
     x[4 * v] = t[0];
     x[4 * v + 1] = t[1];
     x[4 * v + 2] = t[2];
@@ -154,415 +73,353 @@ __device__ __forceinline__ void load_row16(const float* p, float* x) {
   }
 }
 
-__device__ __forceinline__ void store_row16(float* p, const float* x) {
-  f32x4* s = reinterpret_cast<f32x4*>(p);
+// y[r] = b[c0+r] + sum_i W[(c0+r)*16 + i] * x[i], r = 0..3  (W, b in LDS; x = full 16-vector in registers)
+__device__ __forceinline__ f32x4 mv_slice(const float* W, const float* b, int c0, const float* x) {
+  f32x4 y;
 #pragma unroll
-  for (int v = 0; v < 4; ++v) s[v] = (f32x4){x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3]};
+  for (int r = 0; r < 4; ++r) {
+    float s = b[c0 + r];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      f32x4 w = ld4(W + (c0 + r) * 16 + 4 * v);
+      s = fmaf(w[0], x[4 * v], s);
+      s = fmaf(w[1], x[4 * v + 1], s);
+      s = fmaf(w[2], x[4 * v + 2], s);
+      s = fmaf(w[3], x[4 * v + 3], s);
+    }
+    y[r] = s;
+  }
+  return y;
 }
 
-// attention forward for the lane's query against all N keys (two passes: max, then exp/accumulate)
-__device__ __forceinline__ void attn_fwd_lane(const float* qs, const float* Ks, const float* Vs, int N, float* o, float* m,
-                                              float* linv) {
+// y[ii] += sum_o W[o*16 + c0+ii] * g[o], ii = 0..3  (transposed product restricted to the wave's columns)
+__device__ __forceinline__ void mvt_slice_acc(const float* W, int c0, const float* g, f32x4& y) {
 #pragma unroll
-  for (int h = 0; h < 8; ++h) m[h] = -INFINITY;
-  for (int j = 0; j < N; ++j) {
-    float kj[16];
-    load_row16(Ks + j * 16, kj);
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      float s = fmaf(qs[2 * h], kj[2 * h], qs[2 * h + 1] * kj[2 * h + 1]);
-      m[h] = fmaxf(m[h], s);
-    }
-  }
-  float l[8];
-#pragma unroll
-  for (int h = 0; h < 8; ++h) l[h] = 0.f;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) o[e] = 0.f;
-  for (int j = 0; j < N; ++j) {
-    float kj[16], vj[16];
-    load_row16(Ks + j * 16, kj);
-    load_row16(Vs + j * 16, vj);
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      float s = fmaf(qs[2 * h], kj[2 * h], qs[2 * h + 1] * kj[2 * h + 1]);
-      float p = __expf(s - m[h]);
-      l[h] += p;
-      o[2 * h] = fmaf(p, vj[2 * h], o[2 * h]);
-      o[2 * h + 1] = fmaf(p, vj[2 * h + 1], o[2 * h + 1]);
-    }
-  }
-#pragma unroll
-  for (int h = 0; h < 8; ++h) {
-    linv[h] = 1.f / l[h];
-    o[2 * h] *= linv[h];
-    o[2 * h + 1] *= linv[h];
+  for (int o = 0; o < 16; ++o) {
+    f32x4 w = ld4(W + o * 16 + c0);
+    y[0] = fmaf(w[0], g[o], y[0]);
+    y[1] = fmaf(w[1], g[o], y[1]);
+    y[2] = fmaf(w[2], g[o], y[2]);
+    y[3] = fmaf(w[3], g[o], y[3]);
   }
 }
 
-__global__ __launch_bounds__(64) void mha_fwd_kernel(const nasrec_mha_desc_t d) {
+__device__ __forceinline__ float sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+// mean and 1/std of a 16-vector whose four slices live in the four waves (lane = token); two LDS exchanges
+__device__ __forceinline__ void ln_stats(f32x4 v, float* redA, float* redB, int w, int lane, float& mu, float& rstd) {
+  redA[w * 64 + lane] = sum4(v);
+  __syncthreads();
+  mu = ((redA[lane] + redA[64 + lane]) + (redA[128 + lane] + redA[192 + lane])) * (1.f / 16.f);
+  f32x4 c = v - mu;
+  redB[w * 64 + lane] = sum4(c * c);
+  __syncthreads();
+  const float var = ((redB[lane] + redB[64 + lane]) + (redB[128 + lane] + redB[192 + lane])) * (1.f / 16.f);
+  rstd = 1.f / sqrtf(var + 1e-5f);
+}
+
+__global__ __launch_bounds__(256) void mha_fwd_kernel(const nasrec_mha_desc_t d) {
+  __shared__ __attribute__((aligned(16))) float Wsh[NASREC_MHA_PARAMS];
   __shared__ __attribute__((aligned(16))) float Ks[MHA_N * 16];
   __shared__ __attribute__((aligned(16))) float Vs[MHA_N * 16];
-  const int b = blockIdx.x, lane = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float Ob[MHA_N * 16];
+  __shared__ __attribute__((aligned(16))) float Hb[MHA_N * 16];
+  __shared__ __attribute__((aligned(16))) float Fb[MHA_N * 16];
+  __shared__ float red[4][256];
+  const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c0 = 4 * w;
   const int N = d.N;
   const bool active = lane < N;
-  __shared__ __attribute__((aligned(16))) float Wsh[NASREC_MHA_PARAMS];
-  __shared__ __attribute__((aligned(16))) float Scr[MHA_N * SCR_LD];
-  float* scr = Scr + lane * SCR_LD;
-  stage_params(d, Wsh, lane);
-  const float* Win = Wsh + OFF_WIN;
-  const float* bin = Wsh + OFF_BIN;
+  stage_params(d, Wsh, tid);
   float x[16];
   if (active) {
-    load_row16(d.x + (long)b * d.ldx + lane * 16, x);
+    ld_row(d.x + (long)b * d.ldx + lane * 16, x);
   } else {
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = 0.f;
   }
   __syncthreads();
-  float q[16], k[16], v[16];
-  matvec16(Win, bin, x, q, scr);
-  matvec16(Win + 256, bin + 16, x, k, scr);
-  matvec16(Win + 512, bin + 32, x, v, scr);
-  store_row16(Ks + lane * 16, k);
-  store_row16(Vs + lane * 16, v);
+  // in-projection, the wave's 4 columns of q, k, v
+  f32x4 q4 = mv_slice(Wsh + OFF_WIN, Wsh + OFF_BIN, c0, x) * MHA_SCALE;
+  const f32x4 k4 = mv_slice(Wsh + OFF_WIN + 256, Wsh + OFF_BIN + 16, c0, x);
+  const f32x4 v4 = mv_slice(Wsh + OFF_WIN + 512, Wsh + OFF_BIN + 32, c0, x);
+  st4(Ks + lane * 16 + c0, k4);
+  st4(Vs + lane * 16 + c0, v4);
   __syncthreads();
-#pragma unroll
-  for (int e = 0; e < 16; ++e) q[e] *= MHA_SCALE;
-  float o[16], m[8], linv[8];
-  attn_fwd_lane(q, Ks, Vs, N, o, m, linv);
-  float a[16];
-  matvec16(Wsh + OFF_WOUT, Wsh + OFF_BOUT, o, a, scr);
-#pragma unroll
-  for (int e = 0; e < 16; ++e) a[e] += x[e];
-  float h1[16], xh1[16], rstd1;
-  ln16_fwd(a, Wsh + OFF_L1W, Wsh + OFF_L1B, h1, xh1, rstd1);
-  float f1[16], f2[16];
-  matvec16(Wsh + OFF_W1, Wsh + OFF_C1, h1, f1, scr);
-#pragma unroll
-  for (int e = 0; e < 16; ++e) f1[e] = fmaxf(f1[e], 0.f);
-  matvec16(Wsh + OFF_W2, Wsh + OFF_C2, f1, f2, scr);
-#pragma unroll
-  for (int e = 0; e < 16; ++e) f2[e] += h1[e];
-  float out[16], xh2[16], rstd2;
-  ln16_fwd(f2, Wsh + OFF_L2W, Wsh + OFF_L2B, out, xh2, rstd2);
-  if (d.dims_in_use >= 0 && lane >= d.dims_in_use) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) out[e] = 0.f;
+  // attention, heads 2w (columns c0, c0+1) and 2w+1 (columns c0+2, c0+3)
+  float mA = -INFINITY, mB = -INFINITY;
+  for (int j = 0; j < N; ++j) {
+    const f32x4 kj = ld4(Ks + j * 16 + c0);
+    mA = fmaxf(mA, fmaf(q4[0], kj[0], q4[1] * kj[1]));
+    mB = fmaxf(mB, fmaf(q4[2], kj[2], q4[3] * kj[3]));
   }
-  if (active) store_row16(d.out + (long)b * d.ldo + lane * 16, out);
+  float lA = 0.f, lB = 0.f;
+  f32x4 o4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < N; ++j) {
+    const f32x4 kj = ld4(Ks + j * 16 + c0);
+    const f32x4 vj = ld4(Vs + j * 16 + c0);
+    const float pA = __expf(fmaf(q4[0], kj[0], q4[1] * kj[1]) - mA);
+    const float pB = __expf(fmaf(q4[2], kj[2], q4[3] * kj[3]) - mB);
+    lA += pA;
+    lB += pB;
+    o4[0] = fmaf(pA, vj[0], o4[0]);
+    o4[1] = fmaf(pA, vj[1], o4[1]);
+    o4[2] = fmaf(pB, vj[2], o4[2]);
+    o4[3] = fmaf(pB, vj[3], o4[3]);
+  }
+  const float liA = 1.f / lA, liB = 1.f / lB;
+  o4[0] *= liA;
+  o4[1] *= liA;
+  o4[2] *= liB;
+  o4[3] *= liB;
+  st4(Ob + lane * 16 + c0, o4);
+  __syncthreads();
+  // out-projection + residual + LayerNorm 1
+  float row[16];
+  ld_row(Ob + lane * 16, row);
+  f32x4 r1 = mv_slice(Wsh + OFF_WOUT, Wsh + OFF_BOUT, c0, row);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) r1[r] += x[c0 + r];
+  float mu1, rstd1;
+  ln_stats(r1, red[0], red[1], w, lane, mu1, rstd1);
+  const f32x4 xh1 = (r1 - mu1) * rstd1;
+  const f32x4 h1 = xh1 * ld4(Wsh + OFF_L1W + c0) + ld4(Wsh + OFF_L1B + c0);
+  st4(Hb + lane * 16 + c0, h1);
+  __syncthreads();
+  // FFN
+  ld_row(Hb + lane * 16, row);
+  f32x4 f1 = mv_slice(Wsh + OFF_W1, Wsh + OFF_C1, c0, row);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) f1[r] = fmaxf(f1[r], 0.f);
+  st4(Fb + lane * 16 + c0, f1);
+  __syncthreads();
+  ld_row(Fb + lane * 16, row);
+  const f32x4 r2 = mv_slice(Wsh + OFF_W2, Wsh + OFF_C2, c0, row) + h1;
+  float mu2, rstd2;
+  ln_stats(r2, red[2], red[3], w, lane, mu2, rstd2);
+  const f32x4 xh2 = (r2 - mu2) * rstd2;
+  f32x4 out = xh2 * ld4(Wsh + OFF_L2W + c0) + ld4(Wsh + OFF_L2B + c0);
+  if (d.dims_in_use >= 0 && lane >= d.dims_in_use) out = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (active) st4(d.out + (long)b * d.ldo + lane * 16 + c0, out);
   if (d.saved != nullptr && active) {  // training: keep what the backward needs instead of recomputing it there
     float* sv = d.saved + ((long)b * N + lane) * NASREC_MHA_SAVED;
-    store_row16(sv + SV_Q, q);
-    store_row16(sv + SV_K, k);
-    store_row16(sv + SV_V, v);
-    store_row16(sv + SV_O, o);
-    store_row16(sv + SV_H1, h1);
-    store_row16(sv + SV_XH1, xh1);
-    store_row16(sv + SV_F1, f1);
-    store_row16(sv + SV_XH2, xh2);
-    float ml[16];
+    st4(sv + SV_Q + c0, q4);
+    st4(sv + SV_K + c0, k4);
+    st4(sv + SV_V + c0, v4);
+    st4(sv + SV_O + c0, o4);
+    st4(sv + SV_H1 + c0, h1);
+    st4(sv + SV_XH1 + c0, xh1);
+    st4(sv + SV_F1 + c0, f1);
+    st4(sv + SV_XH2 + c0, xh2);
+    sv[SV_M + 2 * w] = mA;
+    sv[SV_M + 2 * w + 1] = mB;
+    sv[SV_M + 8 + 2 * w] = liA;
+    sv[SV_M + 8 + 2 * w + 1] = liB;
+    if (w == 0) st4(sv + SV_RSTD, (f32x4){rstd1, rstd2, 0.f, 0.f});
+  }
+}
+
+// Weight-gradient slice of one product y = W v (W [16,16]): dW[c0+o][i] = sum_tok G[tok][c0+o] * V[tok][i], o < 4.
+// lane = one of the wave's 64 entries (o = lane >> 4, i = lane & 15); G, V are LDS rows [token][16].
+__device__ __forceinline__ void wgrad_slice(const float* G, const float* V, int c0, int lane, int N, float* out) {
+  const int o = lane >> 4, i = lane & 15;
+  float s = 0.f;
+  for (int t = 0; t < N; ++t) s = fmaf(G[t * 16 + c0 + o], V[t * 16 + i], s);
+  out[(c0 + o) * 16 + i] = s;
+}
+
+// bias-like gradient slice: out[c0+r] = sum over tokens (lanes) of g[r]
+__device__ __forceinline__ void bgrad_slice(f32x4 g, int c0, int lane, float* out) {
 #pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      ml[h] = m[h];
-      ml[8 + h] = linv[h];
-    }
-    store_row16(sv + SV_M, ml);
-    *reinterpret_cast<f32x4*>(sv + SV_RSTD) = (f32x4){rstd1, rstd2, 0.f, 0.f};
+  for (int r = 0; r < 4; ++r) {
+    const float s = wave_sum(g[r]);
+    if (lane == 0) out[c0 + r] = s;
   }
 }
 
-// LDS outer-product stage: entry(o,i) = sum_tok L[tok][o] * R[tok][i], i in [0,16]; R[tok][16] == 1 gives the
-// column sums of L.  diag_only: only entries (e,e) and (e,16).
-#define ST_LD 17
-__device__ __forceinline__ void stage_rows(float* Ls, float* Rs, int lane, const float* l, const float* r) {
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    Ls[lane * ST_LD + e] = l[e];
-    Rs[lane * ST_LD + e] = r[e];
-  }
-  Rs[lane * ST_LD + 16] = 1.f;
-}
-
-__device__ __forceinline__ void stage_reduce(const float* Ls, const float* Rs, int lane, int N, float* outW, float* outB) {
-  // 16 x 17 entries over 64 lanes
-  for (int ent = lane; ent < 16 * 17; ent += 64) {
-    const int o = ent / 17, i = ent % 17;
-    float s = 0.f;
-    for (int t = 0; t < N; ++t) s = fmaf(Ls[t * ST_LD + o], Rs[t * ST_LD + i], s);
-    if (i < 16)
-      outW[o * 16 + i] = s;
-    else
-      outB[o] = s;
-  }
-}
-
-__device__ __forceinline__ void stage_reduce_diag(const float* Ls, const float* Rs, int lane, int N, float* outW, float* outB) {
-  if (lane < 32) {
-    const int o = lane & 15, i = lane < 16 ? o : 16;
-    float s = 0.f;
-    for (int t = 0; t < N; ++t) s = fmaf(Ls[t * ST_LD + o], Rs[t * ST_LD + i], s);
-    if (lane < 16)
-      outW[o] = s;
-    else
-      outB[o] = s;
-  }
-}
-
-__global__ __launch_bounds__(64) void mha_bwd_kernel(const nasrec_mha_desc_t d) {
-  __shared__ __attribute__((aligned(16))) float Ks[MHA_N * 16];
-  __shared__ __attribute__((aligned(16))) float Vs[MHA_N * 16];
-  __shared__ __attribute__((aligned(16))) float Qs[MHA_N * 16];
-  __shared__ __attribute__((aligned(16))) float DOs[MHA_N * 16];
-  __shared__ __attribute__((aligned(16))) float Ms[MHA_N * 8];
-  __shared__ __attribute__((aligned(16))) float Li[MHA_N * 8];
-  __shared__ __attribute__((aligned(16))) float Dl[MHA_N * 8];
-  __shared__ float Ls[MHA_N * ST_LD];
-  __shared__ float Rs[MHA_N * ST_LD];
-  const int b = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void mha_bwd_kernel(const nasrec_mha_desc_t d) {
+  __shared__ __attribute__((aligned(16))) float Wsh[NASREC_MHA_PARAMS];
+  __shared__ __attribute__((aligned(16))) float Bf[9][MHA_N * 16];
+  __shared__ __attribute__((aligned(16))) float Mb[MHA_N * 8];
+  __shared__ __attribute__((aligned(16))) float Lb[MHA_N * 8];
+  __shared__ __attribute__((aligned(16))) float Db[MHA_N * 8];
+  __shared__ float red[4][256];
+  // LDS rows [token][16]; buffers are re-used once their previous content is dead (a barrier separates the uses)
+  float* Xb = Bf[0];
+  float* Qb = Bf[1];
+  float* Kb = Bf[2];
+  float* Vb = Bf[3];
+  float* Ob = Bf[4];
+  float* F1b = Bf[5];
+  float* DOb = Bf[5];   // after the FFN-2 stage
+  float* H1b = Bf[6];
+  float* DQb = Bf[6];   // after the FFN-1 stage
+  float* DR2b = Bf[7];
+  float* DR1b = Bf[7];  // after the FFN-2 stage
+  float* DKb = Bf[7];   // after the out-projection stage
+  float* DF1b = Bf[8];
+  float* DVb = Bf[8];   // after the FFN-1 stage
+  const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c0 = 4 * w;
   const int N = d.N;
   const bool active = lane < N;
-  __shared__ __attribute__((aligned(16))) float Wsh[NASREC_MHA_PARAMS];
-  __shared__ __attribute__((aligned(16))) float Scr[MHA_N * SCR_LD];
-  float* scr = Scr + lane * SCR_LD;
-  stage_params(d, Wsh, lane);
-  const float* Win = Wsh + OFF_WIN;
-  const float* bin = Wsh + OFF_BIN;
-  const float* Wout = Wsh + OFF_WOUT;
-  const float* l1w = Wsh + OFF_L1W;
-  const float* W1 = Wsh + OFF_W1;
-  const float* W2 = Wsh + OFF_W2;
-  const float* l2w = Wsh + OFF_L2W;
   float* gp = d.dparams_partial + (long)b * NASREC_MHA_PARAMS;
-
-  // ---------------- forward state: saved by the forward launch, or recomputed from x ----------------
-  float x[16];
+  stage_params(d, Wsh, tid);
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 x4 = zero4, q4 = zero4, k4 = zero4, v4 = zero4, o4 = zero4, h1 = zero4, xh1 = zero4, f1 = zero4, xh2 = zero4, dout = zero4;
+  float mA = 0.f, mB = 0.f, liA = 1.f, liB = 1.f, rstd1 = 1.f, rstd2 = 1.f;
   if (active) {
-    load_row16(d.x + (long)b * d.ldx + lane * 16, x);
-  } else {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = 0.f;
+    const float* sv = d.saved + ((long)b * N + lane) * NASREC_MHA_SAVED;
+    x4 = ld4(d.x + (long)b * d.ldx + lane * 16 + c0);
+    q4 = ld4(sv + SV_Q + c0);
+    k4 = ld4(sv + SV_K + c0);
+    v4 = ld4(sv + SV_V + c0);
+    o4 = ld4(sv + SV_O + c0);
+    h1 = ld4(sv + SV_H1 + c0);
+    xh1 = ld4(sv + SV_XH1 + c0);
+    f1 = ld4(sv + SV_F1 + c0);
+    xh2 = ld4(sv + SV_XH2 + c0);
+    mA = sv[SV_M + 2 * w];
+    mB = sv[SV_M + 2 * w + 1];
+    liA = sv[SV_M + 8 + 2 * w];
+    liB = sv[SV_M + 8 + 2 * w + 1];
+    rstd1 = sv[SV_RSTD];
+    rstd2 = sv[SV_RSTD + 1];
+    if (!(d.dims_in_use >= 0 && lane >= d.dims_in_use)) dout = ld4(d.dout + (long)b * d.ldo + lane * 16 + c0);
   }
+  st4(Xb + lane * 16 + c0, x4);
+  st4(Qb + lane * 16 + c0, q4);
+  st4(Kb + lane * 16 + c0, k4);
+  st4(Vb + lane * 16 + c0, v4);
+  st4(Ob + lane * 16 + c0, o4);
+  st4(F1b + lane * 16 + c0, f1);
+  st4(H1b + lane * 16 + c0, h1);
+  Mb[lane * 8 + 2 * w] = mA;
+  Mb[lane * 8 + 2 * w + 1] = mB;
+  Lb[lane * 8 + 2 * w] = liA;
+  Lb[lane * 8 + 2 * w + 1] = liB;
+  // ---- LayerNorm 2 ----
+  bgrad_slice(dout * xh2, c0, lane, gp + OFF_L2W);
+  bgrad_slice(dout, c0, lane, gp + OFF_L2B);
+  __syncthreads();  // parameters and the token rows are in LDS
+  f32x4 gw = dout * ld4(Wsh + OFF_L2W + c0);
+  red[0][w * 64 + lane] = sum4(gw);
+  red[1][w * 64 + lane] = sum4(gw * xh2);
   __syncthreads();
-  float qs[16], k[16], v[16], o[16], m[8], linv[8], h1[16], xhat1[16], rstd1, f1[16], xhat2[16], rstd2;
-  if (d.saved != nullptr) {
-    if (active) {
-      const float* sv = d.saved + ((long)b * N + lane) * NASREC_MHA_SAVED;
-      load_row16(sv + SV_Q, qs);
-      load_row16(sv + SV_K, k);
-      load_row16(sv + SV_V, v);
-      load_row16(sv + SV_O, o);
-      load_row16(sv + SV_H1, h1);
-      load_row16(sv + SV_XH1, xhat1);
-      load_row16(sv + SV_F1, f1);
-      load_row16(sv + SV_XH2, xhat2);
-      float ml[16];
-      load_row16(sv + SV_M, ml);
-#pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        m[h] = ml[h];
-        linv[h] = ml[8 + h];
-      }
-      const f32x4 rs = *reinterpret_cast<const f32x4*>(sv + SV_RSTD);
-      rstd1 = rs[0];
-      rstd2 = rs[1];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) qs[e] = k[e] = v[e] = o[e] = h1[e] = xhat1[e] = f1[e] = xhat2[e] = 0.f;
-#pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        m[h] = 0.f;
-        linv[h] = 1.f;
-      }
-      rstd1 = rstd2 = 1.f;
-    }
-    store_row16(Ks + lane * 16, k);
-    store_row16(Vs + lane * 16, v);
-    store_row16(Qs + lane * 16, qs);
-    __syncthreads();
-  } else {
-    matvec16(Win, bin, x, qs, scr);
-    matvec16(Win + 256, bin + 16, x, k, scr);
-    matvec16(Win + 512, bin + 32, x, v, scr);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) qs[e] *= MHA_SCALE;
-    store_row16(Ks + lane * 16, k);
-    store_row16(Vs + lane * 16, v);
-    store_row16(Qs + lane * 16, qs);
-    __syncthreads();
-    attn_fwd_lane(qs, Ks, Vs, N, o, m, linv);
-    float r1[16];
-    matvec16(Wout, Wsh + OFF_BOUT, o, r1, scr);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) r1[e] += x[e];
-    ln16_fwd(r1, l1w, Wsh + OFF_L1B, h1, xhat1, rstd1);
-    float r2[16], y2[16];
-    matvec16(W1, Wsh + OFF_C1, h1, f1, scr);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) f1[e] = fmaxf(f1[e], 0.f);
-    matvec16(W2, Wsh + OFF_C2, f1, r2, scr);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) r2[e] += h1[e];
-    ln16_fwd(r2, l2w, Wsh + OFF_L2B, y2, xhat2, rstd2);
-  }
-
-  // ---------------- backward ----------------
-  float dout[16];
-  const bool has_grad = active && !(d.dims_in_use >= 0 && lane >= d.dims_in_use);
-  if (has_grad) {
-    load_row16(d.dout + (long)b * d.ldo + lane * 16, dout);
-  } else {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dout[e] = 0.f;
-  }
-  // LN2 parameter grads: dl2w = sum dout*xhat2 (diagonal), dl2b = sum dout
-  stage_rows(Ls, Rs, lane, dout, xhat2);
+  float c1 = ((red[0][lane] + red[0][64 + lane]) + (red[0][128 + lane] + red[0][192 + lane])) * (1.f / 16.f);
+  float c2 = ((red[1][lane] + red[1][64 + lane]) + (red[1][128 + lane] + red[1][192 + lane])) * (1.f / 16.f);
+  const f32x4 dr2 = (gw - c1 - xh2 * c2) * rstd2;
+  st4(DR2b + lane * 16 + c0, dr2);
   __syncthreads();
-  stage_reduce_diag(Ls, Rs, lane, N, gp + OFF_L2W, gp + OFF_L2B);
-  __syncthreads();
-  float dr2[16];
-  ln16_bwd(dout, l2w, xhat2, rstd2, dr2);
-  // FFN second layer: f2 = W2 f1 + c2
-  stage_rows(Ls, Rs, lane, dr2, f1);
-  __syncthreads();
-  stage_reduce(Ls, Rs, lane, N, gp + OFF_W2, gp + OFF_C2);
-  __syncthreads();
-  float df1[16];
+  // ---- FFN 2: f2 = W2 f1 + c2 ----
+  wgrad_slice(DR2b, F1b, c0, lane, N, gp + OFF_W2);
+  bgrad_slice(dr2, c0, lane, gp + OFF_C2);
+  float row[16];
+  ld_row(DR2b + lane * 16, row);
+  f32x4 df1 = zero4;
+  mvt_slice_acc(Wsh + OFF_W2, c0, row, df1);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) df1[e] = 0.f;
-  matvec16_t_acc(W2, dr2, df1, scr);
-#pragma unroll
-  for (int e = 0; e < 16; ++e) df1[e] = f1[e] > 0.f ? df1[e] : 0.f;
-  // FFN first layer
-  stage_rows(Ls, Rs, lane, df1, h1);
+  for (int r = 0; r < 4; ++r) df1[r] = f1[r] > 0.f ? df1[r] : 0.f;
+  st4(DF1b + lane * 16 + c0, df1);
   __syncthreads();
-  stage_reduce(Ls, Rs, lane, N, gp + OFF_W1, gp + OFF_C1);
+  // ---- FFN 1: f1 = relu(W1 h1 + c1) ----
+  wgrad_slice(DF1b, H1b, c0, lane, N, gp + OFF_W1);
+  bgrad_slice(df1, c0, lane, gp + OFF_C1);
+  ld_row(DF1b + lane * 16, row);
+  f32x4 dh1 = dr2;
+  mvt_slice_acc(Wsh + OFF_W1, c0, row, dh1);
+  // ---- LayerNorm 1 ----
+  bgrad_slice(dh1 * xh1, c0, lane, gp + OFF_L1W);
+  bgrad_slice(dh1, c0, lane, gp + OFF_L1B);
+  gw = dh1 * ld4(Wsh + OFF_L1W + c0);
+  red[2][w * 64 + lane] = sum4(gw);
+  red[3][w * 64 + lane] = sum4(gw * xh1);
+  __syncthreads();  // also: every wave is done reading DR2b / F1b / H1b / DF1b
+  c1 = ((red[2][lane] + red[2][64 + lane]) + (red[2][128 + lane] + red[2][192 + lane])) * (1.f / 16.f);
+  c2 = ((red[3][lane] + red[3][64 + lane]) + (red[3][128 + lane] + red[3][192 + lane])) * (1.f / 16.f);
+  const f32x4 dr1 = (gw - c1 - xh1 * c2) * rstd1;
+  st4(DR1b + lane * 16 + c0, dr1);
   __syncthreads();
-  float dh1[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) dh1[e] = dr2[e];
-  matvec16_t_acc(W1, df1, dh1, scr);
-  // LN1
-  stage_rows(Ls, Rs, lane, dh1, xhat1);
-  __syncthreads();
-  stage_reduce_diag(Ls, Rs, lane, N, gp + OFF_L1W, gp + OFF_L1B);
-  __syncthreads();
-  float dr1[16];
-  ln16_bwd(dh1, l1w, xhat1, rstd1, dr1);
-  // out-projection: a = Wout o + bout
-  stage_rows(Ls, Rs, lane, dr1, o);
-  __syncthreads();
-  stage_reduce(Ls, Rs, lane, N, gp + OFF_WOUT, gp + OFF_BOUT);
-  __syncthreads();
-  float dO[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) dO[e] = 0.f;
-  matvec16_t_acc(Wout, dr1, dO, scr);
-  // attention backward
-  float delta[8];
-#pragma unroll
-  for (int h = 0; h < 8; ++h) delta[h] = fmaf(dO[2 * h], o[2 * h], dO[2 * h + 1] * o[2 * h + 1]);
-  store_row16(DOs + lane * 16, dO);
-#pragma unroll
-  for (int h = 0; h < 8; ++h) {
-    Ms[lane * 8 + h] = m[h];
-    Li[lane * 8 + h] = linv[h];
-    Dl[lane * 8 + h] = delta[h];
-  }
-  __syncthreads();
-  // phase A: lane = query -> dq
-  float dq[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+  // ---- out-projection: a = Wout o + bout ----
+  wgrad_slice(DR1b, Ob, c0, lane, N, gp + OFF_WOUT);
+  bgrad_slice(dr1, c0, lane, gp + OFF_BOUT);
+  ld_row(DR1b + lane * 16, row);
+  f32x4 dO = zero4;
+  mvt_slice_acc(Wsh + OFF_WOUT, c0, row, dO);
+  const float dA = fmaf(dO[0], o4[0], dO[1] * o4[1]);
+  const float dB = fmaf(dO[2], o4[2], dO[3] * o4[3]);
+  st4(DOb + lane * 16 + c0, dO);
+  Db[lane * 8 + 2 * w] = dA;
+  Db[lane * 8 + 2 * w + 1] = dB;
+  __syncthreads();  // also: every wave is done reading DR1b
+  // ---- attention backward, heads 2w and 2w+1 ----
+  f32x4 dq = zero4;  // phase A: lane = query
   for (int j = 0; j < N; ++j) {
-    float kj[16], vj[16];
-    load_row16(Ks + j * 16, kj);
-    load_row16(Vs + j * 16, vj);
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      float s = fmaf(qs[2 * h], kj[2 * h], qs[2 * h + 1] * kj[2 * h + 1]);
-      float p = __expf(s - m[h]) * linv[h];
-      float dp = fmaf(dO[2 * h], vj[2 * h], dO[2 * h + 1] * vj[2 * h + 1]);
-      float ds = p * (dp - delta[h]);
-      dq[2 * h] = fmaf(ds, kj[2 * h], dq[2 * h]);
-      dq[2 * h + 1] = fmaf(ds, kj[2 * h + 1], dq[2 * h + 1]);
-    }
+    const f32x4 kj = ld4(Kb + j * 16 + c0);
+    const f32x4 vj = ld4(Vb + j * 16 + c0);
+    const float pA = __expf(fmaf(q4[0], kj[0], q4[1] * kj[1]) - mA) * liA;
+    const float pB = __expf(fmaf(q4[2], kj[2], q4[3] * kj[3]) - mB) * liB;
+    const float dsA = pA * (fmaf(dO[0], vj[0], dO[1] * vj[1]) - dA);
+    const float dsB = pB * (fmaf(dO[2], vj[2], dO[3] * vj[3]) - dB);
+    dq[0] = fmaf(dsA, kj[0], dq[0]);
+    dq[1] = fmaf(dsA, kj[1], dq[1]);
+    dq[2] = fmaf(dsB, kj[2], dq[2]);
+    dq[3] = fmaf(dsB, kj[3], dq[3]);
   }
-#pragma unroll
-  for (int e = 0; e < 16; ++e) dq[e] *= MHA_SCALE;
-  // phase B: lane = key -> dk, dv
-  float dk[16], dv[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    dk[e] = 0.f;
-    dv[e] = 0.f;
-  }
+  dq = dq * MHA_SCALE;
+  f32x4 dk = zero4, dv = zero4;  // phase B: lane = key
   for (int i = 0; i < N; ++i) {
-    float qi[16], doi[16], mi[8], li[8], di[8];
-    load_row16(Qs + i * 16, qi);
-    load_row16(DOs + i * 16, doi);
-    {
-      const f32x4* pm = reinterpret_cast<const f32x4*>(Ms + i * 8);
-      const f32x4* pl = reinterpret_cast<const f32x4*>(Li + i * 8);
-      const f32x4* pd = reinterpret_cast<const f32x4*>(Dl + i * 8);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        f32x4 a = pm[u], c = pl[u], e4 = pd[u];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          mi[4 * u + w] = a[w];
-          li[4 * u + w] = c[w];
-          di[4 * u + w] = e4[w];
-        }
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      float s = fmaf(qi[2 * h], k[2 * h], qi[2 * h + 1] * k[2 * h + 1]);
-      float p = __expf(s - mi[h]) * li[h];
-      dv[2 * h] = fmaf(p, doi[2 * h], dv[2 * h]);
-      dv[2 * h + 1] = fmaf(p, doi[2 * h + 1], dv[2 * h + 1]);
-      float dp = fmaf(doi[2 * h], v[2 * h], doi[2 * h + 1] * v[2 * h + 1]);
-      float ds = p * (dp - di[h]);
-      dk[2 * h] = fmaf(ds, qi[2 * h], dk[2 * h]);
-      dk[2 * h + 1] = fmaf(ds, qi[2 * h + 1], dk[2 * h + 1]);
-    }
+    const f32x4 qi = ld4(Qb + i * 16 + c0);
+    const f32x4 doi = ld4(DOb + i * 16 + c0);
+    const float miA = Mb[i * 8 + 2 * w], miB = Mb[i * 8 + 2 * w + 1];
+    const float lA_ = Lb[i * 8 + 2 * w], lB_ = Lb[i * 8 + 2 * w + 1];
+    const float diA = Db[i * 8 + 2 * w], diB = Db[i * 8 + 2 * w + 1];
+    const float pA = __expf(fmaf(qi[0], k4[0], qi[1] * k4[1]) - miA) * lA_;
+    const float pB = __expf(fmaf(qi[2], k4[2], qi[3] * k4[3]) - miB) * lB_;
+    dv[0] = fmaf(pA, doi[0], dv[0]);
+    dv[1] = fmaf(pA, doi[1], dv[1]);
+    dv[2] = fmaf(pB, doi[2], dv[2]);
+    dv[3] = fmaf(pB, doi[3], dv[3]);
+    const float dsA = pA * (fmaf(doi[0], v4[0], doi[1] * v4[1]) - diA);
+    const float dsB = pB * (fmaf(doi[2], v4[2], doi[3] * v4[3]) - diB);
+    dk[0] = fmaf(dsA, qi[0], dk[0]);
+    dk[1] = fmaf(dsA, qi[1], dk[1]);
+    dk[2] = fmaf(dsB, qi[2], dk[2]);
+    dk[3] = fmaf(dsB, qi[3], dk[3]);
   }
   if (!active) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      dk[e] = 0.f;
-      dv[e] = 0.f;
-      dq[e] = 0.f;
-    }
+    dq = zero4;
+    dk = zero4;
+    dv = zero4;
   }
-  // in-projection parameter grads (three 16-row stages) and dx
-  float dx[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) dx[e] = dr1[e];
-  stage_rows(Ls, Rs, lane, dq, x);
+  __syncthreads();  // every wave is done with Qb/DOb (DQb aliases H1b, DKb aliases DR1b, DVb aliases DF1b: all dead)
+  st4(DQb + lane * 16 + c0, dq);
+  st4(DKb + lane * 16 + c0, dk);
+  st4(DVb + lane * 16 + c0, dv);
   __syncthreads();
-  stage_reduce(Ls, Rs, lane, N, gp + OFF_WIN, gp + OFF_BIN);
-  __syncthreads();
-  matvec16_t_acc(Win, dq, dx, scr);
-  stage_rows(Ls, Rs, lane, dk, x);
-  __syncthreads();
-  stage_reduce(Ls, Rs, lane, N, gp + OFF_WIN + 256, gp + OFF_BIN + 16);
-  __syncthreads();
-  matvec16_t_acc(Win + 256, dk, dx, scr);
-  stage_rows(Ls, Rs, lane, dv, x);
-  __syncthreads();
-  stage_reduce(Ls, Rs, lane, N, gp + OFF_WIN + 512, gp + OFF_BIN + 32);
-  matvec16_t_acc(Win + 512, dv, dx, scr);
-  if (active) store_row16(d.dx + (long)b * d.ldx + lane * 16, dx);
+  // ---- in-projection: [q;k;v] = Win x + bin ----
+  wgrad_slice(DQb, Xb, c0, lane, N, gp + OFF_WIN);
+  wgrad_slice(DKb, Xb, c0, lane, N, gp + OFF_WIN + 256);
+  wgrad_slice(DVb, Xb, c0, lane, N, gp + OFF_WIN + 512);
+  bgrad_slice(dq, c0, lane, gp + OFF_BIN);
+  bgrad_slice(dk, c0, lane, gp + OFF_BIN + 16);
+  bgrad_slice(dv, c0, lane, gp + OFF_BIN + 32);
+  f32x4 dx = dr1;
+  ld_row(DQb + lane * 16, row);
+  mvt_slice_acc(Wsh + OFF_WIN, c0, row, dx);
+  ld_row(DKb + lane * 16, row);
+  mvt_slice_acc(Wsh + OFF_WIN + 256, c0, row, dx);
+  ld_row(DVb + lane * 16, row);
+  mvt_slice_acc(Wsh + OFF_WIN + 512, c0, row, dx);
+  if (active) st4(d.dx + (long)b * d.ldx + lane * 16 + c0, dx);
 }
 
 int launch_mha(hipStream_t st, const nasrec_mha_desc_t* d) {
   if (d->N < 1 || d->N > MHA_N) return nasrec_set_error(-2, "mha: N=%d out of range [1,%d]", d->N, MHA_N);
   if (d->B == 0) return 0;
-  if (d->kind == NASREC_OP_MHA_FWD)
-    hipLaunchKernelGGL(mha_fwd_kernel, dim3(d->B), dim3(64), 0, st, *d);
-  else
-    hipLaunchKernelGGL(mha_bwd_kernel, dim3(d->B), dim3(64), 0, st, *d);
+  if (d->kind == NASREC_OP_MHA_FWD) {
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3(d->B), dim3(256), 0, st, *d);
+  } else {
+    if (d->saved == nullptr) return nasrec_set_error(-2, "mha backward needs the state saved by the forward launch (desc.saved)");
+    hipLaunchKernelGGL(mha_bwd_kernel, dim3(d->B), dim3(256), 0, st, *d);
+  }
   return nasrec_check_launch("mha");
 }

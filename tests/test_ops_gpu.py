@@ -315,7 +315,7 @@ def _mha_ref(x, p, dims):
 @pytest.mark.parametrize("use_saved", [False, True])
 @pytest.mark.parametrize("N,dims", [(16, -1), (64, -1), (48, 32), (7, -1)])
 def test_mha_ffn(lib, N, dims, use_saved):
-    """backward either recomputes the forward from x or reads the state the forward launch saved"""
+    """the forward runs with or without saving its per-token state; the backward always consumes a saved state"""
     torch.manual_seed(7 + N)
     B = 13
     shapes = [(48, 16), (48,), (16, 16), (16,), (16,), (16,), (16, 16), (16,), (16, 16), (16,), (16,), (16,)]
@@ -329,11 +329,16 @@ def test_mha_ffn(lib, N, dims, use_saved):
     d = L.MhaDesc()
     d.kind, d.B, d.N, d.ldx, d.ldo, d.dims_in_use = L.OP_MHA_FWD, B, N, N * 16, N * 16, dims
     d.x, d.out = gx.data_ptr(), out.data_ptr()
-    saved = dev(torch.zeros(B * N * L.MHA_SAVED)) if use_saved else None
+    saved = dev(torch.zeros(B * N * L.MHA_SAVED))
     d.saved = saved.data_ptr() if use_saved else None
     for q in range(12):
         d.params[q] = gp[q].data_ptr()
     launch(lib, d)
+    if not use_saved:  # produce the state for the backward with a second, saving launch; outputs must not change
+        first = out.clone()
+        d.saved = saved.data_ptr()
+        launch(lib, d)
+        assert torch.equal(first, out)
     pd = [t.double().requires_grad_(True) for t in p]
     xd = x.double().requires_grad_(True)
     ref = _mha_ref(xd, pd, dims)
@@ -344,7 +349,7 @@ def test_mha_ffn(lib, N, dims, use_saved):
     e = L.MhaDesc()
     e.kind, e.B, e.N, e.ldx, e.ldo, e.dims_in_use = L.OP_MHA_BWD, B, N, N * 16, N * 16, dims
     e.x, e.dout, e.dx, e.dparams_partial = gx.data_ptr(), gdo.data_ptr(), dx.data_ptr(), part.data_ptr()
-    e.saved = saved.data_ptr() if use_saved else None
+    e.saved = saved.data_ptr()
     for q in range(12):
         e.params[q] = gp[q].data_ptr()
     launch(lib, e)
