@@ -321,10 +321,22 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue(const nasrec_gemm_de
     i = (int)(e / N);
     j = (int)(e % N);
   }
-  const float* slab = d.workspace + ((long)z * S) * Mmax * Nmax;
-  float v = 0.f;
-  for (int q = 0; q < S; ++q) v += slab[(long)q * Mmax * Nmax + (long)i * N + j];
-  epilogue_store<CM>(d, sg, i, j, v);
+  const float* slab = d.workspace + ((long)z * S) * Mmax * Nmax + (long)i * N + j;
+  const long stride = (long)Mmax * Nmax;
+  // four independent partial sums keep several slab loads in flight (every kernel starts on a cold L2); the
+  // association order is still a fixed function of S, so results stay reproducible
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int q = 0;
+  for (; q + 4 <= S; q += 4) {
+    const float a0 = slab[(long)q * stride], a1 = slab[(long)(q + 1) * stride];
+    const float a2 = slab[(long)(q + 2) * stride], a3 = slab[(long)(q + 3) * stride];
+    v0 += a0;
+    v1 += a1;
+    v2 += a2;
+    v3 += a3;
+  }
+  for (; q < S; ++q) v0 += slab[(long)q * stride];
+  epilogue_store<CM>(d, sg, i, j, (v0 + v1) + (v2 + v3));
 }
 
 template <int AM, int BMODE, int CM>
