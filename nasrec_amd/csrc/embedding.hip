@@ -124,9 +124,82 @@ __global__ __launch_bounds__(256) void emb_dedup_kernel(const nasrec_emb_dedup_d
   if (tid == 0) d.sumsq_partial[(long)f * gridDim.y + blockIdx.y] = red[0];
 }
 
+// Batch <= 256 (one workgroup per field, thread = sample): every sample parks its 64-byte gradient row in LDS with ONE
+// parallel round of global loads, then duplicates are folded into their leader's row in rank order (round r: the r-th
+// duplicate of every row adds itself; no two threads touch the same row in a round), so a 64-fold duplicate on a 4-row
+// table costs 64 LDS rounds instead of dependent global loads, and the order is ascending b (same as the scan kernel).
+__global__ __launch_bounds__(256) void emb_dedup_small_kernel(const nasrec_emb_dedup_desc_t d) {
+  __shared__ __attribute__((aligned(16))) int sidx[256];
+  __shared__ __attribute__((aligned(16))) float acc[256 * 20];  // 20-float rows: 16-byte aligned, bank-spread
+  __shared__ float red[256];
+  const int f = blockIdx.x, b = threadIdx.x;
+  const bool live = b < d.B;
+  const int my = live ? (int)d.idx[(long)b * d.Fs + f] : -1 - b;  // dead lanes get unique negative ids
+  sidx[b] = my;
+  f32x4 g[4];
+  if (live) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(d.dout + ((long)b * d.Fs + f) * 16);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) g[v] = src[v];
+  } else {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) g[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(&acc[b * 20 + 4 * v]) = g[v];
+  __syncthreads();
+  int first = b, rank = 0;
+  {
+    const int4* s4 = reinterpret_cast<const int4*>(sidx);
+    first = 1 << 30;
+    for (int q = 0; q < 64; ++q) {
+      const int4 v = s4[q];
+      const int m0 = v.x == my, m1 = v.y == my, m2 = v.z == my, m3 = v.w == my;
+      if (m0 | m1 | m2 | m3) {
+        const int p = 4 * q + (m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3)));
+        first = min(first, p);
+        rank += (m0 && 4 * q < b) + (m1 && 4 * q + 1 < b) + (m2 && 4 * q + 2 < b) + (m3 && 4 * q + 3 < b);
+      }
+    }
+  }
+  const bool lead = live && first == b;
+  for (int r = 1;; ++r) {
+    if (live && rank == r) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        f32x4* dst = reinterpret_cast<f32x4*>(&acc[first * 20 + 4 * v]);
+        *dst = *dst + g[v];
+      }
+    }
+    if (__syncthreads_count(live && rank > r) == 0) break;
+  }
+  float ss = 0.f;
+  if (live) d.leader[(long)b * d.Fs + f] = lead ? 1 : 0;
+  if (lead) {
+    f32x4* dst = reinterpret_cast<f32x4*>(d.gsum + ((long)b * d.Fs + f) * 16);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(&acc[b * 20 + 4 * v]);
+      dst[v] = x;
+      ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    }
+  }
+  red[b] = ss;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (b < o) red[b] += red[b + o];
+    __syncthreads();
+  }
+  if (b == 0) d.sumsq_partial[f] = red[0];
+}
+
 int launch_emb_dedup(hipStream_t st, const nasrec_emb_dedup_desc_t* d) {
   if (d->B == 0) return 0;
   if (d->B > DEDUP_MAXB) return nasrec_set_error(-2, "emb_dedup: B=%d > %d", d->B, DEDUP_MAXB);
+  if (d->B <= 256) {
+    hipLaunchKernelGGL(emb_dedup_small_kernel, dim3(d->Fs), dim3(256), 0, st, *d);
+    return nasrec_check_launch("emb_dedup");
+  }
   dim3 grid(d->Fs, (d->B + 255) / 256);
   hipLaunchKernelGGL(emb_dedup_kernel, grid, dim3(256), 0, st, *d);
   return nasrec_check_launch("emb_dedup");
