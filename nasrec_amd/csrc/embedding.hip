@@ -124,13 +124,14 @@ __global__ __launch_bounds__(256) void emb_dedup_kernel(const nasrec_emb_dedup_d
   if (tid == 0) d.sumsq_partial[(long)f * gridDim.y + blockIdx.y] = red[0];
 }
 
-// Batch <= 256 (one workgroup per field, thread = sample): every sample parks its 64-byte gradient row in LDS with ONE
-// parallel round of global loads, then duplicates are folded into their leader's row in rank order (round r: the r-th
-// duplicate of every row adds itself; no two threads touch the same row in a round), so a 64-fold duplicate on a 4-row
-// table costs 64 LDS rounds instead of dependent global loads, and the order is ascending b (same as the scan kernel).
+// Batch <= 256 (one workgroup per field, thread = sample): every sample parks its id and its 64-byte gradient row in
+// LDS with ONE parallel round of global loads; then each thread scans the ids in ascending order, four per
+// ds_read_b128 (all lanes read the same address: broadcast): a match below b means "not the leader", and a leader adds
+// the LDS rows of the later matches to its own row in registers.  A 64-fold duplicate on a 4-row table costs 64 LDS row
+// reads in one lane instead of 64 dependent global loads; the summation order is ascending b.
 __global__ __launch_bounds__(256) void emb_dedup_small_kernel(const nasrec_emb_dedup_desc_t d) {
   __shared__ __attribute__((aligned(16))) int sidx[256];
-  __shared__ __attribute__((aligned(16))) float acc[256 * 20];  // 20-float rows: 16-byte aligned, bank-spread
+  __shared__ __attribute__((aligned(16))) float rows[256 * 20];  // 20-float rows: 16-byte aligned, bank-spread
   __shared__ float red[256];
   const int f = blockIdx.x, b = threadIdx.x;
   const bool live = b < d.B;
@@ -146,32 +147,39 @@ __global__ __launch_bounds__(256) void emb_dedup_small_kernel(const nasrec_emb_d
     for (int v = 0; v < 4; ++v) g[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
-  for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(&acc[b * 20 + 4 * v]) = g[v];
+  for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(&rows[b * 20 + 4 * v]) = g[v];
   __syncthreads();
-  int first = b, rank = 0;
-  {
-    const int4* s4 = reinterpret_cast<const int4*>(sidx);
-    first = 1 << 30;
-    for (int q = 0; q < 64; ++q) {
-      const int4 v = s4[q];
-      const int m0 = v.x == my, m1 = v.y == my, m2 = v.z == my, m3 = v.w == my;
-      if (m0 | m1 | m2 | m3) {
-        const int p = 4 * q + (m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3)));
-        first = min(first, p);
-        rank += (m0 && 4 * q < b) + (m1 && 4 * q + 1 < b) + (m2 && 4 * q + 2 < b) + (m3 && 4 * q + 3 < b);
-      }
-    }
-  }
-  const bool lead = live && first == b;
-  for (int r = 1;; ++r) {
-    if (live && rank == r) {
+  // branch-free scan: a 256-bit match mask per thread (the loop is fully unrolled, so the LDS reads pipeline)
+  const int4* s4 = reinterpret_cast<const int4*>(sidx);
+  unsigned mask[8];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        f32x4* dst = reinterpret_cast<f32x4*>(&acc[first * 20 + 4 * v]);
-        *dst = *dst + g[v];
+  for (int w = 0; w < 8; ++w) mask[w] = 0u;
+#pragma unroll
+  for (int q = 0; q < 64; ++q) {
+    const int4 v = s4[q];
+    const unsigned m = (unsigned)(v.x == my) | ((unsigned)(v.y == my) << 1) | ((unsigned)(v.z == my) << 2) | ((unsigned)(v.w == my) << 3);
+    mask[q >> 3] |= m << ((q & 7) * 4);
+  }
+  bool lead = live;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    // bits strictly below b in word w
+    const unsigned below = (b >= 32 * (w + 1)) ? 0xffffffffu : (b <= 32 * w ? 0u : ((1u << (b - 32 * w)) - 1u));
+    if (mask[w] & below) lead = false;
+  }
+  if (lead) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      // bits strictly above b in word w
+      const unsigned above = (b < 32 * w) ? 0xffffffffu : (b >= 32 * w + 31 ? 0u : ~((2u << (b - 32 * w)) - 1u));
+      unsigned mm = mask[w] & above;
+      while (mm) {
+        const int p = 32 * w + __ffs((int)mm) - 1;
+        mm &= mm - 1;
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) g[vv] = g[vv] + *reinterpret_cast<const f32x4*>(&rows[p * 20 + 4 * vv]);
       }
     }
-    if (__syncthreads_count(live && rank > r) == 0) break;
   }
   float ss = 0.f;
   if (live) d.leader[(long)b * d.Fs + f] = lead ? 1 : 0;
@@ -179,9 +187,8 @@ __global__ __launch_bounds__(256) void emb_dedup_small_kernel(const nasrec_emb_d
     f32x4* dst = reinterpret_cast<f32x4*>(d.gsum + ((long)b * d.Fs + f) * 16);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(&acc[b * 20 + 4 * v]);
-      dst[v] = x;
-      ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+      dst[v] = g[v];
+      ss += g[v][0] * g[v][0] + g[v][1] * g[v][1] + g[v][2] * g[v][2] + g[v][3] * g[v][3];
     }
   }
   red[b] = ss;
