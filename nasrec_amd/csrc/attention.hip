@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const nasrec_mha_desc_t d)
   __syncthreads();
   // attention, heads 2w (columns c0, c0+1) and 2w+1 (columns c0+2, c0+3)
   float mA = -INFINITY, mB = -INFINITY;
+#pragma unroll 4
   for (int j = 0; j < N; ++j) {
     const f32x4 kj = ld4(Ks + j * 16 + c0);
     mA = fmaxf(mA, fmaf(q4[0], kj[0], q4[1] * kj[1]));
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const nasrec_mha_desc_t d)
   }
   float lA = 0.f, lB = 0.f;
   f32x4 o4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
   for (int j = 0; j < N; ++j) {
     const f32x4 kj = ld4(Ks + j * 16 + c0);
     const f32x4 vj = ld4(Vs + j * 16 + c0);
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const nasrec_mha_desc_t d)
 __device__ __forceinline__ void wgrad_slice(const float* G, const float* V, int c0, int lane, int N, float* out) {
   const int o = lane >> 4, i = lane & 15;
   float s = 0.f;
+#pragma unroll 8
   for (int t = 0; t < N; ++t) s = fmaf(G[t * 16 + c0 + o], V[t * 16 + i], s);
   out[(c0 + o) * 16 + i] = s;
 }
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const nasrec_mha_desc_t d)
   __syncthreads();  // also: every wave is done reading DR1b
   // ---- attention backward, heads 2w and 2w+1 ----
   f32x4 dq = zero4;  // phase A: lane = query
+#pragma unroll 4
   for (int j = 0; j < N; ++j) {
     const f32x4 kj = ld4(Kb + j * 16 + c0);
     const f32x4 vj = ld4(Vb + j * 16 + c0);
@@ -366,6 +370,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const nasrec_mha_desc_t d)
   }
   dq = dq * MHA_SCALE;
   f32x4 dk = zero4, dv = zero4;  // phase B: lane = key
+#pragma unroll 4
   for (int i = 0; i < N; ++i) {
     const f32x4 qi = ld4(Qb + i * 16 + c0);
     const f32x4 doi = ld4(DOb + i * 16 + c0);
