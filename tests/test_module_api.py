@@ -87,3 +87,16 @@ def test_deepcopy_and_modes():
     m.set_mode_to_normal_mode()
     assert all(p.requires_grad for p in m.parameters())
     assert len(m.get_sparse_parameters()) == 10 and len(m.get_dense_parameters()) == len(list(m.parameters())) - 10
+
+
+def test_reference_import_paths_resolve_to_the_engine():
+    """the import statements of the reference's callers (supernet.py:34-51, train_utils.py:27-33, main_train.py:71)"""
+    from nasrec.supernet.modules import (CleverMaskGenerator, CleverZeroTensorGenerator, DotProduct, ElasticLinear,  # noqa: F401
+                                         ElasticLinear3D, FactorizationMachine3D, SigmoidGating, Sum, Transformer, Zeros2D,
+                                         Zeros3D)
+    from nasrec.supernet.supernet import SuperNet as S2, ops_config_lib as lib2  # noqa: F401
+    from nasrec.supernet.utils import anypath_choice_fn, assert_valid_ops_config  # noqa: F401
+    from nasrec.utils.config import NUM_EMBEDDINGS_CRITEO
+    assert S2 is SuperNet and len(NUM_EMBEDDINGS_CRITEO) == 26
+    m = CleverMaskGenerator()(8, 3)
+    assert m.tolist() == [1, 1, 1, 0, 0, 0, 0, 0]
