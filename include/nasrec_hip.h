@@ -89,12 +89,14 @@ typedef struct nasrec_gemm_seg {
   float* C;          /* used per z-problem (zmode=1); seg[0].C otherwise */
   const float* Aaux; /* optional: A(r,k) is taken as 0 where Aaux(r,k) <= 0 (fused ReLU backward) */
   const float* Baux; /* same for B */
+  float* rowsum;     /* ones_col destination of THIS problem (overrides desc.rowsum_out when non-NULL): lets one zmode
+                        launch carry the bias gradients of several independent weight-gradient products */
   int32_t M, N, K;
   int32_t lda, ldb, ldc;
   int32_t Mvalid;    /* rows r >= Mvalid of A read as 0 (prefix mask on the row axis) */
   int32_t accumulate;/* zmode: C += result */
   int32_t ones_col;  /* 1: this problem's last column j = N-1 is virtual: B(N-1,k) = 1, and C(i,N-1) = sum_k A(i,k) is
-                        written to desc.rowsum_out[i] instead of C (bias gradient fused into the weight-gradient product) */
+                        written to rowsum[i] (or desc.rowsum_out[i]) instead of C (bias gradient fused into the weight-gradient product) */
   int32_t _pad;
 } nasrec_gemm_seg_t;
 

@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnasrec_hip.so")
+# NASREC_HIP_LIB points the loader at another build of the same library (kernel A/B experiments).
+LIB_PATH = os.environ.get("NASREC_HIP_LIB") or os.path.join(_HERE, "lib", "libnasrec_hip.so")
 
 MAX_SEGS = 8
 MAX_TABLES = 32
@@ -35,7 +36,7 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 
 class GemmSeg(C.Structure):
-    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("Aaux", vp), ("Baux", vp), ("M", i32), ("N", i32), ("K", i32),
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("Aaux", vp), ("Baux", vp), ("rowsum", vp), ("M", i32), ("N", i32), ("K", i32),
                 ("lda", i32), ("ldb", i32), ("ldc", i32), ("Mvalid", i32), ("accumulate", i32), ("ones_col", i32), ("_pad", i32)]
 
 
@@ -197,8 +198,8 @@ def load():
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
                  "nasrec_adagrad_rows"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 1:
-        raise EngineError("ABI version mismatch: library %d, binding 1" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 2:
+        raise EngineError("ABI version mismatch: library %d, binding 2" % lib.nasrec_abi_version())
     sizes = (i32 * 32)()
     n = lib.nasrec_desc_sizes(sizes, 32)
     for kind, cls in DESC_BY_KIND.items():

@@ -12,15 +12,18 @@
 // identically for A and B, which only reorders the fp32 summation.
 #include "common.h"
 
+#ifndef GEMM_TK_DEEP
+#define GEMM_TK_DEEP 64
+#endif
 #define BM 64
 #define BN 64
-#define BK 32
+// BK (the k depth of a staged tile) is a template parameter TK: 32 in the throughput regime, GEMM_TK_DEEP in the latency regime.
 // The kernel is instantiated for 256 threads (4 waves, 2x2, 32x32 each: large products, throughput regime) and for
 // 512 threads (8 waves, 2x4, 32x16 each: two waves per SIMD, so one wave's waits hide under the other's MFMAs; 10-15 %
 // faster in the latency regime of batch 256 where a launch has fewer workgroups than the chip has CUs).
-#define NIT (BM * BK / NT)  // staging loads per thread and operand
+#define NIT (BM * TK / NT)  // staging loads per thread and operand
 #define NB (128 * 64 / NT)  // output columns per wave: waves are laid out 2 (m) x NT/128 (n), each 32 x NB
-#define LDS_LD (BK + 4)    // +4 pad: rows stay 16-byte aligned for ds_read_b128 and spread over banks
+#define LDS_LD (TK + 4)    // +4 pad: rows stay 16-byte aligned for ds_read_b128 and spread over banks
 
 template <int MODE>
 __device__ __forceinline__ float load_operand(const float* __restrict__ p, const float* __restrict__ aux, int r, int k,
@@ -35,11 +38,11 @@ __device__ __forceinline__ float load_operand(const float* __restrict__ p, const
 }
 
 // thread -> (row, k) mapping of the staging loads: lanes run along the contiguous axis of the operand
-template <int MODE, int NT>
+template <int MODE, int NT, int TK>
 __device__ __forceinline__ void stage_coords(int tid, int it, int& rr, int& kk) {
   if (MODE == NASREC_AM_KC || MODE == NASREC_AM_TOKK) {
-    kk = tid & (BK - 1);
-    rr = tid / BK + (NT / BK) * it;
+    kk = tid & (TK - 1);
+    rr = tid / TK + (NT / TK) * it;
   } else {
     rr = tid & 63;
     kk = (tid >> 6) + (NT / 64) * it;
@@ -63,7 +66,7 @@ template <int CM>
 __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, const nasrec_gemm_seg_t& sg, int i, int j,
                                                float v) {
   if (sg.ones_col && j == sg.N - 1) {  // virtual column: row sums of A (bias gradient)
-    d.rowsum_out[i] = v;
+    (sg.rowsum ? sg.rowsum : d.rowsum_out)[i] = v;
     return;
   }
   const long o = c_offset<CM>(i, j, sg.ldc);
@@ -81,7 +84,7 @@ __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, cons
   sg.C[o] = v;
 }
 
-template <int AM, int BMODE, int CM, int NT>
+template <int AM, int BMODE, int CM, int NT, int TK>
 __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, int Mmax, int Nmax) {
   __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
@@ -100,10 +103,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
   // live k-tiles of this problem and the range owned by this split
   int T = 0;
   if (d.zmode) {
-    T = s0.A ? (s0.K + BK - 1) / BK : 0;
+    T = s0.A ? (s0.K + TK - 1) / TK : 0;
   } else {
     for (int q = 0; q < d.nseg; ++q)
-      if (d.seg[q].A) T += (d.seg[q].K + BK - 1) / BK;
+      if (d.seg[q].A) T += (d.seg[q].K + TK - 1) / TK;
   }
   const int t0 = (int)((long)T * ks / S), t1 = (int)((long)T * (ks + 1) / S);
   int s = z, kt = t0;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
     s = 0;
     int skip = t0;
     while (s < d.nseg) {
-      int nt = d.seg[s].A ? (d.seg[s].K + BK - 1) / BK : 0;
+      int nt = d.seg[s].A ? (d.seg[s].K + TK - 1) / TK : 0;
       if (skip < nt) break;
       skip -= nt;
       ++s;
@@ -153,18 +156,18 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
     const int lda = sg.lda, ldb = sg.ldb;
     const int Ra = (sg.Mvalid > 0 && sg.Mvalid < M) ? sg.Mvalid : M;
     const int Rb = cOnes ? N - 1 : N;
-    // every addressing mode is linear in k across k-tiles (BK is a multiple of 16)
-    stepA = 4 * operand_offset<AM>(0, BK, lda);
-    stepB = 4 * operand_offset<BMODE>(0, BK, ldb);
+    // every addressing mode is linear in k across k-tiles (TK is a multiple of 16)
+    stepA = 4 * operand_offset<AM>(0, TK, lda);
+    stepB = 4 * operand_offset<BMODE>(0, TK, ldb);
     edgeA = (m0 + BM > Ra);
     edgeB = (n0 + BN > Rb);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int rr, kk;
-      stage_coords<AM, NT>(tid, it, rr, kk);
+      stage_coords<AM, NT, TK>(tid, it, rr, kk);
       rvA[it] = (m0 + rr) < Ra;
       voffA[it] = 4u * (unsigned)operand_offset<AM>(rvA[it] ? m0 + rr : 0, kk, lda);
-      stage_coords<BMODE, NT>(tid, it, rr, kk);
+      stage_coords<BMODE, NT, TK>(tid, it, rr, kk);
       rvB[it] = (n0 + rr) < Rb;
       oneB[it] = cOnes && (n0 + rr == N - 1);
       voffB[it] = 4u * (unsigned)operand_offset<BMODE>(rvB[it] ? n0 + rr : 0, kk, ldb);
@@ -176,10 +179,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
   bool hasAaux = false, hasBaux = false, ktail = false;
   int tailK = 0;  // valid k in a tail tile
   auto fetch = [&](int ktq) {
-    const int k0 = ktq * BK;
+    const int k0 = ktq * TK;
     const char* pa = cA + (long)ktq * stepA;
     const char* pb = cB + (long)ktq * stepB;
-    ktail = (k0 + BK > cK);
+    ktail = (k0 + TK > cK);
     tailK = cK - k0;
     hasAaux = cAaux != nullptr;
     hasBaux = cBaux != nullptr;
@@ -204,9 +207,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         int rr, kk;
-        stage_coords<AM, NT>(tid, it, rr, kk);
+        stage_coords<AM, NT, TK>(tid, it, rr, kk);
         const unsigned oa = (kk < tailK) ? voffA[it] : voffA[it] - 4u * (unsigned)operand_offset<AM>(0, kk, seg_ld(d, cur, 0));
-        stage_coords<BMODE, NT>(tid, it, rr, kk);
+        stage_coords<BMODE, NT, TK>(tid, it, rr, kk);
         const unsigned ob = (kk < tailK) ? voffB[it] : voffB[it] - 4u * (unsigned)operand_offset<BMODE>(0, kk, seg_ld(d, cur, 1));
         ra[it] = *reinterpret_cast<const float*>(pa + oa);
         rb[it] = *reinterpret_cast<const float*>(pb + ob);
@@ -224,8 +227,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
       if (edgeA) a = rvA[it] ? a : 0.f;
       if (edgeB) b = rvB[it] ? b : 0.f;
       int rrA, kkA, rrB, kkB;
-      stage_coords<AM, NT>(tid, it, rrA, kkA);
-      stage_coords<BMODE, NT>(tid, it, rrB, kkB);
+      stage_coords<AM, NT, TK>(tid, it, rrA, kkA);
+      stage_coords<BMODE, NT, TK>(tid, it, rrB, kkB);
       if (ktail) {
         a = (kkA < tailK) ? a : 0.f;
         b = (kkB < tailK) ? b : 0.f;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
     // advance to the next live tile and prefetch it while the MFMAs run
     ++kt;
     if (!d.zmode) {
-      while (s < d.nseg && (!d.seg[s].A || kt * BK >= d.seg[s].K)) {
+      while (s < d.nseg && (!d.seg[s].A || kt * TK >= d.seg[s].K)) {
         ++s;
         kt = 0;
       }
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
     }
 
 #pragma unroll
-    for (int kb = 0; kb < BK / 16; ++kb) {
+    for (int kb = 0; kb < TK / 16; ++kb) {
       f32x4 af[2], bf[NB / 16];
 #pragma unroll
       for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + a * 16 + fr) * LDS_LD + kb * 16 + 4 * fg]);
@@ -351,10 +354,20 @@ static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
   const int S = d->splitk > 1 ? d->splitk : 1;
   if (S > 1 && d->workspace == nullptr) return nasrec_set_error(-3, "gemm: splitk=%d needs a workspace", S);
   dim3 grid((Nmax + BN - 1) / BN, (Mmax + BM - 1) / BM, nprob * S);
-  if ((long)grid.x * grid.y * grid.z < 1024)  // fewer than ~4 workgroups per CU: latency regime
-    hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM, 512>), grid, dim3(512), 0, st, *d, Mmax, Nmax);
-  else
-    hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM, 256>), grid, dim3(256), 0, st, *d, Mmax, Nmax);
+  if ((long)grid.x * grid.y * grid.z < 1024) {
+    // fewer than ~4 workgroups per CU: latency regime.  Every kernel starts on a cold L2, so each staged tile costs
+    // one ~1 us memory round trip whatever its size: stage GEMM_TK_DEEP-deep tiles (fewer round trips and barriers; 64 measured best, 128 loses to its partial tiles)
+    // unless no segment is deeper than one 32-wide tile.
+    int Kmax = 0;
+    for (int q = 0; q < d->nseg; ++q)
+      if (d->seg[q].A && d->seg[q].K > Kmax) Kmax = d->seg[q].K;
+    if (Kmax > 32)
+      hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM, 512, GEMM_TK_DEEP>), grid, dim3(512), 0, st, *d, Mmax, Nmax);
+    else
+      hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM, 512, 32>), grid, dim3(512), 0, st, *d, Mmax, Nmax);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM, 256, 32>), grid, dim3(256), 0, st, *d, Mmax, Nmax);
+  }
   if (S > 1) {
     long elems = (long)Mmax * Nmax;
     dim3 g2((unsigned)((elems + 255) / 256), 1, nprob);

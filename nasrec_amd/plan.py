@@ -159,6 +159,8 @@ class Ctx:
         self.used_params: List[str] = []
         self.grad_params: List[str] = []  # parameters whose gradient the backward program writes
         self.out = self.fwd  # current emission target
+        self.deferred: List = []  # weight-gradient products parked until the end of the backward program
+        self.defer_dw = True
 
     # -- memory -----------------------------------------------------------------------------------------------
     def alloc(self, numel):
@@ -210,6 +212,7 @@ class Ctx:
         self.out = self.bwd
         for fn in reversed(self.closures):
             fn()
+        _flush_deferred(self)
         self.out = self.fwd
 
     # gradient destination of a view: returns (ptr, accumulate) or (None, 0) if no gradient is wanted
@@ -217,6 +220,16 @@ class Ctx:
         buf = view.buf
         if not buf.need_grad:
             return None, 0
+        if self.deferred and buf.g is not None and not self.shape_only:
+            # A parked weight-gradient product reads this gradient storage as its dz operand, and a write is about to
+            # land in it (gradient storage shared through _alias_add: the pre-FM block output takes further
+            # contributions after the FM projection consumed the sum): issue those products first.
+            lo = buf.g.data_ptr()
+            hi = lo + 4 * buf.numel
+            hit = [e for e in self.deferred if lo <= e[4]["A"] < hi]
+            if hit:
+                self.deferred = [e for e in self.deferred if not (lo <= e[4]["A"] < hi)]
+                _flush_deferred(self, hit)
         acc = buf.grad_written
         if not acc and not view.full(self.B):
             self.emit(memset_desc(buf.grad_tensor()))
@@ -289,7 +302,8 @@ def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, **kw):
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     if zmode:
         kt = max((sd["K"] + 31) // 32 for sd in segs)
-        S = _splitk_for(tiles, kt, len(segs))
+        live_tiles = sum(((sd["M"] + 63) // 64) * ((sd["N"] + 63) // 64) for sd in segs)  # the grid is padded to Mmax x Nmax
+        S = _splitk_for(live_tiles, kt)
     else:
         kt = sum((sd["K"] + 31) // 32 for sd in segs)
         S = _splitk_for(tiles, kt)
@@ -334,18 +348,46 @@ def _cover_pieces(live: List[Seg]):
 def _emit_z_groups(ctx, am, bm, cm, items, rowsum_out=None):
     """items: [(group_index, seg_dict)] -> one launch per group (in order), <= MAX_SEGS problems per launch.
     rowsum_out: fuse the bias gradient into the first problem as a virtual ones-column (B(N-1,k) = 1)."""
-    first = True
+    items = _with_rowsum(items, rowsum_out)
     for gi in sorted({g for g, _ in items}):
         grp = [d for g, d in items if g == gi]
         for i in range(0, len(grp), L.MAX_SEGS):
-            chunk = grp[i:i + L.MAX_SEGS]
-            ro = None
-            if first and rowsum_out is not None:
-                chunk[0] = dict(chunk[0], N=chunk[0]["N"] + 1, ones_col=1)
-                ro = rowsum_out
-            first = False
-            for d in gemm_descs(ctx, am, bm, cm, chunk, 1, rowsum_out=ro):
+            for d in gemm_descs(ctx, am, bm, cm, grp[i:i + L.MAX_SEGS], 1):
                 ctx.emit(d)
+
+
+def _with_rowsum(items, rowsum_out):
+    if rowsum_out is None or not items:
+        return list(items)
+    items = list(items)
+    g0 = min(g for g, _ in items)
+    i0 = next(i for i, (g, _) in enumerate(items) if g == g0)
+    g, d = items[i0]
+    items[i0] = (g, dict(d, N=d["N"] + 1, ones_col=1, rowsum=rowsum_out))
+    return items
+
+
+def _weight_grad_products(ctx, am, bm, cm, items, rowsum_out=None):
+    """dW products have no consumer inside the backward pass (only the optimizer / the gradient exchange read them), and
+    their operands (dz, the saved activations) stay untouched once produced.  At batch 256 each of them is a
+    launch-latency-bound kernel (+ a split-K second pass), so they are parked and issued at the END of the backward
+    program as a few zmode launches of up to MAX_SEGS independent problems each (_flush_deferred)."""
+    if not ctx.defer_dw:
+        return _emit_z_groups(ctx, am, bm, cm, items, rowsum_out)
+    for rank, d in _with_rowsum(items, rowsum_out):
+        ctx.deferred.append((am, bm, cm, rank, d))
+
+
+def _flush_deferred(ctx, todo=None):
+    if todo is None:
+        todo, ctx.deferred = ctx.deferred, []
+    keys = sorted({(rank, am, bm, cm, d["K"]) for am, bm, cm, rank, d in todo})  # rank r accumulates over rank r-1: later launch
+    for key in keys:
+        grp = [d for am, bm, cm, rank, d in todo if (rank, am, bm, cm, d["K"]) == key]
+        grp.sort(key=lambda d: -d["M"] * d["N"])  # problems of similar size share a launch (its grid is Mmax x Nmax)
+        for i in range(0, len(grp), L.MAX_SEGS):
+            for g in gemm_descs(ctx, key[1], key[2], key[3], grp[i:i + L.MAX_SEGS], 1):
+                ctx.emit(g)
 
 
 def _dx_groups(ctx, live, mk):
@@ -464,7 +506,7 @@ def linear_dense(ctx, segs: List[Seg], Ktot, wname, nout, bias: bool, out: DV, a
             A=dz_ptr, Aaux=aux_ptr, B=W + 4 * s.koff, C=gp, M=B, N=s.width, K=kd, lda=dz_ld, ldb=Ktot, ldc=s.view.ld, accumulate=acc)))
         # dW per covered piece of the K axis (columns of zero segments keep the zero the flat gradient buffer was reset to)
         gW = ctx.gparam(wname + ".weight")
-        _emit_z_groups(ctx, L.AM_RC, L.AM_RC, L.CM_PLAIN, [(rank, dict(
+        _weight_grad_products(ctx, L.AM_RC, L.AM_RC, L.CM_PLAIN, [(rank, dict(
             A=dz_ptr, Aaux=aux_ptr, B=s.view.ptr + 4 * (a - s.koff), C=gW + 4 * a, M=nout, N=b - a, K=B, lda=dz_ld, ldb=s.view.ld, ldc=Ktot,
             Mvalid=kd, accumulate=int(rank > 0))) for s, a, b, rank in _cover_pieces(live)],
             rowsum_out=ctx.gparam(wname + ".bias") if (bias and live) else None)
@@ -543,7 +585,7 @@ def linear_tokens(ctx, segs: List[Seg], Ntot, wname, nout, bias: bool, out: SV, 
         _emit_z_groups(ctx, L.AM_RC, L.AM_TOKR, L.CM_TOKJ, _dx_groups(ctx, live, lambda s, gp, acc: dict(
             A=W + 4 * s.koff, B=dz_ptr, Baux=aux_ptr, C=gp, M=s.width, N=B * E, K=kd, lda=Ntot, ldb=dz_ld, ldc=s.view.ld, accumulate=acc)))
         gW = ctx.gparam(wname + ".weight")
-        _emit_z_groups(ctx, L.AM_TOKK, L.AM_TOKK, L.CM_PLAIN, [(rank, dict(
+        _weight_grad_products(ctx, L.AM_TOKK, L.AM_TOKK, L.CM_PLAIN, [(rank, dict(
             A=dz_ptr, Aaux=aux_ptr, B=s.view.ptr + 4 * (a - s.koff) * E, C=gW + 4 * a, M=nout, N=b - a, K=B * E, lda=dz_ld, ldb=s.view.ld,
             ldc=Ntot, Mvalid=kd, accumulate=int(rank > 0))) for s, a, b, rank in _cover_pieces(live)],
             rowsum_out=ctx.gparam(wname + ".bias") if (bias and live) else None)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-launch table of one training step of the bench workload (Criteo best-1shot, B=256): every descriptor of the step
+timed on its own with HIP events (back-to-back launches of the same descriptor: L2 cold at every kernel boundary, MALL
+warm — the conditions it sees inside the step)."""
+import ctypes as C, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from nasrec_amd import _lib as L, plan as P
+from nasrec_amd.engine import SupernetEngine
+from nasrec_amd.search_space import ops_config_lib
+from nasrec_amd.utils.config import NUM_EMBEDDINGS_CRITEO
+
+B = int(os.environ.get("B", "256"))
+lib = L.load()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+ca = json.load(open(os.path.join(ROOT, "nasrec_amd", "configs", "criteo", "ea_criteo_kaggle_xlarge_best_1shot.json")))
+choice = {"macro": ca["macro"], "micro": ca["micro"]}
+cfg = P.NetConfig(ca["num_blocks"], ops_config_lib[ca["config"]], False, "relu", fixed=True)
+eng = SupernetEngine(cfg, 13, 26, NUM_EMBEDDINGS_CRITEO, device=dev, warm_choice=choice)
+eng.init_weights(seed=0)
+bx = bench.synthetic_batches(1, 13, NUM_EMBEDDINGS_CRITEO, dev, 1)[0]
+eng.train_step(bx[0], bx[1], bx[2], 1e-3, choice=choice)
+cp = eng.compile(choice, B, train=True)
+sp = eng.stream.cuda_stream
+names = {getattr(L, n): n[3:] for n in dir(L) if n.startswith("OP_")}
+tot = 0.0
+rows = []
+with torch.cuda.stream(eng.stream):
+    for phase, prog in (("fwd", cp.fwd), ("bwd", cp.bwd), ("opt", cp.opt)):
+        for d in prog.descs:
+            us = bench.time_desc(lib, L, sp, d, iters=100) * 1e3
+            tot += us
+            info = ""
+            if isinstance(d, L.GemmDesc):
+                segs = [(d.seg[q].M, d.seg[q].N, d.seg[q].K) for q in range(d.nseg) if d.seg[q].A]
+                M, N = segs[0][0], segs[0][1]
+                Kt = sum(s[2] for s in segs)
+                fl = bench.gemm_flops(d)
+                info = "am=%d bm=%d cm=%d z=%d M=%d N=%d K=%s splitk=%d act=%d  %.1f TF/s" % (
+                    d.amode, d.bmode, d.cmode, d.zmode, M, N, "+".join(str(s[2]) for s in segs) if not d.zmode else "%dx%d" % (len(segs), segs[0][2]),
+                    d.splitk, d.act, fl / us / 1e6)
+            rows.append((phase, names.get(d.kind, str(d.kind)), us, info))
+for r in rows:
+    print("%s %-14s %7.2f us  %s" % r)
+print("sum of isolated launches: %.1f us over %d launches" % (tot, len(rows)))
