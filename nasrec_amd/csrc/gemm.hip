@@ -15,15 +15,18 @@
 #ifndef GEMM_TK_DEEP
 #define GEMM_TK_DEEP 64
 #endif
-#define BM 64
-#define BN 64
-// BK (the k depth of a staged tile) is a template parameter TK: 32 in the throughput regime, GEMM_TK_DEEP in the latency regime.
-// The kernel is instantiated for 256 threads (4 waves, 2x2, 32x32 each: large products, throughput regime) and for
-// 512 threads (8 waves, 2x4, 32x16 each: two waves per SIMD, so one wave's waits hide under the other's MFMAs; 10-15 %
-// faster in the latency regime of batch 256 where a launch has fewer workgroups than the chip has CUs).
-#define NIT (BM * TK / NT)  // staging loads per thread and operand
-#define NB (128 * 64 / NT)  // output columns per wave: waves are laid out 2 (m) x NT/128 (n), each 32 x NB
-#define LDS_LD (TK + 4)    // +4 pad: rows stay 16-byte aligned for ds_read_b128 and spread over banks
+#ifndef GEMM_SKINNY_BELOW
+#define GEMM_SKINNY_BELOW 128  // launches with fewer 64x64 workgroups than this use the skinny tiles
+#endif
+// Tile configurations (template parameters NT threads, TK staged k depth, TBM x TBN block tile):
+//   256 thr, 32, 64x64  4 waves 2x2, 32x32 each — large products, throughput regime (>= 4 workgroups per CU);
+//   512 thr, TK, 64x64  8 waves 2x4, 32x16 each — two waves per SIMD, one wave's waits hide under the other's MFMAs;
+//   256 thr, TK, 64x16 / 16x64  4 waves, one 16x16 MFMA tile each — "skinny" products of the batch-256 step (a
+//     [B,n]x[n,16] Linear, a token-axis Linear over B*16 columns): a 64x64 tiling would leave them on 4..64 of the 256
+//     CUs, and because every kernel starts on a cold L2 a CU only sustains ~13 KB/us of staging loads (outstanding
+//     misses x ~1 us latency) — so the operand traffic has to be spread over as many CUs as the problem allows.
+// TK = 32 when no k-segment is deeper than one 32-wide tile, else GEMM_TK_DEEP (fewer round trips and barriers; 64
+// measured best, 128 loses to its partial tiles).
 
 template <int MODE>
 __device__ __forceinline__ float load_operand(const float* __restrict__ p, const float* __restrict__ aux, int r, int k,
@@ -37,15 +40,15 @@ __device__ __forceinline__ float load_operand(const float* __restrict__ p, const
   return 0.f;
 }
 
-// thread -> (row, k) mapping of the staging loads: lanes run along the contiguous axis of the operand
-template <int MODE, int NT, int TK>
+// thread -> (row, k) mapping of the staging loads of an R x TK operand tile: lanes run along the contiguous axis
+template <int MODE, int NT, int TK, int R>
 __device__ __forceinline__ void stage_coords(int tid, int it, int& rr, int& kk) {
   if (MODE == NASREC_AM_KC || MODE == NASREC_AM_TOKK) {
     kk = tid & (TK - 1);
     rr = tid / TK + (NT / TK) * it;
   } else {
-    rr = tid & 63;
-    kk = (tid >> 6) + (NT / 64) * it;
+    rr = tid & (R - 1);
+    kk = tid / R + (NT / R) * it;
   }
 }
 
@@ -84,20 +87,28 @@ __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, cons
   sg.C[o] = v;
 }
 
-template <int AM, int BMODE, int CM, int NT, int TK>
+template <int AM, int BMODE, int CM, int NT, int TK, int TBM, int TBN>
 __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, int Mmax, int Nmax) {
-  __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+  constexpr int LDS_LD = TK + 4;  // +4 pad: rows stay 16-byte aligned for ds_read_b128 and spread over banks
+  constexpr int NITA = TBM * TK / NT, NITB = TBN * TK / NT;  // staging loads per thread
+  constexpr int NITX = NITA > NITB ? NITA : NITB;
+  constexpr int PER_WAVE = (TBM / 16) * (TBN / 16) / (NT / 64);  // 16x16 MFMA tiles per wave
+  constexpr int WTM = (PER_WAVE >= 2 && TBM >= 32) ? 32 : 16;    // wave tile
+  constexpr int WTN = 16 * PER_WAVE / (WTM / 16);
+  constexpr int FA = WTM / 16, FB = WTN / 16;
+  static_assert(NITA >= 1 && NITB >= 1 && PER_WAVE >= 1 && (TBM / WTM) * (TBN / WTN) == NT / 64, "tile configuration");
+  __shared__ __attribute__((aligned(16))) float As[TBM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[TBN * LDS_LD];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / (64 / NB), wn = wave % (64 / NB);
+  const int wm = wave / (TBN / WTN), wn = wave % (TBN / WTN);
   const int fr = lane & 15, fg = lane >> 4;
   const int S = d.splitk > 1 ? d.splitk : 1;
   const int z = d.zmode ? (int)(blockIdx.z / S) : 0;
   const int ks = (int)(blockIdx.z % S);
   const nasrec_gemm_seg_t& s0 = d.seg[z];
   const int M = s0.M, N = s0.N;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
   if (m0 >= M || n0 >= N) return;
 
   // live k-tiles of this problem and the range owned by this split
@@ -122,11 +133,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
     kt = skip;
   }
 
-  f32x4 acc[2][NB / 16];
+  f32x4 acc[FA][FB];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < FA; ++a)
 #pragma unroll
-    for (int b = 0; b < NB / 16; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < FB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // Staging loads.  The per-iteration instruction budget decides this kernel at small batch (one wave per SIMD: every
   // VALU instruction costs >= 4 cycles), so everything loop-invariant is hoisted to segment entry:
@@ -142,8 +153,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
   const char* cBaux = nullptr;
   int cK = 0, cOnes = 0, cur = -1;
   long stepA = 0, stepB = 0;          // bytes per k-tile
-  unsigned voffA[NIT], voffB[NIT];   // byte offset of (row, kk) at k-tile 0
-  bool rvA[NIT], rvB[NIT], oneB[NIT];
+  unsigned voffA[NITX], voffB[NITX];  // byte offset of (row, kk) at k-tile 0
+  bool rvA[NITX], rvB[NITX], oneB[NITX];
   bool edgeA = false, edgeB = false;  // any row of this tile outside the operand?
   auto load_seg = [&](int sq) {
     const nasrec_gemm_seg_t& sg = d.seg[sq];
@@ -159,23 +170,27 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
     // every addressing mode is linear in k across k-tiles (TK is a multiple of 16)
     stepA = 4 * operand_offset<AM>(0, TK, lda);
     stepB = 4 * operand_offset<BMODE>(0, TK, ldb);
-    edgeA = (m0 + BM > Ra);
-    edgeB = (n0 + BN > Rb);
+    edgeA = (m0 + TBM > Ra);
+    edgeB = (n0 + TBN > Rb);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    for (int it = 0; it < NITX; ++it) {
       int rr, kk;
-      stage_coords<AM, NT, TK>(tid, it, rr, kk);
-      rvA[it] = (m0 + rr) < Ra;
-      voffA[it] = 4u * (unsigned)operand_offset<AM>(rvA[it] ? m0 + rr : 0, kk, lda);
-      stage_coords<BMODE, NT, TK>(tid, it, rr, kk);
-      rvB[it] = (n0 + rr) < Rb;
-      oneB[it] = cOnes && (n0 + rr == N - 1);
-      voffB[it] = 4u * (unsigned)operand_offset<BMODE>(rvB[it] ? n0 + rr : 0, kk, ldb);
+      if (it < NITA) {
+        stage_coords<AM, NT, TK, TBM>(tid, it, rr, kk);
+        rvA[it] = (m0 + rr) < Ra;
+        voffA[it] = 4u * (unsigned)operand_offset<AM>(rvA[it] ? m0 + rr : 0, kk, lda);
+      }
+      if (it < NITB) {
+        stage_coords<BMODE, NT, TK, TBN>(tid, it, rr, kk);
+        rvB[it] = (n0 + rr) < Rb;
+        oneB[it] = cOnes && (n0 + rr == N - 1);
+        voffB[it] = 4u * (unsigned)operand_offset<BMODE>(rvB[it] ? n0 + rr : 0, kk, ldb);
+      }
     }
     cur = sq;
   };
   // fetch() only ISSUES loads; commit() applies predicates and parks the tile in LDS one iteration later.
-  float ra[NIT], rb[NIT], xa[NIT], xb[NIT];
+  f32x4 ra[(NITX + 3) / 4], rb[(NITX + 3) / 4], xa[(NITX + 3) / 4], xb[(NITX + 3) / 4];  // staged values, 4 slots per vector register group
   bool hasAaux = false, hasBaux = false, ktail = false;
   int tailK = 0;  // valid k in a tail tile
   auto fetch = [&](int ktq) {
@@ -188,54 +203,61 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
     hasBaux = cBaux != nullptr;
     if (!ktail) {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        ra[it] = *reinterpret_cast<const float*>(pa + voffA[it]);
-        rb[it] = *reinterpret_cast<const float*>(pb + voffB[it]);
+      for (int it = 0; it < NITX; ++it) {
+        if (it < NITA) ra[it >> 2][it & 3] = *reinterpret_cast<const float*>(pa + voffA[it]);
+        if (it < NITB) rb[it >> 2][it & 3] = *reinterpret_cast<const float*>(pb + voffB[it]);
       }
       if (hasAaux) {
         const char* xp = cAaux + (long)ktq * stepA;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) xa[it] = *reinterpret_cast<const float*>(xp + voffA[it]);
+        for (int it = 0; it < NITA; ++it) xa[it >> 2][it & 3] = *reinterpret_cast<const float*>(xp + voffA[it]);
       }
       if (hasBaux) {
         const char* xp = cBaux + (long)ktq * stepB;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) xb[it] = *reinterpret_cast<const float*>(xp + voffB[it]);
+        for (int it = 0; it < NITB; ++it) xb[it >> 2][it & 3] = *reinterpret_cast<const float*>(xp + voffB[it]);
       }
     } else {
       // last (partial) k-tile of the segment: k beyond K is redirected to kk = 0 of the slot's row and zeroed at commit
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
+      for (int it = 0; it < NITX; ++it) {
         int rr, kk;
-        stage_coords<AM, NT, TK>(tid, it, rr, kk);
-        const unsigned oa = (kk < tailK) ? voffA[it] : voffA[it] - 4u * (unsigned)operand_offset<AM>(0, kk, seg_ld(d, cur, 0));
-        stage_coords<BMODE, NT, TK>(tid, it, rr, kk);
-        const unsigned ob = (kk < tailK) ? voffB[it] : voffB[it] - 4u * (unsigned)operand_offset<BMODE>(0, kk, seg_ld(d, cur, 1));
-        ra[it] = *reinterpret_cast<const float*>(pa + oa);
-        rb[it] = *reinterpret_cast<const float*>(pb + ob);
-        if (hasAaux) xa[it] = *reinterpret_cast<const float*>(cAaux + (long)ktq * stepA + oa);
-        if (hasBaux) xb[it] = *reinterpret_cast<const float*>(cBaux + (long)ktq * stepB + ob);
+        if (it < NITA) {
+          stage_coords<AM, NT, TK, TBM>(tid, it, rr, kk);
+          const unsigned oa = (kk < tailK) ? voffA[it] : voffA[it] - 4u * (unsigned)operand_offset<AM>(0, kk, seg_ld(d, cur, 0));
+          ra[it >> 2][it & 3] = *reinterpret_cast<const float*>(pa + oa);
+          if (hasAaux) xa[it >> 2][it & 3] = *reinterpret_cast<const float*>(cAaux + (long)ktq * stepA + oa);
+        }
+        if (it < NITB) {
+          stage_coords<BMODE, NT, TK, TBN>(tid, it, rr, kk);
+          const unsigned ob = (kk < tailK) ? voffB[it] : voffB[it] - 4u * (unsigned)operand_offset<BMODE>(0, kk, seg_ld(d, cur, 1));
+          rb[it >> 2][it & 3] = *reinterpret_cast<const float*>(pb + ob);
+          if (hasBaux) xb[it >> 2][it & 3] = *reinterpret_cast<const float*>(cBaux + (long)ktq * stepB + ob);
+        }
       }
     }
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      float a = ra[it], b = rb[it];
-      if (hasAaux) a = (xa[it] > 0.f) ? a : 0.f;
-      if (hasBaux) b = (xb[it] > 0.f) ? b : 0.f;
-      if (edgeA) a = rvA[it] ? a : 0.f;
-      if (edgeB) b = rvB[it] ? b : 0.f;
-      int rrA, kkA, rrB, kkB;
-      stage_coords<AM, NT, TK>(tid, it, rrA, kkA);
-      stage_coords<BMODE, NT, TK>(tid, it, rrB, kkB);
-      if (ktail) {
-        a = (kkA < tailK) ? a : 0.f;
-        b = (kkB < tailK) ? b : 0.f;
+    for (int it = 0; it < NITX; ++it) {
+      int rr, kk;
+      if (it < NITA) {
+        float a = ra[it >> 2][it & 3];
+        if (hasAaux) a = (xa[it >> 2][it & 3] > 0.f) ? a : 0.f;
+        if (edgeA) a = rvA[it] ? a : 0.f;
+        stage_coords<AM, NT, TK, TBM>(tid, it, rr, kk);
+        if (ktail) a = (kk < tailK) ? a : 0.f;
+        As[rr * LDS_LD + kk] = a;
       }
-      if (cOnes && oneB[it]) b = (!ktail || kkB < tailK) ? 1.f : 0.f;
-      As[rrA * LDS_LD + kkA] = a;
-      Bs[rrB * LDS_LD + kkB] = b;
+      if (it < NITB) {
+        float b = rb[it >> 2][it & 3];
+        if (hasBaux) b = (xb[it >> 2][it & 3] > 0.f) ? b : 0.f;
+        if (edgeB) b = rvB[it] ? b : 0.f;
+        stage_coords<BMODE, NT, TK, TBN>(tid, it, rr, kk);
+        if (ktail) b = (kk < tailK) ? b : 0.f;
+        if (cOnes && oneB[it]) b = (!ktail || kk < tailK) ? 1.f : 0.f;
+        Bs[rr * LDS_LD + kk] = b;
+      }
     }
   };
 
@@ -262,17 +284,17 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
 
 #pragma unroll
     for (int kb = 0; kb < TK / 16; ++kb) {
-      f32x4 af[2], bf[NB / 16];
+      f32x4 af[FA], bf[FB];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + a * 16 + fr) * LDS_LD + kb * 16 + 4 * fg]);
+      for (int a = 0; a < FA; ++a) af[a] = *reinterpret_cast<const f32x4*>(&As[(wm * WTM + a * 16 + fr) * LDS_LD + kb * 16 + 4 * fg]);
 #pragma unroll
-      for (int b = 0; b < NB / 16; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&Bs[(wn * NB + b * 16 + fr) * LDS_LD + kb * 16 + 4 * fg]);
+      for (int b = 0; b < FB; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&Bs[(wn * WTN + b * 16 + fr) * LDS_LD + kb * 16 + 4 * fg]);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < FA; ++a)
 #pragma unroll
-          for (int b = 0; b < NB / 16; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < FB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
     }
   }
 
@@ -284,23 +306,23 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, in
     // workgroup reading S slabs costs more than the extra ~5 us launch of a fully parallel second pass.
     float* slab = d.workspace + ((long)(z * S + ks)) * Mmax * Nmax;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < FA; ++a)
 #pragma unroll
-      for (int b = 0; b < NB / 16; ++b)
+      for (int b = 0; b < FB; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int i = m0 + wm * 32 + a * 16 + 4 * fg + r, j = n0 + wn * NB + b * 16 + fr;
+          int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
           if (i < M && j < N) slab[(long)i * N + j] = acc[a][b][r];
         }
     return;
   }
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < FA; ++a)
 #pragma unroll
-    for (int b = 0; b < NB / 16; ++b)
+    for (int b = 0; b < FB; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int i = m0 + wm * 32 + a * 16 + 4 * fg + r, j = n0 + wn * NB + b * 16 + fr;
+        int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
         if (i < M && j < N) epilogue_store<CM>(d, s0, i, j, acc[a][b][r]);
       }
 }
@@ -342,31 +364,39 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue(const nasrec_gemm_de
   epilogue_store<CM>(d, sg, i, j, (v0 + v1) + (v2 + v3));
 }
 
+template <int AM, int BMODE, int CM, int NT, int TK, int TBM, int TBN>
+static void launch_cfg(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, int Nmax, int zdim) {
+  dim3 grid((Nmax + TBN - 1) / TBN, (Mmax + TBM - 1) / TBM, zdim);
+  hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM, NT, TK, TBM, TBN>), grid, dim3(NT), 0, st, *d, Mmax, Nmax);
+}
+
 template <int AM, int BMODE, int CM>
 static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
-  int Mmax = 0, Nmax = 0;
+  int Mmax = 0, Nmax = 0, Kmax = 0;
   const int nprob = d->zmode ? d->nseg : 1;
   for (int q = 0; q < nprob; ++q) {
     if (d->seg[q].M > Mmax) Mmax = d->seg[q].M;
     if (d->seg[q].N > Nmax) Nmax = d->seg[q].N;
   }
+  for (int q = 0; q < d->nseg; ++q)
+    if (d->seg[q].A && d->seg[q].K > Kmax) Kmax = d->seg[q].K;
   if (Mmax <= 0 || Nmax <= 0) return 0;
   const int S = d->splitk > 1 ? d->splitk : 1;
   if (S > 1 && d->workspace == nullptr) return nasrec_set_error(-3, "gemm: splitk=%d needs a workspace", S);
-  dim3 grid((Nmax + BN - 1) / BN, (Mmax + BM - 1) / BM, nprob * S);
-  if ((long)grid.x * grid.y * grid.z < 1024) {
-    // fewer than ~4 workgroups per CU: latency regime.  Every kernel starts on a cold L2, so each staged tile costs
-    // one ~1 us memory round trip whatever its size: stage GEMM_TK_DEEP-deep tiles (fewer round trips and barriers; 64 measured best, 128 loses to its partial tiles)
-    // unless no segment is deeper than one 32-wide tile.
-    int Kmax = 0;
-    for (int q = 0; q < d->nseg; ++q)
-      if (d->seg[q].A && d->seg[q].K > Kmax) Kmax = d->seg[q].K;
-    if (Kmax > 32)
-      hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM, 512, GEMM_TK_DEEP>), grid, dim3(512), 0, st, *d, Mmax, Nmax);
-    else
-      hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM, 512, 32>), grid, dim3(512), 0, st, *d, Mmax, Nmax);
+  const int zdim = nprob * S;
+  const long wgs = (long)((Mmax + 63) / 64) * ((Nmax + 63) / 64) * zdim;  // workgroups of a 64x64 tiling
+  const bool deep = Kmax > 32;
+  if (wgs >= 1024) {
+    launch_cfg<AM, BMODE, CM, 256, 32, 64, 64>(st, d, Mmax, Nmax, zdim);
+  } else if (wgs >= GEMM_SKINNY_BELOW) {
+    if (deep) launch_cfg<AM, BMODE, CM, 512, GEMM_TK_DEEP, 64, 64>(st, d, Mmax, Nmax, zdim);
+    else launch_cfg<AM, BMODE, CM, 512, 32, 64, 64>(st, d, Mmax, Nmax, zdim);
+  } else if (Nmax >= Mmax) {
+    if (deep) launch_cfg<AM, BMODE, CM, 256, GEMM_TK_DEEP, 64, 16>(st, d, Mmax, Nmax, zdim);
+    else launch_cfg<AM, BMODE, CM, 256, 32, 64, 16>(st, d, Mmax, Nmax, zdim);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM, 256, 32>), grid, dim3(256), 0, st, *d, Mmax, Nmax);
+    if (deep) launch_cfg<AM, BMODE, CM, 256, GEMM_TK_DEEP, 16, 64>(st, d, Mmax, Nmax, zdim);
+    else launch_cfg<AM, BMODE, CM, 256, 32, 16, 64>(st, d, Mmax, Nmax, zdim);
   }
   if (S > 1) {
     long elems = (long)Mmax * Nmax;
