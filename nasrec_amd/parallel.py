@@ -65,24 +65,21 @@ class DataParallelStep:
             if self.graph:
                 self.fb.capture(engine.stream.cuda_stream)
                 self.opt.capture(engine.stream.cuda_stream)
+        engine.stream.synchronize()
 
     def step(self, int_x, cat_x, y, lr: float):
         eng = self.engine
         if not self.exchange:
             return eng.train_step(int_x, cat_x, y, lr, self.choice, self.clip, self.eps, graph=self.graph)
-        cur = torch.cuda.current_stream(eng.device)
-        eng.stream.wait_stream(cur)
-        with torch.cuda.stream(eng.stream):
-            eng._stage_inputs(self.cp, int_x, cat_x, y, lr)
-            sp = eng.stream.cuda_stream
-            if self.graph:
-                self.fb.replay(sp)
-            else:
-                self.fb.run(sp)
-            exchange_gradients(eng.flat_g, self.cp.cat_x, self.cp.sparse0.grad_tensor(), self.cat_all, self.sg_all)
-            if self.graph:
-                self.opt.replay(sp)
-            else:
-                self.opt.run(sp)
-        cur.wait_stream(eng.stream)
+        sp = eng._sp()
+        eng._stage_inputs(sp, self.cp, int_x, cat_x, y, lr)
+        if self.graph:
+            self.fb.replay(sp)
+        else:
+            self.fb.run(sp)
+        exchange_gradients(eng.flat_g, self.cp.cat_x, self.cp.sparse0.grad_tensor(), self.cat_all, self.sg_all)
+        if self.graph:
+            self.opt.replay(sp)
+        else:
+            self.opt.run(sp)
         return self.cp.loss
