@@ -74,7 +74,9 @@ enum {
   NASREC_OP_ADD_SEGS = 24,
   NASREC_OP_SCALE = 25,
   NASREC_OP_ACT_BWD = 26,
-  NASREC_OP_STAGE_INPUTS = 27
+  NASREC_OP_STAGE_INPUTS = 27,
+  NASREC_OP_OPT_REDUCE = 28,
+  NASREC_OP_OPT_APPLY = 29
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -349,6 +351,29 @@ typedef struct nasrec_adagrad_rows_desc {
   const float* coef;
 } nasrec_adagrad_rows_desc_t;
 
+/* Fused optimizer tail for batch <= 256 (the two grid-wide dependencies of clip_grad_norm_ + Adagrad need two
+ * launches, not five):
+ *   OPT_REDUCE = EMB_DEDUP (workgroups [0, Fs)) + SUMSQ of the dense gradient arena (the remaining workgroups);
+ *   OPT_APPLY  = every workgroup re-derives the clip coefficient from the partial sums (same fixed-order fp64 sum as
+ *                CLIP_COEF, so all workgroups agree bit-for-bit; workgroup 0 also writes clip.out), then ADAGRAD_DENSE
+ *                (workgroups [0, dense_blocks)) and ADAGRAD_ROWS (the remaining workgroups).
+ * The embedded descriptors have the meaning of their stand-alone ops; their `kind`, `dense.coef` and `rows.coef` fields
+ * are ignored. */
+typedef struct nasrec_opt_reduce_desc {
+  int32_t kind; /* NASREC_OP_OPT_REDUCE */
+  int32_t _pad;
+  nasrec_emb_dedup_desc_t dedup; /* B <= 256 */
+  nasrec_sumsq_desc_t sumsq;
+} nasrec_opt_reduce_desc_t;
+
+typedef struct nasrec_opt_apply_desc {
+  int32_t kind; /* NASREC_OP_OPT_APPLY */
+  int32_t dense_blocks;
+  nasrec_clip_coef_desc_t clip;
+  nasrec_adagrad_dense_desc_t dense;
+  nasrec_adagrad_rows_desc_t rows;
+} nasrec_opt_apply_desc_t;
+
 typedef struct nasrec_memset_desc {
   int32_t kind; /* NASREC_OP_MEMSET */
   int32_t _pad;
@@ -439,6 +464,8 @@ int nasrec_final_logit(void* stream, const nasrec_final_desc_t* d);
 int nasrec_bce_logits(void* stream, const nasrec_bce_desc_t* d);
 int nasrec_adagrad_dense(void* stream, const nasrec_adagrad_dense_desc_t* d);
 int nasrec_adagrad_rows(void* stream, const nasrec_adagrad_rows_desc_t* d);
+int nasrec_opt_reduce(void* stream, const nasrec_opt_reduce_desc_t* d);
+int nasrec_opt_apply(void* stream, const nasrec_opt_apply_desc_t* d);
 
 /* HIP-event timing on an arbitrary stream (bench.py measures kernels on the engine's own stream). */
 int nasrec_event_create(void** ev);

@@ -58,6 +58,8 @@ static int dispatch(hipStream_t st, const void* desc) {
     case NASREC_OP_SCALE: return launch_scale(st, (const nasrec_scale_desc_t*)desc);
     case NASREC_OP_ACT_BWD: return launch_act_bwd(st, (const nasrec_act_bwd_desc_t*)desc);
     case NASREC_OP_STAGE_INPUTS: return launch_stage(st, (const nasrec_stage_desc_t*)desc);
+    case NASREC_OP_OPT_REDUCE: return launch_opt_reduce(st, (const nasrec_opt_reduce_desc_t*)desc);
+    case NASREC_OP_OPT_APPLY: return launch_opt_apply(st, (const nasrec_opt_apply_desc_t*)desc);
     default: return nasrec_set_error(-1, "unknown op kind %d", kind);
   }
 }
@@ -144,6 +146,8 @@ TYPED(nasrec_final_logit, nasrec_final_desc_t, kind == NASREC_OP_FINAL_FWD || ki
 TYPED(nasrec_bce_logits, nasrec_bce_desc_t, kind == NASREC_OP_BCE)
 TYPED(nasrec_adagrad_dense, nasrec_adagrad_dense_desc_t, kind == NASREC_OP_ADAGRAD_DENSE)
 TYPED(nasrec_adagrad_rows, nasrec_adagrad_rows_desc_t, kind == NASREC_OP_ADAGRAD_ROWS)
+TYPED(nasrec_opt_reduce, nasrec_opt_reduce_desc_t, kind == NASREC_OP_OPT_REDUCE)
+TYPED(nasrec_opt_apply, nasrec_opt_apply_desc_t, kind == NASREC_OP_OPT_APPLY)
 
 int nasrec_event_create(void** ev) {
   hipEvent_t e;
@@ -174,7 +178,7 @@ int nasrec_event_destroy(void* ev) {
 
 const char* nasrec_last_error(void) { return g_err; }
 
-int nasrec_abi_version(void) { return 2; }
+int nasrec_abi_version(void) { return 3; }
 
 int nasrec_desc_sizes(int32_t* out, int n) {
   static const int32_t sizes[] = {
@@ -206,6 +210,8 @@ int nasrec_desc_sizes(int32_t* out, int n) {
       (int32_t)sizeof(nasrec_scale_desc_t),         // 25
       (int32_t)sizeof(nasrec_act_bwd_desc_t),       // 26
       (int32_t)sizeof(nasrec_stage_desc_t),         // 27
+      (int32_t)sizeof(nasrec_opt_reduce_desc_t),    // 28
+      (int32_t)sizeof(nasrec_opt_apply_desc_t),     // 29
   };
   const int total = (int)(sizeof(sizes) / sizeof(sizes[0]));
   int w = 0;

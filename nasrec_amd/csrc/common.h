@@ -63,3 +63,5 @@ int launch_layernorm(hipStream_t s, const nasrec_layernorm_desc_t* d);
 int launch_scale(hipStream_t s, const nasrec_scale_desc_t* d);
 int launch_act_bwd(hipStream_t s, const nasrec_act_bwd_desc_t* d);
 int launch_stage(hipStream_t s, const nasrec_stage_desc_t* d);
+int launch_opt_reduce(hipStream_t s, const nasrec_opt_reduce_desc_t* d);
+int launch_opt_apply(hipStream_t s, const nasrec_opt_apply_desc_t* d);

@@ -5,6 +5,7 @@
 // field per sample.  A row is moved by 4 lanes x float4, so a wavefront moves 16 rows = 1 KiB per
 // instruction and the output [B,Fs,16] is written fully coalesced.
 #include "common.h"
+#include "optimizer_bodies.h"
 
 __global__ __launch_bounds__(256) void embed_gather_kernel(const nasrec_embed_desc_t d) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -129,11 +130,8 @@ __global__ __launch_bounds__(256) void emb_dedup_kernel(const nasrec_emb_dedup_d
 // ds_read_b128 (all lanes read the same address: broadcast): a match below b means "not the leader", and a leader adds
 // the LDS rows of the later matches to its own row in registers.  A 64-fold duplicate on a 4-row table costs 64 LDS row
 // reads in one lane instead of 64 dependent global loads; the summation order is ascending b.
-__global__ __launch_bounds__(256) void emb_dedup_small_kernel(const nasrec_emb_dedup_desc_t d) {
-  __shared__ __attribute__((aligned(16))) int sidx[256];
-  __shared__ __attribute__((aligned(16))) float rows[256 * 20];  // 20-float rows: 16-byte aligned, bank-spread
-  __shared__ float red[256];
-  const int f = blockIdx.x, b = threadIdx.x;
+__device__ __forceinline__ void dedup_small_body(const nasrec_emb_dedup_desc_t& d, int f, int* sidx, float* rows, float* red) {
+  const int b = threadIdx.x;
   const bool live = b < d.B;
   const int my = live ? (int)d.idx[(long)b * d.Fs + f] : -1 - b;  // dead lanes get unique negative ids
   sidx[b] = my;
@@ -200,6 +198,62 @@ __global__ __launch_bounds__(256) void emb_dedup_small_kernel(const nasrec_emb_d
   if (b == 0) d.sumsq_partial[f] = red[0];
 }
 
+__global__ __launch_bounds__(256) void emb_dedup_small_kernel(const nasrec_emb_dedup_desc_t d) {
+  __shared__ __attribute__((aligned(16))) int sidx[256];
+  __shared__ __attribute__((aligned(16))) float rows[256 * 20];  // 20-float rows: 16-byte aligned, bank-spread
+  __shared__ float red[256];
+  dedup_small_body(d, blockIdx.x, sidx, rows, red);
+}
+
+// NASREC_OP_OPT_REDUCE: workgroups [0, Fs) deduplicate one field each, the rest square-sum the dense gradient arena
+__global__ __launch_bounds__(256) void opt_reduce_kernel(const nasrec_opt_reduce_desc_t d) {
+  __shared__ __attribute__((aligned(16))) int sidx[256];
+  __shared__ __attribute__((aligned(16))) float rows[256 * 20];
+  __shared__ float red[256];
+  const int nd = d.dedup.Fs;
+  if ((int)blockIdx.x < nd)
+    dedup_small_body(d.dedup, blockIdx.x, sidx, rows, red);
+  else
+    sumsq_body(d.sumsq, (int)blockIdx.x - nd, d.sumsq.nblocks, red);
+}
+
+int launch_opt_reduce(hipStream_t st, const nasrec_opt_reduce_desc_t* d) {
+  if (d->dedup.B < 1 || d->dedup.B > 256) return nasrec_set_error(-2, "opt_reduce: B=%d outside [1,256]", d->dedup.B);
+  if (d->sumsq.nblocks < 1) return nasrec_set_error(-2, "opt_reduce: sumsq.nblocks=%d", d->sumsq.nblocks);
+  hipLaunchKernelGGL(opt_reduce_kernel, dim3(d->dedup.Fs + d->sumsq.nblocks), dim3(256), 0, st, *d);
+  return nasrec_check_launch("opt_reduce");
+}
+
+// NASREC_OP_OPT_APPLY: clip coefficient (re-derived per workgroup) + Adagrad on the dense arena and on the touched rows
+__global__ __launch_bounds__(256) void opt_apply_kernel(const nasrec_opt_apply_desc_t d) {
+  __shared__ float sh_coef;
+  if (threadIdx.x < 64) {
+    float total;
+    const float c = clip_coef_wave(d.clip, threadIdx.x, &total);
+    if (threadIdx.x == 0) {
+      sh_coef = c;
+      if (blockIdx.x == 0) {
+        d.clip.out[0] = c;
+        d.clip.out[1] = total;
+      }
+    }
+  }
+  __syncthreads();
+  const float coef = sh_coef, lr = *d.dense.lr;
+  if ((int)blockIdx.x < d.dense_blocks)
+    adagrad_dense_body(d.dense, blockIdx.x, d.dense_blocks, lr, coef);
+  else
+    adagrad_rows_body(d.rows, (int)blockIdx.x - d.dense_blocks, lr, coef);
+}
+
+int launch_opt_apply(hipStream_t st, const nasrec_opt_apply_desc_t* d) {
+  const long threads = (long)d->rows.B * d->rows.Fs * 4;
+  const int nrows = (int)((threads + 255) / 256);
+  if (d->dense_blocks < 0 || d->dense_blocks + nrows < 1) return nasrec_set_error(-2, "opt_apply: empty launch");
+  hipLaunchKernelGGL(opt_apply_kernel, dim3(d->dense_blocks + nrows), dim3(256), 0, st, *d);
+  return nasrec_check_launch("opt_apply");
+}
+
 int launch_emb_dedup(hipStream_t st, const nasrec_emb_dedup_desc_t* d) {
   if (d->B == 0) return 0;
   if (d->B > DEDUP_MAXB) return nasrec_set_error(-2, "emb_dedup: B=%d > %d", d->B, DEDUP_MAXB);
@@ -212,30 +266,8 @@ int launch_emb_dedup(hipStream_t st, const nasrec_emb_dedup_desc_t* d) {
   return nasrec_check_launch("emb_dedup");
 }
 
-// Row-sparse clip + Adagrad on the touched rows only (4 lanes x float4 per row).
 __global__ __launch_bounds__(256) void adagrad_rows_kernel(const nasrec_adagrad_rows_desc_t d) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  const long pair = t >> 2;
-  const int q = (int)(t & 3);
-  if (pair >= (long)d.B * d.Fs) return;
-  if (!d.leader[pair]) return;
-  const int f = (int)(pair % d.Fs);
-  const long row = d.idx[pair];
-  const float lr = *d.lr, coef = *d.coef;
-  float4 g = *reinterpret_cast<const float4*>(d.gsum + pair * 16 + q * 4);
-  float4* sp = reinterpret_cast<float4*>(d.state[f] + row * 16 + q * 4);
-  float4* pp = reinterpret_cast<float4*>(d.table[f] + row * 16 + q * 4);
-  float4 s = *sp, p = *pp;
-  float gg[4] = {g.x * coef, g.y * coef, g.z * coef, g.w * coef};
-  float ssv[4] = {s.x, s.y, s.z, s.w};
-  float pv[4] = {p.x, p.y, p.z, p.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    ssv[e] = fmaf(gg[e], gg[e], ssv[e]);
-    pv[e] = pv[e] - lr * (gg[e] / (sqrtf(ssv[e]) + d.eps));
-  }
-  *sp = make_float4(ssv[0], ssv[1], ssv[2], ssv[3]);
-  *pp = make_float4(pv[0], pv[1], pv[2], pv[3]);
+  adagrad_rows_body(d, blockIdx.x, *d.lr, *d.coef);
 }
 
 int launch_adagrad_rows(hipStream_t st, const nasrec_adagrad_rows_desc_t* d) {

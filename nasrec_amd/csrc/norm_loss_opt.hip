@@ -1,6 +1,7 @@
 // Final logit + BCE loss, LayerNorm, and the optimizer tail (clip_grad_norm_ + Adagrad) of the training step
 // (reference: supernet.py:592-598/657-664, main_train.py:122, train_utils.py:262-286, main_train.py:152-154).
 #include "common.h"
+#include "optimizer_bodies.h"
 
 // ---------------------------------------------------------------------------------------------------
 // final logit: one wavefront per sample, lanes stride the (segmented) feature axis
@@ -122,18 +123,7 @@ int launch_bce(hipStream_t st, const nasrec_bce_desc_t* d) {
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sumsq_kernel(const nasrec_sumsq_desc_t d) {
   __shared__ float red[256];
-  float s = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long)gridDim.x * 256) {
-    const float v = d.x[i];
-    s = fmaf(v, v, s);
-  }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) d.partial[blockIdx.x] = red[0];
+  sumsq_body(d, blockIdx.x, gridDim.x, red);
 }
 
 int launch_sumsq(hipStream_t st, const nasrec_sumsq_desc_t* d) {
@@ -142,18 +132,10 @@ int launch_sumsq(hipStream_t st, const nasrec_sumsq_desc_t* d) {
   return nasrec_check_launch("sumsq");
 }
 
-// one wavefront: lanes take the partials round-robin (fixed assignment), fp64 butterfly -> same value in every lane
 __global__ __launch_bounds__(64) void clip_coef_kernel(const nasrec_clip_coef_desc_t d) {
-  const int lane = threadIdx.x;
-  double s = 0.0;
-  for (int i = lane; i < d.n_a; i += 64) s += (double)d.partial_a[i];
-  for (int i = lane; i < d.n_b; i += 64) s += (double)d.partial_b[i];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) {
-    const float total = (float)sqrt(s);
-    float coef = 1.f;
-    if (d.max_norm > 0.f) coef = fminf(d.max_norm / (total + 1e-6f), 1.f);
+  float total;
+  const float coef = clip_coef_wave(d, threadIdx.x, &total);
+  if (threadIdx.x == 0) {
     d.out[0] = coef;
     d.out[1] = total;
   }
@@ -165,20 +147,12 @@ int launch_clip_coef(hipStream_t st, const nasrec_clip_coef_desc_t* d) {
 }
 
 __global__ __launch_bounds__(256) void adagrad_dense_kernel(const nasrec_adagrad_dense_desc_t d) {
-  const float lr = *d.lr, coef = *d.coef;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long)gridDim.x * 256) {
-    const float g = d.g[i] * coef;
-    const float s = fmaf(g, g, d.state[i]);
-    d.state[i] = s;
-    d.p[i] = d.p[i] - lr * (g / (sqrtf(s) + d.eps));
-  }
+  adagrad_dense_body(d, blockIdx.x, gridDim.x, *d.lr, *d.coef);
 }
 
 int launch_adagrad_dense(hipStream_t st, const nasrec_adagrad_dense_desc_t* d) {
   if (d->n == 0) return 0;
-  long blocks = (d->n + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adagrad_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, st, *d);
+  hipLaunchKernelGGL(adagrad_dense_kernel, dim3((unsigned)adagrad_dense_blocks(d->n)), dim3(256), 0, st, *d);
   return nasrec_check_launch("adagrad_dense");
 }
 

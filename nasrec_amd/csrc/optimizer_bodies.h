@@ -1,0 +1,83 @@
+// Device bodies of the optimizer tail (clip_grad_norm_ + Adagrad, train_utils.py:285-286 / main_train.py:152-154), shared
+// by the stand-alone kernels and by the two fused launches NASREC_OP_OPT_REDUCE / NASREC_OP_OPT_APPLY.
+#pragma once
+#include "common.h"
+
+// sum of squares of x[0, n): workgroup `blk` of `nblk` (256 threads), fixed-order tree -> partial[blk]
+__device__ __forceinline__ void sumsq_body(const nasrec_sumsq_desc_t& d, int blk, int nblk, float* red) {
+  const int tid = threadIdx.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains keep several cold loads in flight
+  const long stride = (long)nblk * 256;
+  long i = (long)blk * 256 + tid;
+  for (; i + 3 * stride < d.n; i += 4 * stride) {
+    const float a = d.x[i], b = d.x[i + stride], c = d.x[i + 2 * stride], e = d.x[i + 3 * stride];
+    s0 = fmaf(a, a, s0);
+    s1 = fmaf(b, b, s1);
+    s2 = fmaf(c, c, s2);
+    s3 = fmaf(e, e, s3);
+  }
+  for (; i < d.n; i += stride) {
+    const float a = d.x[i];
+    s0 = fmaf(a, a, s0);
+  }
+  red[tid] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) d.partial[blk] = red[0];
+}
+
+// one wavefront: lanes take the partials round-robin (fixed assignment), fp64 butterfly -> the same value in every lane
+__device__ __forceinline__ float clip_coef_wave(const nasrec_clip_coef_desc_t& d, int lane, float* total_out) {
+  double s = 0.0;
+  for (int i = lane; i < d.n_a; i += 64) s += (double)d.partial_a[i];
+  for (int i = lane; i < d.n_b; i += 64) s += (double)d.partial_b[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float total = (float)sqrt(s);
+  float coef = 1.f;
+  if (d.max_norm > 0.f) coef = fminf(d.max_norm / (total + 1e-6f), 1.f);
+  *total_out = total;
+  return coef;
+}
+
+__device__ __forceinline__ void adagrad_dense_body(const nasrec_adagrad_dense_desc_t& d, int blk, int nblk, float lr, float coef) {
+  for (long i = (long)blk * 256 + threadIdx.x; i < d.n; i += (long)nblk * 256) {
+    const float g = d.g[i] * coef;
+    const float s = fmaf(g, g, d.state[i]);
+    d.state[i] = s;
+    d.p[i] = d.p[i] - lr * (g / (sqrtf(s) + d.eps));
+  }
+}
+
+// Row-sparse clip + Adagrad on the touched rows only (4 lanes x float4 per row); workgroup `blk` of 256 threads
+__device__ __forceinline__ void adagrad_rows_body(const nasrec_adagrad_rows_desc_t& d, int blk, float lr, float coef) {
+  const long t = (long)blk * 256 + threadIdx.x;
+  const long pair = t >> 2;
+  const int q = (int)(t & 3);
+  if (pair >= (long)d.B * d.Fs) return;
+  if (!d.leader[pair]) return;
+  const int f = (int)(pair % d.Fs);
+  const long row = d.idx[pair];
+  float4 g = *reinterpret_cast<const float4*>(d.gsum + pair * 16 + q * 4);
+  float4* sp = reinterpret_cast<float4*>(d.state[f] + row * 16 + q * 4);
+  float4* pp = reinterpret_cast<float4*>(d.table[f] + row * 16 + q * 4);
+  float4 s = *sp, p = *pp;
+  float gg[4] = {g.x * coef, g.y * coef, g.z * coef, g.w * coef};
+  float ssv[4] = {s.x, s.y, s.z, s.w};
+  float pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ssv[e] = fmaf(gg[e], gg[e], ssv[e]);
+    pv[e] = pv[e] - lr * (gg[e] / (sqrtf(ssv[e]) + d.eps));
+  }
+  *sp = make_float4(ssv[0], ssv[1], ssv[2], ssv[3]);
+  *pp = make_float4(pv[0], pv[1], pv[2], pv[3]);
+}
+
+static inline int adagrad_dense_blocks(long n) {
+  long blocks = (n + 255) / 256;
+  return (int)(blocks > 2048 ? 2048 : blocks);
+}

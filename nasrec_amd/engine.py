@@ -273,7 +273,7 @@ class SupernetEngine:
         cp.leader = torch.zeros(Bg * self.Fs, dtype=torch.int32, device=self.device)
         cp.gsum = torch.zeros(Bg * self.Fs * E, dtype=torch.float32, device=self.device)
         cp.emb_partial = torch.zeros(self.Fs * nb, dtype=torch.float32, device=self.device)
-        nblk = max(1, min(1024, (self.flat_numel + 256 * 8 - 1) // (256 * 8)))
+        nblk = max(1, min(256, (self.flat_numel + 256 * 8 - 1) // (256 * 8)))
         cp.dense_partial = torch.zeros(nblk, dtype=torch.float32, device=self.device)
         if sparse_grad is not None:
             dd = L.EmbDedupDesc()
@@ -309,6 +309,16 @@ class SupernetEngine:
                 ar.state[f] = self.table_state[f].data_ptr()
             ar.lr, ar.coef = self.lr_dev.data_ptr(), self.clip_out.data_ptr()
             descs.append(ar)
+        if sparse_grad is not None and Bg <= 256:
+            # batch <= 256: the five launches collapse into the two that the grid-wide dependencies require
+            red = L.OptReduceDesc()
+            red.kind = L.OP_OPT_REDUCE
+            red.dedup, red.sumsq = dd, sq
+            app = L.OptApplyDesc()
+            app.kind = L.OP_OPT_APPLY
+            app.dense_blocks = min(2048, (self.flat_numel + 255) // 256)
+            app.clip, app.dense, app.rows = cc, ad, ar
+            return [red, app]
         return descs
 
     # -------------------------------------------------------------------------------------------------------

@@ -247,6 +247,62 @@ def test_rowsparse_adagrad_equals_dense_reference(lib, B):
         assert torch.equal(lead[:, f], want)
 
 
+@pytest.mark.parametrize("B", [256, 77])
+def test_fused_optimizer_tail_is_bit_identical_to_the_stand_alone_ops(lib, B):
+    """OPT_REDUCE + OPT_APPLY (two launches) == EMB_DEDUP, SUMSQ, CLIP_COEF, ADAGRAD_DENSE, ADAGRAD_ROWS (five launches)"""
+    torch.manual_seed(11)
+    rows, Fs, n = [4, 50, 3000], 3, 70001
+    idx = dev(torch.stack([torch.randint(0, r, (B,)) for r in rows], 1))
+    dout = dev(torch.randn(B, Fs, 16) * 0.1)
+    g = dev(torch.randn(n) * 0.05)
+    lr_d = dev(torch.tensor([0.12]))
+    nblk = 37
+
+    def state():
+        torch.manual_seed(12)
+        return dict(tab=[dev(torch.randn(r, 16)) for r in rows], tst=[dev(torch.rand(r, 16)) for r in rows], p=dev(torch.randn(n)),
+                    st=dev(torch.rand(n)), leader=dev(torch.zeros(B * Fs, dtype=torch.int32)), gsum=dev(torch.zeros(B * Fs * 16)),
+                    pe=dev(torch.zeros(Fs)), pd=dev(torch.zeros(nblk)), coef=dev(torch.zeros(2)))
+
+    def descs(s):
+        dd = L.EmbDedupDesc()
+        dd.kind, dd.B, dd.Fs = L.OP_EMB_DEDUP, B, Fs
+        dd.idx, dd.dout, dd.leader, dd.gsum, dd.sumsq_partial = idx.data_ptr(), dout.data_ptr(), s["leader"].data_ptr(), s["gsum"].data_ptr(), s["pe"].data_ptr()
+        sq = L.SumsqDesc()
+        sq.kind, sq.nblocks, sq.n, sq.x, sq.partial = L.OP_SUMSQ, nblk, n, g.data_ptr(), s["pd"].data_ptr()
+        cc = L.ClipCoefDesc()
+        cc.kind, cc.n_a, cc.n_b, cc.max_norm = L.OP_CLIP_COEF, nblk, Fs, 0.7
+        cc.partial_a, cc.partial_b, cc.out = s["pd"].data_ptr(), s["pe"].data_ptr(), s["coef"].data_ptr()
+        ad = L.AdagradDenseDesc()
+        ad.kind, ad.eps, ad.n = L.OP_ADAGRAD_DENSE, 1e-2, n
+        ad.p, ad.g, ad.state, ad.lr, ad.coef = s["p"].data_ptr(), g.data_ptr(), s["st"].data_ptr(), lr_d.data_ptr(), s["coef"].data_ptr()
+        ar = L.AdagradRowsDesc()
+        ar.kind, ar.B, ar.Fs, ar.eps = L.OP_ADAGRAD_ROWS, B, Fs, 1e-2
+        ar.idx, ar.leader, ar.gsum, ar.lr, ar.coef = idx.data_ptr(), s["leader"].data_ptr(), s["gsum"].data_ptr(), lr_d.data_ptr(), s["coef"].data_ptr()
+        for f in range(Fs):
+            ar.table[f], ar.state[f] = s["tab"][f].data_ptr(), s["tst"][f].data_ptr()
+        return dd, sq, cc, ad, ar
+
+    a, b = state(), state()
+    for d in descs(a):
+        launch(lib, d)
+    dd, sq, cc, ad, ar = descs(b)
+    red = L.OptReduceDesc()
+    red.kind, red.dedup, red.sumsq = L.OP_OPT_REDUCE, dd, sq
+    app = L.OptApplyDesc()
+    app.kind, app.dense_blocks, app.clip, app.dense, app.rows = L.OP_OPT_APPLY, min(2048, (n + 255) // 256), cc, ad, ar
+    launch(lib, red)
+    launch(lib, app)
+    torch.cuda.synchronize()
+    assert float(a["coef"][0]) < 1.0  # the clip is active
+    for k in ("p", "st", "leader", "pe", "pd", "coef"):
+        assert torch.equal(a[k], b[k]), k
+    for f in range(Fs):
+        assert torch.equal(a["tab"][f], b["tab"][f]) and torch.equal(a["tst"][f], b["tst"][f])
+    lead = a["leader"].bool()
+    assert torch.equal(a["gsum"].view(-1, 16)[lead], b["gsum"].view(-1, 16)[lead])
+
+
 @pytest.mark.parametrize("k1", [2, 9, 40, 46])
 def test_dot_tri(lib, k1):
     torch.manual_seed(5)

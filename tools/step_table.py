@@ -46,3 +46,16 @@ with torch.cuda.stream(eng.stream):
 for r in rows:
     print("%s %-14s %7.2f us  %s" % r)
 print("sum of isolated launches: %.1f us over %d launches" % (tot, len(rows)))
+
+# host enqueue time vs GPU time of the graph-replayed step
+import time
+for _ in range(30):
+    eng.train_step(bx[0], bx[1], bx[2], 1e-3, choice=choice, graph=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(300):
+    eng.train_step(bx[0], bx[1], bx[2], 1e-3, choice=choice, graph=True)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("graph step: host enqueue %.1f us/step, total %.1f us/step" % ((t1 - t0) / 300 * 1e6, (t2 - t0) / 300 * 1e6))
