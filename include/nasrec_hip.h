@@ -427,7 +427,8 @@ typedef struct nasrec_act_bwd_desc {
 
 /* Per-step input staging (train_utils.py:257-259 does three .to(gpu) copies): one launch copies the dense features,
  * the ids and the labels into the plan's static buffers and stores the step's learning rate into device memory
- * (lr_scheduler.step(), train_utils.py:386) so that the captured step graph can be replayed unchanged. */
+ * (lr_scheduler.step(), train_utils.py:386) so that the captured step graph can be replayed unchanged.  The launch can
+ * carry the embedding gather of the step as well (the ids are in its hands anyway). */
 typedef struct nasrec_stage_desc {
   int32_t kind; /* NASREC_OP_STAGE_INPUTS */
   int32_t B, Fd, Fs;
@@ -437,6 +438,8 @@ typedef struct nasrec_stage_desc {
   const int64_t* cat_src; int64_t* cat_dst;   /* [B, Fs] */
   const float* y_src;     float* y_dst;       /* [B] (may be NULL) */
   float* lr_dst;                              /* device scalar (may be NULL) */
+  nasrec_embed_desc_t gather;                 /* gather.out != NULL: the same launch also runs the embedding stem on
+                                                 cat_src (gather.idx and gather.kind are ignored; B, Fs from above) */
 } nasrec_stage_desc_t;
 
 /* ------------------------------------------------------------------------------------------------

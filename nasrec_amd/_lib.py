@@ -143,7 +143,7 @@ class ActBwdDesc(C.Structure):
 
 class StageDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("Fd", i32), ("Fs", i32), ("lr", f32), ("_pad", i32), ("int_src", vp), ("int_dst", vp),
-                ("cat_src", vp), ("cat_dst", vp), ("y_src", vp), ("y_dst", vp), ("lr_dst", vp)]
+                ("cat_src", vp), ("cat_dst", vp), ("y_src", vp), ("y_dst", vp), ("lr_dst", vp), ("gather", EmbedDesc)]
 
 
 class OptReduceDesc(C.Structure):

@@ -7,13 +7,13 @@
 #include "common.h"
 #include "optimizer_bodies.h"
 
-__global__ __launch_bounds__(256) void embed_gather_kernel(const nasrec_embed_desc_t d) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+// thread t of the gather: (pair = t >> 2 = (b, f), q = t & 3 = which float4 of the 64-byte row)
+__device__ __forceinline__ void embed_gather_body(const nasrec_embed_desc_t& d, const int64_t* idx, int B, int Fs, long t) {
   const long pair = t >> 2;
   const int q = (int)(t & 3);
-  if (pair >= (long)d.B * d.Fs) return;
-  const int f = (int)(pair % d.Fs);
-  long row = d.idx[pair];
+  if (pair >= (long)B * Fs) return;
+  const int f = (int)(pair % Fs);
+  long row = idx[pair];
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (row >= 0 && row < d.rows[f]) {
     v = *reinterpret_cast<const float4*>(d.table[f] + row * NASREC_EMB_DIM + q * 4);
@@ -21,6 +21,33 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const nasrec_embed_de
     *d.oob = 1;  // torch raises IndexError; the host shim turns this flag into one
   }
   *reinterpret_cast<float4*>(d.out + pair * NASREC_EMB_DIM + q * 4) = v;
+}
+
+__global__ __launch_bounds__(256) void embed_gather_kernel(const nasrec_embed_desc_t d) {
+  embed_gather_body(d, d.idx, d.B, d.Fs, (long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// per-step input staging + learning-rate store (one launch instead of three copies and a fill), optionally with the
+// embedding gather of the step riding along
+__global__ __launch_bounds__(256) void stage_inputs_kernel(const nasrec_stage_desc_t d) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int n_int = d.B * d.Fd, n_cat = d.B * d.Fs;
+  if (t < n_int) d.int_dst[t] = d.int_src[t];
+  if (t < n_cat) d.cat_dst[t] = d.cat_src[t];
+  if (d.y_src != nullptr && t < d.B) d.y_dst[t] = d.y_src[t];
+  if (t == 0 && d.lr_dst != nullptr) d.lr_dst[0] = d.lr;
+  if (d.gather.out != nullptr) embed_gather_body(d.gather, d.cat_src, d.B, d.Fs, t);
+}
+
+int launch_stage(hipStream_t st, const nasrec_stage_desc_t* d) {
+  long n = (long)d->B * (d->Fd > d->Fs ? d->Fd : d->Fs);
+  if (d->gather.out != nullptr) {
+    if (d->Fs < 1 || d->Fs > NASREC_MAX_TABLES) return nasrec_set_error(-2, "stage: Fs=%d out of range", d->Fs);
+    if ((long)d->B * d->Fs * 4 > n) n = (long)d->B * d->Fs * 4;
+  }
+  if (n < 1) n = 1;
+  hipLaunchKernelGGL(stage_inputs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *d);
+  return nasrec_check_launch("stage_inputs");
 }
 
 int launch_embed_gather(hipStream_t st, const nasrec_embed_desc_t* d) {

@@ -365,21 +365,3 @@ int launch_layernorm(hipStream_t st, const nasrec_layernorm_desc_t* d) {
   return nasrec_check_launch("layernorm");
 }
 
-// ---------------------------------------------------------------------------------------------------
-// per-step input staging + learning-rate store (one launch instead of three copies and a fill)
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stage_inputs_kernel(const nasrec_stage_desc_t d) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int n_int = d.B * d.Fd, n_cat = d.B * d.Fs;
-  if (t < n_int) d.int_dst[t] = d.int_src[t];
-  if (t < n_cat) d.cat_dst[t] = d.cat_src[t];
-  if (d.y_src != nullptr && t < d.B) d.y_dst[t] = d.y_src[t];
-  if (t == 0 && d.lr_dst != nullptr) d.lr_dst[0] = d.lr;
-}
-
-int launch_stage(hipStream_t st, const nasrec_stage_desc_t* d) {
-  int n = d->B * (d->Fd > d->Fs ? d->Fd : d->Fs);
-  if (n < 1) n = 1;
-  hipLaunchKernelGGL(stage_inputs_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *d);
-  return nasrec_check_launch("stage_inputs");
-}

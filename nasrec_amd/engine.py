@@ -209,7 +209,15 @@ class SupernetEngine:
                 g.rows[f] = self.num_embeddings[f]
             g.out = sbuf.t.data_ptr()
             g.oob = self.oob.data_ptr()
-            ctx.emit(g)
+            # the gather rides on the per-step staging launch (which holds the caller's id tensor anyway); cp.gather is the
+            # stand-alone descriptor for the paths that stage by other means
+            cp.gather = g
+            st = L.StageDesc()
+            st.kind = L.OP_STAGE_INPUTS
+            st.B, st.Fd, st.Fs = B, self.Fd, self.Fs
+            st.int_dst, st.cat_dst, st.y_dst = cp.int_x.data_ptr(), cp.cat_x.data_ptr(), cp.y.data_ptr()
+            st.gather = g
+            cp.stage = st
             d_last, s_last = P.network_walk(ctx, cfg, choice, dense0, sparse0)
             # final logit (supernet.py:592-598 / 657-664)
             K = d_last.width + s_last.N * E
@@ -339,16 +347,15 @@ class SupernetEngine:
                 cp.y.copy_(y.reshape(cp.y.shape), non_blocking=True)
             if lr is not None:
                 self.lr_dev.fill_(float(lr))
+            L.check(L.load().nasrec_launch(sp, C.addressof(cp.gather)))
             return
-        d = L.StageDesc()
-        d.kind = L.OP_STAGE_INPUTS
-        d.B, d.Fd, d.Fs = cp.int_x.shape[0], self.Fd, self.Fs
-        d.int_src, d.int_dst = int_x.data_ptr(), cp.int_x.data_ptr()
-        d.cat_src, d.cat_dst = cat_x.data_ptr(), cp.cat_x.data_ptr()
-        if y is not None:
-            d.y_src, d.y_dst = y.data_ptr(), cp.y.data_ptr()
+        d = cp.stage  # prebuilt per plan: only the sources change from step to step
+        d.int_src, d.cat_src = int_x.data_ptr(), cat_x.data_ptr()
+        d.y_src = y.data_ptr() if y is not None else None
         if lr is not None:
             d.lr, d.lr_dst = float(lr), self.lr_dev.data_ptr()
+        else:
+            d.lr_dst = None
         L.check(L.load().nasrec_launch(sp, C.addressof(d)))
 
     def forward(self, int_x, cat_x, choice=None, graph=False):
@@ -376,6 +383,7 @@ class SupernetEngine:
             self._stage_inputs(sp, cp, int_x, cat_x, y, lr)
         else:
             self.lr_dev.fill_(float(lr))
+            L.check(L.load().nasrec_launch(sp, C.addressof(cp.gather)))
         if graph:
             cp.step.replay(sp)
         else:

@@ -189,6 +189,20 @@ def test_embedding_gather_bit_exact_and_oob(lib):
     ref = torch.stack([tables[f][idx[:, f]] for f in range(Fs)], 1)
     assert torch.equal(out.cpu(), ref)  # bit-exact
     assert int(oob.item()) == 0
+    # the same gather riding on the per-step staging launch (NASREC_OP_STAGE_INPUTS with desc.gather)
+    Fd = 13
+    int_src, y_src = dev(torch.randn(B, Fd)), dev(torch.rand(B))
+    int_dst, cat_dst, y_dst, lr_dst = dev(torch.zeros(B, Fd)), dev(torch.zeros(B, Fs, dtype=torch.int64)), dev(torch.zeros(B)), dev(torch.zeros(1))
+    out2 = dev(torch.zeros(B, Fs, 16))
+    st = L.StageDesc()
+    st.kind, st.B, st.Fd, st.Fs, st.lr = L.OP_STAGE_INPUTS, B, Fd, Fs, 0.125
+    st.int_src, st.int_dst, st.cat_src, st.cat_dst = int_src.data_ptr(), int_dst.data_ptr(), gi.data_ptr(), cat_dst.data_ptr()
+    st.y_src, st.y_dst, st.lr_dst = y_src.data_ptr(), y_dst.data_ptr(), lr_dst.data_ptr()
+    st.gather = d
+    st.gather.out = out2.data_ptr()
+    launch(lib, st)
+    assert torch.equal(out2.cpu(), ref) and torch.equal(int_dst, int_src) and torch.equal(cat_dst, gi) and torch.equal(y_dst, y_src)
+    assert float(lr_dst.item()) == 0.125 and int(oob.item()) == 0
     gi[5, 1] = 1000  # one past the end
     launch(lib, d)
     assert int(oob.item()) == 1
