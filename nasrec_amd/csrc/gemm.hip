@@ -384,7 +384,9 @@ static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
   const int S = d->splitk > 1 ? d->splitk : 1;
   if (S > 1 && d->workspace == nullptr) return nasrec_set_error(-3, "gemm: splitk=%d needs a workspace", S);
   const int zdim = nprob * S;
-  const long wgs = (long)((Mmax + 63) / 64) * ((Nmax + 63) / 64) * zdim;  // workgroups of a 64x64 tiling
+  // LIVE workgroups of a 64x64 tiling (a zmode grid is padded to Mmax x Nmax: the surplus workgroups exit at once)
+  long wgs = 0;
+  for (int q = 0; q < nprob; ++q) wgs += (long)((d->seg[q].M + 63) / 64) * ((d->seg[q].N + 63) / 64) * S;
   const bool deep = Kmax > 32;
   if (wgs >= 1024) {
     launch_cfg<AM, BMODE, CM, 256, 32, 64, 64>(st, d, Mmax, Nmax, zdim);

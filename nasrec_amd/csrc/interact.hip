@@ -282,8 +282,21 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const nasrec_reduce_ro
   const int cl = threadIdx.x & 15, rq = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   float s = 0.f;
-  if (c < d.C)
-    for (int r = rq; r < d.R; r += 16) s += d.in[(long)r * d.ld + c];
+  if (c < d.C) {
+    // four independent chains: the loads of a cold [R, C] slab pipeline instead of queueing behind one accumulator
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = rq;
+    for (; r + 48 < d.R; r += 64) {
+      const float a0 = d.in[(long)r * d.ld + c], a1 = d.in[(long)(r + 16) * d.ld + c];
+      const float a2 = d.in[(long)(r + 32) * d.ld + c], a3 = d.in[(long)(r + 48) * d.ld + c];
+      s += a0;
+      s1 += a1;
+      s2 += a2;
+      s3 += a3;
+    }
+    for (; r < d.R; r += 16) s += d.in[(long)r * d.ld + c];
+    s = (s + s1) + (s2 + s3);
+  }
   red[rq][cl] = s;
   __syncthreads();
   if (rq == 0 && c < d.C) {
