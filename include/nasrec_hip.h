@@ -279,6 +279,7 @@ typedef struct nasrec_rowsum_desc {
 typedef struct nasrec_final_desc {
   int32_t kind; /* NASREC_OP_FINAL_FWD / _BWD */
   int32_t B, nseg;
+  float grad_scale;    /* bwd with y != NULL: see nasrec_bce_desc_t */
   const float* w;      /* [1, K] */
   const float* bias;   /* [1] */
   float* logits;       /* [B] */
@@ -289,6 +290,12 @@ typedef struct nasrec_final_desc {
   float* dseg[NASREC_MAX_SEGS];  /* bwd: gradient destinations (NULL = skip) */
   int32_t width[NASREC_MAX_SEGS], ld[NASREC_MAX_SEGS], off[NASREC_MAX_SEGS];
   int32_t dseg_accumulate[NASREC_MAX_SEGS];
+  /* bwd, optional: fuse BCEWithLogitsLoss into this launch (one kernel less on the step's critical path).  With
+     y != NULL the incoming gradient is (sigmoid(logits[b]) - y[b]) * grad_scale instead of dlogits[b]; one extra
+     workgroup writes loss[0] (mean BCE, as NASREC_OP_BCE) and, if dlogits_out != NULL, the per-sample gradient. */
+  const float* y;
+  float* loss;
+  float* dlogits_out;
 } nasrec_final_desc_t;
 
 /* BCEWithLogitsLoss(mean) forward + dlogits (main_train.py:122; train_utils.py:266):

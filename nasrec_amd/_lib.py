@@ -95,9 +95,10 @@ class RowsumDesc(C.Structure):
 
 
 class FinalDesc(C.Structure):
-    _fields_ = [("kind", i32), ("B", i32), ("nseg", i32), ("w", vp), ("bias", vp), ("logits", vp), ("dlogits", vp), ("dw", vp),
-                ("dbias", vp), ("seg", vp * MAX_SEGS), ("dseg", vp * MAX_SEGS), ("width", i32 * MAX_SEGS),
-                ("ld", i32 * MAX_SEGS), ("off", i32 * MAX_SEGS), ("dseg_accumulate", i32 * MAX_SEGS)]
+    _fields_ = [("kind", i32), ("B", i32), ("nseg", i32), ("grad_scale", f32), ("w", vp), ("bias", vp), ("logits", vp), ("dlogits", vp),
+                ("dw", vp), ("dbias", vp), ("seg", vp * MAX_SEGS), ("dseg", vp * MAX_SEGS), ("width", i32 * MAX_SEGS),
+                ("ld", i32 * MAX_SEGS), ("off", i32 * MAX_SEGS), ("dseg_accumulate", i32 * MAX_SEGS), ("y", vp), ("loss", vp),
+                ("dlogits_out", vp)]
 
 
 class BceDesc(C.Structure):

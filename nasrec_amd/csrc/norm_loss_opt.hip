@@ -21,9 +21,16 @@ __global__ __launch_bounds__(256) void final_fwd_kernel(const nasrec_final_desc_
   if (lane == 0) d.logits[b] = s + d.bias[0];
 }
 
+__device__ __forceinline__ float bce_grad(float z, float y, float scale) { return (1.f / (1.f + expf(-z)) - y) * scale; }
+__device__ __forceinline__ float bce_term(float z, float y) { return fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z))); }
+
 // backward: part A (blocks [0, nA)): dseg[b,j] (+)= dlogits[b] * w[off+j]
-//           part B (blocks [nA, ..)): dw[k] = sum_b dlogits[b] * feat[b,k]; dbias = sum_b dlogits[b]
-__global__ __launch_bounds__(256) void final_bwd_kernel(const nasrec_final_desc_t d, int K, int nA) {
+//           part B (blocks [nA, nA+nB)): dw[k] = sum_b dlogits[b] * feat[b,k]; dbias = sum_b dlogits[b]
+//           part C (block nA+nB, only with the fused BCE): loss and the per-sample gradient
+// With d.y != NULL, dlogits[b] is derived on the fly from logits[b] and y[b] (BCEWithLogits fused into this launch).
+__global__ __launch_bounds__(256) void final_bwd_kernel(const nasrec_final_desc_t d, int K, int nA, int nB) {
+  const bool fused = d.y != nullptr;
+  auto dl = [&](int b) { return fused ? bce_grad(d.logits[b], d.y[b], d.grad_scale) : d.dlogits[b]; };
   if ((int)blockIdx.x < nA) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long)d.B * K) return;
@@ -33,12 +40,29 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const nasrec_final_desc_
       if (jj >= 0 && jj < d.width[q]) {
         if (d.dseg[q]) {
           float* p = d.dseg[q] + (long)b * d.ld[q] + jj;
-          const float v = d.dlogits[b] * d.w[k];
+          const float v = dl(b) * d.w[k];
           *p = d.dseg_accumulate[q] ? *p + v : v;
         }
         break;
       }
     }
+    return;
+  }
+  if ((int)blockIdx.x >= nA + nB) {  // part C
+    __shared__ float redl[256];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < d.B; b += 256) {
+      const float z = d.logits[b], y = d.y[b];
+      s += bce_term(z, y);
+      if (d.dlogits_out) d.dlogits_out[b] = bce_grad(z, y, d.grad_scale);
+    }
+    redl[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) redl[threadIdx.x] += redl[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0 && d.loss) d.loss[0] = redl[0] / (float)d.B;
     return;
   }
   __shared__ float red[16][17];
@@ -60,7 +84,7 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const nasrec_final_desc_
     }
     for (int b = bq; b < d.B; b += 16) {
       float f = (k == K) ? 1.f : (src ? src[(long)b * ld + jj] : 0.f);
-      s = fmaf(d.dlogits[b], f, s);
+      s = fmaf(dl(b), f, s);
     }
   }
   red[bq][kl] = s;
@@ -86,7 +110,8 @@ int launch_final(hipStream_t st, const nasrec_final_desc_t* d) {
     long tA = (long)d->B * K;
     int nA = (int)((tA + 255) / 256);
     int nB = (K + 1 + 15) / 16;
-    hipLaunchKernelGGL(final_bwd_kernel, dim3(nA + nB), dim3(256), 0, st, *d, K, nA);
+    if (d->y != nullptr && d->logits == nullptr) return nasrec_set_error(-2, "final_bwd: fused BCE needs desc.logits");
+    hipLaunchKernelGGL(final_bwd_kernel, dim3(nA + nB + (d->y != nullptr ? 1 : 0)), dim3(256), 0, st, *d, K, nA, nB);
   }
   return nasrec_check_launch("final");
 }
@@ -99,9 +124,8 @@ __global__ __launch_bounds__(1024) void bce_kernel(const nasrec_bce_desc_t d) {
   float s = 0.f;
   for (int b = threadIdx.x; b < d.B; b += 1024) {
     const float z = d.logits[b], y = d.y[b];
-    s += fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
-    const float sg = 1.f / (1.f + expf(-z));
-    d.dlogits[b] = (sg - y) * d.grad_scale;
+    s += bce_term(z, y);
+    d.dlogits[b] = bce_grad(z, y, d.grad_scale);
   }
   red[threadIdx.x] = s;
   __syncthreads();

@@ -261,7 +261,16 @@ class SupernetEngine:
 
                 ctx.on_backward(final_bwd)
                 ctx.build_backward()
-                cp.bwd = Program(pre + ctx.bwd)
+                # The training programs fold BCEWithLogits into the final-logit backward (the first closure to run); bwd_core
+                # keeps the plain one (d loss / d logits supplied by torch.autograd).
+                fi = next(i for i, dsc in enumerate(ctx.bwd) if isinstance(dsc, L.FinalDesc))
+                plain = ctx.bwd[fi]
+                assert plain.kind == L.OP_FINAL_BWD
+                fused = L.FinalDesc.from_buffer_copy(plain)
+                fused.logits, fused.y, fused.loss, fused.dlogits_out = cp.logits.data_ptr(), cp.y.data_ptr(), cp.loss.data_ptr(), cp.dlogits.data_ptr()
+                fused.grad_scale = bd.grad_scale
+                cp.bce = bd
+                cp.bwd = Program(pre[1:] + ctx.bwd[:fi] + [fused] + ctx.bwd[fi + 1:])
                 cp.bwd_core = Program(pre[1:] + ctx.bwd)  # dlogits supplied by the caller (autograd path)
                 cp.opt = Program(self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if sbuf.grad_written else None, clip, eps))
                 if graph:

@@ -529,6 +529,16 @@ def test_final_bce_and_dense_optimizer(lib):
     close(dsl.reshape(B, -1), feats.grad[:, D:] + 1.0, 1e-5)
     close(dw, wd.grad[0], 1e-5)
     close(db, bd.grad, 1e-5)
+    # BCE fused into the final-logit backward: identical gradients without the separate NASREC_OP_BCE launch
+    ddl2, dsl2, dw2, db2 = dev(torch.zeros(B, D)), dev(torch.ones(B, N, 16)), dev(torch.zeros(K)), dev(torch.zeros(1))
+    loss2, dlog2 = dev(torch.zeros(1)), dev(torch.zeros(B))
+    f2 = L.FinalDesc.from_buffer_copy(f)
+    f2.dlogits = None
+    f2.y, f2.loss, f2.dlogits_out, f2.grad_scale = g["y"].data_ptr(), loss2.data_ptr(), dlog2.data_ptr(), 1.0 / B
+    f2.dw, f2.dbias, f2.dseg[0], f2.dseg[1] = dw2.data_ptr(), db2.data_ptr(), ddl2.data_ptr(), dsl2.data_ptr()
+    launch(lib, f2)
+    assert torch.equal(dlog2, dlog) and torch.equal(ddl2, ddl) and torch.equal(dsl2, dsl) and torch.equal(dw2, dw) and torch.equal(db2, db)
+    close(loss2, ref_loss.reshape(1), 1e-6)
     # flat clip + Adagrad vs torch
     n = 100003
     p0, gr = torch.randn(n), torch.randn(n) * 0.01
