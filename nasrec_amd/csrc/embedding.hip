@@ -58,113 +58,28 @@ int launch_embed_gather(hipStream_t st, const nasrec_embed_desc_t* d) {
   return nasrec_check_launch("embed_gather");
 }
 
-// Row-sparse backward: leader election + duplicate summation, per field.
-// grid = (Fs, ceil(B/256)); all B ids of the field are staged once in LDS as int32 (rows < 2^31).
-//   phase 1 (thread = one (b,f)): scan the ids four at a time (ds_read_b128 broadcast): first occurrence + count.
-//            Unique rows (the common case on the big tables) just copy their 64-byte gradient row.
-//   phase 2 (wavefront = one duplicated row at a time): ballot the matching samples 64 at a time and add their
-//            gradient rows four per round (lane group g takes the g-th match), so a 64-fold duplicate on a 4-row table
-//            costs 16 load rounds instead of a 64-long dependent chain in one lane.
-// The summation order is a fixed function of the ids, so results are reproducible run to run.
+// Row-sparse backward: leader election + duplicate summation, per field.  "Leader" = first occurrence of a row id in
+// sample order; its gsum row is the sum of the gradient rows of all occurrences in ascending sample order, so results are
+// reproducible run to run and independent of how the batch was split over ranks.
 #define DEDUP_MAXB 8192
-__global__ __launch_bounds__(256) void emb_dedup_kernel(const nasrec_emb_dedup_desc_t d) {
-  __shared__ __attribute__((aligned(16))) int sidx[DEDUP_MAXB];
-  __shared__ float red[256];
-  __shared__ int multi[256];
-  __shared__ int nmulti;
-  const int f = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int b = blockIdx.y * 256 + tid;
-  const int Bp = (d.B + 3) & ~3;
-  if (tid == 0) nmulti = 0;
-  for (int q = tid; q < Bp; q += 256) sidx[q] = q < d.B ? (int)d.idx[(long)q * d.Fs + f] : -1;
-  __syncthreads();
-  const bool live = b < d.B;
-  const int my = live ? sidx[b] : -2;
-  int first = b, count = 0;
-  if (live) {
-    first = 1 << 30;
-    const int4* s4 = reinterpret_cast<const int4*>(sidx);
-    for (int q = 0; q < Bp / 4; ++q) {
-      const int4 v = s4[q];
-      const int m0 = v.x == my, m1 = v.y == my, m2 = v.z == my, m3 = v.w == my;
-      count += m0 + m1 + m2 + m3;
-      if (m0 | m1 | m2 | m3) {
-        const int p = 4 * q + (m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3)));
-        first = min(first, p);
-      }
-    }
-  }
-  const bool lead = live && first == b;
-  float ss = 0.f;
-  if (live) d.leader[(long)b * d.Fs + f] = lead ? 1 : 0;
-  if (lead && count == 1) {
-    const float4* src = reinterpret_cast<const float4*>(d.dout + ((long)b * d.Fs + f) * 16);
-    float4* dst = reinterpret_cast<float4*>(d.gsum + ((long)b * d.Fs + f) * 16);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const float4 x = src[v];
-      dst[v] = x;
-      ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
-    }
-  } else if (lead) {
-    multi[atomicAdd(&nmulti, 1)] = tid;
-  }
-  red[tid] = ss;
-  __syncthreads();
-  const int nm = nmulti;
-  const int g = lane >> 4, e = lane & 15;
-  for (int i = wave; i < nm; i += 4) {
-    const int tl = multi[i];
-    const int v = sidx[blockIdx.y * 256 + tl];
-    float acc = 0.f;
-    for (int c0 = 0; c0 < d.B; c0 += 64) {
-      const bool m = (c0 + lane < d.B) && (sidx[c0 + lane] == v);
-      unsigned long long mask = __ballot(m);
-      while (mask) {
-        int mypos = -1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (mask) {
-            const int pos = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            if (g == r) mypos = pos;
-          }
-        }
-        if (mypos >= 0) acc += d.dout[((long)(c0 + mypos) * d.Fs + f) * 16 + e];
-      }
-    }
-    acc += __shfl_xor(acc, 16, 64);
-    acc += __shfl_xor(acc, 32, 64);
-    float sq = acc * acc;
-    sq += __shfl_xor(sq, 1, 64);
-    sq += __shfl_xor(sq, 2, 64);
-    sq += __shfl_xor(sq, 4, 64);
-    sq += __shfl_xor(sq, 8, 64);
-    if (g == 0) d.gsum[((long)(blockIdx.y * 256 + tl) * d.Fs + f) * 16 + e] = acc;
-    if (lane == 0) red[tl] = sq;
-  }
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) red[tid] += red[tid + o];
-    __syncthreads();
-  }
-  if (tid == 0) d.sumsq_partial[(long)f * gridDim.y + blockIdx.y] = red[0];
-}
 
 // Batch <= 256 (one workgroup per field, thread = sample): every sample parks its id and its 64-byte gradient row in
 // LDS with ONE parallel round of global loads; then each thread scans the ids in ascending order, four per
 // ds_read_b128 (all lanes read the same address: broadcast): a match below b means "not the leader", and a leader adds
 // the LDS rows of the later matches to its own row in registers.  A 64-fold duplicate on a 4-row table costs 64 LDS row
 // reads in one lane instead of 64 dependent global loads; the summation order is ascending b.
-__device__ __forceinline__ void dedup_small_body(const nasrec_emb_dedup_desc_t& d, int f, int* sidx, float* rows, float* red) {
+// `chunk`: the body works on samples [256*chunk, 256*chunk + 256) (batches > 256 run it once per chunk and merge the
+// chunk leaders afterwards, emb_dedup_merge_kernel); `final`: write the sum-of-squares partial of the leaders.
+__device__ __forceinline__ void dedup_small_body(const nasrec_emb_dedup_desc_t& d, int f, int chunk, bool final, int* sidx, float* rows,
+                                                 float* red) {
   const int b = threadIdx.x;
-  const bool live = b < d.B;
-  const int my = live ? (int)d.idx[(long)b * d.Fs + f] : -1 - b;  // dead lanes get unique negative ids
+  const long gb = (long)chunk * 256 + b;  // sample index in the batch
+  const bool live = gb < d.B;
+  const int my = live ? (int)d.idx[gb * d.Fs + f] : -1 - b;  // dead lanes get unique negative ids
   sidx[b] = my;
   f32x4 g[4];
   if (live) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(d.dout + ((long)b * d.Fs + f) * 16);
+    const f32x4* src = reinterpret_cast<const f32x4*>(d.dout + (gb * d.Fs + f) * 16);
 #pragma unroll
     for (int v = 0; v < 4; ++v) g[v] = src[v];
   } else {
@@ -207,15 +122,16 @@ __device__ __forceinline__ void dedup_small_body(const nasrec_emb_dedup_desc_t& 
     }
   }
   float ss = 0.f;
-  if (live) d.leader[(long)b * d.Fs + f] = lead ? 1 : 0;
+  if (live) d.leader[gb * d.Fs + f] = lead ? 1 : 0;
   if (lead) {
-    f32x4* dst = reinterpret_cast<f32x4*>(d.gsum + ((long)b * d.Fs + f) * 16);
+    f32x4* dst = reinterpret_cast<f32x4*>(d.gsum + (gb * d.Fs + f) * 16);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       dst[v] = g[v];
       ss += g[v][0] * g[v][0] + g[v][1] * g[v][1] + g[v][2] * g[v][2] + g[v][3] * g[v][3];
     }
   }
+  if (!final) return;
   red[b] = ss;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -229,7 +145,7 @@ __global__ __launch_bounds__(256) void emb_dedup_small_kernel(const nasrec_emb_d
   __shared__ __attribute__((aligned(16))) int sidx[256];
   __shared__ __attribute__((aligned(16))) float rows[256 * 20];  // 20-float rows: 16-byte aligned, bank-spread
   __shared__ float red[256];
-  dedup_small_body(d, blockIdx.x, sidx, rows, red);
+  dedup_small_body(d, blockIdx.x, 0, true, sidx, rows, red);
 }
 
 // NASREC_OP_OPT_REDUCE: workgroups [0, Fs) deduplicate one field each, the rest square-sum the dense gradient arena
@@ -239,7 +155,7 @@ __global__ __launch_bounds__(256) void opt_reduce_kernel(const nasrec_opt_reduce
   __shared__ float red[256];
   const int nd = d.dedup.Fs;
   if ((int)blockIdx.x < nd)
-    dedup_small_body(d.dedup, blockIdx.x, sidx, rows, red);
+    dedup_small_body(d.dedup, blockIdx.x, 0, true, sidx, rows, red);
   else
     sumsq_body(d.sumsq, (int)blockIdx.x - nd, d.sumsq.nblocks, red);
 }
@@ -281,6 +197,96 @@ int launch_opt_apply(hipStream_t st, const nasrec_opt_apply_desc_t* d) {
   return nasrec_check_launch("opt_apply");
 }
 
+// Batches > 256 (the global batch of a data-parallel step): O(B) instead of an all-pairs scan.
+//   pass 1  grid (Fs, ceil(B/256)): the <= 256 kernel on every 256-sample chunk -> chunk leaders + their partial sums;
+//   pass 2  grid (Fs): merge the chunk leaders in chunk order through an LDS hash table keyed by row id.  Within one round
+//           all candidates have distinct ids (they lead their chunk), so a slot is claimed by exactly one thread (ds CAS)
+//           and an earlier owner's row is updated by exactly one thread: no floating-point atomics, and the sum runs in
+//           ascending chunk (= sample) order.
+#define DEDUP_SLOTS (2 * DEDUP_MAXB)
+__global__ __launch_bounds__(256) void emb_dedup_chunk_kernel(const nasrec_emb_dedup_desc_t d) {
+  __shared__ __attribute__((aligned(16))) int sidx[256];
+  __shared__ __attribute__((aligned(16))) float rows[256 * 20];
+  __shared__ float red[256];
+  dedup_small_body(d, blockIdx.x, blockIdx.y, false, sidx, rows, red);
+}
+
+__global__ __launch_bounds__(256) void emb_dedup_merge_kernel(const nasrec_emb_dedup_desc_t d, int slots) {
+  __shared__ int keys[DEDUP_SLOTS];
+  __shared__ int owner[DEDUP_SLOTS];
+  __shared__ float red[256];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int nchunk = (d.B + 255) / 256;
+  for (int i = tid; i < slots; i += 256) keys[i] = -1;
+  // this thread's candidate of every round, fetched up front (one memory round trip instead of two per round)
+  constexpr int MAXC = DEDUP_MAXB / 256;
+  int cid[MAXC];
+  bool clead[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const long b = (long)c * 256 + tid;
+    const bool in = c < nchunk && b < d.B;
+    clead[c] = in && d.leader[b * d.Fs + f] != 0;
+    cid[c] = in ? (int)d.idx[b * d.Fs + f] : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    if (c < nchunk) {  // uniform
+      const long b = (long)c * 256 + tid;
+      if (clead[c]) {
+        const int id = cid[c];
+        unsigned h = ((unsigned)id * 2654435761u) >> 7;
+        int ob = -1;
+        for (;;) {
+          h &= (unsigned)(slots - 1);
+          const int prev = atomicCAS(&keys[h], -1, id);
+          if (prev == -1) {  // first occurrence of this row in the batch: stays the leader
+            owner[h] = (int)b;
+            break;
+          }
+          if (prev == id) {  // claimed in an earlier round (ids are distinct within a round)
+            ob = owner[h];
+            break;
+          }
+          ++h;
+        }
+        if (ob >= 0) {
+          clead[c] = false;
+          d.leader[b * d.Fs + f] = 0;
+          const f32x4* src = reinterpret_cast<const f32x4*>(d.gsum + (b * d.Fs + f) * 16);
+          f32x4* dst = reinterpret_cast<f32x4*>(d.gsum + ((long)ob * d.Fs + f) * 16);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) dst[v] = dst[v] + src[v];
+        }
+      }
+      __threadfence_block();
+      __syncthreads();  // owner[] and the updated rows of this round are visible to the next one
+    }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    if (clead[c]) {  // still a leader after the merge
+      const long b = (long)c * 256 + tid;
+      const f32x4* g = reinterpret_cast<const f32x4*>(d.gsum + (b * d.Fs + f) * 16);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 t = g[v];
+        ss += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+      }
+    }
+  }
+  red[tid] = ss;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  // the descriptor reserves ceil(B/256) partials per field: the total goes to the first, the rest are zero
+  for (int c = tid; c < nchunk; c += 256) d.sumsq_partial[f * nchunk + c] = (c == 0) ? red[0] : 0.f;
+}
+
 int launch_emb_dedup(hipStream_t st, const nasrec_emb_dedup_desc_t* d) {
   if (d->B == 0) return 0;
   if (d->B > DEDUP_MAXB) return nasrec_set_error(-2, "emb_dedup: B=%d > %d", d->B, DEDUP_MAXB);
@@ -289,7 +295,10 @@ int launch_emb_dedup(hipStream_t st, const nasrec_emb_dedup_desc_t* d) {
     return nasrec_check_launch("emb_dedup");
   }
   dim3 grid(d->Fs, (d->B + 255) / 256);
-  hipLaunchKernelGGL(emb_dedup_kernel, grid, dim3(256), 0, st, *d);
+  hipLaunchKernelGGL(emb_dedup_chunk_kernel, grid, dim3(256), 0, st, *d);
+  int slots = 512;
+  while (slots < 2 * d->B) slots *= 2;
+  hipLaunchKernelGGL(emb_dedup_merge_kernel, dim3(d->Fs), dim3(256), 0, st, *d, slots);
   return nasrec_check_launch("emb_dedup");
 }
 

@@ -271,6 +271,7 @@ class SupernetEngine:
                 fused.grad_scale = bd.grad_scale
                 cp.bce = bd
                 cp.bwd = Program(pre[1:] + ctx.bwd[:fi] + [fused] + ctx.bwd[fi + 1:])
+                cp.bwd_tail_start = len(pre) - 1 + ctx.bwd_tail_start  # cp.bwd.descs[this:] = the parked weight-gradient products
                 cp.bwd_core = Program(pre[1:] + ctx.bwd)  # dlogits supplied by the caller (autograd path)
                 cp.opt = Program(self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if sbuf.grad_written else None, clip, eps))
                 if graph:
@@ -326,16 +327,18 @@ class SupernetEngine:
                 ar.state[f] = self.table_state[f].data_ptr()
             ar.lr, ar.coef = self.lr_dev.data_ptr(), self.clip_out.data_ptr()
             descs.append(ar)
-        if sparse_grad is not None and Bg <= 256:
-            # batch <= 256: the five launches collapse into the two that the grid-wide dependencies require
-            red = L.OptReduceDesc()
-            red.kind = L.OP_OPT_REDUCE
-            red.dedup, red.sumsq = dd, sq
+        if sparse_grad is not None:
             app = L.OptApplyDesc()
             app.kind = L.OP_OPT_APPLY
             app.dense_blocks = min(2048, (self.flat_numel + 255) // 256)
             app.clip, app.dense, app.rows = cc, ad, ar
-            return [red, app]
+            if Bg <= 256:
+                # the five launches collapse into the two that the grid-wide dependencies require
+                red = L.OptReduceDesc()
+                red.kind = L.OP_OPT_REDUCE
+                red.dedup, red.sumsq = dd, sq
+                return [red, app]
+            return [dd, sq, app]  # global batch of a data-parallel step: chunked dedup + merge (two launches), then the same apply
         return descs
 
     # -------------------------------------------------------------------------------------------------------

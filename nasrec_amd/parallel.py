@@ -8,6 +8,11 @@ local forward/backward:
     instead of all-reducing 2.16 GB of dense table gradient — then every rank runs the same row-sparse
     dedup + clip + Adagrad over the global batch, so the replicated tables stay bit-identical across ranks;
   * the global-norm clip coefficient comes out identical on every rank because it is computed from identical data.
+Overlap (DataParallelStep.step): the three collectives are issued asynchronously on RCCL's stream as soon as their
+inputs exist — the ids right after staging (hidden under the whole forward/backward), the row gradients when the
+backward chain reaches the embedding stem (hidden under the weight-gradient products, which the plan parks at the end
+of the backward program), the dense arena after the last product — and the compute stream only waits for them in front
+of the optimizer launches.
 The reference has no distributed code at all; equivalence target = a single process at the global batch.
 """
 from typing import Optional
@@ -28,8 +33,17 @@ def all_gather_rows(out: torch.Tensor, local: torch.Tensor):
         dist.all_gather(chunks, local.reshape(-1))
 
 
+def all_gather_rows_async(out: torch.Tensor, local: torch.Tensor):
+    """all_gather_rows without blocking the compute stream; returns the work handle (None if it completed inline)"""
+    try:
+        return dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), async_op=True)
+    except (RuntimeError, NotImplementedError):
+        all_gather_rows(out, local)
+        return None
+
+
 def exchange_gradients(flat_g: torch.Tensor, cat_local: torch.Tensor, sg_local: torch.Tensor, cat_all: torch.Tensor, sg_all: torch.Tensor):
-    """the only cross-rank traffic of a step (see module docstring)"""
+    """the only cross-rank traffic of a step (see module docstring), issued back to back"""
     dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
     all_gather_rows(cat_all, cat_local)
     all_gather_rows(sg_all, sg_local)
@@ -61,9 +75,14 @@ class DataParallelStep:
             self.sg_all = torch.zeros(Bg * engine.Fs * 16, dtype=torch.float32, device=engine.device)
             self.holder = _Holder()
             self.opt = Program(engine._optimizer_descs(self.holder, Bg, self.cat_all, self.sg_all, clip, eps))
-            self.fb = Program(self.cp.fwd.descs + self.cp.bwd.descs)
+            # forward + backward chain | parked weight-gradient products: the row-gradient all-gather runs under the latter
+            cut = self.cp.bwd_tail_start
+            self.fb = Program(self.cp.fwd.descs + self.cp.bwd.descs[:cut])
+            self.tail = Program(self.cp.bwd.descs[cut:]) if cut < len(self.cp.bwd.descs) else None
             if self.graph:
                 self.fb.capture(engine.stream.cuda_stream)
+                if self.tail is not None:
+                    self.tail.capture(engine.stream.cuda_stream)
                 self.opt.capture(engine.stream.cuda_stream)
         engine.stream.synchronize()
 
@@ -72,14 +91,16 @@ class DataParallelStep:
         if not self.exchange:
             return eng.train_step(int_x, cat_x, y, lr, self.choice, self.clip, self.eps, graph=self.graph)
         sp = eng._sp()
+        run = (lambda prog: prog.replay(sp)) if self.graph else (lambda prog: prog.run(sp))
         eng._stage_inputs(sp, self.cp, int_x, cat_x, y, lr)
-        if self.graph:
-            self.fb.replay(sp)
-        else:
-            self.fb.run(sp)
-        exchange_gradients(eng.flat_g, self.cp.cat_x, self.cp.sparse0.grad_tensor(), self.cat_all, self.sg_all)
-        if self.graph:
-            self.opt.replay(sp)
-        else:
-            self.opt.run(sp)
+        pending = [all_gather_rows_async(self.cat_all, self.cp.cat_x)]
+        run(self.fb)
+        pending.append(all_gather_rows_async(self.sg_all, self.cp.sparse0.grad_tensor()))
+        if self.tail is not None:
+            run(self.tail)
+        pending.append(dist.all_reduce(eng.flat_g, op=dist.ReduceOp.SUM, async_op=True))
+        for w in pending:
+            if w is not None:
+                w.wait()  # nccl: the compute stream waits for the collective (no host block)
+        run(self.opt)
         return self.cp.loss

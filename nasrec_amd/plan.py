@@ -160,6 +160,7 @@ class Ctx:
         self.grad_params: List[str] = []  # parameters whose gradient the backward program writes
         self.out = self.fwd  # current emission target
         self.deferred: List = []  # weight-gradient products parked until the end of the backward program
+        self.bwd_tail_start = 0
         self.defer_dw = True
 
     # -- memory -----------------------------------------------------------------------------------------------
@@ -212,6 +213,7 @@ class Ctx:
         self.out = self.bwd
         for fn in reversed(self.closures):
             fn()
+        self.bwd_tail_start = len(self.bwd)  # from here on: only the parked weight-gradient products
         _flush_deferred(self)
         self.out = self.fwd
 

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from nasrec_amd.parallel import exchange_gradients
+from nasrec_amd.parallel import all_gather_rows_async, exchange_gradients
 
 WORLD, B, FS, ROWS = 2, 6, 3, [4, 50, 7]
 
@@ -46,6 +46,14 @@ def _worker(rank, port, out):
     sg_all = torch.zeros(WORLD * B * FS * 16, dtype=torch.float64)
     local_flat = flat_g.clone()
     exchange_gradients(flat_g, cat, sg, cat_all, sg_all)
+    # the overlapped form DataParallelStep.step uses: asynchronous collectives, waited for in front of the optimizer
+    cat_all2, sg_all2, flat2 = torch.zeros_like(cat_all), torch.zeros_like(sg_all), local_flat.clone()
+    pending = [all_gather_rows_async(cat_all2, cat), all_gather_rows_async(sg_all2, sg),
+               dist.all_reduce(flat2, op=dist.ReduceOp.SUM, async_op=True)]
+    for w in pending:
+        if w is not None:
+            w.wait()
+    assert torch.equal(cat_all2, cat_all) and torch.equal(sg_all2, sg_all) and torch.equal(flat2, flat_g)
     out[rank] = dict(local_flat=local_flat, flat=flat_g, cat=cat, sg=sg, cat_all=cat_all, sg_all=sg_all.view(WORLD * B, FS, 16))
     dist.destroy_process_group()
 

@@ -208,7 +208,7 @@ def test_embedding_gather_bit_exact_and_oob(lib):
     assert int(oob.item()) == 1
 
 
-@pytest.mark.parametrize("B", [600, 256, 77])
+@pytest.mark.parametrize("B", [2048, 600, 256, 77])
 def test_rowsparse_adagrad_equals_dense_reference(lib, B):
     """dedup + row-sparse clip·Adagrad == embedding_dense_backward + clip_grad_norm_ + torch.optim.Adagrad (dense).
     B > 256 runs the scan/ballot kernel over several row-blocks, B <= 256 the single-workgroup LDS rank-round kernel."""

@@ -5,8 +5,8 @@ path = sys.argv[1]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-# step boundaries: embed_gather_kernel occurrences followed (eventually) by adagrad_rows
-idx = [i for i, n in enumerate(names) if n.startswith("adagrad_rows")]
+# step boundaries: the last kernel of the optimizer tail
+idx = [i for i, n in enumerate(names) if n.startswith("adagrad_rows") or n.startswith("opt_apply")]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 a, b = idx[which - 1] + 1, idx[which] + 1
 step = rows[a:b]
