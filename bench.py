@@ -205,6 +205,17 @@ def main():
                               "kernel": "gemm_kernel<%d,%d,%d> M=%d N=%d K=%d nseg=%d splitk=%d" % (
                                   dom.amode, dom.bmode, dom.cmode, s0.M, s0.N, sum(dom.seg[q].K for q in range(dom.nseg)), dom.nseg, dom.splitk),
                               "flops_per_launch": fl, "avg_launch_us": ms * 1e3}
+        # HBM/fabric traffic of that launch: PMC counters cannot be collected from inside this process, so the value is the
+        # committed rocprofv3 measurement of exactly this launch (profiles/r01_dominant_gemm_traffic.json: FETCH_SIZE x2
+        # per the gfx950 correction + WRITE_SIZE, separate --pmc passes); null if the dominant launch is a different one
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_dominant_gemm_traffic.json")))
+            if (s0.M, s0.N, sum(dom.seg[q].K for q in range(dom.nseg)), dom.splitk) == (256, 768, 1565, 5):
+                result["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
+                result["roofline"]["traffic_unit"] = "bytes per launch (PMC, see profiles/r01_dominant_gemm_traffic.json)"
+                result["roofline"]["algorithmic_bytes"] = tj["algorithmic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         # whole-step accounting: executed GEMM FLOPs per step and the HBM bytes the step must move at minimum
         step_flops = sum(gemm_flops(d) for d in allg)
         result["step_gemm_gflop"] = step_flops / 1e9
