@@ -262,10 +262,11 @@ def memset_desc(t):
 
 
 def _splitk_for(tiles_mn, ktiles, nprob=1):
-    """pick a split-K factor so that the launch has a few hundred workgroups and >= 4 k-tiles per split"""
+    """pick a split-K factor so that the launch stays within one wave of workgroups (256 CUs: `tools/splitk_sweep.py` shows
+    a cliff right above it) with >= 64 k per split (one staged tile of the latency-regime configuration)"""
     if tiles_mn * nprob >= 192 or ktiles < 8:
         return 1
-    s = min(ktiles // 4, max(1, 256 // max(1, tiles_mn * nprob)))
+    s = min(ktiles // 2, max(1, 256 // max(1, tiles_mn * nprob)))
     return max(1, min(s, 32))
 
 
