@@ -356,6 +356,8 @@ typedef struct nasrec_adagrad_rows_desc {
   float* state[NASREC_MAX_TABLES];
   const float* lr;
   const float* coef;
+  int64_t rows[NASREC_MAX_TABLES]; /* rows of table f: an id outside [0, rows) is skipped (the gather has already flagged it;
+                                      torch would have raised IndexError in the forward pass) */
 } nasrec_adagrad_rows_desc_t;
 
 /* Fused optimizer tail for batch <= 256 (the two grid-wide dependencies of clip_grad_norm_ + Adagrad need two

@@ -120,7 +120,7 @@ class AdagradDenseDesc(C.Structure):
 
 class AdagradRowsDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("Fs", i32), ("eps", f32), ("idx", vp), ("leader", vp), ("gsum", vp),
-                ("table", vp * MAX_TABLES), ("state", vp * MAX_TABLES), ("lr", vp), ("coef", vp)]
+                ("table", vp * MAX_TABLES), ("state", vp * MAX_TABLES), ("lr", vp), ("coef", vp), ("rows", i64 * MAX_TABLES)]
 
 
 class MemsetDesc(C.Structure):
@@ -208,8 +208,8 @@ def load():
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
                  "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 3:
-        raise EngineError("ABI version mismatch: library %d, binding 3" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 4:
+        raise EngineError("ABI version mismatch: library %d, binding 4" % lib.nasrec_abi_version())
     sizes = (i32 * 32)()
     n = lib.nasrec_desc_sizes(sizes, 32)
     for kind, cls in DESC_BY_KIND.items():

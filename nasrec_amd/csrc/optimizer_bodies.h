@@ -61,6 +61,7 @@ __device__ __forceinline__ void adagrad_rows_body(const nasrec_adagrad_rows_desc
   if (!d.leader[pair]) return;
   const int f = (int)(pair % d.Fs);
   const long row = d.idx[pair];
+  if (row < 0 || row >= d.rows[f]) return;  // never write outside a table
   float4 g = *reinterpret_cast<const float4*>(d.gsum + pair * 16 + q * 4);
   float4* sp = reinterpret_cast<float4*>(d.state[f] + row * 16 + q * 4);
   float4* pp = reinterpret_cast<float4*>(d.table[f] + row * 16 + q * 4);

@@ -325,6 +325,7 @@ class SupernetEngine:
             for f in range(self.Fs):
                 ar.table[f] = self.tables[f].data_ptr()
                 ar.state[f] = self.table_state[f].data_ptr()
+                ar.rows[f] = self.num_embeddings[f]
             ar.lr, ar.coef = self.lr_dev.data_ptr(), self.clip_out.data_ptr()
             descs.append(ar)
         if sparse_grad is not None:

@@ -246,7 +246,7 @@ def test_rowsparse_adagrad_equals_dense_reference(lib, B):
         ar.kind, ar.B, ar.Fs, ar.eps = L.OP_ADAGRAD_ROWS, B, Fs, eps
         ar.idx, ar.leader, ar.gsum, ar.lr, ar.coef = gi.data_ptr(), leader.data_ptr(), gsum.data_ptr(), lr_d.data_ptr(), coef.data_ptr()
         for f in range(Fs):
-            ar.table[f], ar.state[f] = gt[f].data_ptr(), gs[f].data_ptr()
+            ar.table[f], ar.state[f], ar.rows[f] = gt[f].data_ptr(), gs[f].data_ptr(), rows[f]
         launch(lib, ar)
         for f in range(Fs):
             close(gt[f], ref_t[f].data, 1e-5)
@@ -259,6 +259,32 @@ def test_rowsparse_adagrad_equals_dense_reference(lib, B):
         want = torch.zeros(B, dtype=torch.int32)
         want[list(first.values())] = 1
         assert torch.equal(lead[:, f], want)
+
+
+def test_rowsparse_adagrad_skips_out_of_range_ids(lib):
+    """an id outside [0, rows) must not be written anywhere (torch raises in the forward pass; the engine flags it in the
+    gather and the optimizer leaves memory alone)"""
+    B, Fs, rows = 4, 1, 5
+    back = dev(torch.full((7, 16), 3.0))  # rows 5, 6 are guard rows behind the 5-row table
+    stat = dev(torch.zeros(7, 16))
+    idx = dev(torch.tensor([[1], [5], [-1], [1]], dtype=torch.int64))
+    dout = dev(torch.ones(B, Fs, 16))
+    leader, gsum, part = dev(torch.zeros(B * Fs, dtype=torch.int32)), dev(torch.zeros(B * Fs * 16)), dev(torch.zeros(Fs))
+    lr_d, coef = dev(torch.tensor([0.5])), dev(torch.tensor([1.0, 0.0]))
+    dd = L.EmbDedupDesc()
+    dd.kind, dd.B, dd.Fs = L.OP_EMB_DEDUP, B, Fs
+    dd.idx, dd.dout, dd.leader, dd.gsum, dd.sumsq_partial = idx.data_ptr(), dout.data_ptr(), leader.data_ptr(), gsum.data_ptr(), part.data_ptr()
+    launch(lib, dd)
+    ar = L.AdagradRowsDesc()
+    ar.kind, ar.B, ar.Fs, ar.eps = L.OP_ADAGRAD_ROWS, B, Fs, 1e-2
+    ar.idx, ar.leader, ar.gsum, ar.lr, ar.coef = idx.data_ptr(), leader.data_ptr(), gsum.data_ptr(), lr_d.data_ptr(), coef.data_ptr()
+    ar.table[0], ar.state[0], ar.rows[0] = back.data_ptr(), stat.data_ptr(), rows
+    launch(lib, ar)
+    torch.cuda.synchronize()
+    want = torch.full((7, 16), 3.0)
+    want[1] = 3.0 - 0.5 * 2.0 / (2.0 + 1e-2)  # two samples hit row 1: g = 2, state = 4
+    close(back, want, 1e-6)
+    assert torch.equal(stat[[0, 2, 3, 4, 5, 6]].cpu(), torch.zeros(6, 16))
 
 
 @pytest.mark.parametrize("B", [256, 77])
@@ -294,7 +320,7 @@ def test_fused_optimizer_tail_is_bit_identical_to_the_stand_alone_ops(lib, B):
         ar.kind, ar.B, ar.Fs, ar.eps = L.OP_ADAGRAD_ROWS, B, Fs, 1e-2
         ar.idx, ar.leader, ar.gsum, ar.lr, ar.coef = idx.data_ptr(), s["leader"].data_ptr(), s["gsum"].data_ptr(), lr_d.data_ptr(), s["coef"].data_ptr()
         for f in range(Fs):
-            ar.table[f], ar.state[f] = s["tab"][f].data_ptr(), s["tst"][f].data_ptr()
+            ar.table[f], ar.state[f], ar.rows[f] = s["tab"][f].data_ptr(), s["tst"][f].data_ptr(), rows[f]
         return dd, sq, cc, ad, ar
 
     a, b = state(), state()
