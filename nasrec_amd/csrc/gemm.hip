@@ -18,12 +18,16 @@
 #ifndef GEMM_XCD_REMAP
 #define GEMM_XCD_REMAP 0  // measured: 3.4x less fabric traffic on the big products, no time gain (Infinity Cache serves the re-reads), +6% step time from the index arithmetic
 #endif
+#ifndef GEMM_MID_NT
+#define GEMM_MID_NT 1024  // threads of the 64x64 latency-regime configuration (A/B on the bench step: 256 -> 0.677, 512 -> 0.646, 1024 -> 0.640 ms)
+#endif
 #ifndef GEMM_SKINNY_BELOW
 #define GEMM_SKINNY_BELOW 128  // launches with fewer 64x64 workgroups than this use the skinny tiles
 #endif
 // Tile configurations (template parameters NT threads, TK staged k depth, TBM x TBN block tile):
 //   256 thr, 32, 64x64  4 waves 2x2, 32x32 each — large products, throughput regime (>= 4 workgroups per CU);
-//   512 thr, TK, 64x64  8 waves 2x4, 32x16 each — two waves per SIMD, one wave's waits hide under the other's MFMAs;
+//   1024 thr, TK, 64x64  16 waves 4x4, one 16x16 MFMA tile each — four waves per SIMD, one wave's waits hide under
+//     the others' MFMAs (GEMM_MID_NT; 512 threads = 8 waves of 32x16 measured 1 % slower, 256 threads 5 % slower);
 //   256 thr, TK, 64x16 / 16x64  4 waves, one 16x16 MFMA tile each — "skinny" products of the batch-256 step (a
 //     [B,n]x[n,16] Linear, a token-axis Linear over B*16 columns): a 64x64 tiling would leave them on 4..64 of the 256
 //     CUs, and because every kernel starts on a cold L2 a CU only sustains ~13 KB/us of staging loads (outstanding
@@ -411,8 +415,8 @@ static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
   if (wgs >= 1024) {
     launch_cfg<AM, BMODE, CM, 256, 32, 64, 64>(st, d, Mmax, Nmax, zdim);
   } else if (wgs >= GEMM_SKINNY_BELOW) {
-    if (deep) launch_cfg<AM, BMODE, CM, 512, GEMM_TK_DEEP, 64, 64>(st, d, Mmax, Nmax, zdim);
-    else launch_cfg<AM, BMODE, CM, 512, 32, 64, 64>(st, d, Mmax, Nmax, zdim);
+    if (deep) launch_cfg<AM, BMODE, CM, GEMM_MID_NT, GEMM_TK_DEEP, 64, 64>(st, d, Mmax, Nmax, zdim);
+    else launch_cfg<AM, BMODE, CM, GEMM_MID_NT, 32, 64, 64>(st, d, Mmax, Nmax, zdim);
   } else if (Nmax >= Mmax) {
     if (deep) launch_cfg<AM, BMODE, CM, 256, GEMM_TK_DEEP, 64, 16>(st, d, Mmax, Nmax, zdim);
     else launch_cfg<AM, BMODE, CM, 256, 32, 64, 16>(st, d, Mmax, Nmax, zdim);
