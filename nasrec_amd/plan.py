@@ -288,6 +288,7 @@ def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, **kw):
     d.bias = kw.get("bias", None)
     d.save_z = kw.get("save_z", None)
     d.save_act = kw.get("save_act", None)
+    d.pre_add = kw.get("pre_add", None)
     mul = kw.get("mul", None)
     if mul:
         assert len(mul) <= L.MAX_SEGS
@@ -458,11 +459,13 @@ def _ln_numel(mode, R, D, ld):
 
 
 def linear_dense(ctx, segs: List[Seg], Ktot, wname, nout, bias: bool, out: DV, act=L.ACT_NONE, dims=-1, beta=0, ln=None,
-                 mul=None, save_act: Optional[DV] = None, pre_dz_cb=None):
+                 mul=None, save_act: Optional[DV] = None, pre_dz_cb=None, pre_add: Optional[DV] = None):
     """y = epilogue(concat(segs) · Wᵀ + b).  `ln`: parameter prefix of a LayerNorm applied after the product
     (then act/mask/beta move to the LN kernel).  `mul`/`save_act`: SigmoidGating epilogue.  Returns nothing;
     registers the backward closure.  pre_dz_cb: if given, called in backward to obtain (dz_ptr, ld) instead of
-    using out.grad (gating)."""
+    using out.grad (gating).  pre_add: a [B, nout] view with out's row stride whose value is added to the product before
+    bias/activation (out = pre_add + x Wᵀ + b written in one pass instead of copy + accumulate); its gradient is the
+    caller's business."""
     B = ctx.B
     W = ctx.param(wname + ".weight", (nout, Ktot))
     bptr = ctx.param(wname + ".bias", (nout,)) if bias else None
@@ -472,6 +475,8 @@ def linear_dense(ctx, segs: List[Seg], Ktot, wname, nout, bias: bool, out: DV, a
             ctx.param(ln + ".bias", (nout,))
         return
     live = _live_segs(segs)
+    if pre_add is not None:
+        assert not ln and act == L.ACT_NONE and dims < 0 and beta == 0 and pre_add.ld == out.ld and pre_add.width == nout
     if len(live) > L.MAX_SEGS and not ln and (act != L.ACT_NONE or mul is not None):
         raise NotImplementedError("more than %d live input segments for the activated product %s" % (L.MAX_SEGS, wname))
     need_z = act == L.ACT_SILU and not ln  # SiLU backward needs the pre-activation
@@ -497,7 +502,7 @@ def linear_dense(ctx, segs: List[Seg], Ktot, wname, nout, bias: bool, out: DV, a
         for d in gemm_descs(ctx, L.AM_KC, L.AM_KC, L.CM_PLAIN, sd[c0:c0 + L.MAX_SEGS], 0, act=g_act, dims=g_dims,
                             beta=g_beta if c0 == 0 else 1, bias=bptr if c0 == 0 else None,
                             save_z=savez.data_ptr() if need_z else None, save_act=save_act.ptr if save_act is not None else None,
-                            mul=mul_list):
+                            mul=mul_list, pre_add=pre_add.ptr if (pre_add is not None and c0 == 0) else None):
             ctx.emit(d)
 
     def backward_products(dz_ptr, dz_ld, aux_ptr, kdims):
@@ -908,8 +913,9 @@ def op_transformer(ctx, cfg, pre, ssegs, Ntot, max_dims, dims, out: SV):
     ctx.on_backward(bwd)
 
 
-def op_fm(ctx, cfg, pre, x: SV, fm_dims, dims, dense_out: DV):
-    """FactorizationMachine3D modules.py:720-750, added into dense_out (supernet.py:1154-1157)."""
+def op_fm(ctx, cfg, pre, x: SV, fm_dims, dims, dense_out: DV, pre_add: Optional[DV] = None):
+    """FactorizationMachine3D modules.py:720-750, added into dense_out (supernet.py:1154-1157).  With pre_add the
+    projection writes dense_out = pre_add + FM term in one pass (dense_out holds nothing beforehand)."""
     B = ctx.B
     use_ln = cfg.use_layernorm
     mask = -1 if cfg.fixed else dims
@@ -942,9 +948,10 @@ def op_fm(ctx, cfg, pre, x: SV, fm_dims, dims, dense_out: DV):
             ctx.emit(e)
 
         ctx.on_backward(bwd)
+    assert pre_add is None or not direct
     if not direct:
-        linear_dense(ctx, [Seg(ix, 0, E)], E, pre + "._linear_proj", fm_dims, not use_ln, dense_out, L.ACT_NONE, mask, 1,
-                     ln=(pre + "._linear_layernorm") if use_ln else None)
+        linear_dense(ctx, [Seg(ix, 0, E)], E, pre + "._linear_proj", fm_dims, not use_ln, dense_out, L.ACT_NONE, mask,
+                     0 if pre_add is not None else 1, ln=(pre + "._linear_layernorm") if use_ln else None, pre_add=pre_add)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -994,6 +1001,13 @@ def block_walk(ctx, cfg: NetConfig, i, ops, choice, d_in, Dtot, s_in, Ntot, l_in
     # ---- dense nodes: sum of node outputs (supernet.py:1133 / 1215) --------------------------------------------
     real_dense = [n for n in dense_nodes if names[n] != "zeros-2d"]
     n_contrib = len(real_dense) + (1 if deep_fm else 0)
+    # One-pass DeepFM merge (fixed sub-networks without LayerNorm): the FM projection can write
+    # block_out = pre_fm + FM term itself (GEMM pre_add), where pre_fm is the buffer holding the node sum.  That removes
+    # (a) the copy of an activated node output into dense_out and (b) the copy that keeps the pre-FM value alive for the
+    # dense->sparse projection; the gradient of pre_fm aliases the gradient of the block output (registered below).
+    fm_dims_fixed = max_dense
+    one_pass_fm = bool(deep_fm == 1 and fixed and not cfg.use_layernorm and fm_dims_fixed != E and not ctx.shape_only)
+    pre_fm = None  # the buffer that holds the node sum when it is not dense_out
     wrote = False
     for n in range(ops["num_nodes"]):
         if n not in dense_nodes:
@@ -1021,10 +1035,14 @@ def block_walk(ctx, cfg: NetConfig, i, ops, choice, d_in, Dtot, s_in, Ntot, l_in
         else:
             raise NotImplementedError(name)
         if tgt.view is not dense_out:
-            _alias_add(ctx, tgt.view, dense_out, 1 if wrote else 0)
+            if one_pass_fm and len(real_dense) == 1:
+                pre_fm = tgt.view  # the only node: its buffer IS the node sum, dense_out is written by the FM projection
+            else:
+                _alias_add(ctx, tgt.view, dense_out, 1 if wrote else 0)
         wrote = True
     if not wrote:
         zero_fill(ctx, dense_out)
+    node_sum = pre_fm if pre_fm is not None else dense_out  # pre-FM value of the block's dense output
 
     # ---- sparse nodes ------------------------------------------------------------------------------------------
     real_sparse = [n for n in sparse_nodes if names[n] != "zeros-3d"]
@@ -1056,18 +1074,35 @@ def block_walk(ctx, cfg: NetConfig, i, ops, choice, d_in, Dtot, s_in, Ntot, l_in
         proj_rows = sparse_all.rows(max_sparse, DS_INTERACT_NUM_SPLITS).dense()  # [B,128] view into the sparse slab
         if dsi == 1:
             if max_dense != E * DS_INTERACT_NUM_SPLITS:
-                linear_dense(ctx, [Seg(dense_out, 0, max_dense)], max_dense, pre + ".project_emb_dim", E * DS_INTERACT_NUM_SPLITS,
+                linear_dense(ctx, [Seg(node_sum, 0, max_dense)], max_dense, pre + ".project_emb_dim", E * DS_INTERACT_NUM_SPLITS,
                              not cfg.use_layernorm, proj_rows, L.ACT_NONE, -1, 0,
                              ln=(pre + ".project_emb_dim_layernorm") if cfg.use_layernorm else None)
             else:
-                copy_into(ctx, [Seg(dense_out, 0, max_dense)], proj_rows)
+                copy_into(ctx, [Seg(node_sum, 0, max_dense)], proj_rows)
         else:
             zero_fill(ctx, proj_rows)
 
     # ---- sparse -> dense merge: DeepFM on the node outputs only (supernet.py:1154-1157 / 1233-1236) -----------
     if deep_fm == 1:
         fm_dims = max_dense if fixed else int(max(ops["dense_node_dims"]))
-        if dsi == 1 and max_dense != E * DS_INTERACT_NUM_SPLITS:
+        keep_pre = dsi == 1 and max_dense != E * DS_INTERACT_NUM_SPLITS  # the projection above needs the pre-FM value again (dW)
+        if one_pass_fm and (pre_fm is not None or keep_pre):
+            src = node_sum
+            if pre_fm is None:  # node sum sits in dense_out: the block output moves to a fresh buffer
+                fbuf = ctx.buf(B * max_dense)
+                dense_out = DV(fbuf, 0, max_dense, max_dense)
+            out_view = dense_out
+            op_fm(ctx, cfg, pre + ".deep_fm", sparse_nodes_out, fm_dims, dd, out_view, pre_add=src)
+
+            def alias_bwd():  # registered last => runs first in backward: d out / d node_sum = I, share the storage
+                if not ctx.live(out_view):
+                    return
+                src.buf.g = out_view.buf.grad_tensor()
+                src.buf.mark()
+
+            ctx.on_backward(alias_bwd)
+            return dense_out, sparse_all
+        if keep_pre:
             # the projection above read dense_out *before* the FM term is added (dense_t_2d_out.clone(), supernet.py:1139)
             # and its weight gradient needs that value again: keep it, add the FM term into a copy
             fbuf = ctx.buf(B * max_dense)
