@@ -1,0 +1,162 @@
+"""Input pipeline of the training harness: sharded TSV readers + column transforms with the reference's contract
+(nasrec/utils/data_pipes.py, nasrec/torchrec/{criteo,avazu,kdd,utils}.py), pinned by tests/golden/datapipes.npz which was
+produced by the real reference readers.
+
+Row format (tab separated, parsed with the `csv` module like the reference): label, Fd integer columns, Fs hexadecimal
+categorical columns.  Casting: label / integers via int() with 0 for anything unparsable (torchrec/utils.py safe_cast);
+an empty categorical field is a missing id.  Transforms (data_pipes.py:137-175):
+    int_x = log(max(0, x) + 1)   float32  (Avazu: zeros — it has no dense features, data_pipes.py:178-183)
+    cat_x = fmod(int(v, 16), n_f - 1) + 1, missing -> fmod(-1, n_f - 1) + 1 = 0      int64
+    y     = label as float32 [B, 1]
+Batches are cut per shard (the last one of a shard may be short); shards are interleaved round-robin, which is the order
+a DataLoader with one worker per shard delivers them (ParallelReadConcat, torchrec/utils.py:225-302).
+
+`--root_dir synthetic[:key=value,...]` (extension; the datasets are not redistributable) yields Criteo/Avazu/KDD-shaped random
+batches instead: keys steps (batches per epoch), test_steps, seed."""
+import csv
+import glob
+import os
+from typing import Iterator, List, Tuple
+
+import torch
+
+from .config import NUM_EMBEDDINGS_AVAZU, NUM_EMBEDDINGS_CRITEO, NUM_EMBEDDINGS_KDD
+
+Batch = Tuple[torch.Tensor, torch.Tensor, torch.Tensor]
+
+
+class DatasetSpec:
+    def __init__(self, name, num_dense, num_sparse, tables, dense_is_zero=False):
+        self.name, self.Fd, self.Fs, self.tables, self.dense_is_zero = name, num_dense, num_sparse, list(tables), dense_is_zero
+
+
+SPECS = {
+    "criteo-kaggle": DatasetSpec("criteo-kaggle", 13, 26, NUM_EMBEDDINGS_CRITEO),
+    "avazu": DatasetSpec("avazu", 1, 23, NUM_EMBEDDINGS_AVAZU, dense_is_zero=True),
+    "kdd": DatasetSpec("kdd", 3, 10, NUM_EMBEDDINGS_KDD),
+}
+
+
+def _to_int(text, base=10):
+    try:
+        return int(text, base)
+    except ValueError:
+        return 0
+
+
+def rows_to_batch(rows: List[List[str]], spec: DatasetSpec) -> Batch:
+    """rows: split TSV lines of one batch -> (int_x f32 [B,Fd], cat_x i64 [B,Fs], y f32 [B,1])"""
+    width = 1 + spec.Fd + spec.Fs
+    for r in rows:
+        if len(r) != width:
+            raise ValueError("expected %d tab-separated columns for %s, got %d" % (width, spec.name, len(r)))
+    y = torch.tensor([[_to_int(r[0])] for r in rows], dtype=torch.int64).float()
+    dense = torch.tensor([[_to_int(v) for v in r[1:1 + spec.Fd]] for r in rows], dtype=torch.int64).view(len(rows), spec.Fd)
+    if spec.dense_is_zero:
+        int_x = torch.zeros(len(rows), spec.Fd, dtype=torch.float32)
+    else:
+        int_x = torch.log(torch.clamp_min(dense, 0) + 1)  # integer tensor -> float32 log, as the reference computes it
+    ids = torch.tensor([[int(v, 16) if v else -1 for v in r[1 + spec.Fd:]] for r in rows], dtype=torch.int64).view(len(rows), spec.Fs)
+    mod = torch.tensor(spec.tables, dtype=torch.int64) - 1
+    cat_x = torch.fmod(ids, mod) + 1
+    return int_x, cat_x, y
+
+
+class TsvShard:
+    """one TSV file, cut into batches of `batch_size` rows (re-iterable)"""
+
+    def __init__(self, path: str, spec: DatasetSpec, batch_size: int):
+        self.path, self.spec, self.batch_size = path, spec, batch_size
+
+    def __iter__(self) -> Iterator[Batch]:
+        with open(self.path, "r", newline="") as f:
+            rows = []
+            for row in csv.reader(f, delimiter="\t"):
+                rows.append(row)
+                if len(rows) == self.batch_size:
+                    yield rows_to_batch(rows, self.spec)
+                    rows = []
+            if rows:
+                yield rows_to_batch(rows, self.spec)
+
+
+class RoundRobinLoader:
+    """interleaves the batches of several shards in the order a one-worker-per-shard DataLoader delivers them"""
+
+    def __init__(self, pipes):
+        self.pipes = list(pipes)
+
+    def __iter__(self) -> Iterator[Batch]:
+        live = [iter(p) for p in self.pipes]
+        while live:
+            nxt = []
+            for it in live:
+                try:
+                    yield next(it)
+                    nxt.append(it)
+                except StopIteration:
+                    pass
+            live = nxt
+
+
+class SyntheticPipe:
+    """SURVEY §8d synthetic inputs: int_x = log(U_int[0,1000) + 1) (Avazu zeros), ids uniform per table, y ~ Bernoulli(0.25)"""
+
+    def __init__(self, spec: DatasetSpec, batch_size: int, steps: int, seed: int):
+        self.spec, self.batch_size, self.steps, self.seed = spec, batch_size, steps, seed
+
+    def __iter__(self) -> Iterator[Batch]:
+        g = torch.Generator().manual_seed(self.seed)
+        B, s = self.batch_size, self.spec
+        for _ in range(self.steps):
+            int_x = torch.zeros(B, s.Fd) if s.dense_is_zero else torch.log(torch.randint(0, 1000, (B, s.Fd), generator=g).float() + 1.0)
+            cat_x = torch.stack([torch.randint(0, int(n), (B,), generator=g) for n in s.tables], dim=1)
+            y = (torch.rand(B, 1, generator=g) < 0.25).float()
+            yield int_x, cat_x, y
+
+
+def _synthetic_options(root_dir):
+    opts = {"steps": 200, "test_steps": 4, "seed": 1234}
+    if ":" in root_dir:
+        for kv in root_dir.split(":", 1)[1].split(","):
+            if kv:
+                k, v = kv.split("=")
+                opts[k] = int(v)
+    return opts
+
+
+def _pipes(args, spec: DatasetSpec):
+    assert args.validate_split in ["val", "test"], ValueError("Invalid validation split! Should be in ['val', 'test'].")
+    if str(args.root_dir).startswith("synthetic"):
+        o = _synthetic_options(args.root_dir)
+        return ([SyntheticPipe(spec, args.train_batch_size, o["steps"], o["seed"])],
+                [SyntheticPipe(spec, args.test_batch_size, o["test_steps"], o["seed"] + 1)], 1, 1)
+    shard_dirs = sorted(glob.glob(os.path.join(args.root_dir, "shard-*")))
+    print("Training directory...", shard_dirs)
+    train_file = "train.txt" if args.train_split == "train" else "trainval.txt"
+    test_file = "{}.txt".format(args.validate_split)
+    train = [TsvShard(os.path.join(d, train_file), spec, args.train_batch_size) for d in shard_dirs]
+    test = [TsvShard(os.path.join(d, test_file), spec, args.test_batch_size) for d in shard_dirs]
+    return train, test, len(shard_dirs), len(shard_dirs)
+
+
+def get_criteo_kaggle_pipes(args):
+    """-> (train pipes, test pipes, number of train workers, number of test workers), data_pipes.py:36-66"""
+    return _pipes(args, SPECS["criteo-kaggle"])
+
+
+def get_avazu_kaggle_pipes(args):
+    return _pipes(args, SPECS["avazu"])
+
+
+def get_kdd_kaggle_pipes(args):
+    return _pipes(args, SPECS["kdd"])
+
+
+GET_PIPES = {"criteo-kaggle": get_criteo_kaggle_pipes, "avazu": get_avazu_kaggle_pipes, "kdd": get_kdd_kaggle_pipes}
+
+
+def make_loaders(args):
+    """train / test loaders of one run (what main_train.py:86-104 builds from the pipes)"""
+    train, test, _, _ = GET_PIPES[args.dataset](args)
+    return RoundRobinLoader(train), RoundRobinLoader(test)
