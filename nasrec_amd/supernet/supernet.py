@@ -428,7 +428,48 @@ class SuperNet(nn.Module):
         choice = self._resolve_choice(None)
         self._ensure_engine(int_feats)
         graph = self._fixed if graph is None else graph
+        self._engine_steps = getattr(self, "_engine_steps", 0) + 1
+        self._last_step_batch = int(int_feats.shape[0])
+        self._last_step_key = (choice, clip, eps, graph)
         return self._engine.train_step(int_feats, cat_feats, y, lr, choice, clip, eps, graph=graph)
+
+    def engine_last_logits(self):
+        """logits [B, 1] of the most recent engine_train_step (what `model(int_x, cat_x)` returned inside that step)"""
+        choice, clip, eps, graph = self._last_step_key
+        B = self._last_step_batch
+        cp = self._engine.compile(choice, B, train=True, clip=clip, eps=eps, graph=graph)
+        return cp.logits.view(B, 1)
+
+    def engine_bind_optimizer(self, optimizer):
+        """Share the Adagrad accumulators between a torch.optim.Adagrad and the engine: existing `sum` state (a resumed
+        checkpoint) is copied into the engine's arenas, then `optimizer.state[p]["sum"]` aliases them, so
+        `optimizer.state_dict()` stays a faithful checkpoint while the fused step does the updates."""
+        eng = self._engine
+        assert eng is not None, "run one forward first (lazy shapes)"
+        eng._ensure_table_state()
+        for name, p in self.named_parameters():
+            if name.startswith("_embedding."):
+                tgt = eng.table_state[int(name.split(".")[1])]
+            elif name in eng.state:
+                tgt = eng.state[name]
+            else:
+                continue
+            st = optimizer.state[p]
+            if "sum" in st and st["sum"].data_ptr() != tgt.data_ptr():
+                tgt.copy_(st["sum"].to(tgt.device).view_as(tgt))
+            st["sum"] = tgt
+            st.setdefault("step", torch.tensor(0.0))
+        self._bound_optimizer_steps = getattr(self, "_engine_steps", 0)
+
+    def engine_sync_optimizer_steps(self, optimizer):
+        """add the fused steps taken since engine_bind_optimizer to the optimizer's per-parameter step counters"""
+        done = getattr(self, "_engine_steps", 0) - getattr(self, "_bound_optimizer_steps", 0)
+        if done:
+            for p in self.parameters():
+                st = optimizer.state.get(p)
+                if st is not None and "step" in st:
+                    st["step"] = st["step"] + float(done)
+            self._bound_optimizer_steps = getattr(self, "_engine_steps", 0)
 
 
 class SuperNetBlock(nn.Module):

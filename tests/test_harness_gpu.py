@@ -1,0 +1,106 @@
+"""The training harness (nasrec_amd/main_train.py, train_supernet.py, utils/train_utils.py — SURVEY §8f-1) end to end on the
+GPU: the command line of the published recipe on TSV shards, the reference's log / checkpoint artefacts, and the fused
+engine step against the operator-by-operator torch route through the same loop."""
+import copy
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+from nasrec_amd import main_train as MT
+from nasrec_amd import train_supernet as TS
+from nasrec_amd.utils import train_utils as TU
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "nasrec_amd", "configs", "criteo", "ea_criteo_kaggle_autoctr_best_1shot.json")
+
+
+def _shards(tmp_path, ds="criteo-kaggle", repeat=3):
+    z = np.load(os.path.join(GOLDEN, "datapipes.npz"), allow_pickle=False)
+    root = tmp_path / "data"
+    for s in range(2):
+        d = root / ("shard-%d" % s)
+        d.mkdir(parents=True)
+        for name in ("trainval.txt", "train.txt", "test.txt"):
+            src = "trainval.txt" if name == "train.txt" else name
+            (d / name).write_text("\n".join([str(z["%s/shard-%d/%s" % (ds, s, src)])] * repeat) + "\n")
+    return str(root)
+
+
+def test_main_train_recipe_runs_and_writes_the_reference_artefacts(tmp_path, capsys):
+    root, logdir = _shards(tmp_path), str(tmp_path / "logs")
+    args = MT.build_parser().parse_args([
+        "--root_dir", root, "--net", "supernet-config", "--supernet_config", CFG, "--num_epochs", "1", "--learning_rate", "0.1",
+        "--train_batch_size", "8", "--test_batch_size", "16", "--wd", "0", "--logging_dir", logdir, "--gpu", "0", "--test_interval", "4",
+        "--display_interval", "2", "--train_limit", "96"])
+    torch.manual_seed(0)
+    logs = MT.main(args)
+    out = capsys.readouterr().out
+    assert "FLOPS:" in out and "Epoch: 0 L2: 0.000000 loss:" in out and "Learning rate: 1e-08" in out and "Test Acc:" in out
+    assert len(logs) == 1
+    log = logs[0]
+    assert set(log) == {"train_loss", "train_AUROC", "train_Accuracy", "test_loss", "test_AUROC", "test_Accuracy", "epoch", "iters"}
+    assert log["iters"] == [0, 2, 4, 6, 8, 10, 11] and len(log["test_loss"]) == 4  # steps 0, 4, 8 and the last one (11)
+    assert all(np.isfinite(v) for v in log["train_loss"] + log["test_loss"])
+    assert pickle.load(open(os.path.join(logdir, "train_test_logs.pickle"), "rb")) == logs
+    ck = torch.load(os.path.join(logdir, "supernet-config_checkpoint.pt"), map_location="cpu")
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict"}
+    model = MT.get_model(args)
+    assert list(ck["model_state_dict"])[:26] == ["_embedding.%d.weight" % f for f in range(26)]
+    osd = ck["optimizer_state_dict"]
+    assert len(osd["state"]) == len(ck["model_state_dict"])  # every parameter carries its Adagrad sum
+    assert all(float(s["step"]) == 12.0 for s in osd["state"].values())
+    assert any(float(s["sum"].abs().sum()) > 0 for s in osd["state"].values())
+    del model
+
+
+def test_fused_engine_step_equals_the_torch_route_through_the_same_loop(tmp_path):
+    root = _shards(tmp_path)
+    args = MT.build_parser().parse_args([
+        "--root_dir", root, "--net", "supernet-config", "--supernet_config", CFG, "--learning_rate", "0.05", "--train_batch_size", "8",
+        "--test_batch_size", "16", "--wd", "0", "--logging_dir", str(tmp_path / "l"), "--gpu", "0", "--train_limit", "48"])
+    from nasrec_amd.utils.data_pipes import make_loaders
+    train_loader, test_loader = make_loaders(args)
+    torch.manual_seed(1)
+    base = MT.get_model(args).to(0)
+    with torch.no_grad():
+        TU.warmup_model(base, train_loader, 0)
+    base.apply(TU.init_weights)
+    results = []
+    for use_engine in (None, False):
+        model = copy.deepcopy(base)
+        opt = MT.build_optimizer("adagrad", model, args.learning_rate)
+        sched = MT.build_lr_scheduler("constant", opt, 6, 2, args.learning_rate)
+        logs = TU.train_and_test_one_epoch(model, 0, opt, sched, train_loader, test_loader, torch.nn.BCEWithLogitsLoss(),
+                                           lambda m: TU.get_l2_loss(m, 0.0, None, gpu=0), 8, 0, display_interval=1, test_interval=100,
+                                           max_train_steps=6, grad_clip_value=5.0, use_engine_step=use_engine)
+        torch.cuda.synchronize()
+        results.append((logs, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                        {i: s["sum"].detach().cpu().clone() for i, s in enumerate(opt.state_dict()["state"].values())}))
+    (la, pa, sa), (lb, pb, sb) = results
+    assert np.allclose(la["train_loss"], lb["train_loss"], rtol=1e-5, atol=1e-6)
+    assert la["iters"] == lb["iters"] == [0, 1, 2, 3, 4, 5]
+    for k in pa:
+        assert torch.allclose(pa[k], pb[k], rtol=0, atol=2e-5), k
+    for i in sa:
+        assert torch.allclose(sa[i], sb[i], rtol=1e-4, atol=1e-7), i
+
+
+def test_train_supernet_cli_on_synthetic_batches(tmp_path, capsys):
+    args = TS.build_parser().parse_args([
+        "--dataset", "kdd", "--root_dir", "synthetic:steps=6,test_steps=1,seed=3", "--logging_dir", str(tmp_path / "sn"), "--config", "autoctr",
+        "--num_blocks", "3", "--use_layernorm", "1", "--strategy", "default", "--anypath_choice", "binomial-0.5", "--supernet_training_steps", "2",
+        "--train_batch_size", "16", "--test_batch_size", "16", "--train_limit", "64", "--learning_rate", "0.05", "--display_interval", "2",
+        "--gpu", "0"])
+    np.random.seed(0)
+    torch.manual_seed(0)
+    logs = TS.main(args)
+    out = capsys.readouterr().out
+    assert "Logging in directory:" in out
+    d = os.path.join(str(tmp_path / "sn"), "supernet_3blocks_layernorm1_default-binomial-0.5_lr0.05_supernetwarmup_2")
+    assert os.path.exists(os.path.join(d, "supernet_checkpoint.pt")) and os.path.exists(os.path.join(d, "train_test_logs.pickle"))
+    assert len(logs[0]["test_loss"]) == 1 and np.isfinite(logs[0]["test_loss"][0])  # test only at the last step
