@@ -485,6 +485,20 @@ int nasrec_event_record(void* ev, void* stream);
 int nasrec_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 int nasrec_event_destroy(void* ev);
 
+/* ------------------------------------------------------------------------------------------------
+ * Input pipeline, host side (no GPU work): parse complete TSV lines `label \t Fd integers \t Fs hexadecimal ids` from
+ * buf[0, len) into label[r], dense[r, Fd] (raw integers; the caller applies log(max(0,x)+1)) and cat[r, Fs] (already
+ * fmod(id, table_rows[f]-1)+1, missing -> 0), at most max_rows of them.  Replaces csv.reader + int() + int(v,16) per field
+ * (torchrec/utils.py:175-193, criteo.py:45-58, data_pipes.py:137-175).  Returns the number of rows written; *consumed =
+ * bytes of buf they occupied (an incomplete last line is left for the next call); *status = NASREC_TSV_OK, or the reason
+ * parsing stopped at the line starting at buf[*consumed]: NEEDS_PYTHON (the line contains a construct on which only
+ * Python's own parsers define the result — the caller parses that one line itself) or BAD_COLUMNS.
+ * Thread-safe (no shared state); callers parse several shards concurrently.
+ * ---------------------------------------------------------------------------------------------- */
+enum { NASREC_TSV_OK = 0, NASREC_TSV_NEEDS_PYTHON = 1, NASREC_TSV_BAD_COLUMNS = 2 };
+int64_t nasrec_tsv_parse(const char* buf, int64_t len, int32_t Fd, int32_t Fs, const int64_t* table_rows, int64_t max_rows,
+                         int64_t* label, int64_t* dense, int64_t* cat, int64_t* consumed, int32_t* status);
+
 const char* nasrec_last_error(void);
 int nasrec_abi_version(void);
 /* sizeof() of every descriptor, so a binding can verify its struct layout: fills out[0..n) in the

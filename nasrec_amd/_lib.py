@@ -25,6 +25,7 @@ MHA_SAVED = 148
 AM_KC, AM_RC, AM_TOKR, AM_TOKK = 0, 1, 2, 3
 CM_PLAIN, CM_TOKJ = 0, 1
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3
+TSV_OK, TSV_NEEDS_PYTHON, TSV_BAD_COLUMNS = 0, 1, 2
 ACT_BY_NAME = {"identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
 
 (OP_GEMM, OP_EMBED_GATHER, OP_DOT_TRI_FWD, OP_DOT_TRI_BWD, OP_FM_FWD, OP_FM_BWD, OP_MHA_FWD, OP_MHA_BWD, OP_REDUCE_ROWS,
@@ -171,7 +172,7 @@ SYMBOLS = [
     "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense", "nasrec_adagrad_rows", "nasrec_opt_reduce",
     "nasrec_opt_apply", "nasrec_event_create",
     "nasrec_event_record", "nasrec_event_elapsed_ms", "nasrec_event_destroy", "nasrec_last_error", "nasrec_abi_version",
-    "nasrec_desc_sizes",
+    "nasrec_desc_sizes", "nasrec_tsv_parse",
 ]
 
 _lib = None
@@ -204,6 +205,8 @@ def load():
     lib.nasrec_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(f32)]
     lib.nasrec_event_destroy.argtypes = [vp]
     lib.nasrec_desc_sizes.argtypes = [C.POINTER(i32), C.c_int]
+    lib.nasrec_tsv_parse.argtypes = [vp, i64, i32, i32, vp, i64, vp, vp, vp, C.POINTER(i64), C.POINTER(i32)]
+    lib.nasrec_tsv_parse.restype = i64
     for name in ("nasrec_gemm", "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm",
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
                  "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply"):

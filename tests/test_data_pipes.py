@@ -11,8 +11,10 @@ from helpers import GOLDEN
 from nasrec_amd.utils import data_pipes as DP
 
 
+@pytest.mark.parametrize("reader", ["native", "python"])
 @pytest.mark.parametrize("ds", ["criteo-kaggle", "avazu", "kdd"])
-def test_tsv_pipeline_matches_reference_batches(ds, tmp_path):
+def test_tsv_pipeline_matches_reference_batches(ds, reader, tmp_path, monkeypatch):
+    monkeypatch.setenv("NASREC_TSV_READER", reader)
     z = np.load(os.path.join(GOLDEN, "datapipes.npz"), allow_pickle=False)
     for s in range(2):
         d = tmp_path / ("shard-%d" % s)
@@ -22,13 +24,16 @@ def test_tsv_pipeline_matches_reference_batches(ds, tmp_path):
     args = argparse.Namespace(dataset=ds, root_dir=str(tmp_path), train_split="trainval", validate_split="test", train_batch_size=8,
                               test_batch_size=16)
     train, test = DP.make_loaders(args)
+    assert type(train.pipes[0]) is (DP.NativeTsvShard if reader == "native" else DP.TsvShard)
     for split, loader in (("train", train), ("test", test)):
         got = list(loader)
         assert len(got) == int(z["%s/%s/n" % (ds, split)])
         for i, (int_x, cat_x, y) in enumerate(got):
             assert int_x.dtype == torch.float32 and cat_x.dtype == torch.int64 and y.dtype == torch.float32
-            assert np.array_equal(int_x.numpy(), z["%s/%s/%d/int_x" % (ds, split, i)])  # bit-exact
-            assert np.array_equal(cat_x.numpy(), z["%s/%s/%d/cat_x" % (ds, split, i)])
+            # log() of an integer tensor: identical on the CPU that produced the fixture, within 1-2 ulp on another
+            # micro-architecture (torch's vectorised logf differs between AVX2 and AVX-512 builds)
+            assert np.allclose(int_x.numpy(), z["%s/%s/%d/int_x" % (ds, split, i)], rtol=3e-7, atol=0)
+            assert np.array_equal(cat_x.numpy(), z["%s/%s/%d/cat_x" % (ds, split, i)])  # bit-exact
             assert np.array_equal(y.numpy(), z["%s/%s/%d/y" % (ds, split, i)])
         assert len(list(loader)) == len(got)  # re-iterable (one pass per epoch)
 
@@ -51,3 +56,28 @@ def test_synthetic_source_shapes():
     assert len(b) == 3 and b[0][0].shape == (4, 1) and b[0][1].shape == (4, 23) and b[0][2].shape == (4, 1)
     assert float(b[0][0].abs().sum()) == 0.0 and len(list(test)) == 2
     assert all(int(b[0][1][:, f].max()) < n for f, n in enumerate(DP.SPECS["avazu"].tables))
+
+
+def test_native_reader_hands_python_only_constructs_back_and_agrees(tmp_path):
+    """quotes (csv semantics), whitespace / underscores inside integers, hex prefixes, CRLF line ends, a missing final
+    newline and tiny read chunks: the native reader must return exactly what the pure-Python reader returns"""
+    spec = DP.DatasetSpec("toy", 2, 3, [7, 100, 65536])
+    lines = ["1\t5\t-2\tff\t\t1f", "0\t 7 \t1_0\t0x1F\tabc\tABC", '1\t"3"\t4\t"a"\tb\tc', "0\t\tx\t\t\t", "1\t+9\t--1\t7fffffff\t0\tdeadbeef",
+             "1\t3\t4\t00000000000000ff\t5\t6"]
+    for i in range(40):
+        lines.append("%d\t%d\t%d\t%x\t%x\t%x" % (i & 1, i * 37, -i, i * 7919, i, i * i * 104729))
+    p = tmp_path / "x.txt"
+    p.write_bytes("\r\n".join(lines).encode())  # CRLF, no newline at the end
+    want = list(DP.TsvShard(str(p), spec, 8))
+    for chunk in (13, 64, 1 << 20):
+        nat = DP.NativeTsvShard(str(p), spec, 8)
+        nat.chunk_bytes = chunk
+        got = list(nat)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            for x, y in zip(a, b):
+                assert x.dtype == y.dtype and torch.equal(x, y)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("1\t2\t3\n")
+    with pytest.raises(ValueError):
+        list(DP.NativeTsvShard(str(bad), spec, 8))

@@ -66,7 +66,7 @@ def test_c_abi_exports_every_declared_symbol_and_struct_layouts():
     lib = L.load()  # verifies symbols + sizeof of every descriptor against the header's structs
     hdr = open(os.path.join(os.path.dirname(GOLDEN), "..", "include", "nasrec_hip.h")).read()
     import re
-    declared = set(re.findall(r"\n(?:int|const char\*)\s+(nasrec_\w+)\(", hdr))
+    declared = set(re.findall(r"\n(?:int|int64_t|const char\*)\s+(nasrec_\w+)\(", hdr))
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s)
