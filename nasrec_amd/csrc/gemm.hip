@@ -18,6 +18,12 @@
 #ifndef GEMM_XCD_REMAP
 #define GEMM_XCD_REMAP 0  // measured: 3.4x less fabric traffic on the big products, no time gain (Infinity Cache serves the re-reads), +6% step time from the index arithmetic
 #endif
+#ifndef GEMM_BIG_NT
+#define GEMM_BIG_NT 256
+#endif
+#ifndef GEMM_BIG_TK
+#define GEMM_BIG_TK 32
+#endif
 #ifndef GEMM_MID_NT
 #define GEMM_MID_NT 1024  // threads of the 64x64 latency-regime configuration (A/B on the bench step: 256 -> 0.677, 512 -> 0.646, 1024 -> 0.640 ms)
 #endif
@@ -413,7 +419,7 @@ static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
   for (int q = 0; q < nprob; ++q) wgs += (long)((d->seg[q].M + 63) / 64) * ((d->seg[q].N + 63) / 64) * S;
   const bool deep = Kmax > 32;
   if (wgs >= 1024) {
-    launch_cfg<AM, BMODE, CM, 256, 32, 64, 64>(st, d, Mmax, Nmax, zdim);
+    launch_cfg<AM, BMODE, CM, GEMM_BIG_NT, GEMM_BIG_TK, 64, 64>(st, d, Mmax, Nmax, zdim);
   } else if (wgs >= GEMM_SKINNY_BELOW) {
     if (deep) launch_cfg<AM, BMODE, CM, GEMM_MID_NT, GEMM_TK_DEEP, 64, 64>(st, d, Mmax, Nmax, zdim);
     else launch_cfg<AM, BMODE, CM, GEMM_MID_NT, 32, 64, 64>(st, d, Mmax, Nmax, zdim);

@@ -90,3 +90,5 @@ int main() {
     }
   return 0;
 }
+// build: hipcc -O3 --offload-arch=gfx950 -o tools/micro/loadrate tools/micro/loadrate.hip   (the binary is git-ignored; it travels
+// to the GPU box with the snapshot)
