@@ -68,7 +68,7 @@ def train_and_eval_one_model(model, args):
     with torch.no_grad():
         model = warmup_model(model, train_loader, args.gpu)
     flops, params = get_model_flops_and_params(model, train_loader, args.gpu)
-    print("FLOPS: {:.4f} M \\t Params: {:.4f} M".format(flops / 1e6, params / 1e6))
+    print("FLOPS: {:.4f} M \t Params: {:.4f} M".format(flops / 1e6, params / 1e6))
     if args.loss_function != "bce":
         raise NotImplementedError("Loss function {} is not implemented!".format(args.loss_function))
     loss_fn = torch.nn.BCEWithLogitsLoss()
