@@ -41,18 +41,6 @@
 // TK = 32 when no k-segment is deeper than one 32-wide tile, else GEMM_TK_DEEP (fewer round trips and barriers; 64
 // measured best, 128 loses to its partial tiles).
 
-template <int MODE>
-__device__ __forceinline__ float load_operand(const float* __restrict__ p, const float* __restrict__ aux, int r, int k,
-                                              int R, int K, int ld) {
-  if (r < R && k < K) {
-    long o = operand_offset<MODE>(r, k, ld);
-    float v = p[o];
-    if (aux != nullptr && !(aux[o] > 0.f)) v = 0.f;
-    return v;
-  }
-  return 0.f;
-}
-
 // thread -> (row, k) mapping of the staging loads of an R x TK operand tile: lanes run along the contiguous axis
 template <int MODE, int NT, int TK, int R>
 __device__ __forceinline__ void stage_coords(int tid, int it, int& rr, int& kk) {

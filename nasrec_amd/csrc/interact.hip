@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void rowsum_tokk_kernel(const nasrec_rowsum_de
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
   if (threadIdx.x == 0) d.out[r] = red[0];
