@@ -18,6 +18,9 @@
 #ifndef GEMM_XCD_REMAP
 #define GEMM_XCD_REMAP 0  // measured: 3.4x less fabric traffic on the big products, no time gain (Infinity Cache serves the re-reads), +6% step time from the index arithmetic
 #endif
+#ifndef GEMM_ZBATCH_TILE32
+#define GEMM_ZBATCH_TILE32 1
+#endif
 #ifndef GEMM_BIG_NT
 #define GEMM_BIG_NT 256
 #endif
@@ -34,6 +37,7 @@
 //   256 thr, 32, 64x64  4 waves 2x2, 32x32 each — large products, throughput regime (>= 4 workgroups per CU);
 //   1024 thr, TK, 64x64  16 waves 4x4, one 16x16 MFMA tile each — four waves per SIMD, one wave's waits hide under
 //     the others' MFMAs (GEMM_MID_NT; 512 threads = 8 waves of 32x16 measured 1 % slower, 256 threads 5 % slower);
+//   256 thr, TK, 32x32  4 waves, one MFMA tile each — zmode batches of unequal products in the latency regime;
 //   256 thr, TK, 64x16 / 16x64  4 waves, one 16x16 MFMA tile each — "skinny" products of the batch-256 step (a
 //     [B,n]x[n,16] Linear, a token-axis Linear over B*16 columns): a 64x64 tiling would leave them on 4..64 of the 256
 //     CUs, and because every kernel starts on a cold L2 a CU only sustains ~13 KB/us of staging loads (outstanding
@@ -409,8 +413,16 @@ static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
   if (wgs >= 1024) {
     launch_cfg<AM, BMODE, CM, GEMM_BIG_NT, GEMM_BIG_TK, 64, 64>(st, d, Mmax, Nmax, zdim);
   } else if (wgs >= GEMM_SKINNY_BELOW) {
-    if (deep) launch_cfg<AM, BMODE, CM, GEMM_MID_NT, GEMM_TK_DEEP, 64, 64>(st, d, Mmax, Nmax, zdim);
-    else launch_cfg<AM, BMODE, CM, GEMM_MID_NT, 32, 64, 64>(st, d, Mmax, Nmax, zdim);
+    if (GEMM_ZBATCH_TILE32 && d->zmode && nprob > 1 && deep) {
+      // a batch of independent products of very different sizes (the parked weight gradients): 32x32 tiles give 4x the
+      // workgroups, which balances the batch over the CUs (dense batch 24.7 -> 17.9 us, token batch 22.8 -> 16.1 us);
+      // on a single large product the same tiles are 1-3 us slower than 64x64
+      launch_cfg<AM, BMODE, CM, 256, GEMM_TK_DEEP, 32, 32>(st, d, Mmax, Nmax, zdim);
+    } else if (deep) {
+      launch_cfg<AM, BMODE, CM, GEMM_MID_NT, GEMM_TK_DEEP, 64, 64>(st, d, Mmax, Nmax, zdim);
+    } else {
+      launch_cfg<AM, BMODE, CM, GEMM_MID_NT, 32, 64, 64>(st, d, Mmax, Nmax, zdim);
+    }
   } else if (Nmax >= Mmax) {
     if (deep) launch_cfg<AM, BMODE, CM, 256, GEMM_TK_DEEP, 64, 16>(st, d, Mmax, Nmax, zdim);
     else launch_cfg<AM, BMODE, CM, 256, 32, 64, 16>(st, d, Mmax, Nmax, zdim);
