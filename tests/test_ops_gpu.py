@@ -90,6 +90,60 @@ def test_gemm_dense_forward_segments(lib, splitk, act, dims):
     close(gy, ref)
 
 
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_gemm_zmode_batch_of_unequal_weight_gradients_every_tile_configuration(lib, splitk):
+    """A parked-weight-gradient style launch: independent dW = (dy ⊙ [y>0])ᵀ x products of very different sizes in ONE zmode
+    launch (ReLU-mask operand, row prefix mask, accumulate, per-problem bias gradient as a virtual ones-column), sized so
+    that the launcher picks, in turn, the skinny tiles, the 32x32 batch tiles of the latency regime and the 64x64 throughput
+    tiles (live 64x64 workgroups < 128, 128..1023, >= 1024)."""
+    torch.manual_seed(21)
+    for scale, B in ((1, 96), (4, 256), (12, 160)):
+        shapes = [(192 * scale, 195 * scale, 150 * scale), (64, 37, 64), (13, 14, 9), (200, 129, 111)]  # (nout, nin, dims)
+        segs, checks, keep = [], [], []
+        for q, (nout, nin, dims) in enumerate(shapes):
+            dy, y, x = torch.randn(B, nout) * 0.3, torch.randn(B, nout), torch.randn(B, nin)
+            dw0 = torch.randn(nout, nin)
+            g = [dev(t) for t in (dy, y, x, dw0.clone(), torch.zeros(nout))]
+            keep.append(g)
+            acc = q % 2
+            segs.append(dict(A=g[0].data_ptr(), Aaux=g[1].data_ptr(), B=g[2].data_ptr(), C=g[3].data_ptr(), M=nout, N=nin + 1, K=B, lda=nout,
+                             ldb=nin, ldc=nin, Mvalid=dims, accumulate=acc, ones_col=1, rowsum=g[4].data_ptr()))
+            dz = (dy * (y > 0)).double()
+            dz[:, dims:] = 0
+            checks.append((g[3], (dw0.double() if acc else 0) + dz.t() @ x.double(), g[4], dz.sum(0)))
+        Mm, Nm = max(s["M"] for s in segs), max(s["N"] for s in segs)
+        ws = dev(torch.zeros(splitk * Mm * Nm * len(segs)))
+        launch(lib, gemm_desc(L.AM_RC, L.AM_RC, L.CM_PLAIN, segs, 1, splitk=splitk, workspace=ws.data_ptr()))
+        for dw, want_w, db, want_b in checks:
+            close(dw, want_w)
+            close(db, want_b)
+
+
+@pytest.mark.parametrize("splitk", [4, 16])
+def test_gemm_token_weight_gradient_batch_in_the_latency_regime(lib, splitk):
+    """token-axis dW[p, n] = sum_{b,e} (dy ⊙ [y>0])[b,p,e] x[b,n,e] for several Transformer / Linear3D projections in one zmode
+    launch at batch 256 (K = 4096): the 32x32 batch tiles with split-K"""
+    torch.manual_seed(22)
+    B = 256
+    shapes = [(48, 73, 40), (64, 27, 64), (16, 104, 9), (39, 162, 39), (8, 26, 8), (32, 64, 20)]  # (tokens out, tokens in, dims)
+    segs, checks, keep = [], [], []
+    for q, (Np, n, dims) in enumerate(shapes):
+        dy, y, x = torch.randn(B, Np, 16) * 0.3, torch.randn(B, Np, 16), torch.randn(B, n, 16)
+        g = [dev(t) for t in (dy, y, x, torch.zeros(Np, n), torch.zeros(Np))]
+        keep.append(g)
+        segs.append(dict(A=g[0].data_ptr(), Aaux=g[1].data_ptr(), B=g[2].data_ptr(), C=g[3].data_ptr(), M=Np, N=n + 1, K=B * 16, lda=Np * 16,
+                         ldb=n * 16, ldc=n, Mvalid=dims, ones_col=1, rowsum=g[4].data_ptr()))
+        dz = (dy * (y > 0)).double()
+        dz[:, dims:] = 0
+        checks.append((g[3], torch.einsum("bpe,bne->pn", dz, x.double()), g[4], dz.sum((0, 2))))
+    Mm, Nm = max(s["M"] for s in segs), max(s["N"] for s in segs)
+    ws = dev(torch.zeros(splitk * Mm * Nm * len(segs)))
+    launch(lib, gemm_desc(L.AM_TOKK, L.AM_TOKK, L.CM_PLAIN, segs, 1, splitk=splitk, workspace=ws.data_ptr()))
+    for dw, want_w, db, want_b in checks:
+        close(dw, want_w)
+        close(db, want_b)
+
+
 def test_gemm_dense_backward_products(lib):
     """dx_seg (+)= (dy ⊙ [y>0])[:, :dims] W[:dims, seg];  dW[:, seg] = (dy ⊙ [y>0])ᵀ x_seg with rows >= dims zero."""
     torch.manual_seed(1)
