@@ -194,7 +194,7 @@ def main():
         # ---- roofline of the dominant kernel: the largest GEMM launch of the step (fp32 MFMA bound) -----------------
         sp = eng.stream.cuda_stream
         cp = dp.cp
-        allg = [d for d in (cp.fwd.descs + cp.bwd.descs) if isinstance(d, L.GemmDesc)]
+        allg = [d for d in P.iter_ops(cp.fwd.descs + cp.bwd.descs) if isinstance(d, L.GemmDesc)]
         dom = max(allg, key=gemm_flops)
         with torch.cuda.stream(eng.stream):
             ms = time_desc(lib, L, sp, dom)

@@ -76,7 +76,8 @@ enum {
   NASREC_OP_ACT_BWD = 26,
   NASREC_OP_STAGE_INPUTS = 27,
   NASREC_OP_OPT_REDUCE = 28,
-  NASREC_OP_OPT_APPLY = 29
+  NASREC_OP_OPT_APPLY = 29,
+  NASREC_OP_SAMPLE_CHAIN = 30
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -452,6 +453,30 @@ typedef struct nasrec_stage_desc {
 } nasrec_stage_desc_t;
 
 /* ------------------------------------------------------------------------------------------------
+ * Per-sample chain (forward).  Every operator between two block-level products is sample-local: the token-axis Linear of
+ * sample b reads only x[b], and so do the Transformer body, the FM and DotProduct cores and segmented copies.  A run of up
+ * to NASREC_CHAIN_MAX such launches that follow each other in the program can therefore execute as ONE launch in which
+ * workgroup b runs the stages for sample b back to back (workgroup barrier + workgroup-scope fence in between) — each stage
+ * saved is one ~5 us cold-L2 kernel start at batch 256.  Results are bit-identical to the separate launches (same bodies,
+ * same per-sample work split).  Constraints (checked by the launcher): at most one stage of each kind; the GEMM stage is a
+ * forward token-axis Linear (amode KC, bmode TOKR, cmode TOKJ, zmode 0, no split-K) with M <= 64 output tokens and N = 16·B
+ * columns, i.e. exactly one 64x16 tile per sample; mha/fm/tri/copy have B samples.
+ * ---------------------------------------------------------------------------------------------- */
+#define NASREC_CHAIN_MAX 4
+typedef struct nasrec_chain_desc {
+  int32_t kind;   /* NASREC_OP_SAMPLE_CHAIN */
+  int32_t B;      /* samples (= workgroups) */
+  int32_t n;      /* number of stages */
+  int32_t stage[NASREC_CHAIN_MAX]; /* NASREC_OP_GEMM / MHA_FWD / FM_FWD / DOT_TRI_FWD / COPY_SEGS, executed in this order */
+  int32_t _pad;
+  nasrec_gemm_desc_t gemm;
+  nasrec_mha_desc_t mha;
+  nasrec_fm_desc_t fm;
+  nasrec_dot_tri_desc_t tri;
+  nasrec_copy_segs_desc_t copy;
+} nasrec_chain_desc_t;
+
+/* ------------------------------------------------------------------------------------------------
  * Entry points
  * ---------------------------------------------------------------------------------------------- */
 /* Launch one op (any descriptor above) on `stream`. */
@@ -478,6 +503,7 @@ int nasrec_adagrad_dense(void* stream, const nasrec_adagrad_dense_desc_t* d);
 int nasrec_adagrad_rows(void* stream, const nasrec_adagrad_rows_desc_t* d);
 int nasrec_opt_reduce(void* stream, const nasrec_opt_reduce_desc_t* d);
 int nasrec_opt_apply(void* stream, const nasrec_opt_apply_desc_t* d);
+int nasrec_sample_chain(void* stream, const nasrec_chain_desc_t* d);
 
 /* HIP-event timing on an arbitrary stream (bench.py measures kernels on the engine's own stream). */
 int nasrec_event_create(void** ev);

@@ -31,7 +31,7 @@ ACT_BY_NAME = {"identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
 (OP_GEMM, OP_EMBED_GATHER, OP_DOT_TRI_FWD, OP_DOT_TRI_BWD, OP_FM_FWD, OP_FM_BWD, OP_MHA_FWD, OP_MHA_BWD, OP_REDUCE_ROWS,
  OP_COPY_SEGS, OP_GATE_BWD, OP_ROWSUM, OP_FINAL_FWD, OP_BCE, OP_FINAL_BWD, OP_EMB_DEDUP, OP_SUMSQ, OP_CLIP_COEF,
  OP_ADAGRAD_DENSE, OP_ADAGRAD_ROWS, OP_MEMSET, OP_LAYERNORM_FWD, OP_LAYERNORM_BWD, OP_ADD_SEGS, OP_SCALE,
- OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY) = range(1, 30)
+ OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY, OP_SAMPLE_CHAIN) = range(1, 31)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -156,6 +156,14 @@ class OptApplyDesc(C.Structure):
     _fields_ = [("kind", i32), ("dense_blocks", i32), ("clip", ClipCoefDesc), ("dense", AdagradDenseDesc), ("rows", AdagradRowsDesc)]
 
 
+CHAIN_MAX = 4
+
+
+class ChainDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("n", i32), ("stage", i32 * CHAIN_MAX), ("_pad", i32), ("gemm", GemmDesc), ("mha", MhaDesc),
+                ("fm", FmDesc), ("tri", DotTriDesc), ("copy", CopySegsDesc)]
+
+
 DESC_BY_KIND = {
     OP_GEMM: GemmDesc, OP_EMBED_GATHER: EmbedDesc, OP_DOT_TRI_FWD: DotTriDesc, OP_DOT_TRI_BWD: DotTriDesc, OP_FM_FWD: FmDesc,
     OP_FM_BWD: FmDesc, OP_MHA_FWD: MhaDesc, OP_MHA_BWD: MhaDesc, OP_REDUCE_ROWS: ReduceRowsDesc, OP_COPY_SEGS: CopySegsDesc,
@@ -163,6 +171,7 @@ DESC_BY_KIND = {
     OP_EMB_DEDUP: EmbDedupDesc, OP_SUMSQ: SumsqDesc, OP_CLIP_COEF: ClipCoefDesc, OP_ADAGRAD_DENSE: AdagradDenseDesc,
     OP_ADAGRAD_ROWS: AdagradRowsDesc, OP_MEMSET: MemsetDesc, OP_LAYERNORM_FWD: LayerNormDesc, OP_LAYERNORM_BWD: LayerNormDesc,
     OP_SCALE: ScaleDesc, OP_ACT_BWD: ActBwdDesc, OP_STAGE_INPUTS: StageDesc, OP_OPT_REDUCE: OptReduceDesc, OP_OPT_APPLY: OptApplyDesc,
+    OP_SAMPLE_CHAIN: ChainDesc,
 }
 
 # every symbol include/nasrec_hip.h declares
@@ -170,7 +179,7 @@ SYMBOLS = [
     "nasrec_launch", "nasrec_program_run", "nasrec_graph_create", "nasrec_graph_launch", "nasrec_graph_destroy", "nasrec_gemm",
     "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm", "nasrec_mha_ffn", "nasrec_layernorm",
     "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense", "nasrec_adagrad_rows", "nasrec_opt_reduce",
-    "nasrec_opt_apply", "nasrec_event_create",
+    "nasrec_opt_apply", "nasrec_sample_chain", "nasrec_event_create",
     "nasrec_event_record", "nasrec_event_elapsed_ms", "nasrec_event_destroy", "nasrec_last_error", "nasrec_abi_version",
     "nasrec_desc_sizes", "nasrec_tsv_parse",
 ]
@@ -209,10 +218,10 @@ def load():
     lib.nasrec_tsv_parse.restype = i64
     for name in ("nasrec_gemm", "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm",
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
-                 "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply"):
+                 "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_sample_chain"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 4:
-        raise EngineError("ABI version mismatch: library %d, binding 4" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 5:
+        raise EngineError("ABI version mismatch: library %d, binding 5" % lib.nasrec_abi_version())
     sizes = (i32 * 32)()
     n = lib.nasrec_desc_sizes(sizes, 32)
     for kind, cls in DESC_BY_KIND.items():

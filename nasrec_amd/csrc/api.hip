@@ -60,6 +60,7 @@ static int dispatch(hipStream_t st, const void* desc) {
     case NASREC_OP_STAGE_INPUTS: return launch_stage(st, (const nasrec_stage_desc_t*)desc);
     case NASREC_OP_OPT_REDUCE: return launch_opt_reduce(st, (const nasrec_opt_reduce_desc_t*)desc);
     case NASREC_OP_OPT_APPLY: return launch_opt_apply(st, (const nasrec_opt_apply_desc_t*)desc);
+    case NASREC_OP_SAMPLE_CHAIN: return launch_sample_chain(st, (const nasrec_chain_desc_t*)desc);
     default: return nasrec_set_error(-1, "unknown op kind %d", kind);
   }
 }
@@ -148,6 +149,7 @@ TYPED(nasrec_adagrad_dense, nasrec_adagrad_dense_desc_t, kind == NASREC_OP_ADAGR
 TYPED(nasrec_adagrad_rows, nasrec_adagrad_rows_desc_t, kind == NASREC_OP_ADAGRAD_ROWS)
 TYPED(nasrec_opt_reduce, nasrec_opt_reduce_desc_t, kind == NASREC_OP_OPT_REDUCE)
 TYPED(nasrec_opt_apply, nasrec_opt_apply_desc_t, kind == NASREC_OP_OPT_APPLY)
+TYPED(nasrec_sample_chain, nasrec_chain_desc_t, kind == NASREC_OP_SAMPLE_CHAIN)
 
 int nasrec_event_create(void** ev) {
   hipEvent_t e;
@@ -178,7 +180,7 @@ int nasrec_event_destroy(void* ev) {
 
 const char* nasrec_last_error(void) { return g_err; }
 
-int nasrec_abi_version(void) { return 4; }
+int nasrec_abi_version(void) { return 5; }
 
 int nasrec_desc_sizes(int32_t* out, int n) {
   static const int32_t sizes[] = {
@@ -212,6 +214,7 @@ int nasrec_desc_sizes(int32_t* out, int n) {
       (int32_t)sizeof(nasrec_stage_desc_t),         // 27
       (int32_t)sizeof(nasrec_opt_reduce_desc_t),    // 28
       (int32_t)sizeof(nasrec_opt_apply_desc_t),     // 29
+      (int32_t)sizeof(nasrec_chain_desc_t),         // 30
   };
   const int total = (int)(sizeof(sizes) / sizeof(sizes[0]));
   int w = 0;

@@ -1,0 +1,299 @@
+// Helpers and the forward body of the fused Transformer kernels (see attention.hip), shared with chain.hip.
+#pragma once
+#include "common.h"
+
+#define MHA_N 64
+#define MHA_SCALE 0.70710678118654752440f  // 1/sqrt(head_dim = 2)
+
+// parameter offsets inside the 1696-float gradient record (order of nasrec_mha_desc_t::params)
+#define OFF_WIN 0
+#define OFF_BIN 768
+#define OFF_WOUT 816
+#define OFF_BOUT 1072
+#define OFF_L1W 1088
+#define OFF_L1B 1104
+#define OFF_W1 1120
+#define OFF_C1 1376
+#define OFF_W2 1392
+#define OFF_C2 1648
+#define OFF_L2W 1664
+#define OFF_L2B 1680
+
+// layout of the per-token forward state kept for the backward (NASREC_MHA_SAVED floats)
+#define SV_Q 0      // scaled query
+#define SV_K 16
+#define SV_V 32
+#define SV_O 48     // attention output (before the out-projection)
+#define SV_H1 64    // LayerNorm-1 output
+#define SV_XH1 80   // LayerNorm-1 x-hat
+#define SV_F1 96    // FFN hidden (post-ReLU)
+#define SV_XH2 112  // LayerNorm-2 x-hat
+#define SV_M 128    // per-head softmax max (8) and 1/sum (8)
+#define SV_RSTD 144 // 1/std of both LayerNorms
+
+// All 1696 parameters of the node are staged once per workgroup into LDS (6.8 KB) and read back with
+// wave-uniform (broadcast) ds_reads: keeping them in SGPRs instead blows the scalar register file.
+static __device__ const int kParamOff[12] = {OFF_WIN, OFF_BIN, OFF_WOUT, OFF_BOUT, OFF_L1W, OFF_L1B,
+                                             OFF_W1,  OFF_C1,  OFF_W2,   OFF_C2,   OFF_L2W, OFF_L2B};
+static __device__ const int kParamLen[12] = {768, 48, 256, 16, 16, 16, 256, 16, 256, 16, 16, 16};
+
+// measured per launch on the bench step (N = 64 / 8 / 48 tokens): forward 15.5 / 8.7 / 13.3 us with 4 waves against
+// 17.6 / 9.0 / 14.8 us with 8; backward 23.9 / 27.3 us with 4 waves against 21.1 / 24.7 us with 8
+#ifndef MHA_SLICE_FWD
+#define MHA_SLICE_FWD 4
+#endif
+#ifndef MHA_SLICE_BWD
+#define MHA_SLICE_BWD 2
+#endif
+
+template <int NT>
+__device__ __forceinline__ void stage_params(const nasrec_mha_desc_t& d, float* Wsh, int tid) {
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    const float* src = d.params[q];
+    for (int i = tid; i < kParamLen[q]; i += NT) Wsh[kParamOff[q] + i] = src[i];
+  }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int S>
+struct Vec {
+  float v[S];
+  __device__ __forceinline__ float& operator[](int i) { return v[i]; }
+  __device__ __forceinline__ const float& operator[](int i) const { return v[i]; }
+};
+template <int S>
+__device__ __forceinline__ Vec<S> vzero() {
+  Vec<S> r;
+#pragma unroll
+  for (int i = 0; i < S; ++i) r[i] = 0.f;
+  return r;
+}
+// S contiguous floats, S*4-byte aligned (LDS or global)
+template <int S>
+__device__ __forceinline__ Vec<S> ldv(const float* p) {
+  Vec<S> r;
+  if (S == 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    r[0] = t[0]; r[1] = t[1]; r[2 % S] = t[2]; r[3 % S] = t[3];
+  } else {
+    const f32x2 t = *reinterpret_cast<const f32x2*>(p);
+    r[0] = t[0]; r[1] = t[1];
+  }
+  return r;
+}
+template <int S>
+__device__ __forceinline__ void stv(float* p, const Vec<S>& v) {
+  if (S == 4) {
+    *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2 % S], v[3 % S]};
+  } else {
+    *reinterpret_cast<f32x2*>(p) = (f32x2){v[0], v[1]};
+  }
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+__device__ __forceinline__ void ld_row(const float* p, float* x) {
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    f32x4 t = ld4(p + 4 * v);
+    x[4 * v] = t[0];
+    x[4 * v + 1] = t[1];
+    x[4 * v + 2] = t[2];
+    x[4 * v + 3] = t[3];
+  }
+}
+
+// y[r] = b[c0+r] + sum_i W[(c0+r)*16 + i] * x[i], r < S  (W, b in LDS; x = full 16-vector in registers)
+template <int S>
+__device__ __forceinline__ Vec<S> mv_slice(const float* W, const float* b, int c0, const float* x) {
+  Vec<S> y;
+#pragma unroll
+  for (int r = 0; r < S; ++r) {
+    float s = b[c0 + r];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      f32x4 w = ld4(W + (c0 + r) * 16 + 4 * v);
+      s = fmaf(w[0], x[4 * v], s);
+      s = fmaf(w[1], x[4 * v + 1], s);
+      s = fmaf(w[2], x[4 * v + 2], s);
+      s = fmaf(w[3], x[4 * v + 3], s);
+    }
+    y[r] = s;
+  }
+  return y;
+}
+
+// y[ii] += sum_o W[o*16 + c0+ii] * g[o], ii < S  (transposed product restricted to the wave's columns)
+template <int S>
+__device__ __forceinline__ void mvt_slice_acc(const float* W, int c0, const float* g, Vec<S>& y) {
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    const Vec<S> w = ldv<S>(W + o * 16 + c0);
+#pragma unroll
+    for (int ii = 0; ii < S; ++ii) y[ii] = fmaf(w[ii], g[o], y[ii]);
+  }
+}
+
+template <int S>
+__device__ __forceinline__ float sumv(const Vec<S>& v) {
+  if (S == 4) return (v[0] + v[1]) + (v[2 % S] + v[3 % S]);
+  return v[0] + v[1];
+}
+
+// sum over the NW wave slices of one value per lane (fixed order)
+template <int NW>
+__device__ __forceinline__ float slice_sum(const float* red, int lane) {
+  float s = 0.f;
+  if (NW == 4) {
+    s = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+  } else {
+    s = ((red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane])) +
+        ((red[256 + lane] + red[320 + lane]) + (red[384 + lane] + red[448 + lane]));
+  }
+  return s;
+}
+
+// mean and 1/std of a 16-vector whose slices live in the NW waves (lane = token); two LDS exchanges
+template <int S>
+__device__ __forceinline__ void ln_stats(const Vec<S>& v, float* redA, float* redB, int w, int lane, float& mu, float& rstd) {
+  constexpr int NW = 16 / S;
+  redA[w * 64 + lane] = sumv<S>(v);
+  __syncthreads();
+  mu = slice_sum<NW>(redA, lane) * (1.f / 16.f);
+  float q = 0.f;
+#pragma unroll
+  for (int r = 0; r < S; ++r) q += (v[r] - mu) * (v[r] - mu);
+  redB[w * 64 + lane] = q;
+  __syncthreads();
+  const float var = slice_sum<NW>(redB, lane) * (1.f / 16.f);
+  rstd = 1.f / sqrtf(var + 1e-5f);
+}
+
+// forward of one sample b by one workgroup of 1024 / S threads (called by mha_fwd_kernel and by the per-sample chain kernel)
+template <int S>
+__device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const int b) {
+  constexpr int NW = 16 / S, NT = 64 * NW, HP = S / 2;
+  __shared__ __attribute__((aligned(16))) float Wsh[NASREC_MHA_PARAMS];
+  __shared__ __attribute__((aligned(16))) float Ks[MHA_N * 16];
+  __shared__ __attribute__((aligned(16))) float Vs[MHA_N * 16];
+  __shared__ __attribute__((aligned(16))) float Ob[MHA_N * 16];
+  __shared__ __attribute__((aligned(16))) float Hb[MHA_N * 16];
+  __shared__ __attribute__((aligned(16))) float Fb[MHA_N * 16];
+  __shared__ float red[4][NT];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c0 = S * w;
+  const int N = d.N;
+  const bool active = lane < N;
+  stage_params<NT>(d, Wsh, tid);
+  float x[16];
+  if (active) {
+    ld_row(d.x + (long)b * d.ldx + lane * 16, x);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = 0.f;
+  }
+  __syncthreads();
+  // in-projection, the wave's S columns of q, k, v
+  Vec<S> q4 = mv_slice<S>(Wsh + OFF_WIN, Wsh + OFF_BIN, c0, x);
+#pragma unroll
+  for (int r = 0; r < S; ++r) q4[r] *= MHA_SCALE;
+  const Vec<S> k4 = mv_slice<S>(Wsh + OFF_WIN + 256, Wsh + OFF_BIN + 16, c0, x);
+  const Vec<S> v4 = mv_slice<S>(Wsh + OFF_WIN + 512, Wsh + OFF_BIN + 32, c0, x);
+  stv<S>(Ks + lane * 16 + c0, k4);
+  stv<S>(Vs + lane * 16 + c0, v4);
+  __syncthreads();
+  // attention, the wave's HP heads (head h = columns c0+2h, c0+2h+1)
+  float mx[HP], ls[HP];
+#pragma unroll
+  for (int h = 0; h < HP; ++h) {
+    mx[h] = -INFINITY;
+    ls[h] = 0.f;
+  }
+#pragma unroll 4
+  for (int j = 0; j < N; ++j) {
+    const Vec<S> kj = ldv<S>(Ks + j * 16 + c0);
+#pragma unroll
+    for (int h = 0; h < HP; ++h) mx[h] = fmaxf(mx[h], fmaf(q4[2 * h], kj[2 * h], q4[2 * h + 1] * kj[2 * h + 1]));
+  }
+  Vec<S> o4 = vzero<S>();
+#pragma unroll 4
+  for (int j = 0; j < N; ++j) {
+    const Vec<S> kj = ldv<S>(Ks + j * 16 + c0);
+    const Vec<S> vj = ldv<S>(Vs + j * 16 + c0);
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+      const float p = __expf(fmaf(q4[2 * h], kj[2 * h], q4[2 * h + 1] * kj[2 * h + 1]) - mx[h]);
+      ls[h] += p;
+      o4[2 * h] = fmaf(p, vj[2 * h], o4[2 * h]);
+      o4[2 * h + 1] = fmaf(p, vj[2 * h + 1], o4[2 * h + 1]);
+    }
+  }
+  float li[HP];
+#pragma unroll
+  for (int h = 0; h < HP; ++h) {
+    li[h] = 1.f / ls[h];
+    o4[2 * h] *= li[h];
+    o4[2 * h + 1] *= li[h];
+  }
+  stv<S>(Ob + lane * 16 + c0, o4);
+  __syncthreads();
+  // out-projection + residual + LayerNorm 1
+  float row[16];
+  ld_row(Ob + lane * 16, row);
+  Vec<S> r1 = mv_slice<S>(Wsh + OFF_WOUT, Wsh + OFF_BOUT, c0, row);
+#pragma unroll
+  for (int r = 0; r < S; ++r) r1[r] += x[c0 + r];
+  float mu1, rstd1;
+  ln_stats<S>(r1, red[0], red[1], w, lane, mu1, rstd1);
+  Vec<S> xh1, h1;
+#pragma unroll
+  for (int r = 0; r < S; ++r) {
+    xh1[r] = (r1[r] - mu1) * rstd1;
+    h1[r] = xh1[r] * Wsh[OFF_L1W + c0 + r] + Wsh[OFF_L1B + c0 + r];
+  }
+  stv<S>(Hb + lane * 16 + c0, h1);
+  __syncthreads();
+  // FFN
+  ld_row(Hb + lane * 16, row);
+  Vec<S> f1 = mv_slice<S>(Wsh + OFF_W1, Wsh + OFF_C1, c0, row);
+#pragma unroll
+  for (int r = 0; r < S; ++r) f1[r] = fmaxf(f1[r], 0.f);
+  stv<S>(Fb + lane * 16 + c0, f1);
+  __syncthreads();
+  ld_row(Fb + lane * 16, row);
+  Vec<S> r2 = mv_slice<S>(Wsh + OFF_W2, Wsh + OFF_C2, c0, row);
+#pragma unroll
+  for (int r = 0; r < S; ++r) r2[r] += h1[r];
+  float mu2, rstd2;
+  ln_stats<S>(r2, red[2], red[3], w, lane, mu2, rstd2);
+  Vec<S> xh2, out;
+  const bool masked = d.dims_in_use >= 0 && lane >= d.dims_in_use;
+#pragma unroll
+  for (int r = 0; r < S; ++r) {
+    xh2[r] = (r2[r] - mu2) * rstd2;
+    out[r] = masked ? 0.f : xh2[r] * Wsh[OFF_L2W + c0 + r] + Wsh[OFF_L2B + c0 + r];
+  }
+  if (active) stv<S>(d.out + (long)b * d.ldo + lane * 16 + c0, out);
+  if (d.saved != nullptr && active) {  // training: keep what the backward needs instead of recomputing it there
+    float* sv = d.saved + ((long)b * N + lane) * NASREC_MHA_SAVED;
+    stv<S>(sv + SV_Q + c0, q4);
+    stv<S>(sv + SV_K + c0, k4);
+    stv<S>(sv + SV_V + c0, v4);
+    stv<S>(sv + SV_O + c0, o4);
+    stv<S>(sv + SV_H1 + c0, h1);
+    stv<S>(sv + SV_XH1 + c0, xh1);
+    stv<S>(sv + SV_F1 + c0, f1);
+    stv<S>(sv + SV_XH2 + c0, xh2);
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+      sv[SV_M + HP * w + h] = mx[h];
+      sv[SV_M + 8 + HP * w + h] = li[h];
+    }
+    if (w == 0) {
+      sv[SV_RSTD] = rstd1;
+      sv[SV_RSTD + 1] = rstd2;
+      sv[SV_RSTD + 2] = 0.f;
+      sv[SV_RSTD + 3] = 0.f;
+    }
+  }
+}
+

@@ -1,0 +1,344 @@
+// Body of the fp32 MFMA GEMM family (see gemm.hip for the launch side): shared by gemm_kernel and by the per-sample
+// chain kernel (chain.hip).
+#pragma once
+#include "common.h"
+
+#ifndef GEMM_TK_DEEP
+#define GEMM_TK_DEEP 64
+#endif
+#ifndef GEMM_XCD_REMAP
+#define GEMM_XCD_REMAP 0  // measured: 3.4x less fabric traffic on the big products, no time gain (Infinity Cache serves the re-reads), +6% step time from the index arithmetic
+#endif
+#ifndef GEMM_ZBATCH_TILE32
+#define GEMM_ZBATCH_TILE32 1
+#endif
+#ifndef GEMM_BIG_NT
+#define GEMM_BIG_NT 256
+#endif
+#ifndef GEMM_BIG_TK
+#define GEMM_BIG_TK 32
+#endif
+#ifndef GEMM_MID_NT
+#define GEMM_MID_NT 1024  // threads of the 64x64 latency-regime configuration (A/B on the bench step: 256 -> 0.677, 512 -> 0.646, 1024 -> 0.640 ms)
+#endif
+#ifndef GEMM_SKINNY_BELOW
+#define GEMM_SKINNY_BELOW 128  // launches with fewer 64x64 workgroups than this use the skinny tiles
+#endif
+// Tile configurations (template parameters NT threads, TK staged k depth, TBM x TBN block tile):
+//   256 thr, 32, 64x64  4 waves 2x2, 32x32 each — large products, throughput regime (>= 4 workgroups per CU);
+//   1024 thr, TK, 64x64  16 waves 4x4, one 16x16 MFMA tile each — four waves per SIMD, one wave's waits hide under
+//     the others' MFMAs (GEMM_MID_NT; 512 threads = 8 waves of 32x16 measured 1 % slower, 256 threads 5 % slower);
+//   256 thr, TK, 32x32  4 waves, one MFMA tile each — zmode batches of unequal products in the latency regime;
+//   256 thr, TK, 64x16 / 16x64  4 waves, one 16x16 MFMA tile each — "skinny" products of the batch-256 step (a
+//     [B,n]x[n,16] Linear, a token-axis Linear over B*16 columns): a 64x64 tiling would leave them on 4..64 of the 256
+//     CUs, and because every kernel starts on a cold L2 a CU only sustains ~13 KB/us of staging loads (outstanding
+//     misses x ~1 us latency) — so the operand traffic has to be spread over as many CUs as the problem allows.
+// TK = 32 when no k-segment is deeper than one 32-wide tile, else GEMM_TK_DEEP (fewer round trips and barriers; 64
+// measured best, 128 loses to its partial tiles).
+
+// thread -> (row, k) mapping of the staging loads of an R x TK operand tile: lanes run along the contiguous axis
+template <int MODE, int NT, int TK, int R>
+__device__ __forceinline__ void stage_coords(int tid, int it, int& rr, int& kk) {
+  if (MODE == NASREC_AM_KC || MODE == NASREC_AM_TOKK) {
+    kk = tid & (TK - 1);
+    rr = tid / TK + (NT / TK) * it;
+  } else {
+    rr = tid & (R - 1);
+    kk = tid / R + (NT / R) * it;
+  }
+}
+
+__device__ __forceinline__ float mul_lookup(const nasrec_gemm_desc_t& d, int i, int j) {
+  for (int q = 0; q < d.mul_nseg; ++q) {
+    int jj = j - d.mul_off[q];
+    if (jj >= 0 && jj < d.mul_width[q]) return d.mul_ptr[q] ? d.mul_ptr[q][(long)i * d.mul_ld[q] + jj] : 0.f;
+  }
+  return 0.f;
+}
+
+// leading dimension of operand A (which = 0) or B (1) of segment sq; only needed on the partial-k-tile path
+__device__ __forceinline__ int seg_ld(const nasrec_gemm_desc_t& d, int sq, int which) {
+  return which ? d.seg[sq].ldb : d.seg[sq].lda;
+}
+
+template <int CM>
+__device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, const nasrec_gemm_seg_t& sg, int i, int j,
+                                               float v) {
+  if (sg.ones_col && j == sg.N - 1) {  // virtual column: row sums of A (bias gradient)
+    (sg.rowsum ? sg.rowsum : d.rowsum_out)[i] = v;
+    return;
+  }
+  const long o = c_offset<CM>(i, j, sg.ldc);
+  if (d.pre_add) v += d.pre_add[o];
+  if (d.bias) v += d.bias_on_rows ? d.bias[i] : d.bias[j];
+  if (d.save_z) d.save_z[o] = v;
+  v = act_apply(v, d.act);
+  if (d.save_act) d.save_act[o] = v;
+  if (d.mul_nseg > 0) v *= mul_lookup(d, i, j);
+  if (d.dims_in_use >= 0) {
+    int idx = d.mask_on_rows ? i : j;
+    if (idx >= d.dims_in_use) v = 0.f;
+  }
+  if (d.zmode ? sg.accumulate : d.beta) v += sg.C[o];
+  sg.C[o] = v;
+}
+
+// One workgroup's share of a GEMM launch: block tile (bx, by) of problem / k-split bz.  Called by gemm_kernel with the
+// hardware block index, and by the per-sample chain kernel (chain.hip) with bx = the sample.
+template <int AM, int BMODE, int CM, int NT, int TK, int TBM, int TBN>
+__device__ __forceinline__ void gemm_tile(const nasrec_gemm_desc_t& d, int Mmax, int Nmax, const int bx_, const int by_, const int bz_) {
+  constexpr int LDS_LD = TK + 4;  // +4 pad: rows stay 16-byte aligned for ds_read_b128 and spread over banks
+  constexpr int NITA = TBM * TK / NT, NITB = TBN * TK / NT;  // staging loads per thread
+  constexpr int NITX = NITA > NITB ? NITA : NITB;
+  constexpr int PER_WAVE = (TBM / 16) * (TBN / 16) / (NT / 64);  // 16x16 MFMA tiles per wave
+  constexpr int WTM = (PER_WAVE >= 2 && TBM >= 32) ? 32 : 16;    // wave tile
+  constexpr int WTN = 16 * PER_WAVE / (WTM / 16);
+  constexpr int FA = WTM / 16, FB = WTN / 16;
+  static_assert(NITA >= 1 && NITB >= 1 && PER_WAVE >= 1 && (TBM / WTM) * (TBN / WTN) == NT / 64, "tile configuration");
+  __shared__ __attribute__((aligned(16))) float As[TBM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[TBN * LDS_LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / (TBN / WTN), wn = wave % (TBN / WTN);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int S = d.splitk > 1 ? d.splitk : 1;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  Give
+  // every XCD one CONTIGUOUS run of the (n fastest, then m, then problem/split) tile order, so the workgroups that share
+  // an A row-panel or a k-split fetch it into one L2 instead of eight.
+  int bx = bx_, by = by_, bz = bz_;
+#if GEMM_XCD_REMAP
+  {
+    const int gx = gridDim.x, gy = gridDim.y;  // (only meaningful when called with the hardware block index)
+    const int total = gx * gy * (int)gridDim.z;
+    const int lin = bx + gx * (by + gy * bz);
+    const int xcd = lin & 7, q = lin >> 3;
+    const int chunk = total >> 3, rem = total & 7;
+    const int lp = xcd * chunk + (xcd < rem ? xcd : rem) + q;
+    bx = lp % gx;
+    by = (lp / gx) % gy;
+    bz = lp / (gx * gy);
+  }
+#endif
+  const int z = d.zmode ? bz / S : 0;
+  const int ks = bz % S;
+  const nasrec_gemm_seg_t& s0 = d.seg[z];
+  const int M = s0.M, N = s0.N;
+  const int m0 = by * TBM, n0 = bx * TBN;
+  if (m0 >= M || n0 >= N) return;
+
+  // live k-tiles of this problem and the range owned by this split
+  int T = 0;
+  if (d.zmode) {
+    T = s0.A ? (s0.K + TK - 1) / TK : 0;
+  } else {
+    for (int q = 0; q < d.nseg; ++q)
+      if (d.seg[q].A) T += (d.seg[q].K + TK - 1) / TK;
+  }
+  const int t0 = (int)((long)T * ks / S), t1 = (int)((long)T * (ks + 1) / S);
+  int s = z, kt = t0;
+  if (!d.zmode) {
+    s = 0;
+    int skip = t0;
+    while (s < d.nseg) {
+      int nt = d.seg[s].A ? (d.seg[s].K + TK - 1) / TK : 0;
+      if (skip < nt) break;
+      skip -= nt;
+      ++s;
+    }
+    kt = skip;
+  }
+
+  f32x4 acc[FA][FB];
+#pragma unroll
+  for (int a = 0; a < FA; ++a)
+#pragma unroll
+    for (int b = 0; b < FB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Staging loads.  The per-iteration instruction budget decides this kernel at small batch (one wave per SIMD: every
+  // VALU instruction costs >= 4 cycles), so everything loop-invariant is hoisted to segment entry:
+  //   * per slot: a 32-bit BYTE offset of (row, kk) relative to the segment base (rows outside the operand are
+  //     redirected to row 0 and zeroed at commit), the LDS slot, the row-valid predicate;
+  //   * per k-tile only the UNIFORM base pointer advances (scalar adds), so a load is `global_load_dword v, voff, s[base]`
+  //     with no vector address arithmetic at all;
+  //   * k bounds matter only in the last tile of a segment -> uniform branch to a checked path;
+  //   * the ReLU-mask operand and the virtual ones-column sit behind uniform branches.
+  const char* cA = nullptr;
+  const char* cB = nullptr;
+  const char* cAaux = nullptr;
+  const char* cBaux = nullptr;
+  int cK = 0, cOnes = 0, cur = -1;
+  long stepA = 0, stepB = 0;          // bytes per k-tile
+  unsigned voffA[NITX], voffB[NITX];  // byte offset of (row, kk) at k-tile 0
+  bool rvA[NITX], rvB[NITX], oneB[NITX];
+  bool edgeA = false, edgeB = false;  // any row of this tile outside the operand?
+  auto load_seg = [&](int sq) {
+    const nasrec_gemm_seg_t& sg = d.seg[sq];
+    cA = reinterpret_cast<const char*>(sg.A);
+    cB = reinterpret_cast<const char*>(sg.B);
+    cAaux = reinterpret_cast<const char*>(sg.Aaux);
+    cBaux = reinterpret_cast<const char*>(sg.Baux);
+    cK = sg.K;
+    cOnes = sg.ones_col;
+    const int lda = sg.lda, ldb = sg.ldb;
+    const int Ra = (sg.Mvalid > 0 && sg.Mvalid < M) ? sg.Mvalid : M;
+    const int Rb = cOnes ? N - 1 : N;
+    // every addressing mode is linear in k across k-tiles (TK is a multiple of 16)
+    stepA = 4 * operand_offset<AM>(0, TK, lda);
+    stepB = 4 * operand_offset<BMODE>(0, TK, ldb);
+    edgeA = (m0 + TBM > Ra);
+    edgeB = (n0 + TBN > Rb);
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      int rr, kk;
+      if (it < NITA) {
+        stage_coords<AM, NT, TK, TBM>(tid, it, rr, kk);
+        rvA[it] = (m0 + rr) < Ra;
+        voffA[it] = 4u * (unsigned)operand_offset<AM>(rvA[it] ? m0 + rr : 0, kk, lda);
+      }
+      if (it < NITB) {
+        stage_coords<BMODE, NT, TK, TBN>(tid, it, rr, kk);
+        rvB[it] = (n0 + rr) < Rb;
+        oneB[it] = cOnes && (n0 + rr == N - 1);
+        voffB[it] = 4u * (unsigned)operand_offset<BMODE>(rvB[it] ? n0 + rr : 0, kk, ldb);
+      }
+    }
+    cur = sq;
+  };
+  // fetch() only ISSUES loads; commit() applies predicates and parks the tile in LDS one iteration later.
+  f32x4 ra[(NITX + 3) / 4], rb[(NITX + 3) / 4], xa[(NITX + 3) / 4], xb[(NITX + 3) / 4];  // staged values, 4 slots per vector register group
+  bool hasAaux = false, hasBaux = false, ktail = false;
+  int tailK = 0;  // valid k in a tail tile
+  auto fetch = [&](int ktq) {
+    const int k0 = ktq * TK;
+    const char* pa = cA + (long)ktq * stepA;
+    const char* pb = cB + (long)ktq * stepB;
+    ktail = (k0 + TK > cK);
+    tailK = cK - k0;
+    hasAaux = cAaux != nullptr;
+    hasBaux = cBaux != nullptr;
+    if (!ktail) {
+#pragma unroll
+      for (int it = 0; it < NITX; ++it) {
+        if (it < NITA) ra[it >> 2][it & 3] = *reinterpret_cast<const float*>(pa + voffA[it]);
+        if (it < NITB) rb[it >> 2][it & 3] = *reinterpret_cast<const float*>(pb + voffB[it]);
+      }
+      if (hasAaux) {
+        const char* xp = cAaux + (long)ktq * stepA;
+#pragma unroll
+        for (int it = 0; it < NITA; ++it) xa[it >> 2][it & 3] = *reinterpret_cast<const float*>(xp + voffA[it]);
+      }
+      if (hasBaux) {
+        const char* xp = cBaux + (long)ktq * stepB;
+#pragma unroll
+        for (int it = 0; it < NITB; ++it) xb[it >> 2][it & 3] = *reinterpret_cast<const float*>(xp + voffB[it]);
+      }
+    } else {
+      // last (partial) k-tile of the segment: k beyond K is redirected to kk = 0 of the slot's row and zeroed at commit
+#pragma unroll
+      for (int it = 0; it < NITX; ++it) {
+        int rr, kk;
+        if (it < NITA) {
+          stage_coords<AM, NT, TK, TBM>(tid, it, rr, kk);
+          const unsigned oa = (kk < tailK) ? voffA[it] : voffA[it] - 4u * (unsigned)operand_offset<AM>(0, kk, seg_ld(d, cur, 0));
+          ra[it >> 2][it & 3] = *reinterpret_cast<const float*>(pa + oa);
+          if (hasAaux) xa[it >> 2][it & 3] = *reinterpret_cast<const float*>(cAaux + (long)ktq * stepA + oa);
+        }
+        if (it < NITB) {
+          stage_coords<BMODE, NT, TK, TBN>(tid, it, rr, kk);
+          const unsigned ob = (kk < tailK) ? voffB[it] : voffB[it] - 4u * (unsigned)operand_offset<BMODE>(0, kk, seg_ld(d, cur, 1));
+          rb[it >> 2][it & 3] = *reinterpret_cast<const float*>(pb + ob);
+          if (hasBaux) xb[it >> 2][it & 3] = *reinterpret_cast<const float*>(cBaux + (long)ktq * stepB + ob);
+        }
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      int rr, kk;
+      if (it < NITA) {
+        float a = ra[it >> 2][it & 3];
+        if (hasAaux) a = (xa[it >> 2][it & 3] > 0.f) ? a : 0.f;
+        if (edgeA) a = rvA[it] ? a : 0.f;
+        stage_coords<AM, NT, TK, TBM>(tid, it, rr, kk);
+        if (ktail) a = (kk < tailK) ? a : 0.f;
+        As[rr * LDS_LD + kk] = a;
+      }
+      if (it < NITB) {
+        float b = rb[it >> 2][it & 3];
+        if (hasBaux) b = (xb[it >> 2][it & 3] > 0.f) ? b : 0.f;
+        if (edgeB) b = rvB[it] ? b : 0.f;
+        stage_coords<BMODE, NT, TK, TBN>(tid, it, rr, kk);
+        if (ktail) b = (kk < tailK) ? b : 0.f;
+        if (cOnes && oneB[it]) b = (!ktail || kk < tailK) ? 1.f : 0.f;
+        Bs[rr * LDS_LD + kk] = b;
+      }
+    }
+  };
+
+  if (t0 < t1) {
+    load_seg(s);
+    fetch(kt);
+  }
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    // advance to the next live tile and prefetch it while the MFMAs run
+    ++kt;
+    if (!d.zmode) {
+      while (s < d.nseg && (!d.seg[s].A || kt * TK >= d.seg[s].K)) {
+        ++s;
+        kt = 0;
+      }
+    }
+    if (t + 1 < t1) {
+      if (s != cur) load_seg(s);
+      fetch(kt);
+    }
+
+#pragma unroll
+    for (int kb = 0; kb < TK / 16; ++kb) {
+      f32x4 af[FA], bf[FB];
+#pragma unroll
+      for (int a = 0; a < FA; ++a) af[a] = *reinterpret_cast<const f32x4*>(&As[(wm * WTM + a * 16 + fr) * LDS_LD + kb * 16 + 4 * fg]);
+#pragma unroll
+      for (int b = 0; b < FB; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&Bs[(wn * WTN + b * 16 + fr) * LDS_LD + kb * 16 + 4 * fg]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+#pragma unroll
+          for (int b = 0; b < FB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
+  if (S > 1) {
+    // split-K: park the partial tile in this split's slab; gemm_splitk_epilogue sums the slabs in fixed order
+    // (deterministic) with one thread per output element.  An in-kernel "last arriver reduces" variant (agent-scope
+    // release/acquire, or sc1 write-through slabs) was measured 1.3-2x slower at these sizes: the serial tail of one
+    // workgroup reading S slabs costs more than the extra ~5 us launch of a fully parallel second pass.
+    float* slab = d.workspace + ((long)(z * S + ks)) * Mmax * Nmax;
+#pragma unroll
+    for (int a = 0; a < FA; ++a)
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
+          if (i < M && j < N) slab[(long)i * N + j] = acc[a][b][r];
+        }
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < FA; ++a)
+#pragma unroll
+    for (int b = 0; b < FB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
+        if (i < M && j < N) epilogue_store<CM>(d, s0, i, j, acc[a][b][r]);
+      }
+}
+

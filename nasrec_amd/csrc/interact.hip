@@ -3,51 +3,18 @@
 // All are HBM/latency-bound integer-indexed fp32 work: no MFMA here by design (E = 16 fits one lane's
 // registers, so a pairwise dot is 16 FMAs on LDS-resident rows — cheaper than a cross-lane reduction).
 #include "common.h"
+#include "interact_bodies.h"
 
 // ---------------------------------------------------------------------------------------------------
 // DotProduct core (modules.py:366-383).  One wavefront per sample, 4 samples per workgroup.
 // T[b] (k1 x 16, k1 <= 46) is staged in LDS with 20-float rows (bank spread for ds_read_b128).
 // ---------------------------------------------------------------------------------------------------
-#define TRI_MAXK1 64
-#define TRI_LD 20
-
-__device__ __forceinline__ void tri_decode(int p, int& i, int& j) {
-  // p = i(i-1)/2 + j, 0 <= j < i  (row-major strictly-lower triangle == torch.tril_indices(offset=-1))
-  i = (int)((1.f + sqrtf(1.f + 8.f * (float)p)) * 0.5f);
-  while (i * (i - 1) / 2 > p) --i;
-  while ((i + 1) * i / 2 <= p) ++i;
-  j = p - i * (i - 1) / 2;
-}
-
 __global__ __launch_bounds__(256) void dot_tri_fwd_kernel(const nasrec_dot_tri_desc_t d) {
   __shared__ __attribute__((aligned(16))) float Ts[4][TRI_MAXK1 * TRI_LD];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + wave;
   if (b >= d.B) return;  // whole wave exits together; no block-level barrier below
-  const int k1 = d.k1;
-  const float* Tb = d.T + (long)b * k1 * 16;
-  float* ts = Ts[wave];
-  for (int q = lane; q < k1 * 16; q += 64) ts[(q >> 4) * TRI_LD + (q & 15)] = Tb[q];
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  const int P = k1 * (k1 - 1) / 2;
-  float* ob = d.out + (long)b * d.ld_out;
-  for (int p = lane; p < P; p += 64) {
-    int i, j;
-    tri_decode(p, i, j);
-    const f32x4* ri = reinterpret_cast<const f32x4*>(ts + i * TRI_LD);
-    const f32x4* rj = reinterpret_cast<const f32x4*>(ts + j * TRI_LD);
-    float acc = 0.f;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      f32x4 a = ri[v], c = rj[v];
-      acc = fmaf(a[0], c[0], acc);
-      acc = fmaf(a[1], c[1], acc);
-      acc = fmaf(a[2], c[2], acc);
-      acc = fmaf(a[3], c[3], acc);
-    }
-    ob[p] = acc;
-  }
+  dot_tri_fwd_sample(d, b, lane, Ts[wave]);
 }
 
 // dT[b,i,:] = sum_{j<i} dO[p(i,j)] T[j] + sum_{j>i} dO[p(j,i)] T[j]
@@ -106,23 +73,7 @@ __global__ __launch_bounds__(256) void fm_fwd_kernel(const nasrec_fm_desc_t d) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + wave;
   if (b >= d.B) return;
-  const int g = lane >> 4, e = lane & 15;
-  const float* x = d.x + (long)b * d.ldx + e;
-  float s = 0.f, q = 0.f;
-  for (int n = g; n < d.N; n += 4) {
-    float v = x[n * 16];
-    s += v;
-    q = fmaf(v, v, q);
-  }
-  s += __shfl_xor(s, 16, 64);
-  q += __shfl_xor(q, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  q += __shfl_xor(q, 32, 64);
-  if (g == 0) {
-    float r = s * s - q;
-    float* o = d.ix + (long)b * d.ld_ix + e;
-    *o = d.accumulate ? *o + r : r;
-  }
+  fm_fwd_sample(d, b, lane);
 }
 
 __global__ __launch_bounds__(256) void fm_bwd_kernel(const nasrec_fm_desc_t d) {
@@ -159,20 +110,7 @@ int launch_fm(hipStream_t st, const nasrec_fm_desc_t* d) {
 __global__ __launch_bounds__(256) void copy_segs_kernel(const nasrec_copy_segs_desc_t d, int W) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   if (t >= (long)d.B * W) return;
-  const int b = (int)(t / W), j = (int)(t % W);
-  int q = 0;
-  for (; q < d.nseg; ++q)
-    if (j >= d.off[q] && j < d.off[q] + d.width[q]) break;
-  if (q == d.nseg) return;
-  const int jj = j - d.off[q];
-  float* dp = d.dst + (long)b * d.ld_dst + j;
-  if (!d.reverse) {
-    float v = d.seg[q] ? d.seg[q][(long)b * d.ld[q] + jj] : 0.f;
-    *dp = d.accumulate ? *dp + v : v;
-  } else if (d.seg[q]) {
-    float* sp = d.seg[q] + (long)b * d.ld[q] + jj;
-    *sp = d.seg_accumulate[q] ? *sp + *dp : *dp;
-  }
+  copy_segs_element(d, (int)(t / W), (int)(t % W));
 }
 
 int launch_copy_segs(hipStream_t st, const nasrec_copy_segs_desc_t* d) {

@@ -10,6 +10,7 @@ There is no CPU path here: everything below needs the HIP library and a GPU.
 """
 import ctypes as C
 import json
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -73,6 +74,8 @@ class SupernetEngine:
         self.world_size = world_size
         self.stream = torch.cuda.Stream(device=self.device)
         self._last_plan = None
+        # per-sample chains (plan.fuse_sample_chains) are correct but not faster in the captured step: opt-in
+        self.fuse_chains = os.environ.get("NASREC_CHAINS", "0") == "1"
         if cfg.fixed:
             assert warm_choice is not None, "fixed mode needs the fixed choice"
             self.warm_choice = warm_choice
@@ -233,7 +236,7 @@ class SupernetEngine:
             ctx.emit(fd)
             if cfg.use_final_sigmoid:
                 raise NotImplementedError("use_final_sigmoid is never enabled by the reference CLIs")
-            cp.fwd = Program(ctx.fwd)
+            cp.fwd = Program(P.fuse_sample_chains(ctx.fwd, B) if self.fuse_chains else ctx.fwd)
             cp.used_params = list(ctx.used_params)
             if train:
                 self._ensure_table_state()

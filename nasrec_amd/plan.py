@@ -1190,3 +1190,69 @@ def full_path_choice(cfg: NetConfig):
         micro.append({"active_nodes": list(range(ops["num_nodes"])), "dense_in_dims": int(max(ops["dense_node_dims"])),
                       "sparse_in_dims": int(max(ops["sparse_node_dims"])), "dense_sparse_interact": 1, "deep_fm": 1})
     return {"macro": macro, "micro": micro}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# per-sample chains (forward): a peephole over the finished descriptor list
+# ----------------------------------------------------------------------------------------------------------------
+def _chain_stage(d, B):
+    """-> (stage kind, field name) if descriptor d is a sample-local forward operator the chain kernel can run, else None"""
+    if isinstance(d, L.GemmDesc):
+        s0 = d.seg[0]
+        if (d.amode, d.bmode, d.cmode, d.zmode) == (L.AM_KC, L.AM_TOKR, L.CM_TOKJ, 0) and d.splitk <= 1 and 1 <= s0.M <= 64 and s0.N == 16 * B:
+            return L.OP_GEMM, "gemm"
+        return None
+    if isinstance(d, L.MhaDesc) and d.kind == L.OP_MHA_FWD and d.B == B:
+        return L.OP_MHA_FWD, "mha"
+    if isinstance(d, L.FmDesc) and d.kind == L.OP_FM_FWD and d.B == B:
+        return L.OP_FM_FWD, "fm"
+    if isinstance(d, L.DotTriDesc) and d.kind == L.OP_DOT_TRI_FWD and d.B == B:
+        return L.OP_DOT_TRI_FWD, "tri"
+    if isinstance(d, L.CopySegsDesc) and d.B == B and not d.reverse:
+        return L.OP_COPY_SEGS, "copy"
+    return None
+
+
+def fuse_sample_chains(descs, B, max_batch=256):
+    """Merge runs of consecutive sample-local forward launches into NASREC_OP_SAMPLE_CHAIN launches (workgroup b runs the
+    stages for sample b back to back).  Program order is kept and no operator in the set reads another sample's data, so
+    any run qualifies; a chain holds at most one stage of each kind and CHAIN_MAX stages.  Only used in the latency
+    regime (B <= max_batch: one 64x16 GEMM tile per sample is what the stand-alone launcher would pick there too)."""
+    if B > max_batch:
+        return list(descs)
+    out, run = [], []
+
+    def flush():
+        if len(run) >= 2:
+            c = L.ChainDesc()
+            c.kind, c.B, c.n = L.OP_SAMPLE_CHAIN, B, len(run)
+            for i, (kind, field, d) in enumerate(run):
+                c.stage[i] = kind
+                setattr(c, field, d)
+            out.append(c)
+        else:
+            out.extend(d for _, _, d in run)
+        run.clear()
+
+    for d in descs:
+        st = _chain_stage(d, B)
+        if st is None:
+            flush()
+            out.append(d)
+            continue
+        if len(run) == L.CHAIN_MAX or any(f == st[1] for _, f, _ in run):
+            flush()
+        run.append((st[0], st[1], d))
+    flush()
+    return out
+
+
+def iter_ops(descs):
+    """the operator descriptors of a program with chains expanded back into their stages (for FLOP counting, reports)"""
+    names = {L.OP_GEMM: "gemm", L.OP_MHA_FWD: "mha", L.OP_FM_FWD: "fm", L.OP_DOT_TRI_FWD: "tri", L.OP_COPY_SEGS: "copy"}
+    for d in descs:
+        if isinstance(d, L.ChainDesc):
+            for i in range(d.n):
+                yield getattr(d, names[d.stage[i]])
+        else:
+            yield d

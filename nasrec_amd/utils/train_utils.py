@@ -240,6 +240,7 @@ def get_model_flops_and_params(model, train_loader, gpu):
     (train_utils.py:436-452), which counts one flop per MAC of Linear / matmul / bmm and ignores the rest; here the same
     quantity is read off the engine's launch plan for the model's current choice."""
     from .. import _lib as L
+    from .. import plan as P
     model = model.to(gpu)
     int_x, cat_x, _ = next(iter(train_loader))
     int_x, cat_x = int_x.to(gpu), cat_x.to(gpu)
@@ -249,7 +250,7 @@ def get_model_flops_and_params(model, train_loader, gpu):
     eng = model._engine
     cp = eng.compile(model.choice, B, train=False)
     macs = 0
-    for d in cp.fwd.descs:
+    for d in P.iter_ops(cp.fwd.descs):
         if isinstance(d, L.GemmDesc):
             macs += sum(d.seg[q].M * d.seg[q].N * d.seg[q].K for q in range(d.nseg) if d.seg[q].A)
         elif isinstance(d, L.MhaDesc):  # in/out projections + FFN (4 x 16x16 ... per token) and the two attention products

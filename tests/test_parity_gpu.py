@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from helpers import golden_files, load_golden, oracle_cfg, oracle_params, proj_checksum
+from nasrec_amd import _lib as L
 from nasrec_amd import plan as P
 from nasrec_amd.engine import SupernetEngine
 from nasrec_amd.search_space import ops_config_lib
@@ -206,3 +207,23 @@ def test_data_parallel_code_path_single_rank():
     finally:
         if own_pg:
             dist.destroy_process_group()
+
+
+def test_sample_chains_are_bit_identical_to_the_separate_launches():
+    """NASREC_OP_SAMPLE_CHAIN (plan.fuse_sample_chains): the forward of a fixed sub-network with its sample-local runs fused into
+    chain launches must reproduce the unfused program bit for bit — same bodies, same per-sample work split."""
+    z, meta = load_golden(os.path.join(os.path.dirname(NPZ[0]), "fixed_criteo_xlarge.npz"))
+    int_x, cat_x = torch.tensor(z["int_x"]).cuda(), torch.tensor(z["cat_x"]).cuda()
+    outs, nchain = [], []
+    for fuse in (False, True):
+        eng = build_engine(z, meta)
+        eng.fuse_chains = fuse
+        outs.append(eng.forward(int_x, cat_x, meta["choice"]).clone())
+        cp = eng.compile(meta["choice"], int_x.shape[0], train=False)
+        nchain.append(sum(isinstance(d, L.ChainDesc) for d in cp.fwd.descs))
+        y = torch.tensor(z["y"]).cuda().view(-1)
+        loss = eng.train_step(int_x, cat_x, y, 0.05, meta["choice"])
+        torch.cuda.synchronize()
+        outs.append(eng.flat_p.clone())
+    assert nchain[0] == 0 and nchain[1] >= 3
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
