@@ -103,3 +103,96 @@ def test_exchange_and_rowsparse_equivalence():
     for f in range(FS):
         assert torch.allclose(mine_t[f], tables[f].data, rtol=0, atol=1e-12)
     assert torch.allclose(mine_d, dense.data, rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the whole data-parallel step against a single process at the global batch, with the oracle as the per-rank engine
+# ------------------------------------------------------------------------------------------------------------------
+def _dp_oracle_worker(rank, port, out):
+    """What DataParallelStep.step does on each rank, with the fp64 oracle standing in for the HIP engine: local
+    forward/backward with d loss / d logits pre-scaled by 1 / (B_local * world), asynchronous all-gather of (ids, per-sample
+    embedding-row gradients) and all-reduce of the dense gradients, then the same global-batch clip + row-sparse Adagrad on
+    every rank."""
+    import json
+    from helpers import GOLDEN, load_golden, oracle_cfg, oracle_params
+    from oracle import nasrec_oracle as O
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    z, meta = load_golden(os.path.join(GOLDEN, "fixed_criteo_autoctr.npz"))
+    cfg, P = oracle_cfg(meta), oracle_params(meta)
+    int_x, cat_x, y = torch.tensor(z["int_x"]).double(), torch.tensor(z["cat_x"]), torch.tensor(z["y"]).double().view(-1, 1)
+    Bg = int_x.shape[0]
+    Bl = Bg // WORLD
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    Fs = cat_x.shape[1]
+    lr, eps, clip = 0.05, 1e-2, 5.0
+    state = {}
+    for step in range(2):
+        leaves = {k: v.detach().requires_grad_(True) for k, v in P.items() if not k.startswith("_embedding.")}
+        Pl = O.Params(P.dtype, frozen=True)
+        Pl.update(leaves)
+        rows = torch.stack([P["_embedding.%d.weight" % f][cat_x[sl, f]] for f in range(Fs)], 1).detach().requires_grad_(True)  # [Bl,Fs,16]
+        for f in range(Fs):  # the stem as a gather of leaf rows, so that d loss / d rows is the per-sample row gradient
+            Pl["_embedding.%d.weight" % f] = rows[:, f]
+        ids_local = torch.arange(Bl).view(Bl, 1).expand(Bl, Fs).contiguous()
+        logits = O.supernet_forward(Pl, cfg, int_x[sl], ids_local, meta["choice"])
+        per_sample = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), y[sl].view(-1), reduction="sum")
+        loss = per_sample / (Bl * WORLD)  # == grad_scale 1/(B_local*world) folded into d logits
+        names = list(leaves)
+        grads = torch.autograd.grad(loss, [leaves[k] for k in names] + [rows], allow_unused=True)
+        flat = torch.cat([(g if g is not None else torch.zeros_like(leaves[k])).reshape(-1) for k, g in zip(names, grads[:-1])])
+        sg = grads[-1].contiguous()
+        cat_all, sg_all = torch.zeros(Bg, Fs, dtype=torch.int64), torch.zeros(Bg * Fs * 16, dtype=torch.float64)
+        pending = [all_gather_rows_async(cat_all, cat_x[sl].contiguous()), all_gather_rows_async(sg_all, sg),
+                   dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)]
+        for w in pending:
+            if w is not None:
+                w.wait()
+        sg_all = sg_all.view(Bg, Fs, 16)
+        # global-batch optimizer, identical on every rank: dedup rows (ascending sample order), clip over dense + unique rows
+        uniq = []
+        for f in range(Fs):
+            ids, inv = torch.unique(cat_all[:, f], return_inverse=True)
+            uniq.append((ids, torch.zeros(len(ids), 16, dtype=torch.float64).index_add_(0, inv, sg_all[:, f])))
+        total = torch.sqrt(flat.pow(2).sum() + sum(g.pow(2).sum() for _, g in uniq))
+        coef = min(1.0, clip / (float(total) + 1e-6))
+        with torch.no_grad():
+            off = 0
+            for k in names:
+                n = leaves[k].numel()
+                g = flat[off:off + n].view_as(P[k]) * coef
+                off += n
+                if not bool((g != 0).any()) and k not in state and k in meta["grad_none"]:
+                    continue  # parameters outside the path: torch skips grad=None
+                st = state.setdefault(k, torch.zeros_like(P[k]))
+                O.adagrad_step_(P[k], g, st, lr, eps)
+            for f, (ids, g) in enumerate(uniq):
+                k = "_embedding.%d.weight" % f
+                st = state.setdefault(k, torch.zeros_like(P[k]))
+                g = g * coef
+                st[ids] += g * g
+                P[k][ids] -= lr * g / (st[ids].sqrt() + eps)
+    out[rank] = {k: v.detach().clone() for k, v in P.items()}
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_equals_single_process_at_the_global_batch():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import GOLDEN, load_golden, oracle_cfg, oracle_params
+    from oracle import nasrec_oracle as O
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_oracle_worker, args=(port, out), nprocs=WORLD, join=True)
+    z, meta = load_golden(os.path.join(GOLDEN, "fixed_criteo_autoctr.npz"))
+    cfg, P = oracle_cfg(meta), oracle_params(meta)
+    int_x, cat_x, y = torch.tensor(z["int_x"]).double(), torch.tensor(z["cat_x"]), torch.tensor(z["y"]).double().view(-1, 1)
+    state = {}
+    for step in range(2):
+        O.train_step(P, state, cfg, meta["choice"], int_x, cat_x, y, lr=0.05)
+    for r in range(WORLD):
+        for k, v in P.items():
+            assert torch.allclose(out[r][k], v, rtol=0, atol=1e-10), (r, k)
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k  # replicas stay bit-identical
