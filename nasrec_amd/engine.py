@@ -276,6 +276,12 @@ class SupernetEngine:
                 cp.bwd = Program(pre[1:] + ctx.bwd[:fi] + [fused] + ctx.bwd[fi + 1:])
                 cp.bwd_tail_start = len(pre) - 1 + ctx.bwd_tail_start  # cp.bwd.descs[this:] = the parked weight-gradient products
                 cp.bwd_core = Program(pre[1:] + ctx.bwd)  # dlogits supplied by the caller (autograd path)
+                # fine-tune-last-layer mode (SuperNet.set_mode_to_finelune_last_only, the searcher's candidate evaluation):
+                # only d loss / d _final is wanted, i.e. the weight part of the final-logit backward and nothing else
+                last = L.FinalDesc.from_buffer_copy(plain)
+                for q in range(L.MAX_SEGS):
+                    last.dseg[q] = None
+                cp.bwd_final_only = Program(pre[1:] + [last])
                 cp.opt = Program(self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if sbuf.grad_written else None, clip, eps))
                 if graph:
                     cp.step = Program(cp.fwd.descs + cp.bwd.descs + cp.opt.descs)
@@ -414,10 +420,10 @@ class SupernetEngine:
         self._stage_inputs(sp, cp, int_x, cat_x)
         cp.fwd.run(sp)
 
-    def run_backward(self, cp, dlogits):
+    def run_backward(self, cp, dlogits, final_only: bool = False):
         """backward program with an externally supplied d(loss)/d(logits) [B,1] (torch.autograd entry)"""
         cp.dlogits.copy_(dlogits.reshape(-1), non_blocking=True)
-        cp.bwd_core.run(self._sp())
+        (cp.bwd_final_only if final_only else cp.bwd_core).run(self._sp())
 
     def forward_backward(self, int_x, cat_x, y, choice=None, grad_scale=None):
         """forward + BCE + backward only (gradients left in self.grads / plan.sparse0 gradient); used by the data-parallel

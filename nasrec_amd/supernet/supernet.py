@@ -76,10 +76,12 @@ class _SupernetFunction(torch.autograd.Function):
     def backward(ctx, dlogits):
         model, cp = ctx.model, ctx.cp
         eng = model._engine
-        eng.run_backward(cp, dlogits)
-        written = set(cp.ctx.grad_params) | {"_final.weight", "_final.bias"}
+        # only the last layer trains (set_mode_to_finelune_last_only): skip the network's backward altogether
+        final_only = all(name.startswith("_final.") or not p.requires_grad for name, p in model._param_names)
+        eng.run_backward(cp, dlogits, final_only=final_only)
+        written = {"_final.weight", "_final.bias"} if final_only else set(cp.ctx.grad_params) | {"_final.weight", "_final.bias"}
         grads = []
-        sg = cp.sparse0.grad_tensor().view(dlogits.shape[0], eng.Fs, 16) if cp.sparse0.grad_written else None
+        sg = cp.sparse0.grad_tensor().view(dlogits.shape[0], eng.Fs, 16) if (cp.sparse0.grad_written and not final_only) else None
         for name, p in model._param_names:
             if not p.requires_grad:
                 grads.append(None)

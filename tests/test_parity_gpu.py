@@ -227,3 +227,33 @@ def test_sample_chains_are_bit_identical_to_the_separate_launches():
         outs.append(eng.flat_p.clone())
     assert nchain[0] == 0 and nchain[1] >= 3
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+
+
+def test_finetune_last_layer_mode_runs_only_the_final_backward():
+    """SuperNet.set_mode_to_finelune_last_only (the searcher's candidate evaluation, eval_subnet_from_supernet.py): the gradient
+    of _final equals the full backward's, every other parameter keeps grad None, and only the final-logit backward is launched."""
+    from nasrec_amd.supernet.supernet import SuperNet
+    z, meta = load_golden(os.path.join(os.path.dirname(NPZ[0]), "fixed_criteo_autoctr.npz"))
+    int_x, cat_x, y = torch.tensor(z["int_x"]).cuda(), torch.tensor(z["cat_x"]).cuda(), torch.tensor(z["y"]).cuda().view(-1, 1)
+    torch.manual_seed(0)
+    m = SuperNet(num_blocks=meta["num_blocks"], ops_config=ops_config_lib[meta["config"]], use_layernorm=meta["use_layernorm"],
+                 activation=meta["activation"], num_embeddings=meta["tables"], sparse_input_size=cat_x.shape[1],
+                 path_sampling_strategy="fixed-path", fixed=True, fixed_choice=meta["choice"]).cuda()
+    with torch.no_grad():
+        m(int_x, cat_x)
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    loss_fn(m(int_x, cat_x), y).backward()
+    full = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    m.set_mode_to_finelune_last_only()
+    loss_fn(m(int_x, cat_x), y).backward()
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert set(got) == {"_final.weight", "_final.bias"}
+    for k in got:
+        assert torch.equal(got[k], full[k]), k
+    cp = m._engine.compile(m.choice, int_x.shape[0], train=True)
+    assert len(cp.bwd_final_only.descs) == 1
+    m.set_mode_to_normal_mode()
+    m.zero_grad(set_to_none=True)
+    loss_fn(m(int_x, cat_x), y).backward()
+    assert len([1 for p in m.parameters() if p.grad is not None]) == len(full)
