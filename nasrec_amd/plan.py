@@ -991,11 +991,18 @@ def block_walk(ctx, cfg: NetConfig, i, ops, choice, d_in, Dtot, s_in, Ntot, l_in
     if not fixed:
         assert dense_nodes and sparse_nodes or True
     extra = DS_INTERACT_NUM_SPLITS if (dsi == 1 or not fixed) else 0
-    dbuf = ctx.buf(B * max_dense)
-    dense_out = DV(dbuf, 0, max_dense, max_dense)
     sbuf = ctx.buf(B * (max_sparse + extra) * E)
     sparse_all = SV(sbuf, 0, max_sparse + extra, (max_sparse + extra) * E)
     sparse_nodes_out = sparse_all.rows(0, max_sparse)
+    # dense -> sparse merge without projection (the dense output is already 8 x 16 wide) and no DeepFM term added later:
+    # the reference copies dense_out into the 8 extra token rows (supernet.py:1145-1146); here the dense output simply
+    # LIVES in those rows (a strided [B,128] view of the sparse slab), so neither the copy nor its gradient fan-in exists
+    share_rows = bool(extra and dsi == 1 and max_dense == E * DS_INTERACT_NUM_SPLITS and deep_fm == 0 and not ctx.shape_only)
+    if share_rows:
+        dense_out = sparse_all.rows(max_sparse, DS_INTERACT_NUM_SPLITS).dense()
+    else:
+        dbuf = ctx.buf(B * max_dense)
+        dense_out = DV(dbuf, 0, max_dense, max_dense)
     act = L.ACT_BY_NAME[cfg.activation]
 
     # ---- dense nodes: sum of node outputs (supernet.py:1133 / 1215) --------------------------------------------
@@ -1077,7 +1084,7 @@ def block_walk(ctx, cfg: NetConfig, i, ops, choice, d_in, Dtot, s_in, Ntot, l_in
                 linear_dense(ctx, [Seg(node_sum, 0, max_dense)], max_dense, pre + ".project_emb_dim", E * DS_INTERACT_NUM_SPLITS,
                              not cfg.use_layernorm, proj_rows, L.ACT_NONE, -1, 0,
                              ln=(pre + ".project_emb_dim_layernorm") if cfg.use_layernorm else None)
-            else:
+            elif not share_rows:
                 copy_into(ctx, [Seg(node_sum, 0, max_dense)], proj_rows)
         else:
             zero_fill(ctx, proj_rows)
