@@ -189,6 +189,7 @@ typedef struct nasrec_fm_desc {
   float* ix;        /* fwd out [B,16] */
   const float* dix; /* bwd in  [B,16] */
   float* dx;        /* bwd out [B,N,16] */
+  const float* add; /* fwd, optional [B,16] with row stride ld_ix: ix = add + fm (instead of accumulating in place) */
 } nasrec_fm_desc_t;
 
 /* ------------------------------------------------------------------------------------------------

@@ -65,7 +65,7 @@ class DotTriDesc(C.Structure):
 
 class FmDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("N", i32), ("ldx", i32), ("ld_ix", i32), ("accumulate", i32), ("x", vp), ("ix", vp),
-                ("dix", vp), ("dx", vp)]
+                ("dix", vp), ("dx", vp), ("add", vp)]
 
 
 class MhaDesc(C.Structure):
@@ -220,8 +220,8 @@ def load():
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
                  "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_sample_chain"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 5:
-        raise EngineError("ABI version mismatch: library %d, binding 5" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 6:
+        raise EngineError("ABI version mismatch: library %d, binding 6" % lib.nasrec_abi_version())
     sizes = (i32 * 32)()
     n = lib.nasrec_desc_sizes(sizes, 32)
     for kind, cls in DESC_BY_KIND.items():

@@ -56,6 +56,7 @@ __device__ __forceinline__ void fm_fwd_sample(const nasrec_fm_desc_t& d, int b, 
   if (g == 0) {
     float r = s * s - q;
     float* o = d.ix + (long)b * d.ld_ix + e;
+    if (d.add) r += d.add[(long)b * d.ld_ix + e];
     *o = d.accumulate ? *o + r : r;
   }
 }

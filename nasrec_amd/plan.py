@@ -931,8 +931,11 @@ def op_fm(ctx, cfg, pre, x: SV, fm_dims, dims, dense_out: DV, pre_add: Optional[
     if not ctx.shape_only:
         d = L.FmDesc()
         d.kind = L.OP_FM_FWD
-        d.B, d.N, d.ldx, d.ld_ix, d.accumulate = B, x.N, x.ld, ix.ld, 1 if direct else 0
+        d.B, d.N, d.ldx, d.ld_ix, d.accumulate = B, x.N, x.ld, ix.ld, 1 if (direct and pre_add is None) else 0
         d.x, d.ix = x.ptr, ix.ptr
+        if direct and pre_add is not None:  # block_out = node_sum + FM term in one pass (dense_out holds nothing beforehand)
+            assert pre_add.ld == ix.ld and pre_add.width == E
+            d.add = pre_add.ptr
         ctx.emit(d)
 
         def bwd():
@@ -948,7 +951,6 @@ def op_fm(ctx, cfg, pre, x: SV, fm_dims, dims, dense_out: DV, pre_add: Optional[
             ctx.emit(e)
 
         ctx.on_backward(bwd)
-    assert pre_add is None or not direct
     if not direct:
         linear_dense(ctx, [Seg(ix, 0, E)], E, pre + "._linear_proj", fm_dims, not use_ln, dense_out, L.ACT_NONE, mask,
                      0 if pre_add is not None else 1, ln=(pre + "._linear_layernorm") if use_ln else None, pre_add=pre_add)
@@ -1013,7 +1015,7 @@ def block_walk(ctx, cfg: NetConfig, i, ops, choice, d_in, Dtot, s_in, Ntot, l_in
     # (a) the copy of an activated node output into dense_out and (b) the copy that keeps the pre-FM value alive for the
     # dense->sparse projection; the gradient of pre_fm aliases the gradient of the block output (registered below).
     fm_dims_fixed = max_dense
-    one_pass_fm = bool(deep_fm == 1 and fixed and not cfg.use_layernorm and fm_dims_fixed != E and not ctx.shape_only)
+    one_pass_fm = bool(deep_fm == 1 and fixed and not cfg.use_layernorm and not ctx.shape_only)  # (fm_dims == E: the FM kernel adds itself)
     pre_fm = None  # the buffer that holds the node sum when it is not dense_out
     wrote = False
     for n in range(ops["num_nodes"]):
