@@ -216,19 +216,23 @@ typedef struct nasrec_mha_desc {
   float* saved;         /* optional [B, N, NASREC_MHA_SAVED]: forward intermediates per token (scaled q, k, v, attention
                            output, softmax max / 1/sum per head, both LayerNorm x-hats and 1/std, FFN hidden) written by the
                            forward launch and read by the backward launch instead of recomputing the forward */
+  int32_t partial_ld;   /* bwd: row stride of dparams_partial in floats (0 = NASREC_MHA_PARAMS); lets several Transformer nodes
+                           share one partial buffer [B, n * NASREC_MHA_PARAMS] that ONE NASREC_OP_REDUCE_ROWS launch sums */
+  int32_t _pad;
 } nasrec_mha_desc_t;
 
-/* out[c] = sum_r in[r*ld + c], r < R, c < C, fixed order.  Optionally scattered to up to 16 destination
+/* out[c] = sum_r in[r*ld + c], r < R, c < C, fixed order.  Optionally scattered to up to NASREC_REDUCE_MAX_DST destination
  * tensors (parameter .grad buffers) by column ranges. */
+#define NASREC_REDUCE_MAX_DST 48
 typedef struct nasrec_reduce_rows_desc {
   int32_t kind; /* NASREC_OP_REDUCE_ROWS */
   int32_t R, C, ld;
   const float* in;
   int32_t ndst;
   int32_t _pad;
-  float* dst[16];
-  int32_t dst_off[16];   /* first column of each destination */
-  int32_t dst_len[16];
+  float* dst[NASREC_REDUCE_MAX_DST];
+  int32_t dst_off[NASREC_REDUCE_MAX_DST];   /* first column of each destination */
+  int32_t dst_len[NASREC_REDUCE_MAX_DST];
 } nasrec_reduce_rows_desc_t;
 
 /* Strided copy / accumulate of a segmented dense view:  dst[b, j] (=|+=) concat_j(seg)[b, j].

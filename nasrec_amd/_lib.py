@@ -21,6 +21,7 @@ MAX_TABLES = 32
 EMB_DIM = 16
 MHA_PARAMS = 1696
 MHA_SAVED = 148
+REDUCE_MAX_DST = 48
 
 AM_KC, AM_RC, AM_TOKR, AM_TOKK = 0, 1, 2, 3
 CM_PLAIN, CM_TOKJ = 0, 1
@@ -70,12 +71,12 @@ class FmDesc(C.Structure):
 
 class MhaDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("N", i32), ("ldx", i32), ("ldo", i32), ("dims_in_use", i32), ("x", vp), ("out", vp),
-                ("dout", vp), ("dx", vp), ("dparams_partial", vp), ("params", vp * 12), ("saved", vp)]
+                ("dout", vp), ("dx", vp), ("dparams_partial", vp), ("params", vp * 12), ("saved", vp), ("partial_ld", i32), ("_pad", i32)]
 
 
 class ReduceRowsDesc(C.Structure):
-    _fields_ = [("kind", i32), ("R", i32), ("C", i32), ("ld", i32), ("in_", vp), ("ndst", i32), ("_pad", i32), ("dst", vp * 16),
-                ("dst_off", i32 * 16), ("dst_len", i32 * 16)]
+    _fields_ = [("kind", i32), ("R", i32), ("C", i32), ("ld", i32), ("in_", vp), ("ndst", i32), ("_pad", i32), ("dst", vp * REDUCE_MAX_DST),
+                ("dst_off", i32 * REDUCE_MAX_DST), ("dst_len", i32 * REDUCE_MAX_DST)]
 
 
 class CopySegsDesc(C.Structure):
@@ -220,8 +221,8 @@ def load():
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
                  "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_sample_chain"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 6:
-        raise EngineError("ABI version mismatch: library %d, binding 6" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 7:
+        raise EngineError("ABI version mismatch: library %d, binding 7" % lib.nasrec_abi_version())
     sizes = (i32 * 32)()
     n = lib.nasrec_desc_sizes(sizes, 32)
     for kind, cls in DESC_BY_KIND.items():

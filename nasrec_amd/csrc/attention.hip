@@ -81,7 +81,7 @@ __global__ __launch_bounds__(1024 / S) void mha_bwd_kernel(const nasrec_mha_desc
   const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c0 = S * w;
   const int N = d.N;
   const bool active = lane < N;
-  float* gp = d.dparams_partial + (long)b * NASREC_MHA_PARAMS;
+  float* gp = d.dparams_partial + (long)b * (d.partial_ld > 0 ? d.partial_ld : NASREC_MHA_PARAMS);
   stage_params<NT>(d, Wsh, tid);
   Vec<S> x4 = vzero<S>(), q4 = vzero<S>(), k4 = vzero<S>(), v4 = vzero<S>(), o4 = vzero<S>(), h1 = vzero<S>(), xh1 = vzero<S>(),
          f1 = vzero<S>(), xh2 = vzero<S>(), dout = vzero<S>();

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const nasrec_reduce_ro
 
 int launch_reduce_rows(hipStream_t st, const nasrec_reduce_rows_desc_t* d) {
   if (d->C == 0) return 0;
-  if (d->ndst < 1 || d->ndst > 16) return nasrec_set_error(-2, "reduce_rows: ndst=%d", d->ndst);
+  if (d->ndst < 1 || d->ndst > NASREC_REDUCE_MAX_DST) return nasrec_set_error(-2, "reduce_rows: ndst=%d", d->ndst);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((d->C + 15) / 16), dim3(256), 0, st, *d);
   return nasrec_check_launch("reduce_rows");
 }

@@ -161,6 +161,7 @@ class Ctx:
         self.out = self.fwd  # current emission target
         self.deferred: List = []  # weight-gradient products parked until the end of the backward program
         self.bwd_tail_start = 0
+        self.mha_reduce: List = []  # (MHA backward descriptor, [(grad ptr, column offset, length)]) awaiting the shared reduction
         self.defer_dw = True
 
     # -- memory -----------------------------------------------------------------------------------------------
@@ -213,6 +214,7 @@ class Ctx:
         self.out = self.bwd
         for fn in reversed(self.closures):
             fn()
+        _flush_mha_reduce(self)
         self.bwd_tail_start = len(self.bwd)  # from here on: only the parked weight-gradient products
         _flush_deferred(self)
         self.out = self.fwd
@@ -380,6 +382,29 @@ def _weight_grad_products(ctx, am, bm, cm, items, rowsum_out=None):
         return _emit_z_groups(ctx, am, bm, cm, items, rowsum_out)
     for rank, d in _with_rowsum(items, rowsum_out):
         ctx.deferred.append((am, bm, cm, rank, d))
+
+
+def _flush_mha_reduce(ctx):
+    """one partial buffer [B, n * MHA_PARAMS] for the n Transformer nodes of the step, one NASREC_OP_REDUCE_ROWS over it"""
+    jobs, ctx.mha_reduce = ctx.mha_reduce, []
+    per = L.REDUCE_MAX_DST // 12
+    for i0 in range(0, len(jobs), per):
+        grp = jobs[i0:i0 + per]
+        ld = len(grp) * L.MHA_PARAMS
+        part = ctx.alloc(ctx.B * ld)
+        r = L.ReduceRowsDesc()
+        r.kind = L.OP_REDUCE_ROWS
+        r.R, r.C, r.ld = ctx.B, ld, ld
+        r.in_ = part.data_ptr()
+        n = 0
+        for j, (e, dsts) in enumerate(grp):
+            e.dparams_partial = part.data_ptr() + 4 * j * L.MHA_PARAMS
+            e.partial_ld = ld
+            for ptr, off, length in dsts:
+                r.dst[n], r.dst_off[n], r.dst_len[n] = ptr, j * L.MHA_PARAMS + off, length
+                n += 1
+        r.ndst = n
+        ctx.emit(r)
 
 
 def _flush_deferred(ctx, todo=None):
@@ -887,28 +912,20 @@ def op_transformer(ctx, cfg, pre, ssegs, Ntot, max_dims, dims, out: SV):
     def bwd():
         if not ctx.live(out):
             return
-        part = ctx.alloc(B * L.MHA_PARAMS)
         e = L.MhaDesc()
         e.kind = L.OP_MHA_BWD
         e.B, e.N, e.ldx, e.ldo, e.dims_in_use = B, max_dims, x.ld, out.ld, mask
         e.x, e.dout = x.ptr, out.gptr
         e.dx = xbuf.grad_tensor().data_ptr()
         xbuf.mark()
-        e.dparams_partial = part.data_ptr()
         e.saved = saved.data_ptr() if saved is not None else None
         for q in range(12):
             e.params[q] = pp[q]
         ctx.emit(e)
-        r = L.ReduceRowsDesc()
-        r.kind = L.OP_REDUCE_ROWS
-        r.R, r.C, r.ld = B, L.MHA_PARAMS, L.MHA_PARAMS
-        r.in_ = part.data_ptr()
-        r.ndst = 12
-        for q, leaf in enumerate(MHA_LEAVES):
-            r.dst[q] = ctx.gparam(pre + "." + leaf)
-            r.dst_off[q] = MHA_OFFS[q]
-            r.dst_len[q] = int(torch.Size(MHA_SHAPES[q]).numel())
-        ctx.emit(r)
+        # the per-sample parameter-gradient partials of ALL Transformer nodes share one buffer and one fixed-order
+        # reduction launch at the end of the backward program (their sums feed only the optimizer): _flush_mha_reduce
+        ctx.mha_reduce.append((e, [(ctx.gparam(pre + "." + leaf), MHA_OFFS[q], int(torch.Size(MHA_SHAPES[q]).numel()))
+                                   for q, leaf in enumerate(MHA_LEAVES)]))
 
     ctx.on_backward(bwd)
 
