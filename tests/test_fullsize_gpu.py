@@ -148,3 +148,16 @@ def test_rowsparse_step_touches_exactly_the_batch_rows_and_is_deterministic(setu
             assert torch.allclose(after[rows].double(), want, rtol=0, atol=1e-7), "table %d" % f
             assert torch.allclose(st_after[rows].double(), st, rtol=1e-6, atol=1e-12), "table %d" % f
     assert moved > 0 and not torch.equal(snap[0], eng.flat_p)
+
+
+def test_large_evaluation_batch_equals_the_batch_256_path(setup):
+    """a 4096-sample forward (the throughput-regime GEMM tiles, the > 256 code paths) reproduces the logits of the same
+    samples pushed through the batch-256 plan, 256 at a time"""
+    eng, choice, _, _, _, _ = setup
+    n = 4096
+    int_x, cat_x, _ = O.synthetic_batch(n, 13, NUM_EMBEDDINGS_CRITEO, seed=99)
+    int_x, cat_x = int_x.cuda(), cat_x.cuda()
+    big = eng.forward(int_x, cat_x, choice).clone()
+    small = torch.cat([eng.forward(int_x[i:i + 256], cat_x[i:i + 256], choice, graph=True).clone() for i in range(0, n, 256)], 0)
+    tol = 1e-5 * max(1.0, float(small.abs().max()))
+    assert float((big - small).abs().max()) <= tol
