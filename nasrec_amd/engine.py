@@ -62,6 +62,20 @@ class CompiledPlan:
     pass
 
 
+def _on_device(fn):
+    """run an engine entry point with the engine's device current: raw kernel launches, memsets, graph capture and event
+    creation all act on the CURRENT device, whatever device the caller left selected (main_train.py --gpu N, N != 0)"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        if torch.cuda.current_device() == self.device.index:
+            return fn(self, *a, **kw)
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **kw)
+    return wrapped
+
+
 class SupernetEngine:
     def __init__(self, cfg: P.NetConfig, Fd: int, Fs: int, num_embeddings: List[int], device="cuda:0", warm_choice=None,
                  world_size: int = 1, tables: Optional[List[torch.Tensor]] = None):
@@ -71,6 +85,8 @@ class SupernetEngine:
         self.cfg, self.Fd, self.Fs = cfg, Fd, Fs
         self.num_embeddings = [int(n) for n in num_embeddings[:Fs]]
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.world_size = world_size
         self.stream = torch.cuda.Stream(device=self.device)
         self._last_plan = None
@@ -124,6 +140,7 @@ class SupernetEngine:
         self.stream.synchronize()
 
     # -------------------------------------------------------------------------------------------------------
+    @_on_device
     def load_params(self, src: Dict[str, torch.Tensor]):
         """copy values (any device/dtype) into the engine's storage; keys = reference state_dict names"""
         with torch.cuda.stream(self.stream):
@@ -135,6 +152,7 @@ class SupernetEngine:
         self.stream.synchronize()
         return missing
 
+    @_on_device
     def init_weights(self, seed: int = 0):
         """train_utils.py:70-89 applied to this parameter set: xavier_normal_ tables, xavier_uniform_ 2-D weights
         (nn.Linear and the MultiheadAttention projections alike), zero biases; LayerNorm stays at its constructor
@@ -173,6 +191,7 @@ class SupernetEngine:
                 self.table_state = [torch.zeros_like(t) for t in self.tables]
 
     # -------------------------------------------------------------------------------------------------------
+    @_on_device
     def compile(self, choice, B: int, train: bool, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = False,
                 grad_scale: Optional[float] = None) -> CompiledPlan:
         fast = (id(choice), B, train, clip, eps, graph, grad_scale)
@@ -380,6 +399,7 @@ class SupernetEngine:
             d.lr_dst = None
         L.check(L.load().nasrec_launch(sp, C.addressof(d)))
 
+    @_on_device
     def forward(self, int_x, cat_x, choice=None, graph=False):
         """logits [B,1] for the given choice (fixed mode: the fixed choice)."""
         choice = choice if choice is not None else self.warm_choice
@@ -393,12 +413,17 @@ class SupernetEngine:
             cp.fwd.run(sp)
         return cp.logits.view(B, 1)
 
+    @_on_device
     def train_step(self, int_x, cat_x, y, lr: float, choice=None, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = False,
                    staged: bool = False):
         """zero_grad -> forward -> BCE -> backward -> clip_grad_norm_ -> Adagrad (train_utils.py:262-286).
         Returns the (device) loss tensor of this step.  `staged`: inputs are already in the plan's static buffers."""
         choice = choice if choice is not None else self.warm_choice
-        B = int(int_x.shape[0]) if int_x is not None else None
+        if int_x is not None:
+            B = int(int_x.shape[0])
+        else:  # pre-staged inputs: the batch size is the one of the plan they were staged into
+            assert staged and self._last_plan is not None, "train_step without inputs needs a previously compiled plan holding them"
+            B = int(self._last_plan[2].cat_x.shape[0])
         cp = self.compile(choice, B, train=True, clip=clip, eps=eps, graph=graph)
         sp = self._sp()
         if not staged:
@@ -414,17 +439,20 @@ class SupernetEngine:
             cp.opt.run(sp)
         return cp.loss
 
+    @_on_device
     def run_forward(self, cp, int_x, cat_x):
         """forward program of an already compiled (training) plan; logits land in cp.logits"""
         sp = self._sp()
         self._stage_inputs(sp, cp, int_x, cat_x)
         cp.fwd.run(sp)
 
+    @_on_device
     def run_backward(self, cp, dlogits, final_only: bool = False):
         """backward program with an externally supplied d(loss)/d(logits) [B,1] (torch.autograd entry)"""
         cp.dlogits.copy_(dlogits.reshape(-1), non_blocking=True)
         (cp.bwd_final_only if final_only else cp.bwd_core).run(self._sp())
 
+    @_on_device
     def forward_backward(self, int_x, cat_x, y, choice=None, grad_scale=None):
         """forward + BCE + backward only (gradients left in self.grads / plan.sparse0 gradient); used by the data-parallel
         wrapper and by the parity tests."""

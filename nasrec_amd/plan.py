@@ -694,6 +694,30 @@ def copy_into(ctx, segs: List[Seg], dst: DV, accumulate=0):
     ctx.on_backward(bwd)
 
 
+def _clip_segs(segs: List[Seg], mask: int):
+    """A 0/1 prefix mask over a virtual concatenation (modules.py:57-96) == the same concatenation cut at column `mask`."""
+    if mask < 0:
+        return list(segs)
+    out = []
+    for s in segs:
+        w = min(s.width, max(0, mask - s.koff))
+        if w <= 0:
+            continue
+        v = s.view
+        if v is not None and w != s.width:
+            v = DV(v.buf, v.off, w, v.ld)
+        out.append(Seg(v, s.koff, w))
+    return out
+
+
+def masked_copy(ctx, src: DV, mask: int, tgt: "Target"):
+    """tgt (+)= src * prefix_mask(mask) for an operator that skipped its projection and has no LayerNorm (the mask is then
+    the only thing left between the operator's core and the node sum)."""
+    if not tgt.accumulate:
+        zero_fill(ctx, tgt.view)
+    copy_into(ctx, _clip_segs([Seg(src, 0, src.width)], mask), tgt.view, 1)
+
+
 def zero_fill(ctx, view_dense: DV):
     """write zeros into a dense view (copy of a single zero segment)"""
     if ctx.shape_only:
@@ -760,8 +784,6 @@ def op_dot_product(ctx, cfg, pre, dsegs, Dtot, ssegs, Ntot, max_dims, dims, tgt:
                       ln=(pre + "._sparse_inp_proj_layernorm") if use_ln else None)
     else:
         copy_into(ctx, [Seg(s.view.dense() if s.view is not None else None, s.koff * E, s.width * E) for s in ssegs], Ty.dense())
-    if P == max_dims:
-        raise NotImplementedError("DotProduct without _linear_proj (triangle size == dims) never occurs for the reference dims")
     tri = ctx.buf(B * P)
     triv = DV(tri, 0, P, P)
     if not ctx.shape_only:
@@ -783,6 +805,12 @@ def op_dot_product(ctx, cfg, pre, dsegs, Dtot, ssegs, Ntot, max_dims, dims, tgt:
 
         ctx.on_backward(bwd)
     mask = -1 if cfg.fixed else dims
+    if P == max_dims:  # the triangle already has the target width: _linear_proj is dropped, the LayerNorm stays (modules.py:383-392)
+        if use_ln:
+            emit_ln_dense(ctx, triv, P, pre + "._linear_layernorm", tgt, L.ACT_NONE, mask)
+        elif not ctx.shape_only:
+            masked_copy(ctx, triv, mask, tgt)
+        return
     linear_dense(ctx, [Seg(triv, 0, P)], P, pre + "._linear_proj", max_dims, not use_ln, tgt.view, L.ACT_NONE, mask, tgt.accumulate,
                  ln=(pre + "._linear_layernorm") if use_ln else None)
 
@@ -808,9 +836,7 @@ def op_sum(ctx, cfg, pre, lsegs, Ltot, rsegs, Rtot, max_dims, dims, tgt: Target)
         _sum_into(ctx, lsegs, rsegs, tv, 0)
         emit_ln_dense(ctx, tv, D, pre + "._layernorm", tgt, L.ACT_NONE, mask)
     else:
-        if mask >= 0 and mask < D:
-            raise NotImplementedError("Sum without projection/LayerNorm under a prefix mask")
-        _sum_into(ctx, lsegs, rsegs, tgt.view, tgt.accumulate)
+        _sum_into(ctx, _clip_segs(lsegs, mask), _clip_segs(rsegs, mask), tgt.view, tgt.accumulate)
 
 
 def _sum_into(ctx, lsegs, rsegs, dst: DV, accumulate):
@@ -848,15 +874,14 @@ def op_sigmoid_gating(ctx, cfg, pre, lsegs, Ltot, rsegs, Rtot, max_dims, dims, t
     need_proj = D != max_dims
     gbuf = ctx.buf(B * D, need_grad=False)
     g = DV(gbuf, 0, D, D)
-    if need_proj or use_ln:
+    masked_plain = (not need_proj) and (not use_ln) and 0 <= mask < D  # the mask is all that follows the gating product
+    if need_proj or use_ln or masked_plain:
         pbuf = ctx.buf(B * D)
         prod = DV(pbuf, 0, D, D)
         ptgt = Target(prod, 0)
     else:
         prod = tgt.view
         ptgt = tgt
-        if mask >= 0 and mask < D:
-            raise NotImplementedError("SigmoidGating without projection/LayerNorm under a prefix mask")
     dzbuf = {}
 
     def pre_dz():
@@ -885,6 +910,8 @@ def op_sigmoid_gating(ctx, cfg, pre, lsegs, Ltot, rsegs, Rtot, max_dims, dims, t
                      ln=(pre + "._layernorm") if use_ln else None)
     elif use_ln:
         emit_ln_dense(ctx, prod, D, pre + "._layernorm", tgt, L.ACT_NONE, mask)
+    elif masked_plain and not ctx.shape_only:
+        masked_copy(ctx, prod, mask, tgt)
 
 
 def op_transformer(ctx, cfg, pre, ssegs, Ntot, max_dims, dims, out: SV):
@@ -936,7 +963,10 @@ def op_fm(ctx, cfg, pre, x: SV, fm_dims, dims, dense_out: DV, pre_add: Optional[
     B = ctx.B
     use_ln = cfg.use_layernorm
     mask = -1 if cfg.fixed else dims
-    direct = fm_dims == E
+    masked_direct = fm_dims == E and 0 <= mask < E  # identity projection under a prefix mask (modules.py:739-749)
+    direct = fm_dims == E and not masked_direct
+    if masked_direct:
+        assert pre_add is None
     if direct:
         ix = dense_out
         if use_ln:  # the LayerNorm module stays registered but unused (modules.py:743)
@@ -968,7 +998,13 @@ def op_fm(ctx, cfg, pre, x: SV, fm_dims, dims, dense_out: DV, pre_add: Optional[
             ctx.emit(e)
 
         ctx.on_backward(bwd)
-    if not direct:
+    if masked_direct:
+        if use_ln:
+            ctx.param(pre + "._linear_layernorm.weight", (fm_dims,), used=False)
+            ctx.param(pre + "._linear_layernorm.bias", (fm_dims,), used=False)
+        if not ctx.shape_only:
+            masked_copy(ctx, ix, mask, Target(dense_out, 1))
+    elif not direct:
         linear_dense(ctx, [Seg(ix, 0, E)], E, pre + "._linear_proj", fm_dims, not use_ln, dense_out, L.ACT_NONE, mask,
                      0 if pre_add is not None else 1, ln=(pre + "._linear_layernorm") if use_ln else None, pre_add=pre_add)
 
@@ -993,10 +1029,10 @@ def _mk_segs(views, widths, selected, fixed):
     return segs, off
 
 
-def block_walk(ctx, cfg: NetConfig, i, ops, choice, d_in, Dtot, s_in, Ntot, l_in, Ltot, r_in, Rtot):
-    """SuperNetBlock.forward supernet.py:1067-1162 / fixed_forward :1185-1242.  Returns (dense DV, sparse SV)."""
+def block_walk(ctx, cfg, pre, ops, choice, d_in, Dtot, s_in, Ntot, l_in, Ltot, r_in, Rtot):
+    """SuperNetBlock.forward supernet.py:1067-1162 / fixed_forward :1185-1242.  `pre` = parameter-name prefix of the block
+    ("_blocks.<i>" inside a SuperNet).  Returns (dense DV, sparse SV)."""
     B = ctx.B
-    pre = "_blocks.%d" % i
     fixed = cfg.fixed
     dd, sdm = int(choice["dense_in_dims"]), int(choice["sparse_in_dims"])
     max_dense = dd if fixed else int(max(ops["dense_node_dims"]))
@@ -1013,10 +1049,11 @@ def block_walk(ctx, cfg: NetConfig, i, ops, choice, d_in, Dtot, s_in, Ntot, l_in
     sbuf = ctx.buf(B * (max_sparse + extra) * E)
     sparse_all = SV(sbuf, 0, max_sparse + extra, (max_sparse + extra) * E)
     sparse_nodes_out = sparse_all.rows(0, max_sparse)
-    # dense -> sparse merge without projection (the dense output is already 8 x 16 wide) and no DeepFM term added later:
-    # the reference copies dense_out into the 8 extra token rows (supernet.py:1145-1146); here the dense output simply
-    # LIVES in those rows (a strided [B,128] view of the sparse slab), so neither the copy nor its gradient fan-in exists
-    share_rows = bool(extra and dsi == 1 and max_dense == E * DS_INTERACT_NUM_SPLITS and deep_fm == 0 and not ctx.shape_only)
+    # dense -> sparse merge without projection (the dense output is already 8 x 16 wide): the reference's 8 extra token rows
+    # are a VIEW of dense_out (no clone, supernet.py:1145-1146 / :1226-1227), and the DeepFM term is added to dense_out IN
+    # PLACE afterwards (:1157 / :1236), so the rows hold the post-FM value.  Here the dense output simply LIVES in those rows
+    # (a strided [B,128] view of the sparse slab): same aliasing, and neither a copy nor a gradient fan-in exists
+    share_rows = bool(extra and dsi == 1 and max_dense == E * DS_INTERACT_NUM_SPLITS and not ctx.shape_only)
     if share_rows:
         dense_out = sparse_all.rows(max_sparse, DS_INTERACT_NUM_SPLITS).dense()
     else:
@@ -1032,7 +1069,7 @@ def block_walk(ctx, cfg: NetConfig, i, ops, choice, d_in, Dtot, s_in, Ntot, l_in
     # (a) the copy of an activated node output into dense_out and (b) the copy that keeps the pre-FM value alive for the
     # dense->sparse projection; the gradient of pre_fm aliases the gradient of the block output (registered below).
     fm_dims_fixed = max_dense
-    one_pass_fm = bool(deep_fm == 1 and fixed and not cfg.use_layernorm and not ctx.shape_only)  # (fm_dims == E: the FM kernel adds itself)
+    one_pass_fm = bool(deep_fm == 1 and fixed and not cfg.use_layernorm and not ctx.shape_only and not share_rows)  # (fm_dims == E: the FM kernel adds itself)
     pre_fm = None  # the buffer that holds the node sum when it is not dense_out
     wrote = False
     for n in range(ops["num_nodes"]):
@@ -1187,7 +1224,7 @@ def network_walk(ctx, cfg: NetConfig, choice, int_x: DV, sparse0: SV):
         s_in, Ntot = _mk_segs(sviews, swidths, _as_set(mac["sparse_idx"]), cfg.fixed)
         l_in, Ltot = _mk_segs(dviews, dwidths, _as_set(mac["dense_left_idx"]), cfg.fixed)
         r_in, Rtot = _mk_segs(dviews, dwidths, _as_set(mac["dense_right_idx"]), cfg.fixed)
-        d_out, s_out = block_walk(ctx, cfg, i, cfg.block_ops(i), choice["micro"][i], d_in, Dtot, s_in, Ntot, l_in, Ltot, r_in, Rtot)
+        d_out, s_out = block_walk(ctx, cfg, "_blocks.%d" % i, cfg.block_ops(i), choice["micro"][i], d_in, Dtot, s_in, Ntot, l_in, Ltot, r_in, Rtot)
         dlist.append(d_out)
         slist.append(s_out)
     return dlist[-1], slist[-1]

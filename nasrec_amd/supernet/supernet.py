@@ -11,6 +11,7 @@ unchanged `clip_grad_norm_` + `torch.optim.Adagrad` harness works).  The fast pa
 `SuperNet.engine_train_step`, whose row-sparse table update is mathematically identical for weight_decay == 0.
 """
 import copy
+import json
 from itertools import combinations
 from typing import Any, List, Optional, Union
 
@@ -33,10 +34,6 @@ _sparse_nodes = ["zeros-3d", "transformer", "linear-3d"]
 assert_valid_ops_config(ops_config_lib)
 
 DS_INTERACT_NUM_SPLITS = 8  # supernet.py:882
-
-# LayerNorm siblings that disappear together with a dropped projection (modules.py:344-345,353-354,363-364; supernet.py:1144,1225)
-_LN_SIBLING = {"_dense_proj": "_dense_layernorm", "_sparse_proj": "_sparse_layernorm",
-               "_sparse_inp_proj": "_sparse_inp_proj_layernorm", "project_emb_dim": "project_emb_dim_layernorm"}
 
 
 def _make_node(name, use_layernorm, dims, activation, embedding_dim, fixed):
@@ -69,13 +66,20 @@ class _SupernetFunction(torch.autograd.Function):
         B = int(int_x.shape[0])
         cp = eng.compile(choice, B, train=True)
         eng.run_forward(cp, int_x, cat_x)
-        ctx.model, ctx.cp, ctx.cat_x = model, cp, cat_x
+        cp.generation = getattr(cp, "generation", 0) + 1
+        ctx.model, ctx.cp, ctx.cat_x, ctx.generation = model, cp, cat_x, cp.generation
         return cp.logits.view(B, 1).clone()
 
     @staticmethod
     def backward(ctx, dlogits):
         model, cp = ctx.model, ctx.cp
         eng = model._engine
+        if getattr(cp, "generation", 0) != ctx.generation:
+            # the activations a backward needs live in the plan's static buffers (one plan per (choice, batch size)): a second
+            # grad-enabled forward through the same plan has overwritten them
+            raise RuntimeError("SuperNet.forward ran again with the same choice and batch size before the backward of an earlier "
+                               "call: the saved activations of that call are gone; run backward (or sum the losses of separately "
+                               "shaped calls) before the next forward")
         # only the last layer trains (set_mode_to_finelune_last_only): skip the network's backward altogether
         final_only = all(name.startswith("_final.") or not p.requires_grad for name, p in model._param_names)
         eng.run_backward(cp, dlogits, final_only=final_only)
@@ -317,31 +321,8 @@ class SuperNet(nn.Module):
         cfg = self._net_config()
         shapes = P.infer_param_shapes(cfg, self._warm_choice(), Fd, self._sparse_input_size, self._num_embeddings)
         self._shapes = shapes
-        for name, shp in shapes.items():
-            if not name.endswith(".weight") or len(shp) != 2 or name.startswith("_embedding."):
-                continue
-            path = name[:-len(".weight")].split(".")
-            parent = self
-            for a in path[:-1]:
-                parent = getattr(parent, a) if not a.isdigit() else parent[int(a)]
-            attr = path[-1]
-            cur = getattr(parent, attr, None)
-            if isinstance(cur, nn.LazyLinear) or cur is None:
-                dev = self._embedding[0].weight.device
-                lin = nn.Linear(shp[1], shp[0], bias=(name[:-len("weight")] + "bias") in shapes).to(dev)
-                setattr(parent, attr, lin)
-                if type(parent).__name__ == "LazySelfLinear":
-                    parent._linear_size = shp[1]
-        # anything still lazy was skipped by the reference's forward and is deleted there
-        for mod in list(self.modules()):
-            for attr, child in list(mod._modules.items()):
-                if isinstance(child, nn.LazyLinear):
-                    setattr(mod, attr, None)
-                    sib = _LN_SIBLING.get(attr)
-                    if sib is not None and hasattr(mod, sib):
-                        setattr(mod, sib, None)
-                    if isinstance(mod, FactorizationMachine3D):
-                        mod._use_layernorm = None  # modules.py:743
+        from ..opexec import materialize_lazies
+        materialize_lazies(self, shapes, delete_unused=True, device=self._embedding[0].weight.device)
         got = {k: tuple(v.shape) for k, v in self.state_dict().items()}
         assert got == {k: tuple(v) for k, v in shapes.items()}, "materialised module tree does not match the inferred parameter set"
         self._materialized = True
@@ -361,6 +342,13 @@ class SuperNet(nn.Module):
                 p.data = eng.params[name]
         self._engine = eng
         self._param_names = list(self.named_parameters())
+        st = self.__dict__.pop("_stashed_opt_state", None)
+        if st is not None:  # accumulators of the engine this one replaces
+            eng._ensure_table_state()
+            for n, t in st.items():
+                tgt = eng.table_state[int(n.split(".")[1])] if n.startswith("_embedding.") else eng.state.get(n)
+                if tgt is not None and tuple(tgt.shape) == tuple(t.shape):
+                    tgt.copy_(t.to(tgt.device))
 
     def _ensure_engine(self, int_feats):
         if not self._materialized:
@@ -390,9 +378,26 @@ class SuperNet(nn.Module):
         return new  # the copy re-binds its own engine at its next forward
 
     def to(self, *args, **kwargs):
+        eng = self._engine
+        before = [p.data_ptr() for p in self.parameters() if not isinstance(p, nn.parameter.UninitializedParameter)] if eng is not None else None
         out = super().to(*args, **kwargs)
-        self._engine = None  # storage moved: re-bind lazily
+        if eng is not None:
+            after = [p.data_ptr() for p in self.parameters() if not isinstance(p, nn.parameter.UninitializedParameter)]
+            if before != after:  # storage really moved (device / dtype change): re-bind lazily
+                self._stash_engine_state()
+                self._engine = None
         return out
+
+    def _stash_engine_state(self):
+        """keep the fused path's Adagrad accumulators across a re-bind (they live only in the engine otherwise)"""
+        eng = self._engine
+        if eng is None:
+            return
+        st = {n: t.detach().clone() for n, t in eng.state.items()}
+        if eng.table_state is not None:
+            for f, t in enumerate(eng.table_state):
+                st["_embedding.%d.weight" % f] = t.detach().clone()
+        self._stashed_opt_state = st
 
     # ------------------------------------------------------------------------------------------------ forward
     def _resolve_choice(self, choices):
@@ -482,6 +487,7 @@ class SuperNetBlock(nn.Module):
                  fixed_micro_choice=None, anypath_choice: str = "uniform", supernet_training_steps: int = 0,
                  sparse_input_size: int = 26):
         super().__init__()
+        self._ops_config = ops_config
         self._num_nodes = ops_config["num_nodes"]
         self._dense_nodes = ops_config["dense_nodes"]
         self._sparse_nodes = ops_config["sparse_nodes"]
@@ -536,7 +542,41 @@ class SuperNetBlock(nn.Module):
         self.choice = []
 
     def forward(self, tensors, choices=None):
-        raise NotImplementedError("a SuperNetBlock is executed as part of its SuperNet's launch plan; call SuperNet.forward")
+        """supernet.py:1067-1162 / fixed_forward :1185-1242: tensors = [dense [B,D], sparse [B,N,16], dense_left, dense_right] ->
+        (dense_out, sparse_out).  Inside a SuperNet the block is part of the network's launch plan; called on its own it compiles
+        a single-block plan from the same emitter (plan.block_walk) and runs it on the HIP engine."""
+        from .. import opexec
+        choice = self._resolve_choice(choices)
+        dense_t, sparse_t, left_t, right_t = tensors
+        self.materialize([t.shape for t in tensors], choice, dense_t.device)
+        key = json.dumps(choice, sort_keys=True, default=lambda o: o.tolist() if hasattr(o, "tolist") else o.item())
+        dense_out, sparse_out = opexec.run(self, self._emitter(choice), [dense_t, sparse_t, left_t, right_t], key_extra=(key,))
+        return dense_out, sparse_out
+
+    def fixed_forward(self, tensors, choices):
+        return self.forward(tensors, choices)
+
+    def _emitter(self, ch):
+        from .. import opexec
+        cfg = opexec.OpConfig(self._use_layernorm, self._activation, self._fixed)
+        ops = self._ops_config
+
+        def emit(ctx, ins):
+            d, s, l, r = ins
+            dv, sv = P.block_walk(ctx, cfg, "op", ops, ch, [P.Seg(d, 0, d.width)], d.width, [P.Seg(s, 0, s.N)], s.N,
+                                  [P.Seg(l, 0, l.width)], l.width, [P.Seg(r, 0, r.width)], r.width)
+            return [dv, sv]
+        return emit
+
+    def materialize(self, in_shapes, choice=None, device=None):
+        """What the reference's first forward does to the module tree (host logic only).  Lazy shapes come from the first
+        inputs; a weight-sharing block materialises every node (the reference warms it up on the full path,
+        train_utils.py:413-433), a fixed block only what its choice reaches."""
+        from .. import opexec
+        if opexec.has_lazies(self):
+            warm = (choice if choice is not None else self._fixed_micro_choice) if self._fixed else \
+                {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in self._get_full_path_choice().items()}
+            opexec.materialize_lazies(self, opexec.infer_shapes(self._emitter(warm), in_shapes), device=device)
 
     def _get_choice(self):
         """supernet.py:1009-1061"""

@@ -38,20 +38,44 @@ class CosineAnnealingWarmupRestarts:
     def get_lr(self):
         return self.lr
 
-    def step(self):
-        self.step_in_cycle += 1
-        if self.step_in_cycle >= self.cur_cycle_steps:
-            self.cycle += 1
-            self.step_in_cycle -= self.cur_cycle_steps
-            self.cur_cycle_steps = int((self.cur_cycle_steps - self.warmup_steps) * self.cycle_mult) + self.warmup_steps
+    def step(self, epoch=None):
+        """lr_schedule.py:121-164; `epoch` = jump to that step index (eval_subnet_from_supernet.py calls step(epoch=-1))"""
+        if epoch is None:
+            self.step_in_cycle += 1
+            if self.step_in_cycle >= self.cur_cycle_steps:
+                self.cycle += 1
+                self.step_in_cycle -= self.cur_cycle_steps
+                self.cur_cycle_steps = int((self.cur_cycle_steps - self.warmup_steps) * self.cycle_mult) + self.warmup_steps
+        elif epoch >= self.first_cycle_steps:
+            if self.cycle_mult == 1.0:
+                self.step_in_cycle = epoch % self.first_cycle_steps
+                self.cycle = epoch // self.first_cycle_steps
+            else:
+                n = int(math.log(epoch / self.first_cycle_steps * (self.cycle_mult - 1) + 1, self.cycle_mult))
+                self.cycle = n
+                self.step_in_cycle = epoch - int(self.first_cycle_steps * (self.cycle_mult ** n - 1) / (self.cycle_mult - 1))
+                self.cur_cycle_steps = self.first_cycle_steps * self.cycle_mult ** n
+        else:
+            self.cur_cycle_steps = self.first_cycle_steps
+            self.step_in_cycle = epoch
         self.max_lr = self.base_max_lr * (self.gamma ** self.cycle)
-        if self.step_in_cycle < self.warmup_steps:
+        if self.step_in_cycle == -1:  # lr_schedule.py:97-98: base_lrs, which init_lr() set to min_lr
+            self.lr = self.min_lr
+        elif self.step_in_cycle < self.warmup_steps:
             self.lr = (self.max_lr - self.min_lr) * self.step_in_cycle / self.warmup_steps + self.min_lr
         else:
             self.lr = self.min_lr + (self.max_lr - self.min_lr) * (
                 1 + math.cos(math.pi * (self.step_in_cycle - self.warmup_steps) / (self.cur_cycle_steps - self.warmup_steps))) / 2
         _publish(self.optimizer, self.lr)
         return self.lr
+
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
+
+    def load_state_dict(self, state):
+        self.__dict__.update(state)
+        _publish(self.optimizer, self.lr)
 
 
 class ConstantWithWarmup:
@@ -76,8 +100,16 @@ class ConstantWithWarmup:
     def get_lr(self):
         return self.lr
 
-    def step(self):
+    def step(self, epoch=None):
+        """the reference's get_lr reads the scheduler's own call counter, whatever `epoch` says (lr_schedule.py:33-43)"""
         self.count += 1
         self.lr = self._at(self.count)
         _publish(self.optimizer, self.lr)
         return self.lr
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
+
+    def load_state_dict(self, state):
+        self.__dict__.update(state)
+        _publish(self.optimizer, self.lr)

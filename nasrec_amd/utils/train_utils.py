@@ -98,6 +98,14 @@ def _fused_step_applies(model, optimizer, l2_loss_fn, use_amp):
             return False
     if len(optimizer.param_groups) != 1:
         return False
+    # the fused step updates the WHOLE dense arena and every touched embedding row: it only stands in for optimizer.step() when
+    # every parameter trains and the optimizer's single group covers all of them (set_mode_to_finelune_last_only /
+    # layernorm_calibrate / finetune_no_embedding, or an optimizer over a parameter subset, take the torch route)
+    params = list(model.parameters())
+    if not all(p.requires_grad for p in params):
+        return False
+    if {id(p) for p in params} != {id(p) for p in optimizer.param_groups[0]["params"]}:
+        return False
     with torch.no_grad():
         return float(l2_loss_fn(model)) == 0.0
 

@@ -408,12 +408,14 @@ def block_forward(P, pre, cfg: NetCfg, ops: dict, tensors, choice: dict, record:
 
     dsi = int(choice["dense_sparse_interact"])
     proj = None
+    proj_aliases_dense = False
     if dsi == 1:  # :1137-1146 / :1218-1227
         if dense_out.shape[-1] != E * DS_INTERACT_NUM_SPLITS:
             proj = _linear(P, pre + ".project_emb_dim", dense_out, E * DS_INTERACT_NUM_SPLITS, bias=not use_ln)
             if use_ln:
                 proj = _layernorm(P, pre + ".project_emb_dim_layernorm", proj)
         else:
+            proj_aliases_dense = True  # no clone here (:1145-1146 / :1226-1227): a VIEW of dense_out, updated by the in-place FM add below
             proj = dense_out
         proj = proj.reshape(-1, DS_INTERACT_NUM_SPLITS, E)
     elif not fixed:  # :1147-1150 (supernet mode appends 8 zero tokens; fixed mode appends nothing :1241-1242)
@@ -422,6 +424,8 @@ def block_forward(P, pre, cfg: NetCfg, ops: dict, tensors, choice: dict, record:
     if int(choice["deep_fm"]) == 1:  # :1154-1157 / :1233-1236 — uses sparse_out BEFORE the dsi concat
         fm_dims = max_dense if fixed else int(max(ops["dense_node_dims"]))  # :1001
         dense_out = dense_out + fm3d(P, pre + ".deep_fm", sparse_out, dd, fm_dims, use_ln, fixed)
+        if proj_aliases_dense:  # `dense_t_2d_out += ...` is in place (:1157 / :1236): the 8 extra token rows see the post-FM value
+            proj = dense_out.reshape(-1, DS_INTERACT_NUM_SPLITS, E)
     if proj is not None:
         sparse_out = torch.cat([sparse_out, proj], dim=1)  # :1161 / :1240
     return dense_out, sparse_out

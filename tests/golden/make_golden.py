@@ -18,18 +18,20 @@ import json
 import os
 import sys
 
-sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, "/root/reference")
+sys.path.insert(0, HERE)
+import _refimport  # noqa: E402
 
-import numpy as np
-import torch
+_refimport.setup()  # /root/reference first, the repository root (and its `nasrec/` shim) OFF sys.path
 
-from nasrec.supernet.supernet import SuperNet, ops_config_lib  # the REAL reference
-from nasrec.utils.lr_schedule import ConstantWithWarmup, CosineAnnealingWarmupRestarts
-from oracle import nasrec_oracle as O
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from nasrec.supernet.supernet import SuperNet, ops_config_lib  # noqa: E402  the REAL reference
+from nasrec.utils.lr_schedule import ConstantWithWarmup, CosineAnnealingWarmupRestarts  # noqa: E402
+
+_refimport.assert_reference_modules()
+O = _refimport.load_oracle()  # by file path: name-seeded weights / synthetic batches / path samplers
 
 torch.set_num_threads(1)
 
@@ -41,6 +43,10 @@ DATASETS = {
     "kdd": dict(Fd=3, Fs=10, tables=[26274, 641708, 14848, 22122011, 1188090, 3735797, 2934102, 20004011, 4, 8]),
 }
 CAP = 997
+OUT = os.environ.get("GOLDEN_OUT", HERE)  # where the fixtures are written (default: next to this script)
+LR = 1e-3  # step size of the 3-step trajectories: the name-seeded weights are not a trained optimum, and at the recipe's
+# lr 0.16 the REFERENCE itself diverges on them within 3 steps (losses 6.9 -> 15 368 -> 93 804 on fixed_criteo_xlarge), which
+# leaves nothing to compare; at 1e-3 all 13 reference trajectories stay bounded (largest loss 113) and every step is checked
 
 
 def batch(ds, B, seed):
@@ -81,9 +87,11 @@ def clean_choice(c):
     return cv(c)
 
 
-def run_case(model_fn, ds, B, seed, out_name, keep_blocks=False, n_steps=3, lr=0.16, extra_meta=None):
+def run_case(model_fn, ds, B, seed, out_name, keep_blocks=False, n_steps=3, lr=None, extra_meta=None):
+    lr = LR if lr is None else lr
     tables, int_x, cat_x, y = batch(ds, B, seed)
     res = {}
+    traj = {}
     shapes = None
     for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
         model = model_fn(tables)
@@ -104,7 +112,7 @@ def run_case(model_fn, ds, B, seed, out_name, keep_blocks=False, n_steps=3, lr=0
             h.remove()
         loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, y.to(dtype))
         res["logits_" + tag] = logits.detach().numpy().copy()
-        res["loss_" + tag] = np.array(float(loss))
+        res["loss_" + tag] = np.array(float(loss.detach()))
         if tag == "f64":
             model.zero_grad()
             loss.backward()
@@ -119,30 +127,45 @@ def run_case(model_fn, ds, B, seed, out_name, keep_blocks=False, n_steps=3, lr=0
             for i, (d, s) in blocks.items():
                 res["block%d_dense" % i] = d.numpy().astype(np.float64)
                 res["block%d_sparse" % i] = s.numpy().astype(np.float64)
-            # 3 real optimizer steps (train_utils.py:262-286, main_train.py:152)
-            opt = torch.optim.Adagrad(model.parameters(), lr=lr, eps=1e-2)
-            losses, norms = [], []
-            for _ in range(n_steps):
-                opt.zero_grad()
-                out = model(xi, cat_x)
-                l = torch.nn.functional.binary_cross_entropy_with_logits(out, y.to(dtype))
-                l.backward()
-                tn = torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
-                opt.step()
-                losses.append(float(l))
-                norms.append(float(tn))
-            res["step_losses"] = np.array(losses)
-            res["step_gradnorms"] = np.array(norms)
-            after = {n: proj_checksum(n, p) for n, p in model.named_parameters()}
+        # n_steps real optimizer steps (train_utils.py:262-286, main_train.py:152), in BOTH precisions: the fp64 run is the
+        # expected value, the reference's own fp32 run measures how far fp32 arithmetic drifts from it (the noise floor the
+        # engine's tolerance is set against, stored as *_f32)
+        before = {n: p.detach().clone() for n, p in model.named_parameters()}
+        opt = torch.optim.Adagrad(model.parameters(), lr=lr, eps=1e-2)
+        losses, norms = [], []
+        for _ in range(n_steps):
+            opt.zero_grad()
+            out = model(xi, cat_x)
+            l = torch.nn.functional.binary_cross_entropy_with_logits(out, y.to(dtype))
+            l.backward()
+            tn = torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+            opt.step()
+            losses.append(float(l.detach()))
+            norms.append(float(tn))
+        suffix = "" if tag == "f64" else "_f32"
+        res["step_losses" + suffix] = np.array(losses)
+        res["step_gradnorms" + suffix] = np.array(norms)
+        traj[tag] = dict(after={n: proj_checksum(n, p) for n, p in model.named_parameters()},
+                         delta={n: proj_checksum(n, p.detach() - before[n]) for n, p in model.named_parameters()})
+        if tag == "f64":
             with torch.no_grad():
                 res["logits_after_f64"] = model(xi, cat_x).numpy().copy()
+    after, delta = traj["f64"]["after"], traj["f64"]["delta"]
+    # drift of the reference's own fp32 trajectory from its fp64 one, relative to each parameter's norm / update norm
+    drift_p = max(max(abs(traj["f32"]["after"][n][i] - after[n][i]) for i in (0, 1)) / max(after[n][1], 1e-12) for n in after)
+    # updates are compared on the scale max(|update|, 1 % of a full-size Adagrad update lr * n_steps * sqrt(numel)): parameters
+    # whose true gradient is ~0 (e.g. a bias in front of a LayerNorm) move by rounding noise only
+    def dscale(n):
+        numel = int(np.prod(shapes[n])) if n in shapes else 1
+        return max(delta[n][1], 1e-2 * lr * n_steps * np.sqrt(numel))
+    drift_d = max(max(abs(traj["f32"]["delta"][n][i] - delta[n][i]) for i in (0, 1)) / dscale(n) for n in delta)
     meta = dict(dataset=ds, B=B, seed=seed, tables=tables, param_shapes=shapes, grads=res_meta_grads, grad_none=res_meta_none,
-                params_after=after, lr=lr, n_steps=n_steps, param_order=[n for n, _ in model.named_parameters()])
+                params_after=after, params_delta=delta, ref_fp32_drift=dict(params=drift_p, delta=drift_d), lr=lr, n_steps=n_steps, param_order=[n for n, _ in model.named_parameters()])
     meta.update(extra_meta or {})
-    np.savez_compressed(os.path.join(HERE, out_name), int_x=int_x.numpy(), cat_x=cat_x.numpy(), y=y.numpy(),
+    np.savez_compressed(os.path.join(OUT, out_name), int_x=int_x.numpy(), cat_x=cat_x.numpy(), y=y.numpy(),
                         meta=np.array(json.dumps(meta)), **res)
     print("wrote", out_name, "logits f64[:3]", res["logits_f64"][:3, 0], "max|f32-f64|",
-          float(np.abs(res["logits_f32"] - res["logits_f64"]).max()))
+          float(np.abs(res["logits_f32"] - res["logits_f64"]).max()), "losses", res["step_losses"], "fp32 drift: params %.2e delta %.2e" % (drift_p, drift_d))
 
 
 def fixed_cases():
@@ -222,7 +245,7 @@ def sampler_traces():
                             seq.append(clean_choice(m.choice))
                     out.append(dict(space=space, num_blocks=nb, strategy=strategy, anypath_choice=anypath,
                                     supernet_training_steps=steps, seed=seed, warmup_forwards=1, choices=seq))
-    json.dump(out, open(os.path.join(HERE, "samplers.json"), "w"))
+    json.dump(out, open(os.path.join(OUT, "samplers.json"), "w"))
     print("wrote samplers.json", len(out), "traces")
 
 
@@ -259,7 +282,20 @@ def lr_traces():
         opt.step()
         sch.step()
     out["constant_warmup"] = dict(base_lr=0.12, num_warmup_steps=8, lrs=seq)
-    json.dump(out, open(os.path.join(HERE, "lr.json"), "w"))
+    # step(epoch=e) jumps followed by a plain step (eval_subnet_from_supernet.py:179 calls lr_scheduler.step(epoch=-1))
+    jumps = []
+    for mult in (1.0, 2.0):
+        opt = torch.optim.Adagrad([p], lr=0.1)
+        sch = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=10, warmup_steps=3, max_lr=0.1, min_lr=1e-3, cycle_mult=mult, gamma=0.5)
+        seq = []
+        for e in (-1, 0, 2, 5, 9, 10, 17, 33, 71):
+            sch.step(epoch=e)
+            a = opt.param_groups[0]["lr"]
+            sch.step()
+            seq.append([e, a, opt.param_groups[0]["lr"]])
+        jumps.append(dict(first_cycle_steps=10, warmup_steps=3, max_lr=0.1, min_lr=1e-3, cycle_mult=mult, gamma=0.5, seq=seq))
+    out["cosine_epoch_jumps"] = jumps
+    json.dump(out, open(os.path.join(OUT, "lr.json"), "w"))
     print("wrote lr.json")
 
 

@@ -104,3 +104,39 @@ def test_train_supernet_cli_on_synthetic_batches(tmp_path, capsys):
     d = os.path.join(str(tmp_path / "sn"), "supernet_3blocks_layernorm1_default-binomial-0.5_lr0.05_supernetwarmup_2")
     assert os.path.exists(os.path.join(d, "supernet_checkpoint.pt")) and os.path.exists(os.path.join(d, "train_test_logs.pickle"))
     assert len(logs[0]["test_loss"]) == 1 and np.isfinite(logs[0]["test_loss"][0])  # test only at the last step
+
+
+def test_finetune_last_layer_only_through_the_harness_leaves_everything_else_untouched(tmp_path):
+    """eval_subnet_from_supernet.py:101-198: set_mode_to_finelune_last_only() + Adagrad(model.parameters(), eps=1e-2) + clip 5 through
+    train_and_test_one_epoch.  The fused engine step would train the whole arena, so the loop must take the torch route on its
+    own (use_engine_step=None) and only `_final` may move — every other parameter stays bit-identical."""
+    root = _shards(tmp_path)
+    args = MT.build_parser().parse_args([
+        "--root_dir", root, "--net", "supernet-config", "--supernet_config", CFG, "--learning_rate", "0.05", "--train_batch_size", "8",
+        "--test_batch_size", "16", "--wd", "0", "--logging_dir", str(tmp_path / "l"), "--gpu", "0", "--train_limit", "48"])
+    from nasrec_amd.utils.data_pipes import make_loaders
+    train_loader, test_loader = make_loaders(args)
+    torch.manual_seed(2)
+    model = MT.get_model(args).to(0)
+    with torch.no_grad():
+        TU.warmup_model(model, train_loader, 0)
+    model.apply(TU.init_weights)
+    model.set_mode_to_finelune_last_only()
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.Adagrad(model.parameters(), lr=0.05, eps=1e-2)
+    assert TU._fused_step_applies(model, opt, lambda m: TU.get_l2_loss(m, 0.0, None, gpu=0), False) is False
+    sched = MT.build_lr_scheduler("constant", opt, 6, 2, 0.05)
+    sched.step(epoch=-1)  # eval_subnet_from_supernet.py:179
+    TU.train_and_test_one_epoch(model, 0, opt, sched, train_loader, test_loader, torch.nn.BCEWithLogitsLoss(),
+                                lambda m: TU.get_l2_loss(m, 0.0, None, gpu=0), 8, 0, display_interval=2, test_interval=100,
+                                max_train_steps=4, grad_clip_value=5.0)
+    torch.cuda.synchronize()
+    after = model.state_dict()
+    moved = [k for k in before if not torch.equal(before[k], after[k])]
+    assert sorted(moved) == ["_final.bias", "_final.weight"], moved
+    # an optimizer over a parameter subset must not take the fused step either
+    model.set_mode_to_normal_mode()
+    sub = torch.optim.Adagrad(model.get_dense_parameters(), lr=0.05, eps=1e-2)
+    assert TU._fused_step_applies(model, sub, lambda m: TU.get_l2_loss(m, 0.0, None, gpu=0), False) is False
+    full = torch.optim.Adagrad(model.parameters(), lr=0.05, eps=1e-2)
+    assert TU._fused_step_applies(model, full, lambda m: TU.get_l2_loss(m, 0.0, None, gpu=0), False) is True

@@ -100,3 +100,34 @@ def test_reference_import_paths_resolve_to_the_engine():
     assert S2 is SuperNet and len(NUM_EMBEDDINGS_CRITEO) == 26
     m = CleverMaskGenerator()(8, 3)
     assert m.tolist() == [1, 1, 1, 0, 0, 0, 0, 0]
+
+
+def test_lr_schedulers_match_reference_traces():
+    """nasrec_amd.utils.lr_schedule (what the harness and bench.py step) against sequences recorded from the reference's own
+    schedulers (tests/golden/lr.json), incl. the `step(epoch=e)` jumps eval_subnet_from_supernet.py:179 makes"""
+    import json
+    import os
+    from helpers import GOLDEN
+    from nasrec_amd.utils.lr_schedule import ConstantWithWarmup, CosineAnnealingWarmupRestarts
+    lr = json.load(open(os.path.join(GOLDEN, "lr.json")))
+    c = lr["cosine_restarts"]
+    s = CosineAnnealingWarmupRestarts(c["first_cycle_steps"], c["cycle_mult"], c["max_lr"], c["min_lr"], c["warmup_steps"], c["gamma"])
+    for want in c["lrs"]:
+        assert abs(s.get_lr() - want) <= 1e-15 + 1e-12 * abs(want)
+        s.step()
+    c = lr["constant_warmup"]
+    s = ConstantWithWarmup(c["base_lr"], c["num_warmup_steps"])
+    for want in c["lrs"]:
+        assert abs(s.get_lr() - want) <= 1e-15 + 1e-12 * abs(want)
+        s.step()
+    for c in lr["cosine_epoch_jumps"]:
+        s = CosineAnnealingWarmupRestarts(c["first_cycle_steps"], c["cycle_mult"], c["max_lr"], c["min_lr"], c["warmup_steps"], c["gamma"])
+        for e, a, b in c["seq"]:
+            s.step(epoch=e)
+            assert abs(s.get_lr() - a) <= 1e-15, (e, s.get_lr(), a)
+            s.step()
+            assert abs(s.get_lr() - b) <= 1e-15, (e, "next", s.get_lr(), b)
+        st = s.state_dict()
+        s2 = CosineAnnealingWarmupRestarts(c["first_cycle_steps"], c["cycle_mult"], c["max_lr"], c["min_lr"], c["warmup_steps"], c["gamma"])
+        s2.load_state_dict(st)
+        assert s2.step() == s.step()

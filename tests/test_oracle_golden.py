@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, golden_files, load_golden, oracle_cfg, oracle_params, proj_checksum
+from helpers import GOLDEN, check_trajectory, golden_files, load_golden, oracle_cfg, oracle_params, proj_checksum
 from oracle import nasrec_oracle as O
 
 NPZ = golden_files("fixed_*.npz") + golden_files("supernet_*.npz")
@@ -61,11 +61,7 @@ def test_grads_and_three_adagrad_steps(path):
                 d, n = proj_checksum(k, gd[k] / coef)
                 assert abs(n - nrm) <= 1e-9 * max(1.0, nrm), k
                 assert abs(d - dot) <= 1e-9 * max(1.0, nrm), k
-    assert np.allclose(losses, z["step_losses"], rtol=1e-9, atol=1e-10)
-    assert np.allclose(norms, z["step_gradnorms"], rtol=1e-10, atol=1e-12)
-    for k, (dot, nrm) in meta["params_after"].items():
-        d, n = proj_checksum(k, P[k])
-        assert abs(d - dot) <= 1e-9 * max(1.0, nrm), k
+    check_trajectory(z, meta, losses, norms, P, rel_params=1e-9, rel_delta=1e-8, rel_loss=1e-9)
     out = O.supernet_forward(P, cfg, int_x, cat_x, meta["choice"])
     assert np.abs(out.numpy() - z["logits_after_f64"]).max() <= 1e-9 * max(1.0, np.abs(z["logits_after_f64"]).max())
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import golden_files, load_golden, oracle_cfg, oracle_params, proj_checksum
+from helpers import check_trajectory, golden_files, load_golden, oracle_cfg, oracle_params, proj_checksum
 from nasrec_amd import _lib as L
 from nasrec_amd import plan as P
 from nasrec_amd.engine import SupernetEngine
@@ -17,6 +17,10 @@ from nasrec_amd.search_space import ops_config_lib
 from oracle import nasrec_oracle as O
 
 pytestmark = pytest.mark.gpu
+# 3-step clipped-Adagrad trajectories (fixtures at lr 1e-3, where the reference itself stays bounded on all 13 networks):
+# parameters within 1e-4 of their norm, updates within 1e-2 of the update scale (the reference's own fp32 run drifts from
+# its fp64 run by 9e-6 / 1.8e-3 on these scales — `ref_fp32_drift` in each fixture), losses / gradient norms within 1e-3
+TRAJ_REL_PARAMS, TRAJ_REL_DELTA, TRAJ_REL_LOSS = 1e-4, 1e-2, 1e-3
 NPZ = golden_files("fixed_*.npz") + golden_files("supernet_*.npz")
 IDS = [os.path.basename(p)[:-4] for p in NPZ]
 
@@ -96,16 +100,8 @@ def test_three_adagrad_steps(path, graph):
         torch.cuda.synchronize()
         losses.append(float(loss.item()))
         norms.append(float(eng.clip_out[1].item()))
-    ref_l, ref_n = z["step_losses"], z["step_gradnorms"]
-    # the first step is a pure function of the inputs; later steps amplify fp32 rounding through lr=0.16 updates
-    assert abs(losses[0] - ref_l[0]) <= 1e-5 * max(1.0, abs(ref_l[0]))
-    assert abs(norms[0] - ref_n[0]) <= 2e-5 * max(1.0, ref_n[0])
-    if np.all(np.abs(ref_l) < 50):  # skip trajectories the reference itself blows up on (lr 0.16 on toy tables)
-        assert np.allclose(losses, ref_l, rtol=2e-3, atol=2e-4), (losses, ref_l)
-        sd = eng.state_dict()
-        for k, (dot, nrm) in meta["params_after"].items():
-            d, n = proj_checksum(k, sd[k])
-            assert abs(n - nrm) <= 2e-3 * max(nrm, 1e-6), (k, n, nrm)
+    # every one of the 13 reference trajectories is checked, every step, every parameter (checksum AND norm)
+    check_trajectory(z, meta, losses, norms, eng.state_dict(), rel_params=TRAJ_REL_PARAMS, rel_delta=TRAJ_REL_DELTA, rel_loss=TRAJ_REL_LOSS)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -148,19 +144,16 @@ def test_module_dropin_with_unchanged_torch_harness(case):
         assert abs(n - nrm) <= 2e-5 * max(nrm, 1e-6), (k, n, nrm)
     # unchanged harness: zero_grad -> forward -> loss -> backward -> clip -> Adagrad
     opt = torch.optim.Adagrad(model.parameters(), lr=meta["lr"], eps=1e-2)
-    losses = []
+    losses, norms = [], []
     for _ in range(meta["n_steps"]):
         opt.zero_grad()
         l = torch.nn.functional.binary_cross_entropy_with_logits(model(int_x, cat_x), y)
         l.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)))
         opt.step()
         losses.append(float(l))
-    assert np.allclose(losses, z["step_losses"], rtol=2e-3, atol=2e-4), (losses, z["step_losses"])
     sd = model.state_dict()
-    for k, (dot, nrm) in meta["params_after"].items():
-        d, n = proj_checksum(k, sd[k])
-        assert abs(n - nrm) <= 2e-3 * max(nrm, 1e-6), (k, n, nrm)
+    check_trajectory(z, meta, losses, norms, sd, rel_params=TRAJ_REL_PARAMS, rel_delta=TRAJ_REL_DELTA, rel_loss=TRAJ_REL_LOSS)
     # the engine's fused step (row-sparse tables) lands on the same parameters as the dense-gradient harness
     model2 = SuperNet(num_blocks=meta["num_blocks"], ops_config=ops_config_lib[meta["config"]], use_layernorm=meta["use_layernorm"],
                       activation=meta["activation"], num_embeddings=meta["tables"], sparse_input_size=Fs,
