@@ -78,7 +78,9 @@ static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
   long wgs = 0;
   for (int q = 0; q < nprob; ++q) wgs += (long)((d->seg[q].M + 63) / 64) * ((d->seg[q].N + 63) / 64) * S;
   const bool deep = Kmax > 32;
-  if (wgs >= 1024) {
+  if (CM == NASREC_CM_PLAIN && gemm_fast_eligible(d, Mmax, Nmax)) {
+    launch_gemm_fast(st, d, Mmax, Nmax, zdim);  // throughput regime: 128x128x32 tiles, 16-byte staging, LDS double buffer (gemm_fast.hip)
+  } else if (wgs >= 1024) {
     launch_cfg<AM, BMODE, CM, GEMM_BIG_NT, GEMM_BIG_TK, 64, 64>(st, d, Mmax, Nmax, zdim);
   } else if (wgs >= GEMM_SKINNY_BELOW) {
     if (GEMM_ZBATCH_TILE32 && d->zmode && nprob > 1 && deep) {

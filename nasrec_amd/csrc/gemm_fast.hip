@@ -1,0 +1,437 @@
+// Throughput-regime fp32 MFMA GEMM for gfx950: the large-batch (supernet) products of the nn.Linear family
+// (modules.py:171,489,515,584; supernet.py:1140 forward, and their two autograd products), C(i,j) = sum_k A(i,k) B(j,k).
+//
+// Same descriptor, bindings KC/KC (y = x W^T), KC/RC (dx = dy W), RC/RC (dW = dy^T x) and epilogue as gemm_kernel
+// (gemm_tile.h); that kernel stays the general fallback (token-axis bindings, ReLU-mask operands, small launches).
+// What differs is the tiling and the staging, chosen for launches with hundreds of full tiles:
+//   * block tile 128 x 128 x 32, 4 wavefronts as 2 x 2, wave tile 64 x 64 = 2 x 2 v_mfma_f32_32x32x2_f32 tiles
+//     (64 accumulator registers, 16 MFMAs = 1024 matrix-pipe cycles per 8 k): half the LDS fragment traffic per flop of the
+//     64 x 64 block tile, and half the L2 -> LDS traffic;
+//   * staging loads are 16-byte BUFFER loads (dword-aligned addresses are enough: weight rows are [N, 13 + 1024 i] floats):
+//     resource descriptor = the operand's extent, per-lane byte offset fixed per segment, the k-tile advance in the scalar
+//     offset — no per-tile address arithmetic, and the hardware bounds check replaces every edge predicate: rows beyond the
+//     operand read other valid bytes of it or 0, and their results are never stored;
+//   * LDS double buffering with ONE barrier per k-tile; k-contiguous operands sit in LDS as [row][32 + 4] (ds_read_b128
+//     fragments, conflict-free with the 36-float pitch), row-contiguous operands as [k][128] (ds_read_b32 fragments, 32
+//     consecutive rows per lane group) — nothing is transposed; both use the same k order inside an 8-deep chunk (lane group
+//     g, MFMA j -> k = 8q + 4g + j), which only permutes the fp32 summation identically for A and B;
+//   * a wave issues in order and a 32x32x2 MFMA holds the matrix pipe for 64 cycles, so what is issued right behind an MFMA
+//     is free and what is issued in a block is not (in-kernel stamps, 1 workgroup per CU: 762 cycles to push 4 waves' staging
+//     loads through the CU's address path, 586 to park them in LDS, 445 for descriptor reads, against 4096 matrix cycles per
+//     k-tile; 84 VALU instructions of address / select arithmetic cost another ~900).  Hence ONE memory instruction behind
+//     one MFMA, pinned with scheduling fences, and no vector ALU work in the loop at all;
+//   * the last partial k-tile of a segment takes a synchronous checked path; the virtual ones-column (bias gradient) is a
+//     template variant, so ordinary tiles pay nothing for it;
+//   * XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2; every XCD gets a contiguous
+//     run of the (n fastest) tile order, i.e. a few A row-panels and all B panels, instead of every A panel.
+// fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain (no reduced-precision path exists on gfx950).
+#include "gemm_tile.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define FT_BM 128
+#define FT_BN 128
+#define FT_BK 32
+#define FT_KC_LD 36                        // [row][32 + 4]
+#define FT_TILE_FLOATS (FT_BM * FT_KC_LD)  // 4608 >= 32 * 128 (the [k][row] form)
+#define FT_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int MODE>
+__device__ __forceinline__ void ft_slot(int tid, int it, int& row, int& k) {
+  const int idx = tid + 256 * it;
+  if (MODE == NASREC_AM_KC) {  // 8 float4 along k per row
+    row = idx >> 3;
+    k = (idx & 7) << 2;
+  } else {                     // 32 float4 along rows per k
+    k = idx >> 5;
+    row = (idx & 31) << 2;
+  }
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ft_rsrc(const float* base, long extent_floats) {
+  const long bytes = extent_floats * 4;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes > 0x7fffffffL ? 0x7fffffff : (int)bytes, 0x00020000);
+}
+
+template <int AM, int BMODE, bool ONES>
+__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const nasrec_gemm_desc_t d, int Mmax, int Nmax, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float smem[2][2][FT_TILE_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fg = lane >> 5;
+  const int S = d.splitk > 1 ? d.splitk : 1;
+
+  // ---- which tile -------------------------------------------------------------------------------------------------
+  const int per_z = tiles_m * tiles_n;
+  int lin = blockIdx.x;
+  {
+    const int total = gridDim.x;
+    const int xcd = lin & 7, q = lin >> 3;
+    const int chunk = total >> 3, rem = total & 7;
+    lin = xcd * chunk + (xcd < rem ? xcd : rem) + q;  // bijective for any grid size
+  }
+  const int bz = lin / per_z;
+  const int t2 = lin - bz * per_z;
+  const int by = t2 / tiles_n, bx = t2 - by * tiles_n;
+  const int z = d.zmode ? bz / S : 0;
+  const int ks = bz % S;
+  const nasrec_gemm_seg_t& s0 = d.seg[z];
+  const int M = s0.M, N = s0.N;
+  const int m0 = by * FT_BM, n0 = bx * FT_BN;
+  if (m0 >= M || n0 >= N) return;
+
+  // ---- k range of this split ----------------------------------------------------------------------------------------
+  int T = 0;
+  if (d.zmode) {
+    T = s0.A ? (s0.K + FT_BK - 1) / FT_BK : 0;
+  } else {
+    for (int q = 0; q < d.nseg; ++q)
+      if (d.seg[q].A) T += (d.seg[q].K + FT_BK - 1) / FT_BK;
+  }
+  const int t0 = (int)((long)T * ks / S), t1 = (int)((long)T * (ks + 1) / S);
+  int s = z, kt = t0;
+  if (!d.zmode) {
+    s = 0;
+    int skip = t0;
+    while (s < d.nseg) {
+      const int nt = d.seg[s].A ? (d.seg[s].K + FT_BK - 1) / FT_BK : 0;
+      if (skip < nt) break;
+      skip -= nt;
+      ++s;
+    }
+    kt = skip;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // ---- staging state (per segment) ------------------------------------------------------------------------------------
+  const bool has_ones = ONES && s0.ones_col != 0;  // (ONES = some problem of the launch has the virtual column; this one: has_ones)
+  const int Rb = has_ones ? N - 1 : N;             // real rows of B
+  const float* pA = nullptr;
+  const float* pB = nullptr;
+  __amdgpu_buffer_rsrc_t rsA = ft_rsrc(nullptr, 0), rsB = ft_rsrc(nullptr, 0);
+  int cK = 0, lda = 0, ldb = 0;
+  int stepA = 0, stepB = 0;  // bytes per k-tile
+  int voffA[4], voffB[4];    // byte offset of the slot's (row, k) at k-tile 0 (rows beyond the operand: bounds-checked garbage / 0)
+  auto load_seg = [&](int sq) {
+    const nasrec_gemm_seg_t& sg = d.seg[sq];
+    pA = sg.A;
+    pB = sg.B;
+    cK = sg.K;
+    lda = sg.lda;
+    ldb = sg.ldb;
+    // extents: last element any in-range (row, k) can touch
+    rsA = ft_rsrc(pA, AM == NASREC_AM_KC ? (long)(M - 1) * lda + cK : (long)(cK - 1) * lda + M);
+    rsB = ft_rsrc(pB, BMODE == NASREC_AM_KC ? (long)(Rb - 1) * ldb + cK : (long)(cK - 1) * ldb + Rb);
+    stepA = 4 * FT_BK * (AM == NASREC_AM_KC ? 1 : lda);
+    stepB = 4 * FT_BK * (BMODE == NASREC_AM_KC ? 1 : ldb);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      int row, k;
+      ft_slot<AM>(tid, it, row, k);
+      // rows beyond M are redirected to row M - 1 for k-contiguous operands (keeps the offset inside 31 bits for any shape);
+      // row-contiguous slots simply run on into the next k-row
+      voffA[it] = 4 * (int)(AM == NASREC_AM_KC ? (long)min(m0 + row, M - 1) * lda + k : (long)k * lda + (m0 + row));
+      ft_slot<BMODE>(tid, it, row, k);
+      voffB[it] = 4 * (int)(BMODE == NASREC_AM_KC ? (long)min(n0 + row, Rb - 1) * ldb + k : (long)k * ldb + (n0 + row));
+    }
+  };
+  // per-thread constants of the ones-column variant: which elements of a B slot belong to column N - 1
+  int oneB[4] = {0, 0, 0, 0};
+  if (has_ones) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      int row, k;
+      ft_slot<BMODE>(tid, it, row, k);
+      if (BMODE == NASREC_AM_KC) {
+        oneB[it] = (n0 + row == N - 1) ? 15 : 0;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) oneB[it] |= (n0 + row + e == N - 1) ? (1 << e) : 0;
+      }
+    }
+  }
+
+  f32x4 ra[4], rb[4];
+  auto parkA = [&](int buf, int it, const f32x4& va) {
+    float* As = smem[buf][0];
+    int row, k;
+    ft_slot<AM>(tid, it, row, k);
+    if (AM == NASREC_AM_KC)
+      *reinterpret_cast<f32x4*>(&As[row * FT_KC_LD + k]) = va;
+    else
+      *reinterpret_cast<f32x4*>(&As[k * FT_BM + row]) = va;
+  };
+  auto parkB = [&](int buf, int it, f32x4 vb, int kmask) {  // kmask: bit e set = element e lies inside the segment's K
+    float* Bs = smem[buf][1];
+    int row, k;
+    ft_slot<BMODE>(tid, it, row, k);
+    if (ONES) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((oneB[it] >> e) & 1) vb[e] = ((kmask >> e) & 1) ? 1.f : 0.f;
+    }
+    if (BMODE == NASREC_AM_KC)
+      *reinterpret_cast<f32x4*>(&Bs[row * FT_KC_LD + k]) = vb;
+    else
+      *reinterpret_cast<f32x4*>(&Bs[k * FT_BN + row]) = vb;
+  };
+  // A partial tile goes global -> LDS in one synchronous, fully checked step (it never shares registers with the asynchronous
+  // path: the compiler would merge the two with register copies right behind the vector loads, i.e. wait for every load at once)
+  auto commit_tail = [&](int buf, int ktq) {
+    const int k0 = ktq * FT_BK;
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+      f32x4 va, vb;
+      int row, k, kmask = 0;
+      ft_slot<AM>(tid, it, row, k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = k0 + k + (AM == NASREC_AM_KC ? e : 0);
+        const int rr = min(m0 + row + (AM == NASREC_AM_KC ? 0 : e), M - 1);
+        const float v = pA[operand_offset<AM>(rr, min(kk, cK - 1), lda)];
+        va[e] = kk < cK ? v : 0.f;
+      }
+      ft_slot<BMODE>(tid, it, row, k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = k0 + k + (BMODE == NASREC_AM_KC ? e : 0);
+        const int rr = min(n0 + row + (BMODE == NASREC_AM_KC ? 0 : e), Rb - 1);
+        const float v = pB[operand_offset<BMODE>(rr, min(kk, cK - 1), ldb)];
+        vb[e] = kk < cK ? v : 0.f;
+        if (kk < cK) kmask |= 1 << e;
+      }
+      parkA(buf, it, va);
+      parkB(buf, it, vb, kmask);
+    }
+  };
+  // one operand fragment (4 k-values of chunk q for this lane's row) of the k-tile parked in LDS buffer `buf`; f[j] feeds MFMA j
+  auto read_fragA = [&](int buf, int q, int a, float (&f)[4]) {
+    const float* As = smem[buf][0];
+    const int row = wm * 64 + a * 32 + fr;
+    if (AM == NASREC_AM_KC) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&As[row * FT_KC_LD + 8 * q + 4 * fg]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = As[(8 * q + 4 * fg + j) * FT_BM + row];
+    }
+  };
+  auto read_fragB = [&](int buf, int q, int b, float (&f)[4]) {
+    const float* Bs = smem[buf][1];
+    const int row = wn * 64 + b * 32 + fr;
+    if (BMODE == NASREC_AM_KC) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[row * FT_KC_LD + 8 * q + 4 * fg]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = Bs[(8 * q + 4 * fg + j) * FT_BN + row];
+    }
+  };
+
+  // ---- main loop: one barrier per k-tile ------------------------------------------------------------------------------
+  if (t0 < t1) {
+    load_seg(s);
+    if ((kt + 1) * FT_BK <= cK) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        ra[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA[it], kt * stepA, 0));
+        rb[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[it], kt * stepB, 0));
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        parkA(0, it, ra[it]);
+        parkB(0, it, rb[it], 15);
+      }
+    } else {
+      commit_tail(0, kt);
+    }
+    __syncthreads();
+  }
+#ifdef FT_STAMPS  // diagnostic build only: cycle stamps of one workgroup / wave 0 into d.counters (s_memtime, shader clock)
+  long long* stamps = reinterpret_cast<long long*>(d.counters);
+  const bool stamp = stamps != nullptr && blockIdx.x == 8 && tid == 0;
+  int sn = 0;
+#define FT_STAMP() do { if (stamp && sn < 512) stamps[sn++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FT_STAMP() do {} while (0)
+#endif
+  const __amdgpu_buffer_rsrc_t rs_null = ft_rsrc(nullptr, 0);  // num_records 0: every load returns 0 without touching memory
+  int seg_tiles = (cK + FT_BK - 1) / FT_BK;  // k-tiles of the current segment (registers: no descriptor reads per tile)
+  float f0a[2][4], f0b[2][4], f1a[2][4], f1b[2][4];
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    FT_STAMP();
+    ++kt;
+    const bool more = t + 1 < t1;
+    if (more && kt >= seg_tiles) {  // segment exhausted (rare): next live segment
+      if (!d.zmode) {
+        do {
+          ++s;
+        } while (s < d.nseg && (!d.seg[s].A || d.seg[s].K <= 0));
+        kt = 0;
+      }
+      load_seg(s);
+      seg_tiles = (cK + FT_BK - 1) / FT_BK;
+    }
+    const bool next_full = more && (kt + 1) * FT_BK <= cK;
+    // without a full next tile the loads still issue (a branch inside the MFMA sequence makes the compiler wait for every
+    // earlier load at the block boundary) — against the null resource, and what they park is never read
+    const __amdgpu_buffer_rsrc_t curA = next_full ? rsA : rs_null;
+    const __amdgpu_buffer_rsrc_t curB = next_full ? rsB : rs_null;
+    const int soffA = next_full ? kt * stepA : 0, soffB = next_full ? kt * stepB : 0;
+    // fragments of chunk 0 (the only LDS latency a k-tile exposes)
+    read_fragA(buf, 0, 0, f0a[0]);
+    read_fragA(buf, 0, 1, f0a[1]);
+    read_fragB(buf, 0, 0, f0b[0]);
+    read_fragB(buf, 0, 1, f0b[1]);
+    FT_FENCE();
+    FT_STAMP();
+#pragma clang loop unroll(full)
+    for (int q = 0; q < 4; ++q)
+#pragma clang loop unroll(full)
+      for (int r = 0; r < 16; ++r) {
+        const int i = 16 * q + r, j = (r >> 2) & 3, a = (r >> 1) & 1, b = r & 1;
+        if (q & 1)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1a[a][j], f1b[b][j], acc[a][b], 0, 0, 0);
+        else
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0a[a][j], f0b[b][j], acc[a][b], 0, 0, 0);
+        FT_FENCE();
+        if (q < 3 && r >= 1 && r <= 4) {  // fragments of chunk q + 1 into the other register set
+          if (q & 1) {
+            if (r == 1) read_fragA(buf, q + 1, 0, f0a[0]);
+            if (r == 2) read_fragA(buf, q + 1, 1, f0a[1]);
+            if (r == 3) read_fragB(buf, q + 1, 0, f0b[0]);
+            if (r == 4) read_fragB(buf, q + 1, 1, f0b[1]);
+          } else {
+            if (r == 1) read_fragA(buf, q + 1, 0, f1a[0]);
+            if (r == 2) read_fragA(buf, q + 1, 1, f1a[1]);
+            if (r == 3) read_fragB(buf, q + 1, 0, f1b[0]);
+            if (r == 4) read_fragB(buf, q + 1, 1, f1b[1]);
+          }
+        }
+#ifndef FT_NO_LOADS
+        if (i >= 6 && i < 38 && ((i - 6) & 3) == 0) {  // staging load l of tile t+1 behind MFMAs 6, 10, ... 34
+          const int l = (i - 6) >> 2;
+          if (l < 4)
+            ra[l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(curA, voffA[l], soffA, 0));
+          else
+            rb[l - 4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(curB, voffB[l - 4], soffB, 0));
+        }
+#endif
+#ifndef FT_NO_PARKS
+        if (i >= 41 && i <= 55 && ((i - 41) & 1) == 0) {  // park slot w in the other LDS buffer behind MFMAs 41, 43, ... 55
+          const int w = (i - 41) >> 1;
+          if (w < 4)
+            parkA(buf ^ 1, w, ra[w]);
+          else
+            parkB(buf ^ 1, w - 4, rb[w - 4], 15);
+        }
+#endif
+        FT_FENCE();
+      }
+    FT_STAMP();
+    if (more && !next_full) commit_tail(buf ^ 1, kt);
+    FT_STAMP();
+    __syncthreads();
+  }
+  FT_STAMP();
+
+  // ---- epilogue: D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = 8 * (reg >> 2) + 4 * (lane >> 5) + (reg & 3) -------
+  const int Mv = (s0.Mvalid > 0 && s0.Mvalid < M) ? s0.Mvalid : M;
+  if (S > 1) {
+    float* slab = d.workspace + ((long)(z * S + ks)) * Mmax * Nmax;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3), j = n0 + wn * 64 + b * 32 + fr;
+          if (i < M && j < N) slab[(long)i * N + j] = i < Mv ? acc[a][b][r] : 0.f;
+        }
+    return;
+  }
+  // plain product (the common case of the large launches: LayerNorm / the split-K pass own the epilogue): straight stores
+  const bool plain = !d.bias && !d.pre_add && !d.save_z && !d.save_act && d.act == NASREC_ACT_NONE && d.mul_nseg == 0 &&
+                     d.dims_in_use < 0 && !(d.zmode ? s0.accumulate : d.beta) && !has_ones && !s0.ones_col;
+  if (plain) {
+    float* Cp = s0.C;
+    const int ldc = s0.ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3), j = n0 + wn * 64 + b * 32 + fr;
+          if (i < M && j < N) Cp[(long)i * ldc + j] = i < Mv ? acc[a][b][r] : 0.f;
+        }
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3), j = n0 + wn * 64 + b * 32 + fr;
+        if (i < M && j < N) epilogue_store<NASREC_CM_PLAIN>(d, s0, i, j, i < Mv ? acc[a][b][r] : 0.f);
+      }
+}
+
+template <int AM, int BMODE>
+static void launch_fast_t(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, int Nmax, int zdim, bool ones) {
+  const int tm = (Mmax + FT_BM - 1) / FT_BM, tn = (Nmax + FT_BN - 1) / FT_BN;
+  const dim3 grid((unsigned)(tm * tn * zdim));
+  if (ones)
+    hipLaunchKernelGGL((gemm_fast_kernel<AM, BMODE, true>), grid, dim3(256), 0, st, *d, Mmax, Nmax, tm, tn);
+  else
+    hipLaunchKernelGGL((gemm_fast_kernel<AM, BMODE, false>), grid, dim3(256), 0, st, *d, Mmax, Nmax, tm, tn);
+}
+
+// Does this launch belong to the throughput regime?  (plan.py mirrors the rule when it sizes split-K: `_fast_gemm_splitk`.)
+bool gemm_fast_eligible(const nasrec_gemm_desc_t* d, int Mmax, int Nmax) {
+  if (d->cmode != NASREC_CM_PLAIN) return false;
+  if ((d->amode != NASREC_AM_KC && d->amode != NASREC_AM_RC) || (d->bmode != NASREC_AM_KC && d->bmode != NASREC_AM_RC)) return false;
+  if (d->amode == NASREC_AM_RC && d->bmode == NASREC_AM_KC) return false;  // no call site
+  const int nprob = d->zmode ? d->nseg : 1;
+  const int S = d->splitk > 1 ? d->splitk : 1;
+  long tiles = 0, kmax = 0;
+  for (int q = 0; q < d->nseg; ++q) {
+    const nasrec_gemm_seg_t& s = d->seg[q];
+    if (s.Aaux || s.Baux) return false;  // ReLU-mask operands: general kernel
+    if (s.A && s.K > kmax) kmax = s.K;
+    // byte offsets of the staging loads are 31-bit: the operands' extents in floats must stay below 2^29
+    const long r = s.M > s.N ? s.M : s.N, ld = s.lda > s.ldb ? s.lda : s.ldb;
+    if (s.A && (r * ld + s.K >= (1L << 29) || (long)s.K * ld + r >= (1L << 29))) return false;
+  }
+  for (int q = 0; q < nprob; ++q) {
+    const nasrec_gemm_seg_t& s = d->seg[q];
+    tiles += (long)((s.M + FT_BM - 1) / FT_BM) * ((s.N + FT_BN - 1) / FT_BN) * S;
+  }
+  (void)Mmax;
+  (void)Nmax;
+  return tiles >= NASREC_GEMM_FAST_MIN_TILES && kmax >= 64;
+}
+
+int launch_gemm_fast(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, int Nmax, int zdim) {
+  bool ones = false;
+  for (int q = 0; q < d->nseg; ++q) ones = ones || d->seg[q].ones_col != 0;
+  if (d->amode == NASREC_AM_KC && d->bmode == NASREC_AM_KC)
+    launch_fast_t<NASREC_AM_KC, NASREC_AM_KC>(st, d, Mmax, Nmax, zdim, ones);
+  else if (d->amode == NASREC_AM_KC && d->bmode == NASREC_AM_RC)
+    launch_fast_t<NASREC_AM_KC, NASREC_AM_RC>(st, d, Mmax, Nmax, zdim, ones);
+  else
+    launch_fast_t<NASREC_AM_RC, NASREC_AM_RC>(st, d, Mmax, Nmax, zdim, ones);
+  return 0;
+}

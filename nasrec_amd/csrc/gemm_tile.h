@@ -24,6 +24,11 @@
 #ifndef GEMM_SKINNY_BELOW
 #define GEMM_SKINNY_BELOW 128  // launches with fewer 64x64 workgroups than this use the skinny tiles
 #endif
+#ifndef NASREC_GEMM_FAST_MIN_TILES
+#define NASREC_GEMM_FAST_MIN_TILES 120  // launches with at least this many 128x128 tiles (x split-K) take gemm_fast.hip
+#endif
+bool gemm_fast_eligible(const nasrec_gemm_desc_t* d, int Mmax, int Nmax);
+int launch_gemm_fast(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, int Nmax, int zdim);
 // Tile configurations (template parameters NT threads, TK staged k depth, TBM x TBN block tile):
 //   256 thr, 32, 64x64  4 waves 2x2, 32x32 each — large products, throughput regime (>= 4 workgroups per CU);
 //   1024 thr, TK, 64x64  16 waves 4x4, one 16x16 MFMA tile each — four waves per SIMD, one wave's waits hide under

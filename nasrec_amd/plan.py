@@ -272,6 +272,29 @@ def _splitk_for(tiles_mn, ktiles, nprob=1):
     return max(1, min(s, 32))
 
 
+GEMM_FAST_MIN_TILES = 120  # csrc/gemm_tile.h NASREC_GEMM_FAST_MIN_TILES
+
+
+def _fast_gemm_splitk(amode, bmode, cmode, segs, zmode):
+    """Mirror of csrc/gemm_fast.hip `gemm_fast_eligible`: does this launch take the throughput-regime kernel (128x128x32
+    tiles), and with which split-K?  -> S (>= 1) or None.  A product with few output tiles but a deep K (the weight gradients
+    of a large batch: K = B) is split so that tiles x S fills the chip, >= 8 k-tiles of 32 per split."""
+    if cmode != L.CM_PLAIN or (amode, bmode) not in ((L.AM_KC, L.AM_KC), (L.AM_KC, L.AM_RC), (L.AM_RC, L.AM_RC)):
+        return None
+    live = [sd for sd in segs if sd.get("A")]
+    if not live or any(sd.get("Aaux") or sd.get("Baux") for sd in segs):
+        return None
+    if max(sd["K"] for sd in live) < 64:
+        return None
+    probs = segs if zmode else segs[:1]
+    tiles = sum(((sd["M"] + 127) // 128) * ((sd["N"] + 127) // 128) for sd in probs)
+    kt = (max((sd["K"] + 31) // 32 for sd in live) if zmode else sum((sd["K"] + 31) // 32 for sd in live))
+    S = 1
+    if tiles < 256:
+        S = max(1, min(-(-256 // tiles), kt // 8, 32))
+    return S if tiles * S >= GEMM_FAST_MIN_TILES else None
+
+
 def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, **kw):
     """One GEMM launch descriptor for <= MAX_SEGS segments (list of dicts with nasrec_gemm_seg_t fields)."""
     if not segs:
@@ -313,6 +336,9 @@ def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, **kw):
     else:
         kt = sum((sd["K"] + 31) // 32 for sd in segs)
         S = _splitk_for(tiles, kt)
+    fast = _fast_gemm_splitk(amode, bmode, cmode, segs, zmode)
+    if fast is not None:
+        S = fast
     S = kw.get("splitk", S)
     d.splitk = 1
     if S > 1:
