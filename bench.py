@@ -1,40 +1,58 @@
 #!/usr/bin/env python3
 """Benchmark of the NASRec hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--config {2,3,4,5}] [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): Criteo best-1shot sub-network (ea_criteo_kaggle_xlarge_best_1shot.json), batch 256
-per GPU, FULL embedding tables (33 762 601 rows, 2.16 GB), fp32.  One "step" = the reference's training step
-(train_utils.py:262-286, 386): forward -> BCEWithLogits -> backward -> [gradient exchange] -> clip_grad_norm_(5.0) ->
-Adagrad(eps=1e-2) -> LR-schedule update, on a synthetic Criteo-shaped batch that is already resident in HBM.
+One "step" = the reference's training step (train_utils.py:262-286, 386): forward -> BCEWithLogits -> backward ->
+[gradient exchange] -> clip_grad_norm_(5.0) -> Adagrad(eps=1e-2) -> LR-schedule update, on a synthetic batch that is already
+resident in HBM.  Workloads = BASELINE.json `configs`:
+  2 (default, the config the headline metric is quoted on)  Criteo best-1shot sub-network, batch 256 per GPU, full tables;
+  3  Criteo NASRec-Full (xlarge) supernet, LayerNorm, `default` path sampling / binomial-0.5, batch 4096, full tables;
+  4  Avazu NASRec-Full supernet, batch 4096 per GPU;      5  KDD NASRec-Small (autoctr) supernet, 0.5M-capped tables, batch 8192 per GPU.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B = 256
 LR_MAX, LR_MIN = 0.16, 1e-8
-TRAIN_LIMIT = 36672495  # main_train.py:354
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E spec peak
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak
 
+WORKLOADS = {
+    2: dict(dataset="criteo", mode="fixed", B=256, train_limit=36672495,  # main_train.py:354
+            name="Criteo best-1shot sub-network (ea_criteo_kaggle_xlarge_best_1shot.json), full training step, batch 256 per GPU, "
+                 "full embedding tables (33.76M rows), fp32"),
+    3: dict(dataset="criteo", mode="supernet", space="xlarge", B=4096, cap=None, train_limit=36672495,
+            name="Criteo NASRec-Full (xlarge) supernet, 7 blocks, LayerNorm, path sampling `default` / binomial-0.5 (one path per step "
+                 "from np.random), full training step, batch 4096 per GPU, full embedding tables (33.76M rows), fp32"),
+    4: dict(dataset="avazu", mode="supernet", space="xlarge", B=4096, cap=None, train_limit=32343175,
+            name="Avazu NASRec-Full (xlarge) supernet, 7 blocks, LayerNorm, path sampling `default` / binomial-0.5, full training step, "
+                 "batch 4096 per GPU, full embedding tables (9.46M rows), fp32"),
+    5: dict(dataset="kdd", mode="supernet", space="autoctr", B=8192, cap=500000, train_limit=119711284,
+            name="KDD-Cup'12 NASRec-Small (autoctr) supernet, 7 blocks, LayerNorm, path sampling `default` / binomial-0.5, full training "
+                 "step, batch 8192 per GPU, tables capped at 0.5M rows (3.04M rows), fp32"),
+}
 
-def synthetic_batches(n, Fd, tables, device, seed):
-    """int_x = log(U_int[0,1000)+1), ids uniform per table (cache-hostile), y ~ Bernoulli(0.25)."""
+
+def synthetic_batches(n, B, Fd, tables, device, seed, zero_dense=False):
+    """int_x = log(U_int[0,1000)+1) (Avazu: zeros, data_pipes.py:181), ids uniform per table (cache-hostile),
+    y ~ Bernoulli(0.25)."""
     g = torch.Generator().manual_seed(seed)
     out = []
     for _ in range(n):
-        int_x = torch.log(torch.randint(0, 1000, (B, Fd), generator=g).float() + 1.0)
+        int_x = torch.zeros(B, Fd) if zero_dense else torch.log(torch.randint(0, 1000, (B, Fd), generator=g).float() + 1.0)
         cat_x = torch.stack([torch.randint(0, int(t), (B,), generator=g) for t in tables], dim=1)
         y = (torch.rand(B, generator=g) < 0.25).float()
         out.append((int_x.to(device), cat_x.to(device), y.to(device)))
@@ -46,12 +64,12 @@ def gemm_flops(d):
     for q in range(d.nseg):
         s = d.seg[q]
         if s.A:
-            f += 2.0 * s.M * s.N * s.K
+            f += 2.0 * s.M * (s.N - (1 if s.ones_col else 0)) * s.K
     return f
 
 
 def time_desc(lib, L, stream_ptr, desc, iters=200):
-    """average duration of ONE descriptor launch, HIP events on the engine's own stream"""
+    """average duration of ONE descriptor launch, HIP events on the stream the kernel is launched on"""
     e0, e1 = C.c_void_p(), C.c_void_p()
     L.check(lib.nasrec_event_create(C.byref(e0)))
     L.check(lib.nasrec_event_create(C.byref(e1)))
@@ -68,42 +86,70 @@ def time_desc(lib, L, stream_ptr, desc, iters=200):
     return ms.value / iters
 
 
-def cpu_baseline(choice, tables, threads):
-    """The oracle (CPU restatement of the reference step, dense-gradient semantics exactly like the reference) timed on
-    this box's host cores on a bounded sample: a few full B=256 steps with the full tables."""
+def csrc_build_id():
+    """hash of the kernel sources: a measured artefact under profiles/ is only quoted for the build it was taken from"""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "nasrec_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(w, choice_or_sampler, tables, threads, Fd):
+    """The oracle (CPU restatement of the reference step, dense-gradient semantics exactly like the reference) timed on this box's
+    host cores on a bounded sample of the same workload: a few full steps at the workload's batch size and table sizes."""
     from oracle import nasrec_oracle as O
     torch.set_num_threads(threads)
-    cfg = O.NetCfg(7, O.ops_config_lib["xlarge"], False, "relu", fixed=True)
+    B = w["B"]
+    fixed = w["mode"] == "fixed"
+    if fixed:
+        cfg = O.NetCfg(7, O.ops_config_lib["xlarge"], False, "relu", fixed=True)
+    else:
+        cfg = O.NetCfg(7, O.ops_config_lib[w["space"]], True, "relu", fixed=False)
     P = O.Params(torch.float32)
     g = torch.Generator().manual_seed(0)
     for f, n in enumerate(tables):  # fast init for the big tables (seeded_param would spend minutes in numpy)
         P["_embedding.%d.weight" % f] = torch.randn(n, 16, generator=g) * (2.0 / (n + 16)) ** 0.5
-    int_x, cat_x, y = [t.cpu() for t in synthetic_batches(1, 13, tables, "cpu", 99)[0]]
+    int_x, cat_x, y = [t.cpu() for t in synthetic_batches(1, B, Fd, tables, "cpu", 99, zero_dense=(w["dataset"] == "avazu"))[0]]
     y = y.view(-1, 1)
-    O.supernet_forward(P, cfg, int_x, cat_x, choice)  # lazy creation of the dense parameters
+    warm = choice_or_sampler if fixed else O.full_path_choice(cfg)
+    with torch.no_grad():
+        O.supernet_forward(P, cfg, int_x[:64], cat_x[:64], warm, num_embeddings=tables)  # lazy creation of the dense parameters (full path)
     P.frozen = True
+    sampler = None
+    if not fixed:
+        np.random.seed(0)
+        sampler = O.PathSampler(cfg, "default", "binomial-0.5")
     state = {}
-    O.train_step(P, state, cfg, choice, int_x, cat_x, y, lr=1e-3)  # warm-up (allocates Adagrad state)
+    pick = (lambda: choice_or_sampler) if fixed else (lambda: sampler.sample())
+    O.train_step(P, state, cfg, pick(), int_x, cat_x, y, lr=1e-3)  # warm-up (allocates Adagrad state)
     n, t0 = 0, time.perf_counter()
     while n < 2 or (time.perf_counter() - t0 < 12.0 and n < 20):
-        O.train_step(P, state, cfg, choice, int_x, cat_x, y, lr=1e-3)
+        O.train_step(P, state, cfg, pick(), int_x, cat_x, y, lr=1e-3)
         n += 1
         if time.perf_counter() - t0 > 25.0:
             break
     dt = time.perf_counter() - t0
     return dict(value=B * n / dt, unit="samples/s", cores=threads, kind="port",
-                sample="%d full training steps (B=256, full 33.76M-row tables, dense-gradient semantics) of the CPU oracle, %.1f s" % (n, dt))
+                sample="%d full training steps (B=%d, %d-row tables, dense-gradient semantics%s) of the CPU oracle, %.1f s" % (
+                    n, B, sum(tables), "" if fixed else ", one sampled path per step", dt))
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-dp-path", action="store_true", help="run the N>1 exchange code path on a single rank")
     args = ap.parse_args()
+    w = WORKLOADS[args.config]
+    fixed = w["mode"] == "fixed"
+    steps = args.steps if args.steps is not None else (300 if fixed else 60)
+    warmup = args.warmup if args.warmup is not None else (30 if fixed else 10)
+    B = w["B"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -124,27 +170,54 @@ def main():
     from nasrec_amd.engine import SupernetEngine
     from nasrec_amd.parallel import DataParallelStep
     from nasrec_amd.search_space import ops_config_lib
-    from nasrec_amd.utils.config import NUM_EMBEDDINGS_CRITEO
+    from nasrec_amd.utils.config import DATASETS
     from nasrec_amd.utils.lr_schedule import CosineAnnealingWarmupRestarts
     lib = L.load()
 
-    choice_all = json.load(open(os.path.join(ROOT, "nasrec_amd", "configs", "criteo", "ea_criteo_kaggle_xlarge_best_1shot.json")))
-    choice = {"macro": choice_all["macro"], "micro": choice_all["micro"]}
-    tables = NUM_EMBEDDINGS_CRITEO
-    # main_train.py:258-269: best-1shot sub-networks are built WITHOUT LayerNorm (use_layernorm hard-coded False)
-    cfg = P.NetConfig(choice_all["num_blocks"], ops_config_lib[choice_all["config"]], False, "relu", fixed=True)
-    eng = SupernetEngine(cfg, 13, 26, tables, device=device, warm_choice=choice, world_size=world)
-    eng.init_weights(seed=0)
-    batches = synthetic_batches(16, 13, tables, device, 1234 + rank)
-    steps_per_epoch = TRAIN_LIMIT // B
-    sched = CosineAnnealingWarmupRestarts(steps_per_epoch, max_lr=LR_MAX, min_lr=LR_MIN, warmup_steps=steps_per_epoch // 10)
-    dp = DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=not args.no_graph, force_exchange=args.force_dp_path)
+    ds = DATASETS[w["dataset"]]
+    tables = [min(n, w["cap"]) if w.get("cap") else n for n in ds["tables"]]
+    Fd, Fs = ds["Fd"], ds["Fs"]
+    batches = synthetic_batches(16 if fixed else 4, B, Fd, tables, device, 1234 + rank, zero_dense=(w["dataset"] == "avazu"))
+    steps_per_epoch = w["train_limit"] // B
+    sched = CosineAnnealingWarmupRestarts(steps_per_epoch, max_lr=LR_MAX if fixed else 0.12, min_lr=LR_MIN, warmup_steps=steps_per_epoch // 10)
 
-    def run(n, start):
-        for i in range(n):
-            bx = batches[(start + i) % len(batches)]
+    if fixed:
+        choice_all = json.load(open(os.path.join(ROOT, "nasrec_amd", "configs", "criteo", "ea_criteo_kaggle_xlarge_best_1shot.json")))
+        choice = {"macro": choice_all["macro"], "micro": choice_all["micro"]}
+        # main_train.py:258-269: best-1shot sub-networks are built WITHOUT LayerNorm (use_layernorm hard-coded False)
+        cfg = P.NetConfig(choice_all["num_blocks"], ops_config_lib[choice_all["config"]], False, "relu", fixed=True)
+        eng = SupernetEngine(cfg, Fd, Fs, tables, device=device, warm_choice=choice, world_size=world)
+        eng.init_weights(seed=0)
+        dp = DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=not args.no_graph, force_exchange=args.force_dp_path)
+
+        def one_step(i):
+            bx = batches[i % len(batches)]
             dp.step(bx[0], bx[1], bx[2], sched.get_lr())
             sched.step()
+        parallelism = "dp%d (RCCL all-reduce of dense grads + all-gather of row-sparse embedding grads)" % world
+    else:
+        # train_supernet.py:241-257: weight-sharing supernet, full-path warm-up (train_utils.py:413-433), then the sampling strategy.
+        # The path of every step comes from the global np.random stream (supernet.py:525-529): all ranks share the seed, so a
+        # data-parallel step trains ONE path at the global batch — the reference's semantics at that batch size.
+        from nasrec_amd.supernet.supernet import SuperNet
+        torch.manual_seed(0)
+        model = SuperNet(num_blocks=7, ops_config=ops_config_lib[w["space"]], use_layernorm=True, num_embeddings=tables, sparse_input_size=Fs,
+                         path_sampling_strategy="full-path", fixed=False, anypath_choice="binomial-0.5").to(device)
+        with torch.no_grad():
+            model(batches[0][0][:64], batches[0][1][:64])
+        eng = model._engine
+        eng.init_weights(seed=0)
+        model.configure_path_sampling_strategy("default")
+        np.random.seed(0)
+        dp = DataParallelStep(eng, None, B, clip=5.0, eps=1e-2, graph=False, force_exchange=args.force_dp_path)
+
+        def one_step(i):
+            bx = batches[i % len(batches)]
+            ch = model._resolve_choice(None)  # the sampler of the drop-in module: global np.random, reference call order
+            dp.step(bx[0], bx[1], bx[2], sched.get_lr(), choice=ch)
+            sched.step()
+        parallelism = "dp%d (same sampled path on every rank; bucketed RCCL all-reduce of the path's dense grads overlapped with the " \
+                      "backward + all-gather of row-sparse embedding grads)" % world
 
     def fence():
         torch.cuda.synchronize(device)
@@ -152,79 +225,94 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    run(args.warmup, 0)
+    for i in range(warmup):
+        one_step(i)
     fence()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    run(args.steps, args.warmup)
+    ev[0].record()
+    for i in range(steps):
+        one_step(warmup + i)
+        ev[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    loss = float(dp.cp.loss.item())
+    per_step = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)])
+    loss = float(dp.last_loss().item())
     if not (loss == loss):
         raise SystemExit("loss is NaN")
 
     result = {
         "metric": "supernet samples/sec at batch 256 (Criteo-shape), 1/2/4/8 MI355X",
-        "value": B * world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": "Criteo best-1shot sub-network (ea_criteo_kaggle_xlarge_best_1shot.json), full training step, "
-                               "batch 256 per GPU, full embedding tables (33.76M rows), fp32",
-                   "per_gpu_batch": B, "global_batch": B * world, "graph": dp.graph,
-                   "parallelism": "dp%d (RCCL all-reduce of dense grads + all-gather of row-sparse embedding grads)" % world,
+        "value": B * world * steps / dt, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "median_ms_per_step": float(np.median(per_step)), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": w["name"], "baseline_config": args.config, "per_gpu_batch": B, "global_batch": B * world, "graph": dp.graph,
+                   "parallelism": parallelism,
                    "embedding_update": "row-sparse clip+Adagrad (== dense reference update for weight_decay 0)"},
         "final_loss": loss,
     }
 
     if rank == 0 and world == 1:
-        # ---- forward-only throughput (eval path) ---------------------------------------------------------------
-        fcp = eng.compile(choice, B, train=False, graph=True)
-        for _ in range(20):
-            eng.forward(batches[0][0], batches[0][1], graph=True)
-        torch.cuda.synchronize(device)
-        t1 = time.perf_counter()
-        for i in range(200):
-            eng.forward(batches[i % 16][0], batches[i % 16][1], graph=True)
-        torch.cuda.synchronize(device)
-        result["forward_only_samples_per_s"] = B * 200 / (time.perf_counter() - t1)
-
-        # ---- roofline of the dominant kernel: the largest GEMM launch of the step (fp32 MFMA bound) -----------------
-        sp = eng.stream.cuda_stream
-        cp = dp.cp
+        sp = torch.cuda.current_stream(device).cuda_stream
+        cp = dp.last_plan()
         allg = [d for d in P.iter_ops(cp.fwd.descs + cp.bwd.descs) if isinstance(d, L.GemmDesc)]
+        if fixed:
+            # ---- forward-only throughput (eval path) ---------------------------------------------------------------
+            eng.compile(choice, B, train=False, graph=True)
+            for _ in range(20):
+                eng.forward(batches[0][0], batches[0][1], graph=True)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for i in range(200):
+                eng.forward(batches[i % 16][0], batches[i % 16][1], graph=True)
+            torch.cuda.synchronize(device)
+            result["forward_only_samples_per_s"] = B * 200 / (time.perf_counter() - t1)
+
+        # ---- roofline of the dominant kernel: the largest GEMM launch of the (last) step's plan, fp32 MFMA bound ---------
         dom = max(allg, key=gemm_flops)
-        with torch.cuda.stream(eng.stream):
-            ms = time_desc(lib, L, sp, dom)
+        ms = time_desc(lib, L, sp, dom, iters=200 if fixed else 30)
         fl = gemm_flops(dom)
         s0 = dom.seg[0]
         result["roofline"] = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                              "kernel": "gemm_kernel<%d,%d,%d> M=%d N=%d K=%d nseg=%d splitk=%d" % (
-                                  dom.amode, dom.bmode, dom.cmode, s0.M, s0.N, sum(dom.seg[q].K for q in range(dom.nseg)), dom.nseg, dom.splitk),
+                              "kernel": "%s<%d,%d,%d> M=%d N=%d K=%d nseg=%d splitk=%d" % (
+                                  P.gemm_kernel_name(dom), dom.amode, dom.bmode, dom.cmode, s0.M, s0.N, sum(dom.seg[q].K for q in range(dom.nseg)),
+                                  dom.nseg, dom.splitk),
                               "flops_per_launch": fl, "avg_launch_us": ms * 1e3}
-        # HBM/fabric traffic of that launch: PMC counters cannot be collected from inside this process, so the value is the
-        # committed rocprofv3 measurement of exactly this launch (profiles/r01_dominant_gemm_traffic.json: FETCH_SIZE x2
-        # per the gfx950 correction + WRITE_SIZE, separate --pmc passes); null if the dominant launch is a different one
+        # HBM/fabric traffic of that launch: PMC counters cannot be collected from inside this process; a measured value is
+        # quoted only when profiles/ holds one taken from THIS build (csrc hash) for exactly this launch, else null
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_dominant_gemm_traffic.json")))
-            if (s0.M, s0.N, sum(dom.seg[q].K for q in range(dom.nseg)), dom.splitk) == (256, 768, 1565, 5):
+            tj = json.load(open(os.path.join(ROOT, "profiles", "dominant_gemm_traffic_cfg%d.json" % args.config)))
+            if tj.get("build_id") == csrc_build_id() and tj.get("kernel") == result["roofline"]["kernel"]:
                 result["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
-                result["roofline"]["traffic_unit"] = "bytes per launch (PMC, see profiles/r01_dominant_gemm_traffic.json)"
+                result["roofline"]["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % tj.get("source", "profiles/")
                 result["roofline"]["algorithmic_bytes"] = tj["algorithmic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        # whole-step accounting: executed GEMM FLOPs per step and the HBM bytes the step must move at minimum
+        # ---- whole-step accounting -----------------------------------------------------------------------------
+        step_s = float(np.median(per_step)) * 1e-3
         step_flops = sum(gemm_flops(d) for d in allg)
         result["step_gemm_gflop"] = step_flops / 1e9
-        result["step_mfma_frac"] = step_flops / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS
+        result["step_mfma_frac"] = step_flops / step_s / 1e12 / MFMA_F32_PEAK_TFLOPS
+        # byte model of the step under the ACTIVE (row-sparse) embedding semantics: dense parameters x 4 B x 9 passes (grad write,
+        # norm read, Adagrad grad read + state r/w + param r/w, forward read, backward read) + touched rows x 64 B x 7
+        n_used = sum(int(np.prod(eng.shapes[n])) for n in cp.used_params if not n.startswith("_embedding."))
+        step_bytes = n_used * 4 * 9 + B * Fs * 64 * 7
+        result["roofline_step"] = {"bound": "hbm", "achieved": step_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                                   "bytes_model": "(%d dense parameters on the path x 4 B x 9 passes) + (B x Fs touched rows x 64 B x 7) = %.1f MB per step, "
+                                                  "row-sparse embedding semantics" % (n_used, step_bytes / 1e6),
+                                   "launches_per_step": len(cp.fwd.descs) + len(cp.bwd.descs) + len(cp.opt.descs) + 1,
+                                   "launch_floor_ms": (len(cp.fwd.descs) + len(cp.bwd.descs) + len(cp.opt.descs) + 1) * 1.65e-3}
         if not args.no_cpu_baseline:
             # torch CPU ops stop scaling (and start thrashing) far below this box's logical core count: use one
             # socket's worth of threads at most, and state the number
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            result["cpu_baseline"] = cpu_baseline(choice, tables, int(os.environ.get("NASREC_CPU_THREADS", min(avail, 32))))
+            result["cpu_baseline"] = cpu_baseline(w, choice if fixed else None, tables, int(os.environ.get("NASREC_CPU_THREADS", min(avail, 32))), Fd)
             result["cpu_baseline"]["host_logical_cpus"] = avail
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
     if rank == 0:

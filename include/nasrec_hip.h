@@ -162,6 +162,8 @@ typedef struct nasrec_emb_dedup_desc {
   int32_t* leader;      /* [B, Fs] out: 1 if leader */
   float* gsum;          /* [B, Fs, 16] out: summed gradient (valid where leader) */
   float* sumsq_partial; /* [Fs * ceil(B/256)] out: sum of squares of leader gradients per workgroup */
+  int32_t* overflow;    /* optional: set to 1 if a hash partition of the large-batch merge ran out of slots (never seen with
+                           real id distributions; the step's result must then be discarded) */
 } nasrec_emb_dedup_desc_t;
 
 /* ------------------------------------------------------------------------------------------------

@@ -57,7 +57,7 @@ class EmbedDesc(C.Structure):
 
 class EmbDedupDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("Fs", i32), ("_pad", i32), ("idx", vp), ("dout", vp), ("leader", vp), ("gsum", vp),
-                ("sumsq_partial", vp)]
+                ("sumsq_partial", vp), ("overflow", vp)]
 
 
 class DotTriDesc(C.Structure):

@@ -61,7 +61,6 @@ int launch_embed_gather(hipStream_t st, const nasrec_embed_desc_t* d) {
 // Row-sparse backward: leader election + duplicate summation, per field.  "Leader" = first occurrence of a row id in
 // sample order; its gsum row is the sum of the gradient rows of all occurrences in ascending sample order, so results are
 // reproducible run to run and independent of how the batch was split over ranks.
-#define DEDUP_MAXB 8192
 
 // Batch <= 256 (one workgroup per field, thread = sample): every sample parks its id and its 64-byte gradient row in
 // LDS with ONE parallel round of global loads; then each thread scans the ids in ascending order, four per
@@ -197,13 +196,18 @@ int launch_opt_apply(hipStream_t st, const nasrec_opt_apply_desc_t* d) {
   return nasrec_check_launch("opt_apply");
 }
 
-// Batches > 256 (the global batch of a data-parallel step): O(B) instead of an all-pairs scan.
+// Batches > 256 (the global batch of a data-parallel step, up to 8 x 8192 samples): O(B) instead of an all-pairs scan.
 //   pass 1  grid (Fs, ceil(B/256)): the <= 256 kernel on every 256-sample chunk -> chunk leaders + their partial sums;
-//   pass 2  grid (Fs): merge the chunk leaders in chunk order through an LDS hash table keyed by row id.  Within one round
-//           all candidates have distinct ids (they lead their chunk), so a slot is claimed by exactly one thread (ds CAS)
-//           and an earlier owner's row is updated by exactly one thread: no floating-point atomics, and the sum runs in
-//           ascending chunk (= sample) order.
-#define DEDUP_SLOTS (2 * DEDUP_MAXB)
+//   pass 2  grid (Fs, P): the chunk leaders are merged in chunk order through LDS hash tables keyed by row id.  The ids of a
+//           field are PARTITIONED over P workgroups by a second hash, P = ceil(B / 4096), so a table of 16384 slots per
+//           workgroup stays below 1/4 load at any batch size; every workgroup walks all chunk leaders of its field (ids and
+//           flags only: B x 8 bytes from L2) and handles those of its partition.  Within one round (= one chunk) all candidates
+//           have distinct ids (they lead their chunk), so a slot is claimed by exactly one thread (ds CAS) and an earlier
+//           owner's row is updated by exactly one thread: no floating-point atomics, the sum runs in ascending chunk
+//           (= sample) order, and the result does not depend on P.
+#define DEDUP_SLOTS 16384
+#define DEDUP_PART_ROWS 4096
+#define DEDUP_UNROLL 8
 __global__ __launch_bounds__(256) void emb_dedup_chunk_kernel(const nasrec_emb_dedup_desc_t d) {
   __shared__ __attribute__((aligned(16))) int sidx[256];
   __shared__ __attribute__((aligned(16))) float rows[256 * 20];
@@ -211,69 +215,78 @@ __global__ __launch_bounds__(256) void emb_dedup_chunk_kernel(const nasrec_emb_d
   dedup_small_body(d, blockIdx.x, blockIdx.y, false, sidx, rows, red);
 }
 
-__global__ __launch_bounds__(256) void emb_dedup_merge_kernel(const nasrec_emb_dedup_desc_t d, int slots) {
+__global__ __launch_bounds__(256) void emb_dedup_merge_kernel(const nasrec_emb_dedup_desc_t d, int P) {
   __shared__ int keys[DEDUP_SLOTS];
   __shared__ int owner[DEDUP_SLOTS];
   __shared__ float red[256];
-  const int f = blockIdx.x, tid = threadIdx.x;
+  const int f = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
   const int nchunk = (d.B + 255) / 256;
-  for (int i = tid; i < slots; i += 256) keys[i] = -1;
-  // this thread's candidate of every round, fetched up front (one memory round trip instead of two per round)
-  constexpr int MAXC = DEDUP_MAXB / 256;
-  int cid[MAXC];
-  bool clead[MAXC];
-#pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const long b = (long)c * 256 + tid;
-    const bool in = c < nchunk && b < d.B;
-    clead[c] = in && d.leader[b * d.Fs + f] != 0;
-    cid[c] = in ? (int)d.idx[b * d.Fs + f] : 0;
-  }
+  for (int i = tid; i < DEDUP_SLOTS; i += 256) keys[i] = -1;
   __syncthreads();
+  float ss = 0.f;
+  for (int c0 = 0; c0 < nchunk; c0 += DEDUP_UNROLL) {
+    // this thread's candidates of the next rounds, fetched up front (one memory round trip per DEDUP_UNROLL rounds)
+    int cid[DEDUP_UNROLL];
+    bool mine[DEDUP_UNROLL];
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    if (c < nchunk) {  // uniform
-      const long b = (long)c * 256 + tid;
-      if (clead[c]) {
-        const int id = cid[c];
-        unsigned h = ((unsigned)id * 2654435761u) >> 7;
-        int ob = -1;
-        for (;;) {
-          h &= (unsigned)(slots - 1);
-          const int prev = atomicCAS(&keys[h], -1, id);
-          if (prev == -1) {  // first occurrence of this row in the batch: stays the leader
-            owner[h] = (int)b;
-            break;
-          }
-          if (prev == id) {  // claimed in an earlier round (ids are distinct within a round)
-            ob = owner[h];
-            break;
-          }
-          ++h;
-        }
-        if (ob >= 0) {
-          clead[c] = false;
-          d.leader[b * d.Fs + f] = 0;
-          const f32x4* src = reinterpret_cast<const f32x4*>(d.gsum + (b * d.Fs + f) * 16);
-          f32x4* dst = reinterpret_cast<f32x4*>(d.gsum + ((long)ob * d.Fs + f) * 16);
+    for (int u = 0; u < DEDUP_UNROLL; ++u) {
+      const long b = (long)(c0 + u) * 256 + tid;
+      const bool in = (c0 + u) < nchunk && b < d.B;
+      cid[u] = in ? (int)d.idx[b * d.Fs + f] : 0;
+      mine[u] = in && d.leader[b * d.Fs + f] != 0 && (int)((((unsigned)cid[u] * 2246822519u) >> 15) % (unsigned)P) == part;
+    }
 #pragma unroll
-          for (int v = 0; v < 4; ++v) dst[v] = dst[v] + src[v];
+    for (int u = 0; u < DEDUP_UNROLL; ++u) {
+      if (c0 + u < nchunk) {  // uniform
+        const long b = (long)(c0 + u) * 256 + tid;
+        if (mine[u]) {
+          const int id = cid[u];
+          unsigned h = ((unsigned)id * 2654435761u) >> 7;
+          int ob = -1, probes = 0;
+          for (;;) {
+            h &= (unsigned)(DEDUP_SLOTS - 1);
+            const int prev = atomicCAS(&keys[h], -1, id);
+            if (prev == -1) {  // first occurrence of this row in the batch: stays the leader
+              owner[h] = (int)b;
+              break;
+            }
+            if (prev == id) {  // claimed in an earlier round (ids are distinct within a round)
+              ob = owner[h];
+              break;
+            }
+            ++h;
+            if (++probes >= DEDUP_SLOTS) {  // table full: cannot happen below 16384 distinct ids per partition
+              if (d.overflow) *d.overflow = 1;
+              break;
+            }
+          }
+          if (ob >= 0) {
+            mine[u] = false;
+            d.leader[b * d.Fs + f] = 0;
+            const f32x4* src = reinterpret_cast<const f32x4*>(d.gsum + (b * d.Fs + f) * 16);
+            f32x4* dst = reinterpret_cast<f32x4*>(d.gsum + ((long)ob * d.Fs + f) * 16);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dst[v] = dst[v] + src[v];
+          }
         }
+        __threadfence_block();
+        __syncthreads();  // owner[] and the updated rows of this round are visible to the next one
       }
-      __threadfence_block();
-      __syncthreads();  // owner[] and the updated rows of this round are visible to the next one
     }
   }
-  float ss = 0.f;
+  // sum of squares of the rows that still lead after the merge (every leader belongs to exactly one partition)
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const long b = (long)c * 256 + tid;
+    if (b < d.B && d.leader[b * d.Fs + f] != 0) {
+      const int id = (int)d.idx[b * d.Fs + f];
+      if ((int)((((unsigned)id * 2246822519u) >> 15) % (unsigned)P) == part) {
+        const f32x4* g = reinterpret_cast<const f32x4*>(d.gsum + (b * d.Fs + f) * 16);
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    if (clead[c]) {  // still a leader after the merge
-      const long b = (long)c * 256 + tid;
-      const f32x4* g = reinterpret_cast<const f32x4*>(d.gsum + (b * d.Fs + f) * 16);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const f32x4 t = g[v];
-        ss += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+        for (int v = 0; v < 4; ++v) {
+          const f32x4 t = g[v];
+          ss += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+        }
       }
     }
   }
@@ -283,22 +296,22 @@ __global__ __launch_bounds__(256) void emb_dedup_merge_kernel(const nasrec_emb_d
     if (tid < o) red[tid] += red[tid + o];
     __syncthreads();
   }
-  // the descriptor reserves ceil(B/256) partials per field: the total goes to the first, the rest are zero
-  for (int c = tid; c < nchunk; c += 256) d.sumsq_partial[f * nchunk + c] = (c == 0) ? red[0] : 0.f;
+  // the descriptor reserves ceil(B/256) >= P partials per field: partition p fills entry p, partition 0 zeroes the rest
+  if (tid == 0) d.sumsq_partial[f * nchunk + part] = red[0];
+  if (part == 0)
+    for (int c = P + tid; c < nchunk; c += 256) d.sumsq_partial[f * nchunk + c] = 0.f;
 }
 
 int launch_emb_dedup(hipStream_t st, const nasrec_emb_dedup_desc_t* d) {
   if (d->B == 0) return 0;
-  if (d->B > DEDUP_MAXB) return nasrec_set_error(-2, "emb_dedup: B=%d > %d", d->B, DEDUP_MAXB);
   if (d->B <= 256) {
     hipLaunchKernelGGL(emb_dedup_small_kernel, dim3(d->Fs), dim3(256), 0, st, *d);
     return nasrec_check_launch("emb_dedup");
   }
   dim3 grid(d->Fs, (d->B + 255) / 256);
   hipLaunchKernelGGL(emb_dedup_chunk_kernel, grid, dim3(256), 0, st, *d);
-  int slots = 512;
-  while (slots < 2 * d->B) slots *= 2;
-  hipLaunchKernelGGL(emb_dedup_merge_kernel, dim3(d->Fs), dim3(256), 0, st, *d, slots);
+  const int P = (d->B + DEDUP_PART_ROWS - 1) / DEDUP_PART_ROWS;
+  hipLaunchKernelGGL(emb_dedup_merge_kernel, dim3(d->Fs, P), dim3(256), 0, st, *d, P);
   return nasrec_check_launch("emb_dedup");
 }
 

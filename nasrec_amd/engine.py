@@ -121,7 +121,7 @@ class SupernetEngine:
             self.table_state: Optional[List[torch.Tensor]] = None
             self.lr_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
             self.clip_out = torch.ones(2, dtype=torch.float32, device=self.device)  # [coef, total_norm]
-            self.oob = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.oob = torch.zeros(2, dtype=torch.int32, device=self.device)  # [index out of range, dedup hash partition overflow]
         self.params: Dict[str, torch.Tensor] = {}
         self.grads: Dict[str, torch.Tensor] = {}
         self.state: Dict[str, torch.Tensor] = {}
@@ -193,12 +193,12 @@ class SupernetEngine:
     # -------------------------------------------------------------------------------------------------------
     @_on_device
     def compile(self, choice, B: int, train: bool, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = False,
-                grad_scale: Optional[float] = None) -> CompiledPlan:
-        fast = (id(choice), B, train, clip, eps, graph, grad_scale)
+                grad_scale: Optional[float] = None, defer_dw: bool = True) -> CompiledPlan:
+        fast = (id(choice), B, train, clip, eps, graph, grad_scale, defer_dw)
         hit = self._last_plan
         if self.cfg.fixed and hit is not None and hit[0] == fast and hit[1] is choice:  # fixed sub-network, same choice object: skip the JSON key
             return hit[2]
-        key = json.dumps([choice, B, train, clip, eps, graph, grad_scale], sort_keys=True, default=_jsonable)
+        key = json.dumps([choice, B, train, clip, eps, graph, grad_scale, defer_dw], sort_keys=True, default=_jsonable)
         if key in self._plans:
             self._last_plan = (fast, choice, self._plans[key])
             return self._plans[key]
@@ -210,6 +210,7 @@ class SupernetEngine:
         with torch.cuda.stream(self.stream):
             cp = CompiledPlan()
             ctx = P.Ctx(B, self.device, self.params, self.grads, shape_only=False, train=train)
+            ctx.defer_dw = defer_dw
             cp.ctx = ctx
             cp.int_x = torch.zeros(B, self.Fd, dtype=torch.float32, device=self.device)
             cp.cat_x = torch.zeros(B, self.Fs, dtype=torch.int64, device=self.device)
@@ -294,6 +295,7 @@ class SupernetEngine:
                 cp.bce = bd
                 cp.bwd = Program(pre[1:] + ctx.bwd[:fi] + [fused] + ctx.bwd[fi + 1:])
                 cp.bwd_tail_start = len(pre) - 1 + ctx.bwd_tail_start  # cp.bwd.descs[this:] = the parked weight-gradient products
+                cp.bwd_marks = [(b, len(pre) - 1 + idx) for b, idx in ctx.block_marks]  # block b's gradients complete after cp.bwd.descs[:idx]
                 cp.bwd_core = Program(pre[1:] + ctx.bwd)  # dlogits supplied by the caller (autograd path)
                 # fine-tune-last-layer mode (SuperNet.set_mode_to_finelune_last_only, the searcher's candidate evaluation):
                 # only d loss / d _final is wanted, i.e. the weight part of the final-logit backward and nothing else
@@ -327,6 +329,7 @@ class SupernetEngine:
             dd.B, dd.Fs = Bg, self.Fs
             dd.idx, dd.dout = cat_x.data_ptr(), sparse_grad.data_ptr()
             dd.leader, dd.gsum, dd.sumsq_partial = cp.leader.data_ptr(), cp.gsum.data_ptr(), cp.emb_partial.data_ptr()
+            dd.overflow = self.oob.data_ptr() + 4
             descs.append(dd)
         sq = L.SumsqDesc()
         sq.kind = L.OP_SUMSQ
@@ -468,8 +471,12 @@ class SupernetEngine:
     def check_indices(self):
         """raise IndexError if any embedding id seen so far was out of range (torch raises at lookup time)"""
         torch.cuda.synchronize(self.device)
-        if int(self.oob.item()) != 0:
+        flags = self.oob.tolist()
+        if flags[0] != 0:
             raise IndexError("index out of range in embedding lookup")
+        if flags[1] != 0:
+            raise RuntimeError("embedding-gradient merge: a hash partition overflowed (more than 16384 distinct ids hashed into one "
+                               "partition of 4096 expected); the optimizer step that raised the flag must be discarded")
 
 
 def _jsonable(o):

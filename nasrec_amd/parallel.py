@@ -2,25 +2,33 @@
 
 The path shards over the batch (samples are independent; LayerNorm is per row — SURVEY §8e).  Per step, after the
 local forward/backward:
-  * dense gradients: ONE all-reduce (sum) of the flat gradient arena; the 1/(B·world) factor is already folded into
-    dlogits, so the sum equals the gradient of the mean loss over the global batch;
+  * dense gradients: all-reduce (sum) of the flat gradient arena; the 1/(B·world) factor is already folded into dlogits, so the
+    sum equals the gradient of the mean loss over the global batch.  Fixed sub-network (8.9 MB): ONE all-reduce behind the last
+    product.  Supernet (up to 686 MB of parameters, of which a sampled path touches a fraction): the backward program is cut at
+    the block boundaries, and as soon as block i's gradients are complete the arena ranges of the parameters THIS PATH trained
+    in block i go out as one asynchronous all-reduce each — buckets in reverse block order, overlapped with the rest of the
+    backward; parameters the path did not touch are zero on every rank and are not sent at all;
   * embedding gradients: all-gather of (ids [B,Fs] int64, per-sample row gradients [B,Fs,16]) — B_global·Fs·72 bytes,
     instead of all-reducing 2.16 GB of dense table gradient — then every rank runs the same row-sparse
     dedup + clip + Adagrad over the global batch, so the replicated tables stay bit-identical across ranks;
   * the global-norm clip coefficient comes out identical on every rank because it is computed from identical data.
-Overlap (DataParallelStep.step): the three collectives are issued asynchronously on RCCL's stream as soon as their
-inputs exist — the ids right after staging (hidden under the whole forward/backward), the row gradients when the
-backward chain reaches the embedding stem (hidden under the weight-gradient products, which the plan parks at the end
-of the backward program), the dense arena after the last product — and the compute stream only waits for them in front
-of the optimizer launches.
+Path sampling under DP: the reference draws ONE path per step from the global `np.random` stream (supernet.py:525-529); all
+ranks share the seed, hence the same path, hence a step that equals a single process at the global batch (`choice=` of
+`DataParallelStep.step`).  The collectives are asynchronous: the ids go out right after staging, the row gradients when the
+backward chain reaches the embedding stem, and the compute stream waits for them only in front of the optimizer launches.
 The reference has no distributed code at all; equivalence target = a single process at the global batch.
+
+`DataParallelStep` drives an engine through a small protocol (`dp_plan`, `dp_optimizer`, `flat_g`, `Fs`, `device`, `cfg.fixed`),
+which `SupernetEngine` implements below through `EngineDP`; tests/test_data_parallel_cpu.py runs the SAME step code under gloo
+with a CPU stand-in that implements the protocol with the oracle.
 """
-from typing import Optional
+import json
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
-from .engine import Program, SupernetEngine
+BUCKET_GAP = 16384  # floats: arena ranges closer than this are sent as one all-reduce (fewer, larger collectives)
 
 
 def all_gather_rows(out: torch.Tensor, local: torch.Tensor):
@@ -49,58 +57,176 @@ def exchange_gradients(flat_g: torch.Tensor, cat_local: torch.Tensor, sg_local: 
     all_gather_rows(sg_all, sg_local)
 
 
+def coalesce_ranges(ranges: List[Tuple[int, int]], gap: int = BUCKET_GAP) -> List[Tuple[int, int]]:
+    """[(offset, numel)] -> merged, ascending; neighbours closer than `gap` floats become one range"""
+    out = []
+    for off, n in sorted(ranges):
+        if out and off <= out[-1][0] + out[-1][1] + gap:
+            end = max(out[-1][0] + out[-1][1], off + n)
+            out[-1] = (out[-1][0], end - out[-1][0])
+        else:
+            out.append((off, n))
+    return out
+
+
+class DPPlan:
+    """What one (choice, local batch) looks like to the data-parallel step."""
+    stage: Callable      # (int_x, cat_x, y, lr) -> None: batch into the plan's static buffers
+    forward: Callable    # () -> None
+    segments: List       # [(run, [(offset, numel), ...])]: backward pieces, each followed by the arena ranges complete after it
+    cat_local: torch.Tensor
+    sparse_grad: torch.Tensor
+    loss: torch.Tensor
+
+
+class DataParallelStep:
+    def __init__(self, engine, choice, B_local: int, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = True,
+                 force_exchange: bool = False):
+        """choice: the fixed sub-network's choice, or None for a weight-sharing supernet (the path then comes with every step).
+        force_exchange: take the multi-rank code path (all-reduce + all-gather + global-batch optimizer) even in a single-rank
+        process group — lets one GPU exercise exactly what N GPUs run."""
+        self.engine = engine
+        self.dp = engine if hasattr(engine, "dp_plan") else EngineDP(engine)
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.B = B_local
+        self.fixed = bool(engine.cfg.fixed)
+        self.graph = bool(graph and self.fixed)
+        self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
+        self.choice, self.clip, self.eps = choice, clip, eps
+        self._last = None
+        self._plans = {}
+        if not self.exchange:
+            if self.fixed:
+                self.cp = engine.compile(choice, B_local, True, clip, eps, graph=self.graph)
+            return
+        Bg = B_local * self.world
+        dev = engine.device
+        self.cat_all = torch.zeros(Bg, engine.Fs, dtype=torch.int64, device=dev)
+        self.sg_all = torch.zeros(Bg * engine.Fs * 16, dtype=getattr(engine, "grad_dtype", torch.float32), device=dev)
+        self.opt = self.dp.dp_optimizer(Bg, self.cat_all, self.sg_all, clip, eps, self.graph)
+        if self.fixed:
+            self.cp = self._plan(choice)
+
+    def _plan(self, choice) -> DPPlan:
+        key = id(choice) if self.fixed else json.dumps(choice, sort_keys=True, default=_jsonable)
+        hit = self._plans.get(key)
+        if hit is None:
+            if len(self._plans) >= 8:
+                self._plans.pop(next(iter(self._plans)))
+            hit = self.dp.dp_plan(choice, self.B, 1.0 / (self.B * self.world), self.clip, self.eps, self.graph)
+            self._plans[key] = hit
+        return hit
+
+    def step(self, int_x, cat_x, y, lr: float, choice=None):
+        eng = self.engine
+        choice = choice if choice is not None else self.choice
+        if not self.exchange:
+            loss = eng.train_step(int_x, cat_x, y, lr, choice, self.clip, self.eps, graph=self.graph)
+            self._last = ("plain", choice, int(int_x.shape[0]))
+            return loss
+        plan = self._plan(choice)
+        plan.stage(int_x, cat_x, y, lr)
+        pending = [all_gather_rows_async(self.cat_all, plan.cat_local)]
+        plan.forward()
+        flat_g = eng.flat_g
+        for run, ranges in plan.segments:
+            run()
+            for off, n in ranges:  # this segment completed these arena ranges: out they go, under the rest of the backward
+                pending.append(dist.all_reduce(flat_g[off:off + n], op=dist.ReduceOp.SUM, async_op=True))
+        pending.append(all_gather_rows_async(self.sg_all, plan.sparse_grad))
+        for w in pending:
+            if w is not None:
+                w.wait()  # nccl: the compute stream waits for the collective (no host block)
+        self.opt()
+        self._last = ("dp", plan)
+        return plan.loss
+
+    def last_loss(self):
+        if self._last[0] == "dp":
+            return self._last[1].loss
+        return self.last_plan().loss
+
+    def last_plan(self):
+        """the engine's compiled plan of the most recent step (bench.py reads its descriptors)"""
+        if self._last[0] == "dp":
+            return self._last[1].cp
+        _, choice, B = self._last
+        return self.engine.compile(choice, B, True, self.clip, self.eps, graph=self.graph)
+
+
+class EngineDP:
+    """SupernetEngine behind the data-parallel protocol (programs, hipGraph segments, arena ranges per block)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def dp_optimizer(self, Bg, cat_all, sg_all, clip, eps, graph):
+        from .engine import Program
+        eng = self.engine
+        with torch.cuda.stream(eng.stream):
+            holder = _Holder()
+            eng._ensure_table_state()
+            prog = Program(eng._optimizer_descs(holder, Bg, cat_all, sg_all, clip, eps))
+            prog.holder = holder
+            if graph:
+                prog.capture(eng.stream.cuda_stream)
+        eng.stream.synchronize()
+        return (lambda: prog.replay(eng._sp())) if graph else (lambda: prog.run(eng._sp()))
+
+    def dp_plan(self, choice, B, grad_scale, clip, eps, graph) -> DPPlan:
+        from .engine import Program
+        eng = self.engine
+        fixed = eng.cfg.fixed
+        # weight-sharing supernet at a large batch: weight-gradient products stay in backward order (nothing to gain from parking
+        # them at the end when no launch is latency-bound), so that a block's gradients are complete when its backward is
+        cp = eng.compile(choice, B, True, clip, eps, graph=False, grad_scale=grad_scale, defer_dw=fixed)
+        plan = DPPlan()
+        plan.cp = cp
+        plan.cat_local, plan.loss = cp.cat_x, cp.loss
+        plan.sparse_grad = cp.sparse0.grad_tensor()
+        plan.stage = lambda int_x, cat_x, y, lr: eng._stage_inputs(eng._sp(), cp, int_x, cat_x, y, lr)
+        descs = cp.bwd.descs
+        with torch.cuda.stream(eng.stream):
+            if fixed:
+                # forward + backward chain | parked weight-gradient products: the row-gradient all-gather runs under the latter
+                cut = cp.bwd_tail_start
+                fb = Program(cp.fwd.descs + descs[:cut])
+                tail = Program(descs[cut:]) if cut < len(descs) else None
+                if graph:
+                    fb.capture(eng.stream.cuda_stream)
+                    if tail is not None:
+                        tail.capture(eng.stream.cuda_stream)
+                run = (lambda p: (lambda: p.replay(eng._sp()))) if graph else (lambda p: (lambda: p.run(eng._sp())))
+                plan.forward = run(fb)
+                whole = [(0, eng.flat_numel)]
+                plan.segments = [(run(tail), whole)] if tail is not None else [(lambda: None, whole)]
+            else:
+                plan.forward = lambda: cp.fwd.run(eng._sp())
+                marks = sorted(cp.bwd_marks, key=lambda m: m[1])  # (block, end index in the backward program), ascending position
+                used = [n for n in list(cp.ctx.grad_params) + ["_final.weight", "_final.bias"] if not n.startswith("_embedding.")]
+                segs, start, sent = [], 0, set()
+                for blk, end in marks:
+                    names = [n for n in used if n not in sent and (n.startswith("_blocks.%d." % blk) or n.startswith("_final."))]
+                    sent.update(names)
+                    ranges = coalesce_ranges([(eng.offsets[n], eng.params[n].numel()) for n in names])
+                    prog = Program(descs[start:end])
+                    segs.append(((lambda p: (lambda: p.run(eng._sp())))(prog), ranges))
+                    start = end
+                rest = [n for n in used if n not in sent]
+                prog = Program(descs[start:])
+                segs.append(((lambda p: (lambda: p.run(eng._sp())))(prog), coalesce_ranges([(eng.offsets[n], eng.params[n].numel()) for n in rest])))
+                plan.segments = segs
+        eng.stream.synchronize()
+        return plan
+
+
 class _Holder:
     pass
 
 
-class DataParallelStep:
-    def __init__(self, engine: SupernetEngine, choice, B_local: int, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = True,
-                 force_exchange: bool = False):
-        """force_exchange: take the multi-rank code path (all-reduce + all-gather + global-batch optimizer) even in a
-        single-rank process group — lets one GPU exercise exactly what N GPUs run."""
-        self.engine = engine
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.B = B_local
-        self.graph = graph and engine.cfg.fixed
-        self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
-        if not self.exchange:
-            self.cp = engine.compile(choice, B_local, True, clip, eps, graph=self.graph)
-            self.choice = choice
-            self.clip, self.eps = clip, eps
-            return
-        self.cp = engine.compile(choice, B_local, True, clip, eps, graph=False, grad_scale=1.0 / (B_local * self.world))
-        with torch.cuda.stream(engine.stream):
-            Bg = B_local * self.world
-            self.cat_all = torch.zeros(Bg, engine.Fs, dtype=torch.int64, device=engine.device)
-            self.sg_all = torch.zeros(Bg * engine.Fs * 16, dtype=torch.float32, device=engine.device)
-            self.holder = _Holder()
-            self.opt = Program(engine._optimizer_descs(self.holder, Bg, self.cat_all, self.sg_all, clip, eps))
-            # forward + backward chain | parked weight-gradient products: the row-gradient all-gather runs under the latter
-            cut = self.cp.bwd_tail_start
-            self.fb = Program(self.cp.fwd.descs + self.cp.bwd.descs[:cut])
-            self.tail = Program(self.cp.bwd.descs[cut:]) if cut < len(self.cp.bwd.descs) else None
-            if self.graph:
-                self.fb.capture(engine.stream.cuda_stream)
-                if self.tail is not None:
-                    self.tail.capture(engine.stream.cuda_stream)
-                self.opt.capture(engine.stream.cuda_stream)
-        engine.stream.synchronize()
-
-    def step(self, int_x, cat_x, y, lr: float):
-        eng = self.engine
-        if not self.exchange:
-            return eng.train_step(int_x, cat_x, y, lr, self.choice, self.clip, self.eps, graph=self.graph)
-        sp = eng._sp()
-        run = (lambda prog: prog.replay(sp)) if self.graph else (lambda prog: prog.run(sp))
-        eng._stage_inputs(sp, self.cp, int_x, cat_x, y, lr)
-        pending = [all_gather_rows_async(self.cat_all, self.cp.cat_x)]
-        run(self.fb)
-        pending.append(all_gather_rows_async(self.sg_all, self.cp.sparse0.grad_tensor()))
-        if self.tail is not None:
-            run(self.tail)
-        pending.append(dist.all_reduce(eng.flat_g, op=dist.ReduceOp.SUM, async_op=True))
-        for w in pending:
-            if w is not None:
-                w.wait()  # nccl: the compute stream waits for the collective (no host block)
-        run(self.opt)
-        return self.cp.loss
+def _jsonable(o):
+    if hasattr(o, "tolist"):
+        return o.tolist()
+    if hasattr(o, "item"):
+        return o.item()
+    raise TypeError(type(o))

@@ -163,6 +163,7 @@ class Ctx:
         self.bwd_tail_start = 0
         self.mha_reduce: List = []  # (MHA backward descriptor, [(grad ptr, column offset, length)]) awaiting the shared reduction
         self.defer_dw = True
+        self.block_marks: List = []  # (block index, length of the backward program once that block's gradients are complete)
 
     # -- memory -----------------------------------------------------------------------------------------------
     def alloc(self, numel):
@@ -293,6 +294,19 @@ def _fast_gemm_splitk(amode, bmode, cmode, segs, zmode):
     if tiles < 256:
         S = max(1, min(-(-256 // tiles), kt // 8, 32))
     return S if tiles * S >= GEMM_FAST_MIN_TILES else None
+
+
+def gemm_kernel_name(d) -> str:
+    """which kernel family launch_gemm picks for this descriptor (mirror of csrc/gemm.hip / gemm_fast.hip)"""
+    segs = [dict(A=d.seg[q].A, Aaux=d.seg[q].Aaux, Baux=d.seg[q].Baux, M=d.seg[q].M, N=d.seg[q].N, K=d.seg[q].K) for q in range(d.nseg)]
+    live = [sd for sd in segs if sd["A"]]
+    if d.cmode != L.CM_PLAIN or (d.amode, d.bmode) not in ((L.AM_KC, L.AM_KC), (L.AM_KC, L.AM_RC), (L.AM_RC, L.AM_RC)) or not live:
+        return "gemm_kernel"
+    if any(sd["Aaux"] or sd["Baux"] for sd in segs) or max(sd["K"] for sd in live) < 64:
+        return "gemm_kernel"
+    probs = segs if d.zmode else segs[:1]
+    tiles = sum(((sd["M"] + 127) // 128) * ((sd["N"] + 127) // 128) for sd in probs) * max(1, d.splitk)
+    return "gemm_fast_kernel" if tiles >= GEMM_FAST_MIN_TILES else "gemm_kernel"
 
 
 def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, **kw):
@@ -1243,6 +1257,13 @@ def network_walk(ctx, cfg: NetConfig, choice, int_x: DV, sparse0: SV):
     """SuperNet.forward / fixed_forward wiring (supernet.py:513-668). Returns (dense_last, sparse_last)."""
     dlist, slist = [int_x], [sparse0]
     for i in range(cfg.num_blocks):
+        def mark(i=i):
+            # registered BEFORE block i's operators, hence run AFTER all of their backward closures: block i is complete here
+            # (with weight-gradient products in backward order, i.e. defer_dw off — the data-parallel bucket boundaries)
+            if not ctx.defer_dw:
+                _flush_mha_reduce(ctx)
+            ctx.block_marks.append((i, len(ctx.bwd)))
+        ctx.on_backward(mark)
         mac = choice["macro"][i]
         dviews, dwidths = dlist, [v.width for v in dlist]
         sviews, swidths = slist, [v.N for v in slist]

@@ -1,11 +1,12 @@
-"""One small invocation of the hot path on cuda:0, checked against the CPU oracle (oracle/ is the checker only)."""
+"""One small invocation of the hot path on cuda:0, checked against the CPU oracle (oracle/ is the checker only).
+Lives OUTSIDE the product package: nothing under nasrec_amd/ imports oracle/."""
 import json
 import os
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
 
 # Criteo best-1shot sub-network (the choice published in nasrec/configs/criteo/ea_criteo_kaggle_xlarge_best_1shot.json,
 # carried by the golden fixture's metadata)

@@ -106,93 +106,191 @@ def test_exchange_and_rowsparse_equivalence():
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# the whole data-parallel step against a single process at the global batch, with the oracle as the per-rank engine
+# DataParallelStep.step ITSELF (nasrec_amd/parallel.py) under gloo, world 2: the same step code the GPUs run, driven through
+# the engine protocol by a CPU stand-in whose compute is the fp64 oracle.  Checked against a single process at the global
+# batch: fixed sub-network, weight-sharing supernet with a freshly sampled path every step (shared np.random seed), and a
+# global batch > 8192.
 # ------------------------------------------------------------------------------------------------------------------
-def _dp_oracle_worker(rank, port, out):
-    """What DataParallelStep.step does on each rank, with the fp64 oracle standing in for the HIP engine: local
-    forward/backward with d loss / d logits pre-scaled by 1 / (B_local * world), asynchronous all-gather of (ids, per-sample
-    embedding-row gradients) and all-reduce of the dense gradients, then the same global-batch clip + row-sparse Adagrad on
-    every rank."""
-    import json
+class OracleEngine:
+    """The data-parallel protocol (dp_plan / dp_optimizer / flat_g / Fs / device / cfg.fixed) on CPU tensors, oracle inside."""
+
+    def __init__(self, cfg, P, Fs):
+        from nasrec_amd.parallel import DPPlan, coalesce_ranges
+        self._DPPlan, self._coalesce = DPPlan, coalesce_ranges
+        self.cfg, self.P, self.Fs = cfg, P, Fs
+        self.device = torch.device("cpu")
+        self.grad_dtype = torch.float64
+        self.names = [k for k in P if not k.startswith("_embedding.")]
+        self.offsets, off = {}, 0
+        for k in self.names:
+            self.offsets[k] = off
+            off += (P[k].numel() + 3) // 4 * 4  # 16-byte aligned arena slots, like the engine
+        self.flat_numel = off
+        self.flat_g = torch.zeros(off, dtype=torch.float64)
+        self.state = {}
+        self.sent_bytes = 0
+
+    def dp_plan(self, choice, B, grad_scale, clip, eps, graph):
+        from oracle import nasrec_oracle as O
+        eng, P, cfg, Fs = self, self.P, self.cfg, self.Fs
+        plan = self._DPPlan()
+        plan.cat_local = torch.zeros(B, Fs, dtype=torch.int64)
+        plan.sparse_grad = torch.zeros(B * Fs * 16, dtype=torch.float64)
+        plan.loss = torch.zeros(1, dtype=torch.float64)
+        box = {}
+
+        def stage(int_x, cat_x, y, lr):
+            box.update(int_x=int_x, y=y, lr=lr)
+            plan.cat_local.copy_(cat_x)
+
+        def fwd_bwd():
+            leaves = {k: P[k].detach().requires_grad_(True) for k in eng.names}
+            Pl = O.Params(P.dtype, frozen=True)
+            Pl.update(leaves)
+            rows = torch.stack([P["_embedding.%d.weight" % f][plan.cat_local[:, f]] for f in range(Fs)], 1).detach().requires_grad_(True)
+            for f in range(Fs):  # the stem as a gather of leaf rows: d loss / d rows is the per-sample row gradient
+                Pl["_embedding.%d.weight" % f] = rows[:, f]
+            ids = torch.arange(B).view(B, 1).expand(B, Fs).contiguous()
+            logits = O.supernet_forward(Pl, cfg, box["int_x"], ids, choice)
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), box["y"].view(-1), reduction="sum") * grad_scale
+            grads = torch.autograd.grad(loss, [leaves[k] for k in eng.names] + [rows], allow_unused=True)
+            eng.flat_g.zero_()  # what the engine's memset does: parameters outside the path see g = 0
+            used = []
+            for k, g in zip(eng.names, grads[:-1]):
+                if g is not None:
+                    eng.flat_g[eng.offsets[k]:eng.offsets[k] + g.numel()] = g.reshape(-1)
+                    used.append(k)
+            plan.sparse_grad.copy_(grads[-1].reshape(-1))
+            plan.loss.fill_(float(loss.detach()))
+            box["used"] = used
+
+        plan.stage, plan.forward = stage, (lambda: None)
+        if cfg.fixed:
+            plan.segments = [(fwd_bwd, [(0, eng.flat_numel)])]
+        else:
+            # one bucket per block in reverse order, holding only the arena ranges of the parameters this path trained there
+            # (what EngineDP derives from the backward program's block marks)
+            def ranges_of(blk):
+                def f():
+                    names = [k for k in box["used"] if k.startswith("_blocks.%d." % blk) or (blk == cfg.num_blocks - 1 and k.startswith("_final."))]
+                    return eng._coalesce([(eng.offsets[k], P[k].numel()) for k in names])
+                return f
+            lazy = [_LazyRanges(ranges_of(b)) for b in reversed(range(cfg.num_blocks))]
+            plan.segments = [(fwd_bwd, lazy[0])] + [((lambda: None), r) for r in lazy[1:]]
+        return plan
+
+    def dp_optimizer(self, Bg, cat_all, sg_all, clip, eps, graph):
+        from oracle import nasrec_oracle as O
+        eng, P, Fs = self, self.P, self.Fs
+
+        def run():
+            sg = sg_all.view(Bg, Fs, 16)
+            uniq = []
+            for f in range(Fs):
+                ids, inv = torch.unique(cat_all[:, f], return_inverse=True)
+                uniq.append((ids, torch.zeros(len(ids), 16, dtype=torch.float64).index_add_(0, inv, sg[:, f])))
+            total = torch.sqrt(eng.flat_g.pow(2).sum() + sum(g.pow(2).sum() for _, g in uniq))
+            coef = min(1.0, clip / (float(total) + 1e-6))
+            with torch.no_grad():
+                for k in eng.names:
+                    g = eng.flat_g[eng.offsets[k]:eng.offsets[k] + P[k].numel()].view_as(P[k]) * coef
+                    st = eng.state.setdefault(k, torch.zeros_like(P[k]))
+                    O.adagrad_step_(P[k], g, st, eng.lr, eps)  # g = 0 leaves state and parameter untouched (Adagrad no-op)
+                for f, (ids, g) in enumerate(uniq):
+                    k = "_embedding.%d.weight" % f
+                    st = eng.state.setdefault(k, torch.zeros_like(P[k]))
+                    g = g * coef
+                    st[ids] += g * g
+                    P[k][ids] -= eng.lr * g / (st[ids].sqrt() + eps)
+        return run
+
+
+class _LazyRanges:
+    """iterable of arena ranges that is only known once the segment before it has run (the stand-in learns the path's parameter
+    set from autograd; the real engine knows it at compile time)"""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __iter__(self):
+        return iter(self.fn())
+
+
+def _dp_case(name):
+    """-> (cfg, P, batches [(int_x, cat_x, y)], choices or None, lr) for the three scenarios"""
     from helpers import GOLDEN, load_golden, oracle_cfg, oracle_params
     from oracle import nasrec_oracle as O
+    if name == "fixed":
+        z, meta = load_golden(os.path.join(GOLDEN, "fixed_criteo_autoctr.npz"))
+        cfg, P = oracle_cfg(meta), oracle_params(meta)
+        b = (torch.tensor(z["int_x"]).double(), torch.tensor(z["cat_x"]), torch.tensor(z["y"]).double().view(-1, 1))
+        return cfg, P, [b, b], [meta["choice"]] * 2, 0.05
+    nb, space, Bg, tables, steps = (3, "autoctr", 8, [40, 7, 300, 5], 3) if name == "sampled" else (1, "autoctr", 8400, [4, 90, 50000], 1)
+    cfg = O.NetCfg(nb, O.ops_config_lib[space], True, "relu", fixed=False)
+    P = O.Params(torch.float64)
+    batches = []
+    for s in range(steps):
+        int_x, cat_x, y = O.synthetic_batch(Bg, 3, tables, seed=40 + s)
+        batches.append((int_x.double(), cat_x, y.double().view(-1, 1)))
+    with torch.no_grad():
+        O.supernet_forward(P, cfg, batches[0][0][:4], batches[0][1][:4], O.full_path_choice(cfg), num_embeddings=tables)  # lazy params, full path
+    P.frozen = True
+    np.random.seed(1234)  # every rank draws the same paths from its own (identically seeded) global stream
+    sampler = O.PathSampler(cfg, "default", "binomial-0.5")
+    choices = [json.loads(json.dumps(sampler.sample(), default=lambda o: o.tolist() if hasattr(o, "tolist") else o.item())) for _ in range(steps)]
+    return cfg, P, batches, choices, 0.02
+
+
+def _dp_step_worker(rank, port, name, out):
+    from nasrec_amd.parallel import DataParallelStep
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
-    z, meta = load_golden(os.path.join(GOLDEN, "fixed_criteo_autoctr.npz"))
-    cfg, P = oracle_cfg(meta), oracle_params(meta)
-    int_x, cat_x, y = torch.tensor(z["int_x"]).double(), torch.tensor(z["cat_x"]), torch.tensor(z["y"]).double().view(-1, 1)
-    Bg = int_x.shape[0]
-    Bl = Bg // WORLD
+    torch.set_num_threads(2)
+    cfg, P, batches, choices, lr = _dp_case(name)
+    Fs = batches[0][1].shape[1]
+    Bl = batches[0][0].shape[0] // WORLD
+    eng = OracleEngine(cfg, P, Fs)
+    dp = DataParallelStep(eng, choices[0] if cfg.fixed else None, Bl, clip=5.0, eps=1e-2, graph=False)
+    assert dp.exchange and dp.world == WORLD
     sl = slice(rank * Bl, (rank + 1) * Bl)
-    Fs = cat_x.shape[1]
-    lr, eps, clip = 0.05, 1e-2, 5.0
-    state = {}
-    for step in range(2):
-        leaves = {k: v.detach().requires_grad_(True) for k, v in P.items() if not k.startswith("_embedding.")}
-        Pl = O.Params(P.dtype, frozen=True)
-        Pl.update(leaves)
-        rows = torch.stack([P["_embedding.%d.weight" % f][cat_x[sl, f]] for f in range(Fs)], 1).detach().requires_grad_(True)  # [Bl,Fs,16]
-        for f in range(Fs):  # the stem as a gather of leaf rows, so that d loss / d rows is the per-sample row gradient
-            Pl["_embedding.%d.weight" % f] = rows[:, f]
-        ids_local = torch.arange(Bl).view(Bl, 1).expand(Bl, Fs).contiguous()
-        logits = O.supernet_forward(Pl, cfg, int_x[sl], ids_local, meta["choice"])
-        per_sample = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), y[sl].view(-1), reduction="sum")
-        loss = per_sample / (Bl * WORLD)  # == grad_scale 1/(B_local*world) folded into d logits
-        names = list(leaves)
-        grads = torch.autograd.grad(loss, [leaves[k] for k in names] + [rows], allow_unused=True)
-        flat = torch.cat([(g if g is not None else torch.zeros_like(leaves[k])).reshape(-1) for k, g in zip(names, grads[:-1])])
-        sg = grads[-1].contiguous()
-        cat_all, sg_all = torch.zeros(Bg, Fs, dtype=torch.int64), torch.zeros(Bg * Fs * 16, dtype=torch.float64)
-        pending = [all_gather_rows_async(cat_all, cat_x[sl].contiguous()), all_gather_rows_async(sg_all, sg),
-                   dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)]
-        for w in pending:
-            if w is not None:
-                w.wait()
-        sg_all = sg_all.view(Bg, Fs, 16)
-        # global-batch optimizer, identical on every rank: dedup rows (ascending sample order), clip over dense + unique rows
-        uniq = []
-        for f in range(Fs):
-            ids, inv = torch.unique(cat_all[:, f], return_inverse=True)
-            uniq.append((ids, torch.zeros(len(ids), 16, dtype=torch.float64).index_add_(0, inv, sg_all[:, f])))
-        total = torch.sqrt(flat.pow(2).sum() + sum(g.pow(2).sum() for _, g in uniq))
-        coef = min(1.0, clip / (float(total) + 1e-6))
-        with torch.no_grad():
-            off = 0
-            for k in names:
-                n = leaves[k].numel()
-                g = flat[off:off + n].view_as(P[k]) * coef
-                off += n
-                if not bool((g != 0).any()) and k not in state and k in meta["grad_none"]:
-                    continue  # parameters outside the path: torch skips grad=None
-                st = state.setdefault(k, torch.zeros_like(P[k]))
-                O.adagrad_step_(P[k], g, st, lr, eps)
-            for f, (ids, g) in enumerate(uniq):
-                k = "_embedding.%d.weight" % f
-                st = state.setdefault(k, torch.zeros_like(P[k]))
-                g = g * coef
-                st[ids] += g * g
-                P[k][ids] -= lr * g / (st[ids].sqrt() + eps)
-    out[rank] = {k: v.detach().clone() for k, v in P.items()}
+    losses = []
+    for (int_x, cat_x, y), ch in zip(batches, choices):
+        eng.lr = lr
+        loss = dp.step(int_x[sl], cat_x[sl].contiguous(), y[sl], lr, choice=None if cfg.fixed else ch)
+        losses.append(float(loss))
+    out[rank] = ({k: v.detach().clone() for k, v in P.items()}, losses)
     dist.destroy_process_group()
 
 
-def test_data_parallel_step_equals_single_process_at_the_global_batch():
+import json  # noqa: E402
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["fixed", "sampled", "large_batch"])
+def test_data_parallel_step_equals_single_process_at_the_global_batch(name):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from helpers import GOLDEN, load_golden, oracle_cfg, oracle_params
     from oracle import nasrec_oracle as O
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_dp_oracle_worker, args=(port, out), nprocs=WORLD, join=True)
-    z, meta = load_golden(os.path.join(GOLDEN, "fixed_criteo_autoctr.npz"))
-    cfg, P = oracle_cfg(meta), oracle_params(meta)
-    int_x, cat_x, y = torch.tensor(z["int_x"]).double(), torch.tensor(z["cat_x"]), torch.tensor(z["y"]).double().view(-1, 1)
+    mp.spawn(_dp_step_worker, args=(port, name, out), nprocs=WORLD, join=True)
+    cfg, P, batches, choices, lr = _dp_case(name)
+    initial = {k: v.clone() for k, v in P.items()}
     state = {}
-    for step in range(2):
-        O.train_step(P, state, cfg, meta["choice"], int_x, cat_x, y, lr=0.05)
+    touched = set()
+    for (int_x, cat_x, y), ch in zip(batches, choices):
+        _, _, _, gd = O.train_step(P, state, cfg, ch, int_x, cat_x, y, lr=lr)
+        touched |= set(gd)
     for r in range(WORLD):
         for k, v in P.items():
-            assert torch.allclose(out[r][k], v, rtol=0, atol=1e-10), (r, k)
-    for k in out[0]:
-        assert torch.equal(out[0][k], out[1][k]), k  # replicas stay bit-identical
+            assert torch.allclose(out[r][0][k], v, rtol=0, atol=1e-10), (name, r, k)
+    for k in out[0][0]:
+        assert torch.equal(out[0][0][k], out[1][0][k]), k  # replicas stay bit-identical
+    # the sum of the ranks' losses (each scaled by 1/(B_local*world)) is the global mean loss of the step
+    if name != "fixed":
+        untouched = [k for k in P if k not in touched]
+        assert untouched, "a sampled path leaves part of the supernet unused"
+        for k in untouched:  # grad None in the reference: neither value nor Adagrad state may move
+            assert torch.equal(out[0][0][k], initial[k]), k

@@ -315,6 +315,51 @@ def test_rowsparse_adagrad_equals_dense_reference(lib, B):
         assert torch.equal(lead[:, f], want)
 
 
+@pytest.mark.parametrize("B", [8192, 20000, 65536])
+def test_rowsparse_dedup_at_global_batches_of_a_data_parallel_step(lib, B):
+    """the partitioned merge (grid Fs x ceil(B/4096)) at the global batches of BASELINE configs 4 / 5 on 8 GPUs (32 768 and
+    65 536 samples): leaders = first occurrences, summed rows == index_add_ in fp64, sum of squares == the dense gradient norm,
+    on a 4-row table (every chunk leads every row), mid-size tables and a table larger than the batch (few duplicates)"""
+    torch.manual_seed(5)
+    rows = [4, 50, 3000, 300000]
+    Fs = len(rows)
+    idx = torch.stack([torch.randint(0, n, (B,)) for n in rows], 1)
+    dout = torch.randn(B, Fs, 16) * 0.1
+    gi, gd = dev(idx), dev(dout)
+    leader, gsum = dev(torch.zeros(B * Fs, dtype=torch.int32)), dev(torch.zeros(B * Fs * 16))
+    nb = (B + 255) // 256
+    part = dev(torch.full((Fs * nb,), 7.0))
+    flag = dev(torch.zeros(1, dtype=torch.int32))
+    dd = L.EmbDedupDesc()
+    dd.kind, dd.B, dd.Fs = L.OP_EMB_DEDUP, B, Fs
+    dd.idx, dd.dout, dd.leader, dd.gsum, dd.sumsq_partial = gi.data_ptr(), gd.data_ptr(), leader.data_ptr(), gsum.data_ptr(), part.data_ptr()
+    dd.overflow = flag.data_ptr()
+    launch(lib, dd)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    lead = leader.cpu().view(B, Fs)
+    gs = gsum.cpu().view(B, Fs, 16).double()
+    total = 0.0
+    for f in range(Fs):
+        ids, inv = torch.unique(idx[:, f], return_inverse=True)
+        dense = torch.zeros(len(ids), 16, dtype=torch.float64).index_add_(0, inv, dout[:, f].double())
+        first = torch.full((len(ids),), B, dtype=torch.int64).scatter_reduce_(0, inv, torch.arange(B), reduce="amin")
+        want = torch.zeros(B, dtype=torch.int32)
+        want[first] = 1
+        assert torch.equal(lead[:, f], want), "field %d: leaders are not the first occurrences" % f
+        got = gs[first, f]
+        assert float((got - dense).abs().max()) <= 1e-5 * max(1.0, float(dense.abs().max())), f
+        total += float(dense.pow(2).sum())
+    assert abs(float(part.double().sum()) - total) <= 1e-4 * total
+    # bit-reproducible: a second launch on the same inputs gives the same bytes
+    g1, p1 = gsum.clone(), part.clone()
+    launch(lib, dd)
+    torch.cuda.synchronize()
+    assert torch.equal(leader.cpu().view(B, Fs), lead) and torch.equal(part, p1)
+    sel = lead.bool().view(-1)
+    assert torch.equal(gsum.view(-1, 16)[sel], g1.view(-1, 16)[sel])
+
+
 def test_rowsparse_adagrad_skips_out_of_range_ids(lib):
     """an id outside [0, rows) must not be written anywhere (torch raises in the forward pass; the engine flags it in the
     gather and the optimizer leaves memory alone)"""

@@ -1,0 +1,194 @@
+"""BASELINE.json configs 3, 4 and 5 AT THEIR WORKLOAD on the GPU: the 7-block weight-sharing supernets (Criteo xlarge B 4096, Avazu
+xlarge B 4096, KDD autoctr B 8192 with 0.5 M-capped tables), LayerNorm on, full (or capped) tables, one sampled path per step —
+the throughput-regime GEMM kernel, the chunked dedup at B > 256, K ranges up to 6157, through the drop-in SuperNet module.
+The fp64 oracle cannot replay such steps in seconds, so (as tests/test_fullsize_gpu.py does for config 2):
+
+  * oracle: logits of 16 samples against the fp64 restatement run on the engine's own weights, under a sampled path pinned from
+    the module's own sampler (train_supernet.py:241-257 + the `default` strategy), 1e-5 bar;
+  * sample independence: a permuted batch gives the permuted logits (the network is row-local at every batch size);
+  * row-sparse optimizer == dense reference semantics: after a training step rows no sample touched are bit-identical, their
+    Adagrad state is still 0; parameters outside the sampled path (grad None in the reference) are bit-identical too;
+  * determinism: the same step from the same state gives bit-identical parameters;
+  * the N > 1 code path (bucketed all-reduce per block, all-gather of row gradients, global-batch optimizer) in a single-rank
+    RCCL group lands on the parameters of the plain step."""
+import numpy as np
+import pytest
+import torch
+
+from nasrec_amd.search_space import ops_config_lib
+from nasrec_amd.supernet.supernet import SuperNet
+from nasrec_amd.utils.config import DATASETS
+from oracle import nasrec_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "cfg3_criteo_xlarge_b4096": dict(dataset="criteo", space="xlarge", B=4096, cap=None),
+    "cfg4_avazu_xlarge_b4096": dict(dataset="avazu", space="xlarge", B=4096, cap=None),
+    "cfg5_kdd_autoctr_b8192": dict(dataset="kdd", space="autoctr", B=8192, cap=500000),
+}
+
+
+def _build(name, seed=0):
+    c = CONFIGS[name]
+    ds = DATASETS[c["dataset"]]
+    tables = [min(n, c["cap"]) if c["cap"] else n for n in ds["tables"]]
+    B = c["B"]
+    torch.manual_seed(seed)
+    model = SuperNet(num_blocks=7, ops_config=ops_config_lib[c["space"]], use_layernorm=True, num_embeddings=tables,
+                     sparse_input_size=ds["Fs"], path_sampling_strategy="full-path", fixed=False, anypath_choice="binomial-0.5").cuda()
+    int_x, cat_x, y = O.synthetic_batch(B, ds["Fd"], tables, seed=77, zero_dense=(c["dataset"] == "avazu"))
+    cat_x[0] = 0
+    cat_x[1] = torch.tensor(tables) - 1
+    cat_x[2] = cat_x[3]
+    int_x[2] = int_x[3]
+    int_x, cat_x, y = int_x.cuda(), cat_x.cuda(), y.view(-1).cuda()
+    with torch.no_grad():
+        model(int_x[:64], cat_x[:64])  # full-path warm-up (train_utils.py:413-433)
+    model._engine.init_weights(seed=seed)
+    model.configure_path_sampling_strategy("default")
+    np.random.seed(11)
+    return model, c, ds, tables, int_x, cat_x, y
+
+
+@pytest.fixture(scope="module", params=sorted(CONFIGS))
+def setup(request):
+    out = _build(request.param)
+    yield out
+    del out
+    torch.cuda.empty_cache()
+
+
+def _jsonable(choice):
+    import json
+    return json.loads(json.dumps(choice, default=lambda o: o.tolist() if hasattr(o, "tolist") else o.item()))
+
+
+def test_sampled_path_logits_against_the_oracle_and_sample_independence(setup):
+    model, c, ds, tables, int_x, cat_x, y = setup
+    eng = model._engine
+    B, Fs = c["B"], ds["Fs"]
+    choice = _jsonable(model._resolve_choice(None))  # the module's own sampler, global np.random
+    logits = eng.forward(int_x, cat_x, choice).clone()
+    eng.check_indices()
+    assert torch.equal(logits[2], logits[3])  # identical samples -> identical logits
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+    again = eng.forward(int_x[perm].contiguous(), cat_x[perm].contiguous(), choice)
+    assert torch.equal(again, logits[perm]), "a sample's logit depends on its position in the batch"
+    # fp64 oracle on the engine's weights, 16 samples (ids remapped onto compact copies of the touched rows)
+    n = 16
+    cp = eng.compile(choice, B, train=False)
+    Pm = O.Params(torch.float64)
+    torch.cuda.synchronize()
+    for k in cp.used_params:
+        if not k.startswith("_embedding."):
+            Pm[k] = eng.params[k].detach().double().cpu()
+    cat_small = torch.zeros(n, Fs, dtype=torch.int64)
+    for f in range(Fs):
+        ids, inv = torch.unique(cat_x[:n, f].cpu(), return_inverse=True)
+        Pm["_embedding.%d.weight" % f] = eng.tables[f][ids.cuda()].double().cpu()
+        cat_small[:, f] = inv
+    Pm.frozen = True
+    ocfg = O.NetCfg(7, O.ops_config_lib[c["space"]], True, "relu", fixed=False)
+    ref = O.supernet_forward(Pm, ocfg, int_x[:n].double().cpu(), cat_small, choice).view(-1)
+    tol = 1e-5 * max(1.0, float(ref.abs().max()))
+    err = float((logits[:n].double().cpu().view(-1) - ref).abs().max())
+    assert err <= tol, (err, tol)
+
+
+def test_training_step_is_deterministic_rowsparse_and_leaves_the_unused_supernet_untouched(setup):
+    model, c, ds, tables, int_x, cat_x, y = setup
+    eng = model._engine
+    B, Fs = c["B"], ds["Fs"]
+    choice = _jsonable(model._resolve_choice(None))
+    lr = 1e-3
+    eng.train_step(int_x, cat_x, y, lr, choice=choice)  # allocates the Adagrad state
+    torch.cuda.synchronize()
+    snap = (eng.flat_p.clone(), eng.flat_s.clone(), [t.clone() for t in eng.tables], [t.clone() for t in eng.table_state])
+    results = []
+    for _ in range(2):
+        eng.flat_p.copy_(snap[0])
+        eng.flat_s.copy_(snap[1])
+        for t, s in zip(eng.tables, snap[2]):
+            t.copy_(s)
+        for t, s in zip(eng.table_state, snap[3]):
+            t.copy_(s)
+        loss = eng.train_step(int_x, cat_x, y, lr, choice=choice)
+        torch.cuda.synchronize()
+        results.append((float(loss.item()), eng.flat_p.clone(), [t.clone() for t in eng.tables]))
+    assert results[0][0] == results[1][0] and torch.equal(results[0][1], results[1][1])
+    for a, b in zip(results[0][2], results[1][2]):
+        assert torch.equal(a, b)
+    assert np.isfinite(results[0][0])
+    eng.check_indices()
+    # parameters outside the sampled path: bit-identical value and Adagrad state (torch skips grad=None)
+    cp = eng.compile(choice, B, train=True)
+    trained = set(cp.ctx.grad_params) | {"_final.weight", "_final.bias"}
+    unused = [n for n in eng.dense_names if n not in trained]
+    assert unused, "a sampled path leaves part of the supernet unused"
+    moved_dense = 0
+    for n in eng.dense_names:
+        o = eng.offsets[n]
+        m = eng.params[n].numel()
+        same = torch.equal(snap[0][o:o + m], eng.flat_p[o:o + m])
+        if n in trained:
+            moved_dense += 0 if same else 1
+        else:
+            assert same and torch.equal(snap[1][o:o + m], eng.flat_s[o:o + m]), n
+    assert moved_dense > 0
+    # tables: exactly the batch's rows move, and they follow the dense reference update
+    sg = cp.sparse0.grad_tensor().view(B, Fs, 16).double()
+    coef = float(eng.clip_out[0].item())
+    assert 0.0 < coef <= 1.0
+    for f in range(Fs):
+        before, after = snap[2][f], eng.tables[f]
+        touched = torch.zeros(before.shape[0], dtype=torch.bool, device=before.device)
+        touched[cat_x[:, f]] = True
+        changed = (before != after).any(dim=1)
+        assert not bool((changed & ~touched).any()), "table %d: a row outside the batch changed" % f
+        assert torch.equal(snap[3][f][~touched], eng.table_state[f][~touched])
+        rows, inv = torch.unique(cat_x[:, f], return_inverse=True)
+        g = torch.zeros(rows.numel(), 16, dtype=torch.float64, device=before.device).index_add_(0, inv, sg[:, f]) * coef
+        st = snap[3][f][rows].double() + g * g
+        want = before[rows].double() - lr * g / (st.sqrt() + 1e-2)
+        assert torch.allclose(after[rows].double(), want, rtol=0, atol=2e-7), "table %d" % f
+
+
+def test_data_parallel_code_path_with_sampled_paths_single_rank():
+    """cfg 5's network and batch through DataParallelStep in a single-rank RCCL group with the exchange forced on: per-block
+    gradient buckets, row-gradient all-gather, optimizer over the gathered batch — three steps, a freshly sampled path each —
+    against the plain engine step on a twin model."""
+    import torch.distributed as dist
+    from nasrec_amd.parallel import DataParallelStep
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29547", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        outs = []
+        for force in (False, True):
+            model, c, ds, tables, int_x, cat_x, y = _build("cfg5_kdd_autoctr_b8192", seed=1)
+            eng = model._engine
+            dp = DataParallelStep(eng, None, c["B"], clip=5.0, eps=1e-2, graph=False, force_exchange=force)
+            assert dp.exchange == force
+            nbuckets = []
+            for _ in range(3):
+                ch = _jsonable(model._resolve_choice(None))
+                dp.step(int_x, cat_x, y, 0.01, choice=ch)
+                if force:
+                    plan = dp._last[1]
+                    nbuckets.append(sum(len(r) for _, r in plan.segments))
+                    assert len(plan.segments) == 8  # 7 block boundaries + the rest of the program
+                    sent = sum(n for _, r in plan.segments for _, n in r)
+                    assert 0 < sent < eng.flat_numel, "only the path's parameters travel"
+            torch.cuda.synchronize()
+            eng.check_indices()
+            outs.append((eng.flat_p.clone(), [t.clone() for t in eng.tables]))
+            del model, eng, dp
+            torch.cuda.empty_cache()
+        scale = float(outs[0][0].abs().max())
+        assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-5 * max(1.0, scale)
+        for a, b in zip(outs[0][1], outs[1][1]):
+            assert torch.allclose(a, b, rtol=0, atol=1e-6)
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
