@@ -62,6 +62,41 @@ class CompiledPlan:
     pass
 
 
+class Arena:
+    """Device memory of one plan slot: buffers are bump-allocated out of a few large chunks that live as long as the engine, so
+    compiling a plan costs no allocator calls (a sampled supernet path almost never repeats: every step compiles a plan with
+    ~10^3 buffers of new sizes, which sent the caching allocator to hipMalloc / hipFree and their device synchronisations).
+    Slots are recycled in stream order: a plan's kernels are enqueued behind those of the plan that used the slot before."""
+
+    CHUNK = 256 << 20  # bytes
+
+    def __init__(self, device):
+        self.device = device
+        self.chunks: List[torch.Tensor] = []
+        self.cur, self.off = 0, 0
+
+    def reset(self):
+        self.cur, self.off = 0, 0
+
+    def alloc_bytes(self, nbytes: int) -> torch.Tensor:
+        nbytes = (int(nbytes) + 255) // 256 * 256
+        while True:
+            if self.cur < len(self.chunks):
+                c = self.chunks[self.cur]
+                if self.off + nbytes <= c.numel():
+                    t = c[self.off:self.off + nbytes]
+                    self.off += nbytes
+                    return t
+                self.cur += 1
+                self.off = 0
+                continue
+            self.chunks.append(torch.empty(max(self.CHUNK, nbytes), dtype=torch.uint8, device=self.device))
+
+    def alloc(self, numel: int, dtype=torch.float32) -> torch.Tensor:
+        item = torch.empty((), dtype=dtype).element_size()
+        return self.alloc_bytes(int(numel) * item)[:int(numel) * item].view(dtype)
+
+
 def _on_device(fn):
     """run an engine entry point with the engine's device current: raw kernel launches, memsets, graph capture and event
     creation all act on the CURRENT device, whatever device the caller left selected (main_train.py --gpu N, N != 0)"""
@@ -137,6 +172,7 @@ class SupernetEngine:
         for f in range(Fs):
             self.params["_embedding.%d.weight" % f] = self.tables[f]
         self._plans: Dict[str, CompiledPlan] = {}
+        self._spare_arenas: List[Arena] = []
         self.stream.synchronize()
 
     # -------------------------------------------------------------------------------------------------------
@@ -202,22 +238,36 @@ class SupernetEngine:
         if key in self._plans:
             self._last_plan = (fast, choice, self._plans[key])
             return self._plans[key]
-        if not self.cfg.fixed and len(self._plans) >= 4:  # sampled paths rarely repeat: keep the cache small
-            torch.cuda.synchronize(self.device)
-            self._plans.pop(next(iter(self._plans)))
-            self._last_plan = None
+        arena = None
+        if not self.cfg.fixed:
+            # Sampled paths rarely repeat: a small cache of plan slots, each with its own arena.  Evicting a plan needs no device
+            # synchronisation: its slot is reused by a plan whose kernels are enqueued, in stream order, behind the evicted one's
+            # (a caller that kept an autograd graph on the evicted plan is told so in backward: cp.evicted).
+            if len(self._plans) >= 4:
+                old = self._plans.pop(next(iter(self._plans)))
+                old.evicted = True
+                arena = old.arena
+                old.arena = None
+                self._last_plan = None
+            if arena is None:
+                arena = self._spare_arenas.pop() if self._spare_arenas else Arena(self.device)
+            arena.reset()
         cfg = self.cfg
         with torch.cuda.stream(self.stream):
             cp = CompiledPlan()
+            cp.arena, cp.evicted = arena, False
             ctx = P.Ctx(B, self.device, self.params, self.grads, shape_only=False, train=train)
             ctx.defer_dw = defer_dw
+            ctx.arena = arena
             cp.ctx = ctx
-            cp.int_x = torch.zeros(B, self.Fd, dtype=torch.float32, device=self.device)
-            cp.cat_x = torch.zeros(B, self.Fs, dtype=torch.int64, device=self.device)
-            cp.y = torch.zeros(B, dtype=torch.float32, device=self.device)
-            cp.logits = torch.zeros(B, dtype=torch.float32, device=self.device)
-            cp.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
-            cp.dlogits = torch.zeros(B, dtype=torch.float32, device=self.device)
+            new = (lambda n, dt=torch.float32: arena.alloc(n, dt)) if arena is not None else \
+                (lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device))
+            cp.int_x = new(B * self.Fd).view(B, self.Fd)
+            cp.cat_x = new(B * self.Fs, torch.int64).view(B, self.Fs)
+            cp.y = new(B)
+            cp.logits = new(B)
+            cp.loss = new(1)
+            cp.dlogits = new(B)
             int_buf = P.Buf(ctx, B * self.Fd, need_grad=False, tensor=cp.int_x)
             dense0 = P.DV(int_buf, 0, self.Fd, self.Fd)
             sbuf = ctx.buf(B * self.Fs * E)
@@ -309,7 +359,8 @@ class SupernetEngine:
                     cp.step.capture(self.stream.cuda_stream)
             elif graph:
                 cp.fwd.capture(self.stream.cuda_stream)
-        self.stream.synchronize()  # plans are built (and captured) on the private stream, and replayed on the caller's
+        if graph or arena is None:
+            self.stream.synchronize()  # these plans are built (zero-filled, captured) on the private stream, and replayed on the caller's
         self._plans[key] = cp
         self._last_plan = (fast, choice, cp)
         return cp
@@ -318,11 +369,14 @@ class SupernetEngine:
         """clip_grad_norm_ + Adagrad (train_utils.py:285-286): row-sparse on the tables, flat on the dense arena."""
         descs = []
         nb = (Bg + 255) // 256
-        cp.leader = torch.zeros(Bg * self.Fs, dtype=torch.int32, device=self.device)
-        cp.gsum = torch.zeros(Bg * self.Fs * E, dtype=torch.float32, device=self.device)
-        cp.emb_partial = torch.zeros(self.Fs * nb, dtype=torch.float32, device=self.device)
+        new = getattr(cp, "arena", None)
+        new = (lambda n, dt=torch.float32: cp.arena.alloc(n, dt)) if new is not None else \
+            (lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device))
+        cp.leader = new(Bg * self.Fs, torch.int32)
+        cp.gsum = new(Bg * self.Fs * E)
+        cp.emb_partial = new(self.Fs * nb)
         nblk = max(1, min(256, (self.flat_numel + 256 * 8 - 1) // (256 * 8)))
-        cp.dense_partial = torch.zeros(nblk, dtype=torch.float32, device=self.device)
+        cp.dense_partial = new(nblk)
         if sparse_grad is not None:
             dd = L.EmbDedupDesc()
             dd.kind = L.OP_EMB_DEDUP

@@ -110,6 +110,8 @@ class DataParallelStep:
     def _plan(self, choice) -> DPPlan:
         key = id(choice) if self.fixed else json.dumps(choice, sort_keys=True, default=_jsonable)
         hit = self._plans.get(key)
+        if hit is not None and getattr(getattr(hit, "cp", None), "evicted", False):
+            hit = None  # the engine recycled this plan's slot for another path
         if hit is None:
             if len(self._plans) >= 8:
                 self._plans.pop(next(iter(self._plans)))

@@ -163,12 +163,15 @@ class Ctx:
         self.bwd_tail_start = 0
         self.mha_reduce: List = []  # (MHA backward descriptor, [(grad ptr, column offset, length)]) awaiting the shared reduction
         self.defer_dw = True
+        self.arena = None  # optional Arena (engine.py): where alloc() takes its buffers from
         self.block_marks: List = []  # (block index, length of the backward program once that block's gradients are complete)
 
     # -- memory -----------------------------------------------------------------------------------------------
     def alloc(self, numel):
         if self.shape_only:
             return _FakeTensor()
+        if self.arena is not None:  # bump allocation from the plan slot's arena: no allocator call per buffer
+            return self.arena.alloc(int(numel))
         t = torch.empty(int(numel), dtype=torch.float32, device=self.device)
         self.keep.append(t)
         return t

@@ -74,6 +74,9 @@ class _SupernetFunction(torch.autograd.Function):
     def backward(ctx, dlogits):
         model, cp = ctx.model, ctx.cp
         eng = model._engine
+        if getattr(cp, "evicted", False):
+            raise RuntimeError("the launch plan of this forward was recycled for another sampled path before its backward ran (the "
+                               "engine keeps 4 supernet plans): run backward before sampling further paths")
         if getattr(cp, "generation", 0) != ctx.generation:
             # the activations a backward needs live in the plan's static buffers (one plan per (choice, batch size)): a second
             # grad-enabled forward through the same plan has overwritten them

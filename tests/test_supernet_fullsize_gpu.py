@@ -185,10 +185,12 @@ def test_data_parallel_code_path_with_sampled_paths_single_rank():
             outs.append((eng.flat_p.clone(), [t.clone() for t in eng.tables]))
             del model, eng, dp
             torch.cuda.empty_cache()
+        # same arithmetic, different launch grouping (weight gradients in backward order instead of parked batches): the two runs
+        # agree to 1e-8 per step and drift to ~2e-6 over three steps (measured); a lost or doubled gradient would show as ~1e-3
         scale = float(outs[0][0].abs().max())
         assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-5 * max(1.0, scale)
         for a, b in zip(outs[0][1], outs[1][1]):
-            assert torch.allclose(a, b, rtol=0, atol=1e-6)
+            assert torch.allclose(a, b, rtol=0, atol=2e-5)
     finally:
         if own_pg:
             dist.destroy_process_group()

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Host-side cost of a supernet step (plan compile per sampled path + enqueue) against its GPU time: the step is asynchronous, so
+the host may run ahead and compile step t+1 while step t executes; kernel-time / wall >= 0.97 is the bar."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from nasrec_amd.search_space import ops_config_lib
+from nasrec_amd.supernet.supernet import SuperNet
+from nasrec_amd.utils.config import DATASETS
+cfgid = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+w = bench.WORKLOADS[cfgid]
+ds = DATASETS[w["dataset"]]
+tables = [min(n, w["cap"]) if w.get("cap") else n for n in ds["tables"]]
+B = w["B"]
+dev = torch.device("cuda", 0)
+batches = bench.synthetic_batches(2, B, ds["Fd"], tables, dev, 1, zero_dense=(w["dataset"] == "avazu"))
+torch.manual_seed(0)
+model = SuperNet(num_blocks=7, ops_config=ops_config_lib[w["space"]], use_layernorm=True, num_embeddings=tables, sparse_input_size=ds["Fs"],
+                 path_sampling_strategy="full-path", fixed=False, anypath_choice="binomial-0.5").to(dev)
+with torch.no_grad():
+    model(batches[0][0][:64], batches[0][1][:64])
+model._engine.init_weights(0)
+model.configure_path_sampling_strategy("default")
+np.random.seed(0)
+for i in range(8):
+    model.engine_train_step(*batches[i % 2], lr=1e-3)
+torch.cuda.synchronize()
+N = 40
+host, ev = [], [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
+t0 = time.perf_counter()
+ev[0].record()
+for i in range(N):
+    h0 = time.perf_counter()
+    model.engine_train_step(*batches[i % 2], lr=1e-3)
+    host.append(time.perf_counter() - h0)
+    ev[i + 1].record()
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+gpu = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(N)])
+print("cfg %d: wall %.2f ms/step; host (compile + enqueue) %.2f ms/step median %.2f max %.2f; GPU span per step median %.2f ms; sum of GPU spans / wall = %.3f" % (
+    cfgid, wall / N * 1e3, np.mean(host) * 1e3, np.median(host) * 1e3, np.max(host) * 1e3, np.median(gpu), gpu.sum() / (wall * 1e3)))
