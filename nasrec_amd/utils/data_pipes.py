@@ -259,6 +259,8 @@ def _pipes(args, spec: DatasetSpec):
     assert args.validate_split in ["val", "test"], ValueError("Invalid validation split! Should be in ['val', 'test'].")
     if str(args.root_dir).startswith("synthetic"):
         o = _synthetic_options(args.root_dir)
+        if o.get("cap"):  # synthetic ids for capped tables (the reference caps by editing MAX_NUM_EMBEDDINGS, config.py:17-19)
+            spec = DatasetSpec(spec.name, spec.Fd, spec.Fs, [min(n, o["cap"]) for n in spec.tables], spec.dense_is_zero)
         return ([SyntheticPipe(spec, args.train_batch_size, o["steps"], o["seed"])],
                 [SyntheticPipe(spec, args.test_batch_size, o["test_steps"], o["seed"] + 1)], 1, 1)
     shard_dirs = sorted(glob.glob(os.path.join(args.root_dir, "shard-*")))

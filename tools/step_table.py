@@ -21,7 +21,7 @@ choice = {"macro": ca["macro"], "micro": ca["micro"]}
 cfg = P.NetConfig(ca["num_blocks"], ops_config_lib[ca["config"]], False, "relu", fixed=True)
 eng = SupernetEngine(cfg, 13, 26, NUM_EMBEDDINGS_CRITEO, device=dev, warm_choice=choice)
 eng.init_weights(seed=0)
-bx = bench.synthetic_batches(1, 13, NUM_EMBEDDINGS_CRITEO, dev, 1)[0]
+bx = bench.synthetic_batches(1, B, 13, NUM_EMBEDDINGS_CRITEO, dev, 1)[0]
 eng.train_step(bx[0], bx[1], bx[2], 1e-3, choice=choice)
 cp = eng.compile(choice, B, train=True)
 sp = eng.stream.cuda_stream
