@@ -493,6 +493,10 @@ int nasrec_program_run(void* stream, const void* const* descs, int n);
 
 /* hipGraph capture of a program: capture once, replay many times (launch-bound B=256 step). */
 int nasrec_graph_create(void* stream, const void* const* descs, int n, void** graph_out);
+/* Two-lane capture (dense branch || sparse branch of a choice block): lanes[i] = 0 / 1, or a marker (descs[i] ignored). */
+#define NASREC_LANE_FORK (-1) /* lane 1 continues from lane 0's current position */
+#define NASREC_LANE_JOIN (-2) /* lane 0 waits for lane 1 */
+int nasrec_graph_create_lanes(void* stream, const void* const* descs, const int32_t* lanes, int n, void** graph_out);
 int nasrec_graph_launch(void* graph, void* stream);
 int nasrec_graph_destroy(void* graph);
 

@@ -175,9 +175,11 @@ DESC_BY_KIND = {
     OP_SAMPLE_CHAIN: ChainDesc,
 }
 
+LANE_FORK, LANE_JOIN = -1, -2  # nasrec_graph_create_lanes markers
+
 # every symbol include/nasrec_hip.h declares
 SYMBOLS = [
-    "nasrec_launch", "nasrec_program_run", "nasrec_graph_create", "nasrec_graph_launch", "nasrec_graph_destroy", "nasrec_gemm",
+    "nasrec_launch", "nasrec_program_run", "nasrec_graph_create", "nasrec_graph_create_lanes", "nasrec_graph_launch", "nasrec_graph_destroy", "nasrec_gemm",
     "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm", "nasrec_mha_ffn", "nasrec_layernorm",
     "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense", "nasrec_adagrad_rows", "nasrec_opt_reduce",
     "nasrec_opt_apply", "nasrec_sample_chain", "nasrec_event_create",
@@ -208,6 +210,7 @@ def load():
     lib.nasrec_launch.argtypes = [vp, vp]
     lib.nasrec_program_run.argtypes = [vp, C.POINTER(vp), C.c_int]
     lib.nasrec_graph_create.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp)]
+    lib.nasrec_graph_create_lanes.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.c_int, C.POINTER(vp)]
     lib.nasrec_graph_launch.argtypes = [vp, vp]
     lib.nasrec_graph_destroy.argtypes = [vp]
     lib.nasrec_event_create.argtypes = [C.POINTER(vp)]

@@ -31,11 +31,13 @@ def _ptr_array(descs):
 class Program:
     """An ordered list of descriptors; runs with one host call (nasrec_program_run) or as a captured hipGraph."""
 
-    def __init__(self, descs: List):
+    def __init__(self, descs: List, sched: Optional[List] = None):
+        """sched: optional two-lane schedule [(lane | LANE_FORK | LANE_JOIN, index into descs)] used when the program is captured"""
         self.descs = list(descs)
         self.arr = _ptr_array(self.descs)
         self.n = len(self.descs)
         self.graph = None
+        self.sched = sched if (sched and os.environ.get("NASREC_LANES", "0") == "1") else None
 
     def run(self, stream_ptr):
         lib = L.load()
@@ -44,7 +46,15 @@ class Program:
     def capture(self, stream_ptr):
         lib = L.load()
         g = C.c_void_p()
-        L.check(lib.nasrec_graph_create(stream_ptr, self.arr, self.n, C.byref(g)))
+        if self.sched is not None and any(lane < 0 for lane, _ in self.sched):
+            m = len(self.sched)
+            arr, lanes = (C.c_void_p * m)(), (C.c_int32 * m)()
+            for k, (lane, idx) in enumerate(self.sched):
+                arr[k] = C.addressof(self.descs[idx]) if idx >= 0 else None
+                lanes[k] = lane
+            L.check(lib.nasrec_graph_create_lanes(stream_ptr, arr, lanes, m, C.byref(g)))
+        else:
+            L.check(lib.nasrec_graph_create(stream_ptr, self.arr, self.n, C.byref(g)))
         self.graph = g
 
     def replay(self, stream_ptr):
@@ -306,7 +316,8 @@ class SupernetEngine:
             ctx.emit(fd)
             if cfg.use_final_sigmoid:
                 raise NotImplementedError("use_final_sigmoid is never enabled by the reference CLIs")
-            cp.fwd = Program(P.fuse_sample_chains(ctx.fwd, B) if self.fuse_chains else ctx.fwd)
+            fwd_sched = None if self.fuse_chains else list(ctx.fwd_sched)
+            cp.fwd = Program(P.fuse_sample_chains(ctx.fwd, B) if self.fuse_chains else ctx.fwd, fwd_sched)
             cp.used_params = list(ctx.used_params)
             if train:
                 self._ensure_table_state()
@@ -355,7 +366,11 @@ class SupernetEngine:
                 cp.bwd_final_only = Program(pre[1:] + [last])
                 cp.opt = Program(self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if sbuf.grad_written else None, clip, eps))
                 if graph:
-                    cp.step = Program(cp.fwd.descs + cp.bwd.descs + cp.opt.descs)
+                    nf = len(cp.fwd.descs)
+                    sched = None
+                    if fwd_sched is not None:
+                        sched = fwd_sched + [(0, nf + i) for i in range(len(cp.bwd.descs) + len(cp.opt.descs))]
+                    cp.step = Program(cp.fwd.descs + cp.bwd.descs + cp.opt.descs, sched)
                     cp.step.capture(self.stream.cuda_stream)
             elif graph:
                 cp.fwd.capture(self.stream.cuda_stream)

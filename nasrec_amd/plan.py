@@ -163,6 +163,8 @@ class Ctx:
         self.bwd_tail_start = 0
         self.mha_reduce: List = []  # (MHA backward descriptor, [(grad ptr, column offset, length)]) awaiting the shared reduction
         self.defer_dw = True
+        self.lane = 0        # lane of the forward descriptors being emitted (0 = main, 1 = the block's sparse branch)
+        self.fwd_sched: List = []  # [(lane | LANE_FORK | LANE_JOIN, index into self.fwd)] in emission order
         self.arena = None  # optional Arena (engine.py): where alloc() takes its buffers from
         self.block_marks: List = []  # (block index, length of the backward program once that block's gradients are complete)
 
@@ -209,6 +211,19 @@ class Ctx:
     def emit(self, desc):
         if not self.shape_only:
             self.out.append(desc)
+            if self.out is self.fwd:
+                self.fwd_sched.append((self.lane, len(self.fwd) - 1))
+
+    # Two-lane schedule of the FORWARD program (graph capture only, api.hip nasrec_graph_create_lanes): inside a choice block the
+    # dense nodes and the sparse nodes are independent until the block's merge, so they are captured as sibling branches.
+    def fork(self):
+        if not self.shape_only:
+            self.fwd_sched.append((L.LANE_FORK, -1))
+
+    def join(self):
+        if not self.shape_only:
+            self.fwd_sched.append((L.LANE_JOIN, -1))
+            self.lane = 0
 
     def on_backward(self, fn):
         if self.train and not self.shape_only:
@@ -1104,6 +1119,7 @@ def block_walk(ctx, cfg, pre, ops, choice, d_in, Dtot, s_in, Ntot, l_in, Ltot, r
         dense_out = DV(dbuf, 0, max_dense, max_dense)
     act = L.ACT_BY_NAME[cfg.activation]
 
+    ctx.fork()  # the sparse nodes below (lane 1) only read previous blocks' outputs and write their own rows of the sparse slab
     # ---- dense nodes: sum of node outputs (supernet.py:1133 / 1215) --------------------------------------------
     real_dense = [n for n in dense_nodes if names[n] != "zeros-2d"]
     n_contrib = len(real_dense) + (1 if deep_fm else 0)
@@ -1151,6 +1167,7 @@ def block_walk(ctx, cfg, pre, ops, choice, d_in, Dtot, s_in, Ntot, l_in, Ltot, r
     node_sum = pre_fm if pre_fm is not None else dense_out  # pre-FM value of the block's dense output
 
     # ---- sparse nodes ------------------------------------------------------------------------------------------
+    ctx.lane = 1
     real_sparse = [n for n in sparse_nodes if names[n] != "zeros-3d"]
     wrote_s = False
     for n in range(ops["num_nodes"]):
@@ -1175,6 +1192,7 @@ def block_walk(ctx, cfg, pre, ops, choice, d_in, Dtot, s_in, Ntot, l_in, Ltot, r
     if not wrote_s:
         zero_fill(ctx, sparse_nodes_out.dense())
 
+    ctx.join()  # the merges read both branches
     # ---- dense -> sparse merge (supernet.py:1137-1150 / 1218-1231) --------------------------------------------
     if extra:
         proj_rows = sparse_all.rows(max_sparse, DS_INTERACT_NUM_SPLITS).dense()  # [B,128] view into the sparse slab

@@ -158,7 +158,7 @@ def test_search_candidates_are_scored_by_last_layer_finetuning(monkeypatch):
         "--dataset", "kdd", "--root_dir", "synthetic:steps=8,test_steps=2,seed=5,cap=1000", "--logging_dir", "/tmp/nasrec_search_test",
         "--config", "autoctr", "--num_blocks", "3", "--use_layernorm", "1", "--max_train_steps", "4", "--max_eval_steps", "2",
         "--train_batch_size", "64", "--test_batch_size", "64", "--method", "random", "--random_budget", "3", "--learning_rate", "0.05",
-        "--display_interval", "2"])
+        "--display_interval", "2", "--test_only_at_last_step", "1"])  # as scripts/run_ea/*.sh: one test per candidate
     args.num_embeddings = tables
     # the supernet checkpoint every candidate starts from
     torch.manual_seed(3)
