@@ -123,7 +123,10 @@ def _on_device(fn):
 
 class SupernetEngine:
     def __init__(self, cfg: P.NetConfig, Fd: int, Fs: int, num_embeddings: List[int], device="cuda:0", warm_choice=None,
-                 world_size: int = 1, tables: Optional[List[torch.Tensor]] = None):
+                 world_size: int = 1, tables: Optional[List[torch.Tensor]] = None, host_embedding: bool = False):
+        """host_embedding: the tables live in host memory (SuperNet(place_embedding_on_cpu=True), supernet.py:231,418-428): the engine
+        holds no table, the caller hands the looked-up rows [B, Fs, 16] to every forward and receives their gradient; only the
+        forward / backward programs are available in this mode (the fused optimizer step needs the tables on the device)."""
         L.load()
         if not torch.cuda.is_available():
             raise L.EngineError("SupernetEngine needs a GPU: there is no CPU fallback")
@@ -157,7 +160,10 @@ class SupernetEngine:
             self.flat_p = torch.zeros(off, dtype=torch.float32, device=self.device)
             self.flat_g = torch.zeros(off, dtype=torch.float32, device=self.device)
             self.flat_s = torch.zeros(off, dtype=torch.float32, device=self.device)
-            if tables is not None:  # adopt the caller's nn.Embedding storage (no copy; PyTorch keeps ownership)
+            self.host_embedding = bool(host_embedding)
+            if self.host_embedding:
+                self.tables = []
+            elif tables is not None:  # adopt the caller's nn.Embedding storage (no copy; PyTorch keeps ownership)
                 for t, n in zip(tables, self.num_embeddings):
                     assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (n, E)
                 self.tables = list(tables)
@@ -179,7 +185,7 @@ class SupernetEngine:
             self.params[n] = self.flat_p[o:o + numel].view(shp)
             self.grads[n] = self.flat_g[o:o + numel].view(shp)
             self.state[n] = self.flat_s[o:o + numel].view(shp)
-        for f in range(Fs):
+        for f in range(len(self.tables)):
             self.params["_embedding.%d.weight" % f] = self.tables[f]
         self._plans: Dict[str, CompiledPlan] = {}
         self._spare_arenas: List[Arena] = []
@@ -287,11 +293,12 @@ class SupernetEngine:
             g.kind = L.OP_EMBED_GATHER
             g.B, g.Fs = B, self.Fs
             g.idx = cp.cat_x.data_ptr()
-            for f in range(self.Fs):
-                g.table[f] = self.tables[f].data_ptr()
-                g.rows[f] = self.num_embeddings[f]
-            g.out = sbuf.t.data_ptr()
-            g.oob = self.oob.data_ptr()
+            if not self.host_embedding:
+                for f in range(self.Fs):
+                    g.table[f] = self.tables[f].data_ptr()
+                    g.rows[f] = self.num_embeddings[f]
+                g.out = sbuf.t.data_ptr()
+                g.oob = self.oob.data_ptr()
             # the gather rides on the per-step staging launch (which holds the caller's id tensor anyway); cp.gather is the
             # stand-alone descriptor for the paths that stage by other means
             cp.gather = g
@@ -299,7 +306,8 @@ class SupernetEngine:
             st.kind = L.OP_STAGE_INPUTS
             st.B, st.Fd, st.Fs = B, self.Fd, self.Fs
             st.int_dst, st.cat_dst, st.y_dst = cp.int_x.data_ptr(), cp.cat_x.data_ptr(), cp.y.data_ptr()
-            st.gather = g
+            if not self.host_embedding:
+                st.gather = g
             cp.stage = st
             d_last, s_last = P.network_walk(ctx, cfg, choice, dense0, sparse0)
             # final logit (supernet.py:592-598 / 657-664)
@@ -364,7 +372,8 @@ class SupernetEngine:
                 for q in range(L.MAX_SEGS):
                     last.dseg[q] = None
                 cp.bwd_final_only = Program(pre[1:] + [last])
-                cp.opt = Program(self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if sbuf.grad_written else None, clip, eps))
+                cp.opt = Program(self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if (sbuf.grad_written and not self.host_embedding)
+                                                       else None, clip, eps))
                 if graph:
                     nf = len(cp.fwd.descs)
                     sched = None
@@ -448,8 +457,13 @@ class SupernetEngine:
         and ~10 us of GPU idle); the private stream only builds and captures plans."""
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def _stage_inputs(self, sp, cp, int_x, cat_x, y=None, lr=None):
-        """one launch: batch -> the plan's static buffers (+ this step's learning rate -> device scalar)"""
+    def _stage_inputs(self, sp, cp, int_x, cat_x, y=None, lr=None, rows=None):
+        """one launch: batch -> the plan's static buffers (+ this step's learning rate -> device scalar); host_embedding: the
+        looked-up rows [B, Fs, 16] come with the batch"""
+        if self.host_embedding:
+            if rows is None:
+                raise L.EngineError("this engine holds no embedding table (place_embedding_on_cpu): pass the looked-up rows")
+            cp.sparse0.t.copy_(rows.reshape(-1).to(torch.float32), non_blocking=True)
         ok = (int_x.is_cuda and cat_x.is_cuda and int_x.dtype == torch.float32 and cat_x.dtype == torch.int64
               and int_x.is_contiguous() and cat_x.is_contiguous()
               and (y is None or (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous())))
@@ -460,7 +474,8 @@ class SupernetEngine:
                 cp.y.copy_(y.reshape(cp.y.shape), non_blocking=True)
             if lr is not None:
                 self.lr_dev.fill_(float(lr))
-            L.check(L.load().nasrec_launch(sp, C.addressof(cp.gather)))
+            if not self.host_embedding:
+                L.check(L.load().nasrec_launch(sp, C.addressof(cp.gather)))
             return
         d = cp.stage  # prebuilt per plan: only the sources change from step to step
         d.int_src, d.cat_src = int_x.data_ptr(), cat_x.data_ptr()
@@ -472,13 +487,13 @@ class SupernetEngine:
         L.check(L.load().nasrec_launch(sp, C.addressof(d)))
 
     @_on_device
-    def forward(self, int_x, cat_x, choice=None, graph=False):
+    def forward(self, int_x, cat_x, choice=None, graph=False, rows=None):
         """logits [B,1] for the given choice (fixed mode: the fixed choice)."""
         choice = choice if choice is not None else self.warm_choice
         B = int(int_x.shape[0])
         cp = self.compile(choice, B, train=False, graph=graph)
         sp = self._sp()
-        self._stage_inputs(sp, cp, int_x, cat_x)
+        self._stage_inputs(sp, cp, int_x, cat_x, rows=rows)
         if graph:
             cp.fwd.replay(sp)
         else:
@@ -491,6 +506,9 @@ class SupernetEngine:
         """zero_grad -> forward -> BCE -> backward -> clip_grad_norm_ -> Adagrad (train_utils.py:262-286).
         Returns the (device) loss tensor of this step.  `staged`: inputs are already in the plan's static buffers."""
         choice = choice if choice is not None else self.warm_choice
+        if self.host_embedding:
+            raise L.EngineError("the fused training step needs the embedding tables on the device (place_embedding_on_cpu keeps them "
+                                "on the host): use the nn.Module path (forward / backward / torch optimizer)")
         if int_x is not None:
             B = int(int_x.shape[0])
         else:  # pre-staged inputs: the batch size is the one of the plan they were staged into
@@ -512,10 +530,10 @@ class SupernetEngine:
         return cp.loss
 
     @_on_device
-    def run_forward(self, cp, int_x, cat_x):
+    def run_forward(self, cp, int_x, cat_x, rows=None):
         """forward program of an already compiled (training) plan; logits land in cp.logits"""
         sp = self._sp()
-        self._stage_inputs(sp, cp, int_x, cat_x)
+        self._stage_inputs(sp, cp, int_x, cat_x, rows=rows)
         cp.fwd.run(sp)
 
     @_on_device

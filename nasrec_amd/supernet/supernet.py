@@ -61,11 +61,14 @@ class _SupernetFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward = forward program, backward = backward program."""
 
     @staticmethod
-    def forward(ctx, model, choice, int_x, cat_x, *params):
+    def forward(ctx, model, choice, int_x, cat_x, rows, *params):
+        """rows: None, or (place_embedding_on_cpu) the looked-up embedding rows [B, Fs, 16] — then a differentiable input whose
+        gradient torch carries back to the host tables"""
         eng = model._engine
         B = int(int_x.shape[0])
         cp = eng.compile(choice, B, train=True)
-        eng.run_forward(cp, int_x, cat_x)
+        eng.run_forward(cp, int_x, cat_x, rows=rows)
+        ctx.has_rows = rows is not None
         cp.generation = getattr(cp, "generation", 0) + 1
         ctx.model, ctx.cp, ctx.cat_x, ctx.generation = model, cp, cat_x, cp.generation
         return cp.logits.view(B, 1).clone()
@@ -102,7 +105,8 @@ class _SupernetFunction(torch.autograd.Function):
                 grads.append(eng.grads[name].clone())
             else:
                 grads.append(None)  # dead branch or unused parameter: autograd leaves .grad = None
-        return (None, None, None, None) + tuple(grads)
+        drows = sg.clone() if (ctx.has_rows and sg is not None) else None
+        return (None, None, None, None, drows) + tuple(grads)
 
 
 class SuperNet(nn.Module):
@@ -115,9 +119,6 @@ class SuperNet(nn.Module):
                  candidate_choices: Optional[List] = None, use_final_sigmoid: bool = False):
         super().__init__()
         assert num_blocks >= 1, ValueError("Supernet must contain a minimum of 1 block, but found {}!".format(num_blocks))
-        if place_embedding_on_cpu:
-            raise NotImplementedError("place_embedding_on_cpu is a memory-saving fallback of the reference that no script "
-                                      "uses (supernet.py:253-254); 288 GB of HBM hold every table")
         self._num_blocks = num_blocks
         self._ops_config = ops_config
         self._use_layernorm = use_layernorm
@@ -334,9 +335,10 @@ class SuperNet(nn.Module):
         from ..engine import SupernetEngine
         params = dict(self.named_parameters())
         Fd = self._Fd
+        host = bool(self._place_embedding_on_cpu)
         eng = SupernetEngine(self._net_config(), Fd, self._sparse_input_size, self._num_embeddings, device=device,
-                             warm_choice=self._warm_choice(), tables=[params["_embedding.%d.weight" % f].data
-                                                                      for f in range(self._sparse_input_size)])
+                             warm_choice=self._warm_choice(), host_embedding=host,
+                             tables=None if host else [params["_embedding.%d.weight" % f].data for f in range(self._sparse_input_size)])
         eng.load_params({k: v.data for k, v in params.items() if not k.startswith("_embedding.")})
         # re-point every dense nn.Parameter at the engine's flat arena (optimizers update in place; kernels read the
         # same bytes each step — SURVEY §8b "no engine-side copy of weights may go stale")
@@ -344,7 +346,7 @@ class SuperNet(nn.Module):
             if not name.startswith("_embedding."):
                 p.data = eng.params[name]
         self._engine = eng
-        self._param_names = list(self.named_parameters())
+        self._param_names = [(n, p) for n, p in self.named_parameters() if not (host and n.startswith("_embedding."))]
         st = self.__dict__.pop("_stashed_opt_state", None)
         if st is not None:  # accumulators of the engine this one replaces
             eng._ensure_table_state()
@@ -363,8 +365,8 @@ class SuperNet(nn.Module):
             raise EngineError("SuperNet.forward runs on the HIP engine: move the model and its inputs to a GPU "
                               "(there is no CPU fallback)")
         if self._engine is None or self._engine.device != dev:
-            if next(self.parameters()).device != dev:
-                super().to(dev)
+            if self._final.weight.device != dev:
+                self.to(dev)
             self._bind_engine(dev)
 
     def __deepcopy__(self, memo):
@@ -381,6 +383,14 @@ class SuperNet(nn.Module):
         return new  # the copy re-binds its own engine at its next forward
 
     def to(self, *args, **kwargs):
+        if self._place_embedding_on_cpu:
+            # supernet.py:826-840: every layer but the embeddings follows the device
+            self._engine = None
+            for name, child in self.named_children():
+                if name != "_embedding":
+                    child.to(*args, **kwargs)
+            self._device_args = args
+            return self
         eng = self._engine
         before = [p.data_ptr() for p in self.parameters() if not isinstance(p, nn.parameter.UninitializedParameter)] if eng is not None else None
         out = super().to(*args, **kwargs)
@@ -420,11 +430,17 @@ class SuperNet(nn.Module):
         choice = self._resolve_choice(choices)  # host-side bookkeeping first: a fixed net may sample its path here
         self._ensure_engine(int_feats)
         eng = self._engine
+        rows = None
+        if self._place_embedding_on_cpu:
+            # supernet.py:418-428: ids to the host, lookup in host memory, rows to the device ("10~100x slow down", :253-254) — the
+            # one place where the reference itself runs the stem on the CPU; everything downstream stays on the engine
+            ids = cat_feats.cpu()
+            rows = torch.stack([emb(ids[:, f]) for f, emb in enumerate(self._embedding)], dim=1).to(int_feats.device)
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for _, p in self._param_names)
         if needs_grad:
-            out = _SupernetFunction.apply(self, choice, int_feats, cat_feats, *[p for _, p in self._param_names])
+            out = _SupernetFunction.apply(self, choice, int_feats, cat_feats, rows, *[p for _, p in self._param_names])
         else:
-            out = eng.forward(int_feats, cat_feats, choice).clone()
+            out = eng.forward(int_feats, cat_feats, choice, rows=rows).clone()
         if self._final_sigmoid is not None:
             out = self._final_sigmoid(out)
         return out
@@ -435,6 +451,10 @@ class SuperNet(nn.Module):
     def engine_train_step(self, int_feats, cat_feats, y, lr: float, clip: Optional[float] = 5.0, eps: float = 1e-2, graph=None):
         """Fused step on the engine (forward, BCE, backward, clip_grad_norm_, Adagrad with row-sparse table update):
         the counterpart of train_utils.py:262-286 for optimizer == Adagrad, weight_decay == 0."""
+        if self._place_embedding_on_cpu:
+            from .._lib import EngineError
+            raise EngineError("engine_train_step needs the tables on the device; with place_embedding_on_cpu use forward / backward "
+                              "and a torch optimizer")
         choice = self._resolve_choice(None)
         self._ensure_engine(int_feats)
         graph = self._fixed if graph is None else graph

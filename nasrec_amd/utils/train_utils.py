@@ -93,6 +93,8 @@ test_one_epoch.__test__ = False  # not a pytest test
 def _fused_step_applies(model, optimizer, l2_loss_fn, use_amp):
     if use_amp or not hasattr(model, "engine_train_step") or type(optimizer) is not torch.optim.Adagrad:
         return False
+    if getattr(model, "_place_embedding_on_cpu", False):
+        return False  # the tables stay on the host: torch's optimizer updates them there
     for g in optimizer.param_groups:
         if g.get("weight_decay", 0) != 0 or g.get("lr_decay", 0) != 0 or g.get("initial_accumulator_value", 0) != 0 or g.get("maximize", False):
             return False

@@ -490,6 +490,7 @@ path_sampling_strategy_lib = {  # supernet.py:188-207
     "any-path": ("any-path", "any-path"),
     "full-path": ("full-path", "full-path"),
     "fixed-path": ("fixed-path", "fixed-path"),
+    "evo-2shot-path": ("evo-2shot-path", "evo-2shot-path"),
 }
 
 
@@ -551,8 +552,9 @@ class PathSampler:
     micro draw)."""
 
     def __init__(self, cfg: NetCfg, strategy: str = "default", anypath_choice: str = "uniform",
-                 supernet_training_steps: int = 0):
+                 supernet_training_steps: int = 0, candidate_choices: Optional[list] = None):
         self.cfg = cfg
+        self.candidates = candidate_choices
         self.macro_strategy, self.micro_strategy = path_sampling_strategy_lib[strategy]
         self.fn = anypath_choice_fn[anypath_choice]
         self.steps = supernet_training_steps
@@ -574,6 +576,10 @@ class PathSampler:
             macro = [macro_full(1 + i) for i in range(nb)] if np.random.random() < th else [macro_any(1 + i, self.fn) for i in range(nb)]
         elif self.macro_strategy == "full-path":
             macro = [macro_full(1 + i) for i in range(nb)]
+        elif self.macro_strategy == "evo-2shot-path":  # :492-500: one of the candidate architectures, macro and micro together
+            cand = self.candidates[np.random.randint(len(self.candidates))]["choice"]
+            self.block_counter = [c + 1 for c in self.block_counter]
+            return {"macro": cand["macro"], "micro": list(cand["micro"])}
         else:
             raise NotImplementedError(self.macro_strategy)
         micro = []

@@ -245,6 +245,27 @@ def sampler_traces():
                             seq.append(clean_choice(m.choice))
                     out.append(dict(space=space, num_blocks=nb, strategy=strategy, anypath_choice=anypath,
                                     supernet_training_steps=steps, seed=seed, warmup_forwards=1, choices=seq))
+    # evo-2shot-path (supernet.py:492-500): every forward draws one of the candidate architectures with np.random.randint
+    cands = []
+    np.random.seed(99)
+    probe = SuperNet(num_blocks=3, ops_config=ops_config_lib["autoctr"], use_layernorm=True, num_embeddings=tables, sparse_input_size=d["Fs"],
+                     path_sampling_strategy="single-path", fixed=False)
+    with torch.no_grad():
+        for _ in range(5):
+            probe(int_x, cat_x)
+            cands.append({"choice": clean_choice(probe.choice)})
+    m = SuperNet(num_blocks=3, ops_config=ops_config_lib["autoctr"], use_layernorm=True, num_embeddings=tables, sparse_input_size=d["Fs"],
+                 path_sampling_strategy="full-path", fixed=False, candidate_choices=cands)
+    with torch.no_grad():
+        m(int_x, cat_x)
+        m.configure_path_sampling_strategy("evo-2shot-path")
+        np.random.seed(123)
+        seq = []
+        for _ in range(10):
+            m(int_x, cat_x)
+            seq.append(clean_choice(m.choice))
+    out.append(dict(space="autoctr", num_blocks=3, strategy="evo-2shot-path", anypath_choice="uniform", supernet_training_steps=0, seed=123,
+                    warmup_forwards=1, choices=seq, candidate_choices=cands))
     json.dump(out, open(os.path.join(OUT, "samplers.json"), "w"))
     print("wrote samplers.json", len(out), "traces")
 

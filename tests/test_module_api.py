@@ -44,7 +44,8 @@ def test_sampling_order_matches_reference_traces():
     for tr in traces:
         m = SuperNet(num_blocks=tr["num_blocks"], ops_config=ops_config_lib[tr["space"]], use_layernorm=True,
                      num_embeddings=[50] * 10, sparse_input_size=10, path_sampling_strategy="full-path", fixed=False,
-                     anypath_choice=tr["anypath_choice"], supernet_training_steps=tr["supernet_training_steps"])
+                     anypath_choice=tr["anypath_choice"], supernet_training_steps=tr["supernet_training_steps"],
+                     candidate_choices=tr.get("candidate_choices"))
         for _ in range(tr["warmup_forwards"]):
             m._resolve_choice(None)  # the full-path warm-up forward advances every counter
         m.configure_path_sampling_strategy(tr["strategy"])

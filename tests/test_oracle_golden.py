@@ -82,7 +82,7 @@ def test_sampler_traces():
     assert len(traces) >= 30
     for tr in traces:
         cfg = O.NetCfg(tr["num_blocks"], O.ops_config_lib[tr["space"]], True)
-        s = O.PathSampler(cfg, tr["strategy"], tr["anypath_choice"], tr["supernet_training_steps"])
+        s = O.PathSampler(cfg, tr["strategy"], tr["anypath_choice"], tr["supernet_training_steps"], tr.get("candidate_choices"))
         # one full-path warm-up forward advanced every counter by one (train_utils.py:431-432)
         s.net_counter += tr["warmup_forwards"]
         s.block_counter = [c + tr["warmup_forwards"] for c in s.block_counter]
