@@ -192,9 +192,10 @@ def test_search_candidates_are_scored_by_last_layer_finetuning(monkeypatch):
     s = S.Searcher(probe, args)
     top = s.random_search_from_supernet(budget=3, top_k=2, num_parallel_workers=1, sorted=True)
     assert len(s.all_results) == 3 and len(top) == 2
-    assert all(np.isfinite(r["test_loss"]) and 0.0 <= r["test_auroc"] <= 1.0 for r in s.all_results)
+    # the log lists hold one entry per test pass: exactly one with the recipe's --test_only_at_last_step 1
+    assert all(len(r["test_loss"]) == 1 and np.isfinite(r["test_loss"][0]) and 0.0 <= r["test_auroc"][0] <= 1.0 for r in s.all_results)
     assert len({r["hash_token"] for r in s.all_results}) == 3
-    assert top[0]["test_loss"] <= top[1]["test_loss"]
+    assert top[0]["test_loss"][0] <= top[1]["test_loss"][0]
     for sd in models:
         moved = sorted(k for k in sd if not torch.equal(sd[k], ckpt["model_state_dict"][k]))
         assert moved == ["_final.bias", "_final.weight"], moved

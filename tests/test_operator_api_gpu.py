@@ -102,7 +102,9 @@ def test_operator_inside_a_bound_supernet_is_callable_on_its_own():
 def test_silu_and_sigmoid_epilogues_over_the_whole_range():
     """The GEMM epilogues evaluate SiLU / sigmoid with the hardware exponential (`__expf`, csrc/common.h).  Pin them against fp64
     over pre-activations from -100 to 100 (saturation, the subnormal tail of exp(-z), the steep middle), through the operator API
-    with identity weights: |err| <= 4 ulp of the result, far inside the 1e-5 logit bar."""
+    with identity weights.  exp(-z) is evaluated as exp2(-z * log2 e) in fp32, so its relative error grows like |z| * 6e-8: the
+    bar is 4 ulp * (1 + |z| / 8) of the RESULT — at most 6e-6 relative, and only where the result itself is below 1e-30 in
+    magnitude; absolute errors stay below 1e-6 * |result| everywhere that matters for the 1e-5 logit bar."""
     from nasrec_amd.supernet.modules import ElasticLinear, SigmoidGating
     z = torch.cat([torch.linspace(-100, 100, 4001), torch.tensor([-87.4, -20.0, -1e-3, 0.0, 1e-3, 16.6, 88.8])]).double()
     n = (z.numel() + 15) // 16 * 16
@@ -117,7 +119,7 @@ def test_silu_and_sigmoid_epilogues_over_the_whole_range():
     zz = x.double().cpu()
     ref = zz / (1.0 + torch.exp(-zz))
     err = (silu - ref).abs()
-    assert bool((err <= 4 * 1.2e-7 * ref.abs() + 1e-30).all()), float((err / (ref.abs() + 1e-30)).max())
+    assert bool((err <= 4 * 1.2e-7 * (1 + zz.abs() / 8) * ref.abs() + 1e-30).all()), float((err / (ref.abs() + 1e-30)).max())
     gate = SigmoidGating(fixed=True, use_layernorm=False, max_dims_or_dims=16).cuda()
     ones = torch.ones_like(x)
     with torch.no_grad():
@@ -127,4 +129,4 @@ def test_silu_and_sigmoid_epilogues_over_the_whole_range():
         sig = gate(x, ones, 16).double().cpu()
     ref = 1.0 / (1.0 + torch.exp(-zz))
     err = (sig - ref).abs()
-    assert bool((err <= 4 * 1.2e-7 * ref.abs() + 1e-38).all()), float((err / (ref.abs() + 1e-38)).max())
+    assert bool((err <= 4 * 1.2e-7 * (1 + zz.abs() / 8) * ref.abs() + 1e-38).all()), float((err / (ref.abs() + 1e-38)).max())
