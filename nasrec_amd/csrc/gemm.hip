@@ -11,10 +11,19 @@
 // The k index inside a 16-deep tile is permuted (lane group g takes k = 4g..4g+3 as one ds_read_b128)
 // identically for A and B, which only reorders the fp32 summation.
 #include "gemm_tile.h"
+#include "gemm_ring.h"
 
 template <int AM, int BMODE, int CM, int NT, int TK, int TBM, int TBN>
 __global__ __launch_bounds__(NT) void gemm_kernel(const nasrec_gemm_desc_t d, int Mmax, int Nmax) {
   gemm_tile<AM, BMODE, CM, NT, TK, TBM, TBN>(d, Mmax, Nmax, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+#ifndef GEMM_RING
+#define GEMM_RING 4  // staged k-tiles in flight per workgroup in the latency-regime configurations (gemm_ring.h)
+#endif
+template <int AM, int BMODE, int CM, int NT, int TK, int TBM, int TBN, bool AUX>
+__global__ __launch_bounds__(NT) void gemm_ring_kernel(const nasrec_gemm_desc_t d, int Mmax, int Nmax) {
+  gemm_tile_ring<AM, BMODE, CM, NT, TK, TBM, TBN, AUX, AUX ? 2 : GEMM_RING>(d, Mmax, Nmax, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // second pass of split-K: fixed-order sum of the partial slabs, then the same epilogue
@@ -60,6 +69,25 @@ static void launch_cfg(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, in
   hipLaunchKernelGGL((gemm_kernel<AM, BMODE, CM, NT, TK, TBM, TBN>), grid, dim3(NT), 0, st, *d, Mmax, Nmax);
 }
 
+// latency-regime configurations run the ring variant unless the launch's k-segments disagree on the row predicates
+template <int AM, int BMODE, int CM, int NT, int TK, int TBM, int TBN>
+static void launch_ring(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, int Nmax, int zdim) {
+  bool aux = false, uniform = true;
+  for (int q = 0; q < d->nseg; ++q) {
+    aux = aux || d->seg[q].Aaux || d->seg[q].Baux;
+    if (!d->zmode && (d->seg[q].ones_col != d->seg[0].ones_col || d->seg[q].Mvalid != d->seg[0].Mvalid)) uniform = false;
+  }
+  if (!uniform || !GEMM_RING) {
+    launch_cfg<AM, BMODE, CM, NT, TK, TBM, TBN>(st, d, Mmax, Nmax, zdim);
+    return;
+  }
+  dim3 grid((Nmax + TBN - 1) / TBN, (Mmax + TBM - 1) / TBM, zdim);
+  if (aux)
+    hipLaunchKernelGGL((gemm_ring_kernel<AM, BMODE, CM, NT, TK, TBM, TBN, true>), grid, dim3(NT), 0, st, *d, Mmax, Nmax);
+  else
+    hipLaunchKernelGGL((gemm_ring_kernel<AM, BMODE, CM, NT, TK, TBM, TBN, false>), grid, dim3(NT), 0, st, *d, Mmax, Nmax);
+}
+
 template <int AM, int BMODE, int CM>
 static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
   int Mmax = 0, Nmax = 0, Kmax = 0;
@@ -87,18 +115,18 @@ static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
       // a batch of independent products of very different sizes (the parked weight gradients): 32x32 tiles give 4x the
       // workgroups, which balances the batch over the CUs (dense batch 24.7 -> 17.9 us, token batch 22.8 -> 16.1 us);
       // on a single large product the same tiles are 1-3 us slower than 64x64
-      launch_cfg<AM, BMODE, CM, 256, GEMM_TK_DEEP, 32, 32>(st, d, Mmax, Nmax, zdim);
+      launch_ring<AM, BMODE, CM, 256, GEMM_TK_DEEP, 32, 32>(st, d, Mmax, Nmax, zdim);
     } else if (deep) {
-      launch_cfg<AM, BMODE, CM, GEMM_MID_NT, GEMM_TK_DEEP, 64, 64>(st, d, Mmax, Nmax, zdim);
+      launch_ring<AM, BMODE, CM, GEMM_MID_NT, GEMM_TK_DEEP, 64, 64>(st, d, Mmax, Nmax, zdim);
     } else {
-      launch_cfg<AM, BMODE, CM, GEMM_MID_NT, 32, 64, 64>(st, d, Mmax, Nmax, zdim);
+      launch_ring<AM, BMODE, CM, GEMM_MID_NT, 32, 64, 64>(st, d, Mmax, Nmax, zdim);
     }
   } else if (Nmax >= Mmax) {
-    if (deep) launch_cfg<AM, BMODE, CM, 256, GEMM_TK_DEEP, 64, 16>(st, d, Mmax, Nmax, zdim);
-    else launch_cfg<AM, BMODE, CM, 256, 32, 64, 16>(st, d, Mmax, Nmax, zdim);
+    if (deep) launch_ring<AM, BMODE, CM, 256, GEMM_TK_DEEP, 64, 16>(st, d, Mmax, Nmax, zdim);
+    else launch_ring<AM, BMODE, CM, 256, 32, 64, 16>(st, d, Mmax, Nmax, zdim);
   } else {
-    if (deep) launch_cfg<AM, BMODE, CM, 256, GEMM_TK_DEEP, 16, 64>(st, d, Mmax, Nmax, zdim);
-    else launch_cfg<AM, BMODE, CM, 256, 32, 16, 64>(st, d, Mmax, Nmax, zdim);
+    if (deep) launch_ring<AM, BMODE, CM, 256, GEMM_TK_DEEP, 16, 64>(st, d, Mmax, Nmax, zdim);
+    else launch_ring<AM, BMODE, CM, 256, 32, 16, 64>(st, d, Mmax, Nmax, zdim);
   }
   if (S > 1) {
     long elems = (long)Mmax * Nmax;

@@ -98,8 +98,10 @@ def train_and_eval_one_model(model, args):
             tb_writer=writer, use_amp=False, grad_clip_value=5.0)
         epoch_logs.append(logs)
     print("Dumping logs to {}!".format(args.logging_dir))
-    save_model_checkpoint(model, os.path.join(args.logging_dir, "{}_checkpoint.pt".format(args.net)), optimizer)
-    dump_pickle_data(os.path.join(args.logging_dir, "train_test_logs.pickle"), epoch_logs)
+    from nasrec_amd.utils.dist import world_info
+    if world_info()[0] == 0:  # replicas are identical: rank 0 writes the artefacts
+        save_model_checkpoint(model, os.path.join(args.logging_dir, "{}_checkpoint.pt".format(args.net)), optimizer)
+        dump_pickle_data(os.path.join(args.logging_dir, "train_test_logs.pickle"), epoch_logs)
     return epoch_logs
 
 
@@ -121,6 +123,8 @@ def get_model(args):
 
 
 def main(args):
+    from nasrec_amd.utils.dist import init_from_env
+    rank, world = init_from_env(args)  # torchrun: one process per GPU, args.gpu = the local rank
     create_dir(args.logging_dir)
     model = get_model(args).to(args.gpu)
     return train_and_eval_one_model(model, args)

@@ -282,11 +282,17 @@ def memset_desc(t):
     return d
 
 
+import os as _os
+_SPLITK_CAP = int(_os.environ["NASREC_SPLITK_CAP"]) if _os.environ.get("NASREC_SPLITK_CAP") else None
+
+
 def _splitk_for(tiles_mn, ktiles, nprob=1):
     """pick a split-K factor so that the launch stays within one wave of workgroups (256 CUs: `tools/splitk_sweep.py` shows
     a cliff right above it) with >= 64 k per split (one staged tile of the latency-regime configuration)"""
     if tiles_mn * nprob >= 192 or ktiles < 8:
         return 1
+    if _SPLITK_CAP is not None:  # experiment knob (tools/ab_bench.sh): NASREC_SPLITK_CAP=1 disables split-K
+        return max(1, min(_SPLITK_CAP, ktiles // 2, max(1, 256 // max(1, tiles_mn * nprob))))
     s = min(ktiles // 2, max(1, 256 // max(1, tiles_mn * nprob)))
     return max(1, min(s, 32))
 

@@ -461,12 +461,25 @@ class SuperNet(nn.Module):
         self._engine_steps = getattr(self, "_engine_steps", 0) + 1
         self._last_step_batch = int(int_feats.shape[0])
         self._last_step_key = (choice, clip, eps, graph)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # one process per GPU (utils/dist.py): the batch is this rank's share of the global batch; same path on every rank
+            from ..parallel import DataParallelStep
+            dp = self.__dict__.get("_dp_step")
+            key = (id(self._engine), int(int_feats.shape[0]), clip, eps, graph)
+            if dp is None or dp[0] != key:
+                dp = (key, DataParallelStep(self._engine, choice if self._fixed else None, int(int_feats.shape[0]), clip=clip, eps=eps, graph=graph))
+                self.__dict__["_dp_step"] = dp
+            return dp[1].step(int_feats, cat_feats, y, lr, choice=None if self._fixed else choice)
         return self._engine.train_step(int_feats, cat_feats, y, lr, choice, clip, eps, graph=graph)
 
     def engine_last_logits(self):
         """logits [B, 1] of the most recent engine_train_step (what `model(int_x, cat_x)` returned inside that step)"""
         choice, clip, eps, graph = self._last_step_key
         B = self._last_step_batch
+        dp = self.__dict__.get("_dp_step")
+        if dp is not None and dp[1].exchange:
+            return dp[1].last_plan().logits.view(B, 1)
         cp = self._engine.compile(choice, B, train=True, clip=clip, eps=eps, graph=graph)
         return cp.logits.view(B, 1)
 

@@ -62,12 +62,16 @@ def train_and_eval_one_model(model, args):
             test_only_at_last_step=True, grad_clip_value=5.0, tb_writer=writer)
         epoch_logs.append(logs)
     print("Dumping logs to {}!".format(logging_dir))
-    dump_pickle_data(os.path.join(logging_dir, "train_test_logs.pickle"), logs)  # the last epoch only, as the reference does
-    save_model_checkpoint(model, os.path.join(logging_dir, "supernet_checkpoint.pt"), optimizer)
+    from nasrec_amd.utils.dist import world_info
+    if world_info()[0] == 0:  # replicas are identical: rank 0 writes the artefacts
+        dump_pickle_data(os.path.join(logging_dir, "train_test_logs.pickle"), logs)  # the last epoch only, as the reference does
+        save_model_checkpoint(model, os.path.join(logging_dir, "supernet_checkpoint.pt"), optimizer)
     return epoch_logs
 
 
 def main(args):
+    from nasrec_amd.utils.dist import init_from_env
+    rank, world = init_from_env(args)  # torchrun: one process per GPU, args.gpu = the local rank; same path seed on every rank
     model = SuperNet(sparse_input_size=_num_sparse_inputs_dict[args.dataset], num_blocks=args.num_blocks,
                      ops_config=ops_config_lib[args.config], use_layernorm=(args.use_layernorm == 1), activation="relu",
                      num_embeddings=_num_embedding_dict[args.dataset], path_sampling_strategy=args.strategy,

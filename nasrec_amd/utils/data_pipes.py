@@ -257,20 +257,27 @@ def _synthetic_options(root_dir):
 
 def _pipes(args, spec: DatasetSpec):
     assert args.validate_split in ["val", "test"], ValueError("Invalid validation split! Should be in ['val', 'test'].")
+    from .dist import world_info
+    rank, world = world_info()
     if str(args.root_dir).startswith("synthetic"):
         o = _synthetic_options(args.root_dir)
+        o["seed"] += 1000 * rank  # every rank of a data-parallel run draws its own share of the global batch
         if o.get("cap"):  # synthetic ids for capped tables (the reference caps by editing MAX_NUM_EMBEDDINGS, config.py:17-19)
             spec = DatasetSpec(spec.name, spec.Fd, spec.Fs, [min(n, o["cap"]) for n in spec.tables], spec.dense_is_zero)
         return ([SyntheticPipe(spec, args.train_batch_size, o["steps"], o["seed"])],
                 [SyntheticPipe(spec, args.test_batch_size, o["test_steps"], o["seed"] + 1)], 1, 1)
     shard_dirs = sorted(glob.glob(os.path.join(args.root_dir, "shard-*")))
+    all_dirs = shard_dirs
+    if world > 1:
+        assert len(shard_dirs) >= world, "data-parallel run on %d GPUs needs at least %d shard-* directories" % (world, world)
+        shard_dirs = shard_dirs[rank::world]  # the TRAIN shards are split over the ranks; every rank evaluates all test shards
     print("Training directory...", shard_dirs)
     train_file = "train.txt" if args.train_split == "train" else "trainval.txt"
     test_file = "{}.txt".format(args.validate_split)
     shard_cls = TsvShard if os.environ.get("NASREC_TSV_READER", "native") == "python" else NativeTsvShard
     train = [shard_cls(os.path.join(d, train_file), spec, args.train_batch_size) for d in shard_dirs]
-    test = [shard_cls(os.path.join(d, test_file), spec, args.test_batch_size) for d in shard_dirs]
-    return train, test, len(shard_dirs), len(shard_dirs)
+    test = [shard_cls(os.path.join(d, test_file), spec, args.test_batch_size) for d in all_dirs]
+    return train, test, len(shard_dirs), len(all_dirs)
 
 
 def get_criteo_kaggle_pipes(args):
