@@ -363,25 +363,263 @@ __global__ __launch_bounds__(256) void ln_bwd_tokr_kernel(const nasrec_layernorm
   }
 }
 
+// ---- register-resident rows ---------------------------------------------------------------------------------------------------
+// A LayerNorm row is read ONCE: dense rows (D <= 1024) live in 4 * NV registers of a wavefront's lanes (16-byte loads and
+// stores), token-axis rows (D = N' <= 64) in up to 64 registers of one thread.  Mean, variance, normalisation (forward) and
+// both reductions plus dx (backward) run on the registers; the general kernels above re-read the row from global memory for
+// every pass and serve unaligned rows (ld or D not a multiple of 4).  Bytes per row: forward 2 * 4D, backward 3 * 4D — the
+// HBM-streaming roofline these kernels are measured against.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kc_vec_kernel(const nasrec_layernorm_desc_t d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= d.R) return;
+  const float* x = d.x + (long)r * d.ldx;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i = 4 * lane + 256 * c;
+    v[c] = (i < d.D) ? *reinterpret_cast<const f32x4*>(x + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+  }
+  const float mu = wave_sum(s) / (float)d.D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i = 4 * lane + 256 * c;
+    if (i < d.D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = v[c][e] - mu;
+        q = fmaf(t, t, q);
+      }
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)d.D + d.eps);
+  if (lane == 0) {
+    d.stats[2 * r] = mu;
+    d.stats[2 * r + 1] = rstd;
+  }
+  float* y = d.y + (long)r * d.ldy;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i = 4 * lane + 256 * c;
+    if (i < d.D) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(d.w + i), bb = *reinterpret_cast<const f32x4*>(d.b + i);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u = fmaf((v[c][e] - mu) * rstd, w[e], bb[e]);
+        u = act_apply(u, d.act);
+        if (d.dims_in_use >= 0 && i + e >= d.dims_in_use) u = 0.f;
+        o[e] = u;
+      }
+      f32x4* yp = reinterpret_cast<f32x4*>(y + i);
+      if (d.accumulate) o = o + *yp;
+      *yp = o;
+    }
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kc_vec_kernel(const nasrec_layernorm_desc_t d) {
+  __shared__ float sdw[4][LN_MAXD];
+  __shared__ float sdb[4][LN_MAXD];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  f32x4 pdw[NV], pdb[NV], w[NV], bb[NV];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i = 4 * lane + 256 * c;
+    pdw[c] = pdb[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    w[c] = (i < d.D) ? *reinterpret_cast<const f32x4*>(d.w + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    bb[c] = (i < d.D && d.act != NASREC_ACT_NONE) ? *reinterpret_cast<const f32x4*>(d.b + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int r = blockIdx.x * 4 + wave; r < d.R; r += gridDim.x * 4) {
+    const float* x = d.x + (long)r * d.ldx;
+    const float* dy = d.dy + (long)r * d.ldy;
+    const float mu = d.stats[2 * r], rstd = d.stats[2 * r + 1];
+    f32x4 xh[NV], g[NV];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const int i = 4 * lane + 256 * c;
+      if (i < d.D) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
+        g[c] = *reinterpret_cast<const f32x4*>(dy + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[c][e] = (xv[e] - mu) * rstd;
+          if (d.dims_in_use >= 0 && i + e >= d.dims_in_use) g[c][e] = 0.f;
+          if (d.act != NASREC_ACT_NONE) g[c][e] *= act_grad(fmaf(xh[c][e], w[c][e], bb[c][e]), d.act);
+          pdw[c][e] = fmaf(g[c][e], xh[c][e], pdw[c][e]);
+          pdb[c][e] += g[c][e];
+          const float gw = g[c][e] * w[c][e];
+          c1 += gw;
+          c2 = fmaf(gw, xh[c][e], c2);
+        }
+      }
+    }
+    c1 = wave_sum(c1) / (float)d.D;
+    c2 = wave_sum(c2) / (float)d.D;
+    float* dx = d.dx + (long)r * d.ldx;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const int i = 4 * lane + 256 * c;
+      if (i < d.D) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (g[c][e] * w[c][e] - c1 - xh[c][e] * c2);
+        f32x4* dp = reinterpret_cast<f32x4*>(dx + i);
+        if (d.accumulate) o = o + *dp;
+        *dp = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i = 4 * lane + 256 * c;
+    if (i < d.D) {
+      *reinterpret_cast<f32x4*>(&sdw[wave][i]) = pdw[c];
+      *reinterpret_cast<f32x4*>(&sdb[wave][i]) = pdb[c];
+    }
+  }
+  __syncthreads();
+  float* out = d.dwb_partial + (long)blockIdx.x * 2 * d.D;
+  for (int i = threadIdx.x; i < d.D; i += 256) {
+    out[i] = (sdw[0][i] + sdw[1][i]) + (sdw[2][i] + sdw[3][i]);
+    out[d.D + i] = (sdb[0][i] + sdb[1][i]) + (sdb[2][i] + sdb[3][i]);
+  }
+}
+
+// token-axis rows held in registers: thread = (b,e) row, NR = 16 / 32 / 48 / 64 >= D elements
+template <int NR>
+__global__ __launch_bounds__(256) void ln_fwd_tokr_reg_kernel(const nasrec_layernorm_desc_t d) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= d.R) return;
+  const float* x = d.x + (long)(r >> 4) * d.ldx + (r & 15);
+  float v[NR];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    v[i] = (i < d.D) ? x[i * 16] : 0.f;
+    s += v[i];
+  }
+  const float mu = s / (float)d.D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const float c = (i < d.D) ? v[i] - mu : 0.f;
+    q = fmaf(c, c, q);
+  }
+  const float rstd = 1.f / sqrtf(q / (float)d.D + d.eps);
+  d.stats[2 * r] = mu;
+  d.stats[2 * r + 1] = rstd;
+  float* y = d.y + (long)(r >> 4) * d.ldy + (r & 15);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    if (i < d.D) {
+      float u = fmaf((v[i] - mu) * rstd, d.w[i], d.b[i]);
+      u = act_apply(u, d.act);
+      if (d.dims_in_use >= 0 && i >= d.dims_in_use) u = 0.f;
+      y[i * 16] = d.accumulate ? y[i * 16] + u : u;
+    }
+  }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256) void ln_bwd_tokr_reg_kernel(const nasrec_layernorm_desc_t d) {
+  __shared__ float red[4][2][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const bool live = r < d.R;
+  const float mu = live ? d.stats[2 * r] : 0.f, rstd = live ? d.stats[2 * r + 1] : 0.f;
+  const float* x = d.x + (long)(r >> 4) * d.ldx + (r & 15);
+  const float* dy = d.dy + (long)(r >> 4) * d.ldy + (r & 15);
+  float xh[NR], g[NR];
+  float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    xh[i] = 0.f;
+    g[i] = 0.f;
+    if (live && i < d.D) {
+      xh[i] = (x[i * 16] - mu) * rstd;
+      float gg = dy[i * 16];
+      if (d.dims_in_use >= 0 && i >= d.dims_in_use) gg = 0.f;
+      if (d.act != NASREC_ACT_NONE) gg *= act_grad(fmaf(xh[i], d.w[i], d.b[i]), d.act);
+      g[i] = gg;
+      const float gw = gg * d.w[i];
+      c1 += gw;
+      c2 = fmaf(gw, xh[i], c2);
+    }
+  }
+  c1 /= (float)d.D;
+  c2 /= (float)d.D;
+  float* dx = d.dx + (long)(r >> 4) * d.ldx + (r & 15);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    if (i < d.D) {  // uniform
+      if (live) {
+        const float v = rstd * (g[i] * d.w[i] - c1 - xh[i] * c2);
+        dx[i * 16] = d.accumulate ? dx[i * 16] + v : v;
+      }
+      const float sw = wave_sum(g[i] * xh[i]), sb = wave_sum(g[i]);
+      if (lane == 0) {
+        red[wave][0][i] = sw;
+        red[wave][1][i] = sb;
+      }
+    }
+  }
+  __syncthreads();
+  float* out = d.dwb_partial + (long)blockIdx.x * 2 * d.D;
+  for (int i = threadIdx.x; i < d.D; i += 256) {
+    out[i] = (red[0][0][i] + red[1][0][i]) + (red[2][0][i] + red[3][0][i]);
+    out[d.D + i] = (red[0][1][i] + red[1][1][i]) + (red[2][1][i] + red[3][1][i]);
+  }
+}
+
+static bool ln_vec_ok(const nasrec_layernorm_desc_t* d, bool fwd) {
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  if ((d->D & 3) || (d->ldx & 3) || (d->ldy & 3)) return false;
+  if (!al(d->x) || !al(d->w) || !al(d->b)) return false;
+  return fwd ? al(d->y) : (al(d->dy) && al(d->dx));
+}
+
 int launch_layernorm(hipStream_t st, const nasrec_layernorm_desc_t* d) {
   if (d->R == 0) return 0;
   const bool fwd = d->kind == NASREC_OP_LAYERNORM_FWD;
   if (d->mode == NASREC_AM_KC) {
     if (d->D > LN_MAXD) return nasrec_set_error(-2, "layernorm: D=%d > %d", d->D, LN_MAXD);
+    const bool vec = ln_vec_ok(d, fwd);
+    const int nv = d->D <= 256 ? 1 : (d->D <= 512 ? 2 : 4);
     if (fwd) {
-      hipLaunchKernelGGL(ln_fwd_kc_kernel, dim3((d->R + 3) / 4), dim3(256), 0, st, *d);
+      const dim3 grid((d->R + 3) / 4);
+      if (vec && nv == 1) hipLaunchKernelGGL(ln_fwd_kc_vec_kernel<1>, grid, dim3(256), 0, st, *d);
+      else if (vec && nv == 2) hipLaunchKernelGGL(ln_fwd_kc_vec_kernel<2>, grid, dim3(256), 0, st, *d);
+      else if (vec) hipLaunchKernelGGL(ln_fwd_kc_vec_kernel<4>, grid, dim3(256), 0, st, *d);
+      else hipLaunchKernelGGL(ln_fwd_kc_kernel, grid, dim3(256), 0, st, *d);
     } else {
       if (d->nblk < 1) return nasrec_set_error(-2, "layernorm bwd: nblk=%d", d->nblk);
-      hipLaunchKernelGGL(ln_bwd_kc_kernel, dim3(d->nblk), dim3(256), 0, st, *d);
+      const dim3 grid(d->nblk);
+      if (vec && nv == 1) hipLaunchKernelGGL(ln_bwd_kc_vec_kernel<1>, grid, dim3(256), 0, st, *d);
+      else if (vec && nv == 2) hipLaunchKernelGGL(ln_bwd_kc_vec_kernel<2>, grid, dim3(256), 0, st, *d);
+      else if (vec) hipLaunchKernelGGL(ln_bwd_kc_vec_kernel<4>, grid, dim3(256), 0, st, *d);
+      else hipLaunchKernelGGL(ln_bwd_kc_kernel, grid, dim3(256), 0, st, *d);
     }
   } else if (d->mode == NASREC_AM_TOKR) {
     if (d->D > 64) return nasrec_set_error(-2, "layernorm(tok): D=%d > 64", d->D);
     const int nb = (d->R + 255) / 256;
     if (fwd) {
-      hipLaunchKernelGGL(ln_fwd_tokr_kernel, dim3(nb), dim3(256), 0, st, *d);
+      if (d->D <= 16) hipLaunchKernelGGL(ln_fwd_tokr_reg_kernel<16>, dim3(nb), dim3(256), 0, st, *d);
+      else if (d->D <= 32) hipLaunchKernelGGL(ln_fwd_tokr_reg_kernel<32>, dim3(nb), dim3(256), 0, st, *d);
+      else if (d->D <= 48) hipLaunchKernelGGL(ln_fwd_tokr_reg_kernel<48>, dim3(nb), dim3(256), 0, st, *d);
+      else hipLaunchKernelGGL(ln_fwd_tokr_reg_kernel<64>, dim3(nb), dim3(256), 0, st, *d);
     } else {
       if (d->nblk != nb) return nasrec_set_error(-2, "layernorm(tok) bwd: nblk=%d, want %d", d->nblk, nb);
-      hipLaunchKernelGGL(ln_bwd_tokr_kernel, dim3(nb), dim3(256), 0, st, *d);
+      if (d->D <= 16) hipLaunchKernelGGL(ln_bwd_tokr_reg_kernel<16>, dim3(nb), dim3(256), 0, st, *d);
+      else if (d->D <= 32) hipLaunchKernelGGL(ln_bwd_tokr_reg_kernel<32>, dim3(nb), dim3(256), 0, st, *d);
+      else if (d->D <= 48) hipLaunchKernelGGL(ln_bwd_tokr_reg_kernel<48>, dim3(nb), dim3(256), 0, st, *d);
+      else hipLaunchKernelGGL(ln_bwd_tokr_reg_kernel<64>, dim3(nb), dim3(256), 0, st, *d);
     }
   } else {
     return nasrec_set_error(-2, "layernorm: unsupported mode %d", d->mode);
