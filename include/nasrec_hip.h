@@ -77,7 +77,8 @@ enum {
   NASREC_OP_STAGE_INPUTS = 27,
   NASREC_OP_OPT_REDUCE = 28,
   NASREC_OP_OPT_APPLY = 29,
-  NASREC_OP_SAMPLE_CHAIN = 30
+  NASREC_OP_SAMPLE_CHAIN = 30,
+  NASREC_OP_CONST_I64 = 31
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -319,6 +320,14 @@ typedef struct nasrec_bce_desc {
   float* dlogits;     /* [B] */
 } nasrec_bce_desc_t;
 
+/* A chunk table restricts a flat-arena op to the parameters of ONE sampled path (a weight-sharing supernet step trains a
+ * fraction of the arena; torch skips parameters whose grad is None, train_utils.py:285-286 — touching only the path's ranges
+ * is the same arithmetic on a quarter of the bytes): chunks = device array of nchunks (offset, count) int64 pairs in units of
+ * 4-byte elements from the op's base pointer, offsets 16-byte aligned; chunks == NULL means the whole buffer [0, n).
+ * NASREC_OP_CONST_I64 writes such a table from the descriptor itself (stream-ordered, no host buffer to keep alive). */
+#define NASREC_CHUNK_ELEMS 65536
+#define NASREC_CONST_I64_MAX 448
+
 /* sum of squares of a flat fp32 buffer -> partial[nblocks] (deterministic two-stage). */
 typedef struct nasrec_sumsq_desc {
   int32_t kind; /* NASREC_OP_SUMSQ */
@@ -326,6 +335,8 @@ typedef struct nasrec_sumsq_desc {
   int64_t n;
   const float* x;
   float* partial;
+  const int64_t* chunks; /* optional chunk table */
+  int64_t nchunks;
 } nasrec_sumsq_desc_t;
 
 /* clip_grad_norm_ coefficient (train_utils.py:285): total = sqrt(sum partials), coef = min(1, max_norm /
@@ -351,6 +362,8 @@ typedef struct nasrec_adagrad_dense_desc {
   float* state;
   const float* lr;    /* device scalar */
   const float* coef;  /* device scalar (clip) */
+  const int64_t* chunks; /* optional chunk table (offsets into p / g / state alike) */
+  int64_t nchunks;
 } nasrec_adagrad_dense_desc_t;
 
 typedef struct nasrec_adagrad_rows_desc {
@@ -396,7 +409,17 @@ typedef struct nasrec_memset_desc {
   int32_t _pad;
   int64_t bytes;
   void* ptr;
+  const int64_t* chunks; /* optional chunk table: zero only these ranges of ptr (4-byte elements) */
+  int64_t nchunks;
 } nasrec_memset_desc_t;
+
+/* dst[0, n) = vals[0, n): small integer tables (chunk tables) travel in the kernel arguments */
+typedef struct nasrec_const_i64_desc {
+  int32_t kind; /* NASREC_OP_CONST_I64 */
+  int32_t n;    /* <= NASREC_CONST_I64_MAX */
+  int64_t* dst;
+  int64_t vals[NASREC_CONST_I64_MAX];
+} nasrec_const_i64_desc_t;
 
 /* LayerNorm over the last axis of a dense [R,D] view (mode KC) or over the token axis of a [B,N',16]
  * tensor per (b,e) (mode TOKR: row r=(b,e), element i=n').  y = mask(act(LN(x)*w + b)) (modules.py:174-178,

@@ -32,7 +32,7 @@ ACT_BY_NAME = {"identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
 (OP_GEMM, OP_EMBED_GATHER, OP_DOT_TRI_FWD, OP_DOT_TRI_BWD, OP_FM_FWD, OP_FM_BWD, OP_MHA_FWD, OP_MHA_BWD, OP_REDUCE_ROWS,
  OP_COPY_SEGS, OP_GATE_BWD, OP_ROWSUM, OP_FINAL_FWD, OP_BCE, OP_FINAL_BWD, OP_EMB_DEDUP, OP_SUMSQ, OP_CLIP_COEF,
  OP_ADAGRAD_DENSE, OP_ADAGRAD_ROWS, OP_MEMSET, OP_LAYERNORM_FWD, OP_LAYERNORM_BWD, OP_ADD_SEGS, OP_SCALE,
- OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY, OP_SAMPLE_CHAIN) = range(1, 31)
+ OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY, OP_SAMPLE_CHAIN, OP_CONST_I64) = range(1, 32)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -109,7 +109,7 @@ class BceDesc(C.Structure):
 
 
 class SumsqDesc(C.Structure):
-    _fields_ = [("kind", i32), ("nblocks", i32), ("n", i64), ("x", vp), ("partial", vp)]
+    _fields_ = [("kind", i32), ("nblocks", i32), ("n", i64), ("x", vp), ("partial", vp), ("chunks", vp), ("nchunks", i64)]
 
 
 class ClipCoefDesc(C.Structure):
@@ -117,7 +117,8 @@ class ClipCoefDesc(C.Structure):
 
 
 class AdagradDenseDesc(C.Structure):
-    _fields_ = [("kind", i32), ("eps", f32), ("n", i64), ("p", vp), ("g", vp), ("state", vp), ("lr", vp), ("coef", vp)]
+    _fields_ = [("kind", i32), ("eps", f32), ("n", i64), ("p", vp), ("g", vp), ("state", vp), ("lr", vp), ("coef", vp),
+                ("chunks", vp), ("nchunks", i64)]
 
 
 class AdagradRowsDesc(C.Structure):
@@ -126,7 +127,15 @@ class AdagradRowsDesc(C.Structure):
 
 
 class MemsetDesc(C.Structure):
-    _fields_ = [("kind", i32), ("_pad", i32), ("bytes", i64), ("ptr", vp)]
+    _fields_ = [("kind", i32), ("_pad", i32), ("bytes", i64), ("ptr", vp), ("chunks", vp), ("nchunks", i64)]
+
+
+CHUNK_ELEMS = 65536     # NASREC_CHUNK_ELEMS
+CONST_I64_MAX = 448     # NASREC_CONST_I64_MAX
+
+
+class ConstI64Desc(C.Structure):
+    _fields_ = [("kind", i32), ("n", i32), ("dst", vp), ("vals", i64 * CONST_I64_MAX)]
 
 
 class LayerNormDesc(C.Structure):
@@ -172,7 +181,7 @@ DESC_BY_KIND = {
     OP_EMB_DEDUP: EmbDedupDesc, OP_SUMSQ: SumsqDesc, OP_CLIP_COEF: ClipCoefDesc, OP_ADAGRAD_DENSE: AdagradDenseDesc,
     OP_ADAGRAD_ROWS: AdagradRowsDesc, OP_MEMSET: MemsetDesc, OP_LAYERNORM_FWD: LayerNormDesc, OP_LAYERNORM_BWD: LayerNormDesc,
     OP_SCALE: ScaleDesc, OP_ACT_BWD: ActBwdDesc, OP_STAGE_INPUTS: StageDesc, OP_OPT_REDUCE: OptReduceDesc, OP_OPT_APPLY: OptApplyDesc,
-    OP_SAMPLE_CHAIN: ChainDesc,
+    OP_SAMPLE_CHAIN: ChainDesc, OP_CONST_I64: ConstI64Desc,
 }
 
 LANE_FORK, LANE_JOIN = -1, -2  # nasrec_graph_create_lanes markers
@@ -224,8 +233,8 @@ def load():
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
                  "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_sample_chain"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 7:
-        raise EngineError("ABI version mismatch: library %d, binding 7" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 8:
+        raise EngineError("ABI version mismatch: library %d, binding 8" % lib.nasrec_abi_version())
     sizes = (i32 * 32)()
     n = lib.nasrec_desc_sizes(sizes, 32)
     for kind, cls in DESC_BY_KIND.items():

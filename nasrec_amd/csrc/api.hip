@@ -48,6 +48,7 @@ static int dispatch(hipStream_t st, const void* desc) {
     case NASREC_OP_ADAGRAD_ROWS: return launch_adagrad_rows(st, (const nasrec_adagrad_rows_desc_t*)desc);
     case NASREC_OP_MEMSET: {
       const nasrec_memset_desc_t* m = (const nasrec_memset_desc_t*)desc;
+      if (m->chunks) return launch_memset_chunks(st, m);
       if (m->bytes == 0) return 0;
       hipError_t e = hipMemsetAsync(m->ptr, 0, (size_t)m->bytes, st);
       if (e != hipSuccess) return nasrec_set_error((int)e, "memset: %s", hipGetErrorString(e));
@@ -58,6 +59,7 @@ static int dispatch(hipStream_t st, const void* desc) {
     case NASREC_OP_SCALE: return launch_scale(st, (const nasrec_scale_desc_t*)desc);
     case NASREC_OP_ACT_BWD: return launch_act_bwd(st, (const nasrec_act_bwd_desc_t*)desc);
     case NASREC_OP_STAGE_INPUTS: return launch_stage(st, (const nasrec_stage_desc_t*)desc);
+    case NASREC_OP_CONST_I64: return launch_const_i64(st, (const nasrec_const_i64_desc_t*)desc);
     case NASREC_OP_OPT_REDUCE: return launch_opt_reduce(st, (const nasrec_opt_reduce_desc_t*)desc);
     case NASREC_OP_OPT_APPLY: return launch_opt_apply(st, (const nasrec_opt_apply_desc_t*)desc);
     case NASREC_OP_SAMPLE_CHAIN: return launch_sample_chain(st, (const nasrec_chain_desc_t*)desc);
@@ -249,7 +251,7 @@ int nasrec_event_destroy(void* ev) {
 
 const char* nasrec_last_error(void) { return g_err; }
 
-int nasrec_abi_version(void) { return 7; }
+int nasrec_abi_version(void) { return 8; }
 
 int nasrec_desc_sizes(int32_t* out, int n) {
   static const int32_t sizes[] = {
@@ -284,6 +286,7 @@ int nasrec_desc_sizes(int32_t* out, int n) {
       (int32_t)sizeof(nasrec_opt_reduce_desc_t),    // 28
       (int32_t)sizeof(nasrec_opt_apply_desc_t),     // 29
       (int32_t)sizeof(nasrec_chain_desc_t),         // 30
+      (int32_t)sizeof(nasrec_const_i64_desc_t),     // 31
   };
   const int total = (int)(sizeof(sizes) / sizeof(sizes[0]));
   int w = 0;

@@ -65,4 +65,6 @@ int launch_act_bwd(hipStream_t s, const nasrec_act_bwd_desc_t* d);
 int launch_stage(hipStream_t s, const nasrec_stage_desc_t* d);
 int launch_opt_reduce(hipStream_t s, const nasrec_opt_reduce_desc_t* d);
 int launch_opt_apply(hipStream_t s, const nasrec_opt_apply_desc_t* d);
+int launch_memset_chunks(hipStream_t s, const nasrec_memset_desc_t* d);
+int launch_const_i64(hipStream_t s, const nasrec_const_i64_desc_t* d);
 int launch_sample_chain(hipStream_t s, const nasrec_chain_desc_t* d);

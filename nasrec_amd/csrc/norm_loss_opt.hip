@@ -175,9 +175,39 @@ __global__ __launch_bounds__(256) void adagrad_dense_kernel(const nasrec_adagrad
 }
 
 int launch_adagrad_dense(hipStream_t st, const nasrec_adagrad_dense_desc_t* d) {
-  if (d->n == 0) return 0;
-  hipLaunchKernelGGL(adagrad_dense_kernel, dim3((unsigned)adagrad_dense_blocks(d->n)), dim3(256), 0, st, *d);
+  if (d->n == 0 || (d->chunks && d->nchunks < 1)) return 0;
+  const long blocks = d->chunks ? (d->nchunks > 2048 ? 2048 : d->nchunks) : adagrad_dense_blocks(d->n);
+  hipLaunchKernelGGL(adagrad_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, st, *d);
   return nasrec_check_launch("adagrad_dense");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// chunk tables (the arena ranges of one sampled path): zero them / write the table itself
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void memset_chunks_kernel(const nasrec_memset_desc_t d) {
+  for (long c = blockIdx.x; c < d.nchunks; c += gridDim.x) {
+    float* x = reinterpret_cast<float*>(d.ptr) + d.chunks[2 * c];
+    const long n = d.chunks[2 * c + 1], n4 = n >> 2;
+    for (long i = threadIdx.x; i < n4; i += 256) *reinterpret_cast<f32x4*>(x + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (long j = 4 * n4 + threadIdx.x; j < n; j += 256) x[j] = 0.f;
+  }
+}
+
+int launch_memset_chunks(hipStream_t st, const nasrec_memset_desc_t* d) {
+  if (d->nchunks < 1) return 0;
+  hipLaunchKernelGGL(memset_chunks_kernel, dim3((unsigned)(d->nchunks > 4096 ? 4096 : d->nchunks)), dim3(256), 0, st, *d);
+  return nasrec_check_launch("memset_chunks");
+}
+
+__global__ __launch_bounds__(256) void const_i64_kernel(const nasrec_const_i64_desc_t d) {
+  for (int i = threadIdx.x; i < d.n; i += 256) d.dst[i] = d.vals[i];
+}
+
+int launch_const_i64(hipStream_t st, const nasrec_const_i64_desc_t* d) {
+  if (d->n < 0 || d->n > NASREC_CONST_I64_MAX) return nasrec_set_error(-2, "const_i64: n=%d outside [0,%d]", d->n, NASREC_CONST_I64_MAX);
+  if (d->n == 0) return 0;
+  hipLaunchKernelGGL(const_i64_kernel, dim3(1), dim3(256), 0, st, *d);
+  return nasrec_check_launch("const_i64");
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -3,22 +3,43 @@
 #pragma once
 #include "common.h"
 
-// sum of squares of x[0, n): workgroup `blk` of `nblk` (256 threads), fixed-order tree -> partial[blk]
+// sum of squares of x[0, n) (or of the chunk table's ranges): workgroup `blk` of `nblk` (256 threads), fixed-order tree -> partial[blk]
 __device__ __forceinline__ void sumsq_body(const nasrec_sumsq_desc_t& d, int blk, int nblk, float* red) {
   const int tid = threadIdx.x;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains keep several cold loads in flight
-  const long stride = (long)nblk * 256;
-  long i = (long)blk * 256 + tid;
-  for (; i + 3 * stride < d.n; i += 4 * stride) {
-    const float a = d.x[i], b = d.x[i + stride], c = d.x[i + 2 * stride], e = d.x[i + 3 * stride];
-    s0 = fmaf(a, a, s0);
-    s1 = fmaf(b, b, s1);
-    s2 = fmaf(c, c, s2);
-    s3 = fmaf(e, e, s3);
-  }
-  for (; i < d.n; i += stride) {
-    const float a = d.x[i];
-    s0 = fmaf(a, a, s0);
+  if (d.chunks) {
+    for (long c = blk; c < d.nchunks; c += nblk) {
+      const float* x = d.x + d.chunks[2 * c];
+      const long n = d.chunks[2 * c + 1], n4 = n >> 2;
+      long i = tid;
+      for (; i + 768 < n4; i += 1024) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + 4 * i), b = *reinterpret_cast<const f32x4*>(x + 4 * (i + 256));
+        const f32x4 c2 = *reinterpret_cast<const f32x4*>(x + 4 * (i + 512)), e = *reinterpret_cast<const f32x4*>(x + 4 * (i + 768));
+        s0 += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+        s1 += (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]);
+        s2 += (c2[0] * c2[0] + c2[1] * c2[1]) + (c2[2] * c2[2] + c2[3] * c2[3]);
+        s3 += (e[0] * e[0] + e[1] * e[1]) + (e[2] * e[2] + e[3] * e[3]);
+      }
+      for (; i < n4; i += 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        s0 += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+      }
+      for (long j = 4 * n4 + tid; j < n; j += 256) s1 = fmaf(x[j], x[j], s1);
+    }
+  } else {
+    const long stride = (long)nblk * 256;
+    long i = (long)blk * 256 + tid;
+    for (; i + 3 * stride < d.n; i += 4 * stride) {
+      const float a = d.x[i], b = d.x[i + stride], c = d.x[i + 2 * stride], e = d.x[i + 3 * stride];
+      s0 = fmaf(a, a, s0);
+      s1 = fmaf(b, b, s1);
+      s2 = fmaf(c, c, s2);
+      s3 = fmaf(e, e, s3);
+    }
+    for (; i < d.n; i += stride) {
+      const float a = d.x[i];
+      s0 = fmaf(a, a, s0);
+    }
   }
   red[tid] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -44,6 +65,33 @@ __device__ __forceinline__ float clip_coef_wave(const nasrec_clip_coef_desc_t& d
 }
 
 __device__ __forceinline__ void adagrad_dense_body(const nasrec_adagrad_dense_desc_t& d, int blk, int nblk, float lr, float coef) {
+  if (d.chunks) {
+    for (long c = blk; c < d.nchunks; c += nblk) {
+      const long off = d.chunks[2 * c], n = d.chunks[2 * c + 1], n4 = n >> 2;
+      const float* gp = d.g + off;
+      float* sp = d.state + off;
+      float* pp = d.p + off;
+      for (long i = threadIdx.x; i < n4; i += 256) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gp + 4 * i);
+        f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + 4 * i), p4 = *reinterpret_cast<const f32x4*>(pp + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = g4[e] * coef;
+          s4[e] = fmaf(g, g, s4[e]);
+          p4[e] = p4[e] - lr * (g / (sqrtf(s4[e]) + d.eps));
+        }
+        *reinterpret_cast<f32x4*>(sp + 4 * i) = s4;
+        *reinterpret_cast<f32x4*>(pp + 4 * i) = p4;
+      }
+      for (long j = 4 * n4 + threadIdx.x; j < n; j += 256) {
+        const float g = gp[j] * coef;
+        const float s = fmaf(g, g, sp[j]);
+        sp[j] = s;
+        pp[j] = pp[j] - lr * (g / (sqrtf(s) + d.eps));
+      }
+    }
+    return;
+  }
   for (long i = (long)blk * 256 + threadIdx.x; i < d.n; i += (long)nblk * 256) {
     const float g = d.g[i] * coef;
     const float s = fmaf(g, g, d.state[i]);

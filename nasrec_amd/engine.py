@@ -335,10 +335,6 @@ class SupernetEngine:
                 bd.grad_scale = grad_scale if grad_scale is not None else 1.0 / B
                 bd.logits, bd.y, bd.loss, bd.dlogits = cp.logits.data_ptr(), cp.y.data_ptr(), cp.loss.data_ptr(), cp.dlogits.data_ptr()
                 pre = [bd]
-                if not cfg.fixed:
-                    # paths differ from step to step: parameters outside this path must see g = 0 (Adagrad no-op ==
-                    # torch skipping grad=None parameters)
-                    pre.append(P.memset_desc(self.flat_g))
 
                 def final_bwd():
                     e = L.FinalDesc()
@@ -353,6 +349,21 @@ class SupernetEngine:
 
                 ctx.on_backward(final_bwd)
                 ctx.build_backward()
+                cp.chunk_tab, cp.nchunks = None, 0
+                if not cfg.fixed:
+                    # Paths differ from step to step.  torch skips parameters whose grad is None (everything outside the path),
+                    # so zero_grad, the norm and Adagrad touch ONLY the arena ranges this path trains — the same arithmetic on
+                    # the path's share of the arena (a quarter of it for a `default` xlarge path).  Gradients left over from
+                    # other paths outside these ranges are never read.
+                    names = [n for n in list(ctx.grad_params) + ["_final.weight", "_final.bias"] if not n.startswith("_embedding.")]
+                    flat = P.path_chunks([(self.offsets[n], self.params[n].numel()) for n in dict.fromkeys(names)])
+                    cp.nchunks = len(flat) // 2
+                    cp.chunk_tab = (arena.alloc(len(flat), torch.int64) if arena is not None
+                                    else torch.empty(len(flat), dtype=torch.int64, device=self.device))
+                    pre += P.const_i64_descs(cp.chunk_tab.data_ptr(), flat)
+                    ms = P.memset_desc(self.flat_g)
+                    ms.chunks, ms.nchunks = cp.chunk_tab.data_ptr(), cp.nchunks
+                    pre.append(ms)
                 # The training programs fold BCEWithLogits into the final-logit backward (the first closure to run); bwd_core
                 # keeps the plain one (d loss / d logits supplied by torch.autograd).
                 fi = next(i for i, dsc in enumerate(ctx.bwd) if isinstance(dsc, L.FinalDesc))
@@ -396,11 +407,15 @@ class SupernetEngine:
         new = getattr(cp, "arena", None)
         new = (lambda n, dt=torch.float32: cp.arena.alloc(n, dt)) if new is not None else \
             (lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device))
-        cp.leader = new(Bg * self.Fs, torch.int32)
-        cp.gsum = new(Bg * self.Fs * E)
-        cp.emb_partial = new(self.Fs * nb)
         nblk = max(1, min(256, (self.flat_numel + 256 * 8 - 1) // (256 * 8)))
-        cp.dense_partial = new(nblk)
+        tab, ntab = getattr(cp, "chunk_tab", None), getattr(cp, "nchunks", 0)
+        if tab is not None:
+            nblk = max(1, min(256, ntab))
+        if getattr(cp, "leader", None) is None:  # (the data-parallel optimizer shares these across the plans of a run)
+            cp.leader = new(Bg * self.Fs, torch.int32)
+            cp.gsum = new(Bg * self.Fs * E)
+            cp.emb_partial = new(self.Fs * nb)
+            cp.dense_partial = new(256)
         if sparse_grad is not None:
             dd = L.EmbDedupDesc()
             dd.kind = L.OP_EMB_DEDUP
@@ -413,6 +428,8 @@ class SupernetEngine:
         sq.kind = L.OP_SUMSQ
         sq.nblocks, sq.n = nblk, self.flat_numel
         sq.x, sq.partial = self.flat_g.data_ptr(), cp.dense_partial.data_ptr()
+        if tab is not None:
+            sq.chunks, sq.nchunks = tab.data_ptr(), ntab
         descs.append(sq)
         cc = L.ClipCoefDesc()
         cc.kind = L.OP_CLIP_COEF
@@ -425,6 +442,8 @@ class SupernetEngine:
         ad.eps, ad.n = eps, self.flat_numel
         ad.p, ad.g, ad.state = self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_s.data_ptr()
         ad.lr, ad.coef = self.lr_dev.data_ptr(), self.clip_out.data_ptr()
+        if tab is not None:
+            ad.chunks, ad.nchunks = tab.data_ptr(), ntab
         descs.append(ad)
         if sparse_grad is not None:
             ar = L.AdagradRowsDesc()
@@ -440,7 +459,7 @@ class SupernetEngine:
         if sparse_grad is not None:
             app = L.OptApplyDesc()
             app.kind = L.OP_OPT_APPLY
-            app.dense_blocks = min(2048, (self.flat_numel + 255) // 256)
+            app.dense_blocks = min(2048, ntab if tab is not None else (self.flat_numel + 255) // 256)
             app.clip, app.dense, app.rows = cc, ad, ar
             if Bg <= 256:
                 # the five launches collapse into the two that the grid-wide dependencies require

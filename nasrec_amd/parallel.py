@@ -139,7 +139,7 @@ class DataParallelStep:
         for w in pending:
             if w is not None:
                 w.wait()  # nccl: the compute stream waits for the collective (no host block)
-        self.opt()
+        self.opt(plan)
         self._last = ("dp", plan)
         return plan.loss
 
@@ -173,7 +173,21 @@ class EngineDP:
             if graph:
                 prog.capture(eng.stream.cuda_stream)
         eng.stream.synchronize()
-        return (lambda: prog.replay(eng._sp())) if graph else (lambda: prog.run(eng._sp()))
+        if eng.cfg.fixed:
+            return (lambda plan: prog.replay(eng._sp())) if graph else (lambda plan: prog.run(eng._sp()))
+
+        def run(plan):
+            # weight-sharing supernet: zero_grad / norm / Adagrad cover the arena ranges of the plan's path only (engine.compile),
+            # so the optimizer program is the plan's: same work buffers, the plan's chunk table
+            if getattr(plan, "opt_prog", None) is None:
+                h = _Holder()
+                h.leader, h.gsum, h.emb_partial, h.dense_partial = holder.leader, holder.gsum, holder.emb_partial, holder.dense_partial
+                h.chunk_tab, h.nchunks = plan.cp.chunk_tab, plan.cp.nchunks
+                plan.opt_prog = Program(eng._optimizer_descs(h, Bg, cat_all, sg_all, clip, eps))
+                plan.opt_prog.holder = h
+            plan.opt_prog.run(eng._sp())
+
+        return run
 
     def dp_plan(self, choice, B, grad_scale, clip, eps, graph) -> DPPlan:
         from .engine import Program

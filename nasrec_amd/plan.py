@@ -282,6 +282,39 @@ def memset_desc(t):
     return d
 
 
+def path_chunks(ranges, chunk=None):
+    """[(offset, numel)] arena ranges (16-byte aligned offsets) -> flat [off0, n0, off1, n1, ...] chunk table of pieces
+    <= NASREC_CHUNK_ELEMS elements: abutting ranges merge, nothing outside the ranges is covered"""
+    chunk = chunk or L.CHUNK_ELEMS
+    merged = []
+    for off, n in sorted(ranges):
+        if n <= 0:
+            continue
+        if merged and off <= merged[-1][0] + merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], off + n - merged[-1][0])
+        else:
+            merged.append([off, n])
+    flat = []
+    for off, n in merged:
+        for o in range(0, n, chunk):
+            flat += [off + o, min(chunk, n - o)]
+    return flat
+
+
+def const_i64_descs(dst_ptr, values):
+    """NASREC_OP_CONST_I64 launches that write `values` to the int64 array at dst_ptr"""
+    out = []
+    for i in range(0, len(values), L.CONST_I64_MAX):
+        part = values[i:i + L.CONST_I64_MAX]
+        d = L.ConstI64Desc()
+        d.kind = L.OP_CONST_I64
+        d.n = len(part)
+        d.dst = dst_ptr + 8 * i
+        d.vals[:len(part)] = part
+        out.append(d)
+    return out
+
+
 import os as _os
 _SPLITK_CAP = int(_os.environ["NASREC_SPLITK_CAP"]) if _os.environ.get("NASREC_SPLITK_CAP") else None
 

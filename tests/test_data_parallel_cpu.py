@@ -183,7 +183,7 @@ class OracleEngine:
         from oracle import nasrec_oracle as O
         eng, P, Fs = self, self.P, self.Fs
 
-        def run():
+        def run(plan=None):
             sg = sg_all.view(Bg, Fs, 16)
             uniq = []
             for f in range(Fs):

@@ -690,6 +690,67 @@ def test_final_bce_and_dense_optimizer(lib):
         close(gp, P.data, 1e-5)
 
 
+def test_chunk_table_restricts_zero_grad_norm_and_adagrad_to_a_path(lib):
+    """A sampled path's arena ranges as a chunk table (NASREC_OP_CONST_I64 writes it from the kernel arguments): memset, sum of
+    squares and Adagrad touch exactly those ranges — everything else (stale gradients of other paths included) is bit-untouched,
+    inside the ranges the update is the whole-buffer kernel's, bit for bit."""
+    from nasrec_amd import plan as P
+    torch.manual_seed(12)
+    n = 1_000_000
+    ranges = [(0, 128), (128, 4), (4096, 70001), (200000, 65536 * 3 + 8), (999000, 999)]
+    flat = P.path_chunks(ranges)
+    assert flat[:2] == [0, 132] and sum(flat[1::2]) == sum(r[1] for r in ranges) and max(flat[1::2]) <= L.CHUNK_ELEMS
+    nch = len(flat) // 2
+    tab = dev(torch.zeros(len(flat), dtype=torch.int64))
+    for d in P.const_i64_descs(tab.data_ptr(), flat):
+        launch(lib, d)
+    assert tab.cpu().tolist() == flat
+    big = list(range(1000))
+    tab2 = dev(torch.zeros(1000, dtype=torch.int64))
+    descs = P.const_i64_descs(tab2.data_ptr(), big)
+    assert len(descs) == 3
+    for d in descs:
+        launch(lib, d)
+    assert tab2.cpu().tolist() == big
+    mask = torch.zeros(n, dtype=torch.bool)
+    for off, m in ranges:
+        mask[off:off + m] = True
+    mask = mask.cuda()
+    g0 = dev(torch.randn(n))
+    # memset
+    g = g0.clone()
+    ms = P.memset_desc(g)
+    ms.chunks, ms.nchunks = tab.data_ptr(), nch
+    launch(lib, ms)
+    assert torch.equal(g[~mask], g0[~mask]) and float(g[mask].abs().max()) == 0.0
+    # sum of squares over the ranges only
+    part = dev(torch.zeros(256))
+    sq = L.SumsqDesc()
+    sq.kind, sq.nblocks, sq.n, sq.x, sq.partial = L.OP_SUMSQ, min(256, nch), n, g0.data_ptr(), part.data_ptr()
+    sq.chunks, sq.nchunks = tab.data_ptr(), nch
+    launch(lib, sq)
+    want = float(g0[mask].double().pow(2).sum())
+    assert abs(float(part.double().sum()) - want) <= 1e-6 * want
+    # Adagrad: ranges == the whole-buffer kernel, outside untouched
+    coef, lr = dev(torch.tensor([0.37, 0.0])), dev(torch.tensor([0.16]))
+    p0, s0 = dev(torch.randn(n)), dev(torch.rand(n))
+    outs = []
+    for chunked in (False, True):
+        p, st = p0.clone(), s0.clone()
+        ad = L.AdagradDenseDesc()
+        ad.kind, ad.eps, ad.n = L.OP_ADAGRAD_DENSE, 1e-2, n
+        ad.p, ad.g, ad.state, ad.lr, ad.coef = p.data_ptr(), g0.data_ptr(), st.data_ptr(), lr.data_ptr(), coef.data_ptr()
+        if chunked:
+            ad.chunks, ad.nchunks = tab.data_ptr(), nch
+        launch(lib, ad)
+        outs.append((p, st))
+    torch.cuda.synchronize()
+    (pw, sw), (pc, sc) = outs
+    assert torch.equal(pc[mask], pw[mask]) and torch.equal(sc[mask], sw[mask])
+    assert torch.equal(pc[~mask], p0[~mask]) and torch.equal(sc[~mask], s0[~mask])
+    assert not torch.equal(pw[~mask], p0[~mask])
+
+
 def test_gate_backward_and_copy_segments(lib):
     torch.manual_seed(10)
     B, D, wr = 21, 32, 13
