@@ -415,12 +415,18 @@ bool gemm_fast_eligible(const nasrec_gemm_desc_t* d, int Mmax, int Nmax) {
     const long r = s.M > s.N ? s.M : s.N, ld = s.lda > s.ldb ? s.lda : s.ldb;
     if (s.A && (r * ld + s.K >= (1L << 29) || (long)s.K * ld + r >= (1L << 29))) return false;
   }
+  long useful = 0, padded = 0;
   for (int q = 0; q < nprob; ++q) {
     const nasrec_gemm_seg_t& s = d->seg[q];
-    tiles += (long)((s.M + FT_BM - 1) / FT_BM) * ((s.N + FT_BN - 1) / FT_BN) * S;
+    const long t = (long)((s.M + FT_BM - 1) / FT_BM) * ((s.N + FT_BN - 1) / FT_BN);
+    tiles += t * S;
+    useful += (long)s.M * s.N;
+    padded += t * FT_BM * FT_BN;
   }
   (void)Mmax;
   (void)Nmax;
+  // skinny problems (a [1024, 13] weight gradient fills a tenth of its 128 x 128 tiles) belong to the small-tile kernel
+  if (2 * useful < padded) return false;
   return tiles >= NASREC_GEMM_FAST_MIN_TILES && kmax >= 64;
 }
 

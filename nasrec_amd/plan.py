@@ -346,6 +346,8 @@ def _fast_gemm_splitk(amode, bmode, cmode, segs, zmode):
         return None
     probs = segs if zmode else segs[:1]
     tiles = sum(((sd["M"] + 127) // 128) * ((sd["N"] + 127) // 128) for sd in probs)
+    if 2 * sum(sd["M"] * sd["N"] for sd in probs) < tiles * 128 * 128:
+        return None  # skinny problems: the small-tile kernel
     kt = (max((sd["K"] + 31) // 32 for sd in live) if zmode else sum((sd["K"] + 31) // 32 for sd in live))
     S = 1
     if tiles < 256:
@@ -362,8 +364,10 @@ def gemm_kernel_name(d) -> str:
     if any(sd["Aaux"] or sd["Baux"] for sd in segs) or max(sd["K"] for sd in live) < 64:
         return "gemm_kernel"
     probs = segs if d.zmode else segs[:1]
-    tiles = sum(((sd["M"] + 127) // 128) * ((sd["N"] + 127) // 128) for sd in probs) * max(1, d.splitk)
-    return "gemm_fast_kernel" if tiles >= GEMM_FAST_MIN_TILES else "gemm_kernel"
+    tiles = sum(((sd["M"] + 127) // 128) * ((sd["N"] + 127) // 128) for sd in probs)
+    if 2 * sum(sd["M"] * sd["N"] for sd in probs) < tiles * 128 * 128:
+        return "gemm_kernel"
+    return "gemm_fast_kernel" if tiles * max(1, d.splitk) >= GEMM_FAST_MIN_TILES else "gemm_kernel"
 
 
 def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, **kw):
@@ -454,9 +458,17 @@ def _emit_z_groups(ctx, am, bm, cm, items, rowsum_out=None):
     items = _with_rowsum(items, rowsum_out)
     for gi in sorted({g for g, _ in items}):
         grp = [d for g, d in items if g == gi]
-        for i in range(0, len(grp), L.MAX_SEGS):
-            for d in gemm_descs(ctx, am, bm, cm, grp[i:i + L.MAX_SEGS], 1):
-                ctx.emit(d)
+        for cls in sorted({_shape_class(ctx, d) for d in grp}):
+            part = [d for d in grp if _shape_class(ctx, d) == cls]
+            for i in range(0, len(part), L.MAX_SEGS):
+                for d in gemm_descs(ctx, am, bm, cm, part[i:i + L.MAX_SEGS], 1):
+                    ctx.emit(d)
+
+
+def _shape_class(ctx, d):
+    """problems of one zmode launch share its tile shape (chosen from Mmax x Nmax): in the throughput regime skinny ones get
+    launches of their own (at batch <= 256 every launch is latency-bound and fewer launches win: 0.61 vs 0.67 ms per step)"""
+    return (d["M"] < 64, d["N"] < 64) if ctx.B > 256 else (False, False)
 
 
 def _with_rowsum(items, rowsum_out):
@@ -507,9 +519,9 @@ def _flush_mha_reduce(ctx):
 def _flush_deferred(ctx, todo=None):
     if todo is None:
         todo, ctx.deferred = ctx.deferred, []
-    keys = sorted({(rank, am, bm, cm, d["K"]) for am, bm, cm, rank, d in todo})  # rank r accumulates over rank r-1: later launch
+    keys = sorted({(rank, am, bm, cm, d["K"], _shape_class(ctx, d)) for am, bm, cm, rank, d in todo})  # rank r accumulates over rank r-1: later launch
     for key in keys:
-        grp = [d for am, bm, cm, rank, d in todo if (rank, am, bm, cm, d["K"]) == key]
+        grp = [d for am, bm, cm, rank, d in todo if (rank, am, bm, cm, d["K"], _shape_class(ctx, d)) == key]
         grp.sort(key=lambda d: -d["M"] * d["N"])  # problems of similar size share a launch (its grid is Mmax x Nmax)
         for i in range(0, len(grp), L.MAX_SEGS):
             for g in gemm_descs(ctx, key[1], key[2], key[3], grp[i:i + L.MAX_SEGS], 1):
