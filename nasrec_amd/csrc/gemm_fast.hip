@@ -71,11 +71,29 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const nasrec_gemm_des
     const int chunk = total >> 3, rem = total & 7;
     lin = xcd * chunk + (xcd < rem ? xcd : rem) + q;  // bijective for any grid size
   }
-  const int bz = lin / per_z;
-  const int t2 = lin - bz * per_z;
-  const int by = t2 / tiles_n, bx = t2 - by * tiles_n;
-  const int z = d.zmode ? bz / S : 0;
-  const int ks = bz % S;
+  int z = 0, ks, by, bx;
+  if (d.zmode) {
+    // a batch of independent problems: the grid holds exactly their LIVE tiles (problem-major, then k-split, m, n), so the
+    // eight contiguous runs the XCDs get carry equal work whatever the mix of problem sizes (a grid padded to Mmax x Nmax
+    // handed six XCDs 72 tiles each — more than their 64 workgroup slots — and two XCDs 8)
+    int rem = lin, tn = 1, per = 1;
+    for (;; ++z) {
+      if (z >= d.nseg) return;
+      tn = (d.seg[z].N + FT_BN - 1) / FT_BN;
+      per = ((d.seg[z].M + FT_BM - 1) / FT_BM) * tn;
+      if (rem < per * S) break;
+      rem -= per * S;
+    }
+    ks = rem / per;
+    const int t2 = rem - ks * per;
+    by = t2 / tn;
+    bx = t2 - by * tn;
+  } else {
+    ks = lin / per_z;
+    const int t2 = lin - ks * per_z;
+    by = t2 / tiles_n;
+    bx = t2 - by * tiles_n;
+  }
   const nasrec_gemm_seg_t& s0 = d.seg[z];
   const int M = s0.M, N = s0.N;
   const int m0 = by * FT_BM, n0 = bx * FT_BN;
@@ -392,7 +410,14 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const nasrec_gemm_des
 template <int AM, int BMODE>
 static void launch_fast_t(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, int Nmax, int zdim, bool ones) {
   const int tm = (Mmax + FT_BM - 1) / FT_BM, tn = (Nmax + FT_BN - 1) / FT_BN;
-  const dim3 grid((unsigned)(tm * tn * zdim));
+  long blocks = (long)tm * tn * zdim;
+  if (d->zmode) {  // live tiles only (zdim = problems x split-K)
+    const int S = d->splitk > 1 ? d->splitk : 1;
+    blocks = 0;
+    for (int q = 0; q < d->nseg; ++q)
+      blocks += (long)((d->seg[q].M + FT_BM - 1) / FT_BM) * ((d->seg[q].N + FT_BN - 1) / FT_BN) * S;
+  }
+  const dim3 grid((unsigned)blocks);
   if (ones)
     hipLaunchKernelGGL((gemm_fast_kernel<AM, BMODE, true>), grid, dim3(256), 0, st, *d, Mmax, Nmax, tm, tn);
   else

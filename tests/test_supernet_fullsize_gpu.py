@@ -170,6 +170,7 @@ def test_data_parallel_code_path_with_sampled_paths_single_rank():
             eng = model._engine
             dp = DataParallelStep(eng, None, c["B"], clip=5.0, eps=1e-2, graph=False, force_exchange=force)
             assert dp.exchange == force
+            p0 = eng.flat_p.clone()
             nbuckets = []
             for _ in range(3):
                 ch = _jsonable(model._resolve_choice(None))
@@ -182,15 +183,22 @@ def test_data_parallel_code_path_with_sampled_paths_single_rank():
                     assert 0 < sent < eng.flat_numel, "only the path's parameters travel"
             torch.cuda.synchronize()
             eng.check_indices()
-            outs.append((eng.flat_p.clone(), [t.clone() for t in eng.tables]))
+            outs.append((eng.flat_p.clone(), [t.clone() for t in eng.tables], p0))
             del model, eng, dp
             torch.cuda.empty_cache()
-        # same arithmetic, different launch grouping (weight gradients in backward order instead of parked batches): the two runs
-        # agree to 1e-8 per step and drift to ~2e-6 over three steps (measured); a lost or doubled gradient would show as ~1e-3
+        # Same arithmetic, different launch grouping (weight gradients in backward order with other split-K factors instead of
+        # parked batches).  At B = 8192 an fp32 gradient of this LayerNorm'd network carries ~2e-4 relative noise whatever the
+        # kernel (tools/scratch/grad_diff.py: three launch arrangements against the fp64 oracle on the full batch, worst
+        # parameter 2.0e-4 .. 2.3e-4 each, 1.6e-4 between them), and Adagrad's first steps pass a gradient difference straight
+        # into the parameter where |g| << eps: measured 1.5e-8 / 1.6e-8 / 1.3e-5 after steps 1 / 2 / 3.  A lost, doubled or
+        # stale gradient moves a parameter by ~lr = 1e-2 per step and shows in the relative distance of the two trajectories.
         scale = float(outs[0][0].abs().max())
-        assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-5 * max(1.0, scale)
+        assert torch.equal(outs[0][2], outs[1][2])
+        assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-4 * max(1.0, scale)
+        moved = float((outs[0][0] - outs[0][2]).norm())
+        assert moved > 0 and float((outs[0][0] - outs[1][0]).norm()) <= 2e-3 * moved
         for a, b in zip(outs[0][1], outs[1][1]):
-            assert torch.allclose(a, b, rtol=0, atol=2e-5)
+            assert torch.allclose(a, b, rtol=0, atol=1e-4)
     finally:
         if own_pg:
             dist.destroy_process_group()
