@@ -396,15 +396,53 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const nasrec_gemm_des
         }
     return;
   }
+  // general epilogue == epilogue_store<NASREC_CM_PLAIN> element by element (gemm_tile.h), with everything that depends on the
+  // column alone looked up once per lane and column: a lane owns 2 columns x 32 rows, and the gating product's segment search
+  // (mul_lookup: a scalar loop over up to 8 k-segments) used to run for each of its 64 elements
+  const bool acc_c = d.zmode ? s0.accumulate != 0 : d.beta != 0;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int b = 0; b < 2; ++b) {
+    const int j = n0 + wn * 64 + b * 32 + fr;
+    if (j >= N) continue;
+    const bool ones_j = s0.ones_col && j == N - 1;
+    const float* mp = nullptr;
+    int mld = 0;
+    if (d.mul_nseg > 0) {
+      for (int q = 0; q < d.mul_nseg; ++q) {
+        const int jj = j - d.mul_off[q];
+        if (jj >= 0 && jj < d.mul_width[q]) {
+          mp = d.mul_ptr[q] ? d.mul_ptr[q] + jj : nullptr;
+          mld = d.mul_ld[q];
+          break;
+        }
+      }
+    }
+    const float bias_j = (d.bias && !d.bias_on_rows) ? d.bias[j] : 0.f;
+    const bool dead_j = d.dims_in_use >= 0 && !d.mask_on_rows && j >= d.dims_in_use;
+    float* rs = s0.rowsum ? s0.rowsum : d.rowsum_out;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int i = m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3), j = n0 + wn * 64 + b * 32 + fr;
-        if (i < M && j < N) epilogue_store<NASREC_CM_PLAIN>(d, s0, i, j, i < Mv ? acc[a][b][r] : 0.f);
+        const int i = m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
+        if (i >= M) continue;
+        float v = i < Mv ? acc[a][b][r] : 0.f;
+        if (ones_j) {
+          rs[i] = v;
+          continue;
+        }
+        const long o = (long)i * s0.ldc + j;
+        if (d.pre_add) v += d.pre_add[o];
+        if (d.bias) v += d.bias_on_rows ? d.bias[i] : bias_j;
+        if (d.save_z) d.save_z[o] = v;
+        v = act_apply(v, d.act);
+        if (d.save_act) d.save_act[o] = v;
+        if (d.mul_nseg > 0) v *= mp ? mp[(long)i * mld] : 0.f;
+        if (dead_j || (d.dims_in_use >= 0 && d.mask_on_rows && i >= d.dims_in_use)) v = 0.f;
+        if (acc_c) v += s0.C[o];
+        s0.C[o] = v;
       }
+  }
 }
 
 template <int AM, int BMODE>
