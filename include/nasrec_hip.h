@@ -117,7 +117,11 @@ typedef struct nasrec_gemm_desc {
                             (CleverMaskGenerator, modules.py:57-96) */
   int32_t beta;      /* zmode=0: C += result */
   int32_t splitk;    /* >1: K is split over `splitk` workgroups per tile; partial slabs go to `workspace`, a second
-                        pass sums them in fixed order and runs the epilogue */
+                        pass sums them in fixed order and runs the epilogue.
+                        NASREC_SPLITK_BALANCED (throughput-regime launches whose tiles all have the same K): the
+                        k-iterations of the tiles that do not fill a round of 512 workgroups are shared equally by 512
+                        workgroups, partial tiles go through `workspace` (>= NASREC_SK_WORKSPACE_FLOATS floats) and a
+                        second pass sums them in ascending k order (deterministic) */
   const float* bias;
   float* save_z;     /* optional store of (acc+bias), addressed like C */
   float* save_act;   /* optional store of act(acc+bias), addressed like C */
@@ -325,6 +329,8 @@ typedef struct nasrec_bce_desc {
  * is the same arithmetic on a quarter of the bytes): chunks = device array of nchunks (offset, count) int64 pairs in units of
  * 4-byte elements from the op's base pointer, offsets 16-byte aligned; chunks == NULL means the whole buffer [0, n).
  * NASREC_OP_CONST_I64 writes such a table from the descriptor itself (stream-ordered, no host buffer to keep alive). */
+#define NASREC_SPLITK_BALANCED (-1)
+#define NASREC_SK_WORKSPACE_FLOATS (512L * 3 * 128 * 128)
 #define NASREC_CHUNK_ELEMS 65536
 #define NASREC_CONST_I64_MAX 448
 

@@ -130,6 +130,8 @@ class MemsetDesc(C.Structure):
     _fields_ = [("kind", i32), ("_pad", i32), ("bytes", i64), ("ptr", vp), ("chunks", vp), ("nchunks", i64)]
 
 
+SPLITK_BALANCED = -1                  # NASREC_SPLITK_BALANCED
+SK_WORKSPACE_FLOATS = 512 * 3 * 128 * 128  # NASREC_SK_WORKSPACE_FLOATS
 CHUNK_ELEMS = 65536     # NASREC_CHUNK_ELEMS
 CONST_I64_MAX = 448     # NASREC_CONST_I64_MAX
 

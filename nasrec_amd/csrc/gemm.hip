@@ -106,8 +106,14 @@ static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
   long wgs = 0;
   for (int q = 0; q < nprob; ++q) wgs += (long)((d->seg[q].M + 63) / 64) * ((d->seg[q].N + 63) / 64) * S;
   const bool deep = Kmax > 32;
-  if (CM == NASREC_CM_PLAIN && gemm_fast_eligible(d, Mmax, Nmax)) {
-    launch_gemm_fast(st, d, Mmax, Nmax, zdim);  // throughput regime: 128x128x32 tiles, 16-byte staging, LDS double buffer (gemm_fast.hip)
+  if (AM == NASREC_AM_TOKK && token_dw_eligible(d)) {
+    launch_token_dw(st, d, Mmax, Nmax);  // large batch: a wavefront per sample, operands straight to MFMA registers (token_linear.hip)
+  } else if (CM == NASREC_CM_PLAIN && gemm_fast_eligible(d, Mmax, Nmax)) {
+    // throughput regime: 128x128x32 tiles, 16-byte staging, LDS double buffer (gemm_fast.hip)
+    const int rc = launch_gemm_fast(st, d, Mmax, Nmax, zdim);
+    if (rc) return rc;
+  } else if (d->splitk == NASREC_SPLITK_BALANCED) {
+    return nasrec_set_error(-2, "gemm: the balanced schedule exists for throughput-regime launches only (plan.py decides both)");
   } else if (wgs >= 1024) {
     launch_cfg<AM, BMODE, CM, GEMM_BIG_NT, GEMM_BIG_TK, 64, 64>(st, d, Mmax, Nmax, zdim);
   } else if (wgs >= GEMM_SKINNY_BELOW) {
@@ -147,8 +153,10 @@ int launch_gemm(hipStream_t st, const nasrec_gemm_desc_t* d) {
     case NASREC_AM_RC * 100 + NASREC_AM_RC * 10 + NASREC_CM_PLAIN:  // dW = dyᵀ x
       return launch_gemm_t<NASREC_AM_RC, NASREC_AM_RC, NASREC_CM_PLAIN>(st, d);
     case NASREC_AM_KC * 100 + NASREC_AM_TOKR * 10 + NASREC_CM_TOKJ:  // token-axis y = W x
+      if (token_linear_eligible(d)) return launch_token_linear(st, d);  // large batch: weights in LDS, a wavefront per sample
       return launch_gemm_t<NASREC_AM_KC, NASREC_AM_TOKR, NASREC_CM_TOKJ>(st, d);
     case NASREC_AM_RC * 100 + NASREC_AM_TOKR * 10 + NASREC_CM_TOKJ:  // token-axis dx = Wᵀ dy
+      if (token_linear_eligible(d)) return launch_token_linear(st, d);
       return launch_gemm_t<NASREC_AM_RC, NASREC_AM_TOKR, NASREC_CM_TOKJ>(st, d);
     case NASREC_AM_TOKK * 100 + NASREC_AM_TOKK * 10 + NASREC_CM_PLAIN:  // token-axis dW = dy xᵀ
       return launch_gemm_t<NASREC_AM_TOKK, NASREC_AM_TOKK, NASREC_CM_PLAIN>(st, d);

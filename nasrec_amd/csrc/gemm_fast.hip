@@ -24,6 +24,14 @@
 //     template variant, so ordinary tiles pay nothing for it;
 //   * XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2; every XCD gets a contiguous
 //     run of the (n fastest) tile order, i.e. a few A row-panels and all B panels, instead of every A panel.
+//   * balanced schedule (desc.splitk == NASREC_SPLITK_BALANCED): a CU holds two workgroups, so a launch runs in "rounds" of
+//     512 tiles and one whose tile count is not a multiple of 512 idles a large part of the chip in its last round (8 x 1024^2
+//     weight gradients = 512 tiles: 142 TFLOP/s; 528 tiles: 94; 320 tiles: 85).  Here the first 512 workgroups share the
+//     k-iterations of the 512 + (tiles mod 512) "odd" tiles EQUALLY (a contiguous run of iterations each, i.e. the tail of one
+//     tile, whole tiles, the head of another), the remaining tiles — a multiple of 512 — follow one per workgroup.  A run that
+//     covers a whole tile finishes it; partial runs dump their accumulators to the workspace and gemm_fast_fixup_kernel sums
+//     the pieces of each split tile in ascending k order (fixed association: results do not depend on timing) and applies the
+//     epilogue.  No inter-workgroup signalling.
 // fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain (no reduced-precision path exists on gfx950).
 #include "gemm_tile.h"
 
@@ -54,31 +62,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ft_rsrc(const float* base, lon
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes > 0x7fffffffL ? 0x7fffffff : (int)bytes, 0x00020000);
 }
 
-template <int AM, int BMODE, bool ONES>
-__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const nasrec_gemm_desc_t d, int Mmax, int Nmax, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) float smem[2][2][FT_TILE_FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 31, fg = lane >> 5;
-  const int S = d.splitk > 1 ? d.splitk : 1;
+#define FT_SK_WGS 512            // workgroups that share the odd tiles' iterations (2 per CU)
+#define FT_SK_PIECES 3           // a share of < 2 tiles touches at most 3 tiles
+#define FT_PIECE_FLOATS (FT_BM * FT_BN)
 
-  // ---- which tile -------------------------------------------------------------------------------------------------
-  const int per_z = tiles_m * tiles_n;
-  int lin = blockIdx.x;
-  {
-    const int total = gridDim.x;
-    const int xcd = lin & 7, q = lin >> 3;
-    const int chunk = total >> 3, rem = total & 7;
-    lin = xcd * chunk + (xcd < rem ? xcd : rem) + q;  // bijective for any grid size
-  }
-  int z = 0, ks, by, bx;
+// tile index (live tiles, problem-major, then k-split, m, n) -> problem z, k-split ks, tile row / column; false: no such tile
+__device__ __forceinline__ bool ft_decode(const nasrec_gemm_desc_t& d, int lin, int S, int tiles_m, int tiles_n, int& z, int& ks, int& by,
+                                          int& bx) {
+  z = 0;
   if (d.zmode) {
-    // a batch of independent problems: the grid holds exactly their LIVE tiles (problem-major, then k-split, m, n), so the
-    // eight contiguous runs the XCDs get carry equal work whatever the mix of problem sizes (a grid padded to Mmax x Nmax
-    // handed six XCDs 72 tiles each — more than their 64 workgroup slots — and two XCDs 8)
+    // a batch of independent problems: the grid holds exactly their LIVE tiles, so the eight contiguous runs the XCDs get
+    // carry equal work whatever the mix of problem sizes (a grid padded to Mmax x Nmax handed six XCDs 72 tiles each — more
+    // than their 64 workgroup slots — and two XCDs 8)
     int rem = lin, tn = 1, per = 1;
     for (;; ++z) {
-      if (z >= d.nseg) return;
+      if (z >= d.nseg) return false;
       tn = (d.seg[z].N + FT_BN - 1) / FT_BN;
       per = ((d.seg[z].M + FT_BM - 1) / FT_BM) * tn;
       if (rem < per * S) break;
@@ -89,17 +87,144 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const nasrec_gemm_des
     by = t2 / tn;
     bx = t2 - by * tn;
   } else {
+    const int per_z = tiles_m * tiles_n;
     ks = lin / per_z;
     const int t2 = lin - ks * per_z;
     by = t2 / tiles_n;
     bx = t2 - by * tiles_n;
   }
+  return true;
+}
+
+// XCD-aware order: ids are dealt round-robin to the 8 XCDs; give every XCD one contiguous run of [0, total) (bijective)
+__device__ __forceinline__ int ft_xcd_run(int id, int total) {
+  const int xcd = id & 7, q = id >> 3;
+  const int chunk = total >> 3, rem = total & 7;
+  return xcd * chunk + (xcd < rem ? xcd : rem) + q;
+}
+
+// first global k-iteration of share w of W iterations split over FT_SK_WGS workgroups
+__device__ __host__ __forceinline__ long ft_share_begin(long W, int w) { return W * w / FT_SK_WGS; }
+
+// epilogue of one finished 128 x 128 tile held in the D layout of v_mfma_f32_32x32x2_f32:
+// col = lane & 31, row = 8 * (reg >> 2) + 4 * (lane >> 5) + (reg & 3)
+__device__ __forceinline__ void ft_epilogue(const nasrec_gemm_desc_t& d, const nasrec_gemm_seg_t& s0, int m0, int n0, int wm, int wn, int fr,
+                                            int fg, const f32x16 (&acc)[2][2]) {
+  const int M = s0.M, N = s0.N;
+  const int Mv = (s0.Mvalid > 0 && s0.Mvalid < M) ? s0.Mvalid : M;
+  // plain product (the common case of the large launches: LayerNorm / the split-K pass own the epilogue): straight stores
+  const bool plain = !d.bias && !d.pre_add && !d.save_z && !d.save_act && d.act == NASREC_ACT_NONE && d.mul_nseg == 0 &&
+                     d.dims_in_use < 0 && !(d.zmode ? s0.accumulate : d.beta) && !s0.ones_col;
+  if (plain) {
+    float* Cp = s0.C;
+    const int ldc = s0.ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3), j = n0 + wn * 64 + b * 32 + fr;
+          if (i < M && j < N) Cp[(long)i * ldc + j] = i < Mv ? acc[a][b][r] : 0.f;
+        }
+    return;
+  }
+  // general epilogue == epilogue_store<NASREC_CM_PLAIN> element by element (gemm_tile.h), with everything that depends on the
+  // column alone looked up once per lane and column: a lane owns 2 columns x 32 rows, and the gating product's segment search
+  // (mul_lookup: a scalar loop over up to 8 k-segments) used to run for each of its 64 elements
+  const bool acc_c = d.zmode ? s0.accumulate != 0 : d.beta != 0;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int j = n0 + wn * 64 + b * 32 + fr;
+    if (j >= N) continue;
+    const bool ones_j = s0.ones_col && j == N - 1;
+    const float* mp = nullptr;
+    int mld = 0;
+    if (d.mul_nseg > 0) {
+      for (int q = 0; q < d.mul_nseg; ++q) {
+        const int jj = j - d.mul_off[q];
+        if (jj >= 0 && jj < d.mul_width[q]) {
+          mp = d.mul_ptr[q] ? d.mul_ptr[q] + jj : nullptr;
+          mld = d.mul_ld[q];
+          break;
+        }
+      }
+    }
+    const float bias_j = (d.bias && !d.bias_on_rows) ? d.bias[j] : 0.f;
+    const bool dead_j = d.dims_in_use >= 0 && !d.mask_on_rows && j >= d.dims_in_use;
+    float* rs = s0.rowsum ? s0.rowsum : d.rowsum_out;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
+        if (i >= M) continue;
+        float v = i < Mv ? acc[a][b][r] : 0.f;
+        if (ones_j) {
+          rs[i] = v;
+          continue;
+        }
+        const long o = (long)i * s0.ldc + j;
+        if (d.pre_add) v += d.pre_add[o];
+        if (d.bias) v += d.bias_on_rows ? d.bias[i] : bias_j;
+        if (d.save_z) d.save_z[o] = v;
+        v = act_apply(v, d.act);
+        if (d.save_act) d.save_act[o] = v;
+        if (d.mul_nseg > 0) v *= mp ? mp[(long)i * mld] : 0.f;
+        if (dead_j || (d.dims_in_use >= 0 && d.mask_on_rows && i >= d.dims_in_use)) v = 0.f;
+        if (acc_c) v += s0.C[o];
+        s0.C[o] = v;
+      }
+  }
+}
+
+// sk_tiles > 0: balanced schedule — workgroups [0, FT_SK_WGS) share the sk_T k-iterations of each of the first sk_tiles tiles
+template <int AM, int BMODE, bool ONES>
+__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const nasrec_gemm_desc_t d, int Mmax, int Nmax, int tiles_m, int tiles_n,
+                                                           int sk_tiles, int sk_T) {
+  __shared__ __attribute__((aligned(16))) float smem[2][2][FT_TILE_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fg = lane >> 5;
+  const int S = d.splitk > 1 ? d.splitk : 1;
+
+  // ---- which piece(s) of work ---------------------------------------------------------------------------------------
+  // plain schedule: one (tile, k-split) per workgroup.  Balanced schedule: workgroup w < FT_SK_WGS runs the global k-iterations
+  // [W w / 512, W (w + 1) / 512) of the first sk_tiles tiles (W = sk_tiles * sk_T), the others one whole tile each.
+  long g = 0, g_end = 1;
+  int lin_dp = -1, piece = 0, w_sk = 0;
+  if (sk_tiles > 0) {
+    if ((int)blockIdx.x < FT_SK_WGS) {
+      w_sk = ft_xcd_run(blockIdx.x, FT_SK_WGS);
+      const long W = (long)sk_tiles * sk_T;
+      g = ft_share_begin(W, w_sk);
+      g_end = ft_share_begin(W, w_sk + 1);
+    } else {
+      lin_dp = sk_tiles + ft_xcd_run(blockIdx.x - FT_SK_WGS, gridDim.x - FT_SK_WGS);
+    }
+  } else {
+    lin_dp = ft_xcd_run(blockIdx.x, gridDim.x);
+  }
+  for (; g < g_end; ++piece) {
+  int lin, pa = 0, pb = 0;  // balanced piece: k-tiles [pa, pb) of tile lin
+  if (lin_dp >= 0) {
+    lin = lin_dp;
+    g = g_end;
+  } else {
+    lin = (int)(g / sk_T);
+    pa = (int)(g - (long)lin * sk_T);
+    const long left = g_end - g;
+    pb = left < sk_T - pa ? pa + (int)left : sk_T;
+    g += pb - pa;
+  }
+  int z, ks, by, bx;
+  if (!ft_decode(d, lin, S, tiles_m, tiles_n, z, ks, by, bx)) continue;
   const nasrec_gemm_seg_t& s0 = d.seg[z];
   const int M = s0.M, N = s0.N;
   const int m0 = by * FT_BM, n0 = bx * FT_BN;
-  if (m0 >= M || n0 >= N) return;
+  if (m0 >= M || n0 >= N) continue;
 
-  // ---- k range of this split ----------------------------------------------------------------------------------------
+  // ---- k range of this split / piece ------------------------------------------------------------------------------------
   int T = 0;
   if (d.zmode) {
     T = s0.A ? (s0.K + FT_BK - 1) / FT_BK : 0;
@@ -107,7 +232,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const nasrec_gemm_des
     for (int q = 0; q < d.nseg; ++q)
       if (d.seg[q].A) T += (d.seg[q].K + FT_BK - 1) / FT_BK;
   }
-  const int t0 = (int)((long)T * ks / S), t1 = (int)((long)T * (ks + 1) / S);
+  const bool sk_piece = lin_dp < 0;
+  const int t0 = sk_piece ? pa : (int)((long)T * ks / S), t1 = sk_piece ? pb : (int)((long)T * (ks + 1) / S);
   int s = z, kt = t0;
   if (!d.zmode) {
     s = 0;
@@ -364,9 +490,20 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const nasrec_gemm_des
   }
   FT_STAMP();
 
-  // ---- epilogue: D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = 8 * (reg >> 2) + 4 * (lane >> 5) + (reg & 3) -------
-  const int Mv = (s0.Mvalid > 0 && s0.Mvalid < M) ? s0.Mvalid : M;
+  // ---- epilogue ---------------------------------------------------------------------------------------------------------
+  if (sk_piece && !(t0 == 0 && t1 == T)) {
+    // a partial run of a tile's k-iterations: raw accumulators to this workgroup's piece slot (gemm_fast_fixup_kernel sums)
+    float* slot = d.workspace + ((long)w_sk * FT_SK_PIECES + piece) * FT_PIECE_FLOATS;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slot[((a * 2 + b) * 16 + r) * 256 + tid] = acc[a][b][r];
+    continue;  // (the main loop ends on a barrier: the next piece may restage the LDS buffers)
+  }
   if (S > 1) {
+    const int Mv = (s0.Mvalid > 0 && s0.Mvalid < M) ? s0.Mvalid : M;
     float* slab = d.workspace + ((long)(z * S + ks)) * Mmax * Nmax;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -377,76 +514,50 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const nasrec_gemm_des
           const int i = m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3), j = n0 + wn * 64 + b * 32 + fr;
           if (i < M && j < N) slab[(long)i * N + j] = i < Mv ? acc[a][b][r] : 0.f;
         }
-    return;
+    continue;
   }
-  // plain product (the common case of the large launches: LayerNorm / the split-K pass own the epilogue): straight stores
-  const bool plain = !d.bias && !d.pre_add && !d.save_z && !d.save_act && d.act == NASREC_ACT_NONE && d.mul_nseg == 0 &&
-                     d.dims_in_use < 0 && !(d.zmode ? s0.accumulate : d.beta) && !has_ones && !s0.ones_col;
-  if (plain) {
-    float* Cp = s0.C;
-    const int ldc = s0.ldc;
+  ft_epilogue(d, s0, m0, n0, wm, wn, fr, fg, acc);
+  }
+}
+
+// second pass of the balanced schedule: one workgroup per odd tile; pieces in ascending k order, then the epilogue
+__global__ __launch_bounds__(256) void gemm_fast_fixup_kernel(const nasrec_gemm_desc_t d, int tiles_m, int tiles_n, int sk_tiles, int sk_T) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fg = lane >> 5;
+  const int t = blockIdx.x;
+  const long W = (long)sk_tiles * sk_T, lo = (long)t * sk_T, hi = lo + sk_T;
+  int w = (int)(lo * FT_SK_WGS / W);
+  while (w > 0 && ft_share_begin(W, w) > lo) --w;
+  while (ft_share_begin(W, w + 1) <= lo) ++w;
+  if (ft_share_begin(W, w) <= lo && ft_share_begin(W, w + 1) >= hi) return;  // one workgroup ran the whole tile and finished it
+  int z, ks, by, bx;
+  if (!ft_decode(d, t, 1, tiles_m, tiles_n, z, ks, by, bx)) return;
+  const nasrec_gemm_seg_t& s0 = d.seg[z];
+  const int m0 = by * FT_BM, n0 = bx * FT_BN;
+  if (m0 >= s0.M || n0 >= s0.N) return;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  for (; w < FT_SK_WGS && ft_share_begin(W, w) < hi; ++w) {
+    const int piece = t - (int)(ft_share_begin(W, w) / sk_T);  // tiles this workgroup touched before tile t
+    const float* slot = d.workspace + ((long)w * FT_SK_PIECES + piece) * FT_PIECE_FLOATS;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3), j = n0 + wn * 64 + b * 32 + fr;
-          if (i < M && j < N) Cp[(long)i * ldc + j] = i < Mv ? acc[a][b][r] : 0.f;
-        }
-    return;
+        for (int r = 0; r < 16; ++r) acc[a][b][r] += slot[((a * 2 + b) * 16 + r) * 256 + tid];
   }
-  // general epilogue == epilogue_store<NASREC_CM_PLAIN> element by element (gemm_tile.h), with everything that depends on the
-  // column alone looked up once per lane and column: a lane owns 2 columns x 32 rows, and the gating product's segment search
-  // (mul_lookup: a scalar loop over up to 8 k-segments) used to run for each of its 64 elements
-  const bool acc_c = d.zmode ? s0.accumulate != 0 : d.beta != 0;
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int j = n0 + wn * 64 + b * 32 + fr;
-    if (j >= N) continue;
-    const bool ones_j = s0.ones_col && j == N - 1;
-    const float* mp = nullptr;
-    int mld = 0;
-    if (d.mul_nseg > 0) {
-      for (int q = 0; q < d.mul_nseg; ++q) {
-        const int jj = j - d.mul_off[q];
-        if (jj >= 0 && jj < d.mul_width[q]) {
-          mp = d.mul_ptr[q] ? d.mul_ptr[q] + jj : nullptr;
-          mld = d.mul_ld[q];
-          break;
-        }
-      }
-    }
-    const float bias_j = (d.bias && !d.bias_on_rows) ? d.bias[j] : 0.f;
-    const bool dead_j = d.dims_in_use >= 0 && !d.mask_on_rows && j >= d.dims_in_use;
-    float* rs = s0.rowsum ? s0.rowsum : d.rowsum_out;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
-        if (i >= M) continue;
-        float v = i < Mv ? acc[a][b][r] : 0.f;
-        if (ones_j) {
-          rs[i] = v;
-          continue;
-        }
-        const long o = (long)i * s0.ldc + j;
-        if (d.pre_add) v += d.pre_add[o];
-        if (d.bias) v += d.bias_on_rows ? d.bias[i] : bias_j;
-        if (d.save_z) d.save_z[o] = v;
-        v = act_apply(v, d.act);
-        if (d.save_act) d.save_act[o] = v;
-        if (d.mul_nseg > 0) v *= mp ? mp[(long)i * mld] : 0.f;
-        if (dead_j || (d.dims_in_use >= 0 && d.mask_on_rows && i >= d.dims_in_use)) v = 0.f;
-        if (acc_c) v += s0.C[o];
-        s0.C[o] = v;
-      }
-  }
+  ft_epilogue(d, s0, m0, n0, wm, wn, fr, fg, acc);
 }
 
 template <int AM, int BMODE>
-static void launch_fast_t(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, int Nmax, int zdim, bool ones) {
+static int launch_fast_t(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, int Nmax, int zdim, bool ones) {
   const int tm = (Mmax + FT_BM - 1) / FT_BM, tn = (Nmax + FT_BN - 1) / FT_BN;
   long blocks = (long)tm * tn * zdim;
   if (d->zmode) {  // live tiles only (zdim = problems x split-K)
@@ -455,11 +566,36 @@ static void launch_fast_t(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax,
     for (int q = 0; q < d->nseg; ++q)
       blocks += (long)((d->seg[q].M + FT_BM - 1) / FT_BM) * ((d->seg[q].N + FT_BN - 1) / FT_BN) * S;
   }
+  int sk_tiles = 0, sk_T = 0;
+  if (d->splitk == NASREC_SPLITK_BALANCED) {
+    // every tile of the launch must have the same number of k-iterations
+    int T = 0;
+    if (d->zmode) {
+      for (int q = 0; q < d->nseg; ++q) {
+        const int tq = d->seg[q].A ? (d->seg[q].K + FT_BK - 1) / FT_BK : 0;
+        if (q > 0 && tq != T) return nasrec_set_error(-2, "gemm: balanced schedule needs equal K over the batch (problem %d)", q);
+        T = tq;
+      }
+    } else {
+      for (int q = 0; q < d->nseg; ++q)
+        if (d->seg[q].A) T += (d->seg[q].K + FT_BK - 1) / FT_BK;
+    }
+    if (T < 1) return nasrec_set_error(-2, "gemm: balanced schedule on an empty product");
+    if (!d->workspace) return nasrec_set_error(-3, "gemm: balanced schedule needs a workspace of NASREC_SK_WORKSPACE_FLOATS floats");
+    const long tiles = blocks;
+    if (tiles % FT_SK_WGS != 0) {
+      sk_tiles = (int)(tiles >= FT_SK_WGS ? FT_SK_WGS + tiles % FT_SK_WGS : tiles);
+      sk_T = T;
+      blocks = FT_SK_WGS + (tiles - sk_tiles);
+    }
+  }
   const dim3 grid((unsigned)blocks);
   if (ones)
-    hipLaunchKernelGGL((gemm_fast_kernel<AM, BMODE, true>), grid, dim3(256), 0, st, *d, Mmax, Nmax, tm, tn);
+    hipLaunchKernelGGL((gemm_fast_kernel<AM, BMODE, true>), grid, dim3(256), 0, st, *d, Mmax, Nmax, tm, tn, sk_tiles, sk_T);
   else
-    hipLaunchKernelGGL((gemm_fast_kernel<AM, BMODE, false>), grid, dim3(256), 0, st, *d, Mmax, Nmax, tm, tn);
+    hipLaunchKernelGGL((gemm_fast_kernel<AM, BMODE, false>), grid, dim3(256), 0, st, *d, Mmax, Nmax, tm, tn, sk_tiles, sk_T);
+  if (sk_tiles > 0) hipLaunchKernelGGL(gemm_fast_fixup_kernel, dim3((unsigned)sk_tiles), dim3(256), 0, st, *d, tm, tn, sk_tiles, sk_T);
+  return 0;
 }
 
 // Does this launch belong to the throughput regime?  (plan.py mirrors the rule when it sizes split-K: `_fast_gemm_splitk`.)
@@ -496,11 +632,7 @@ bool gemm_fast_eligible(const nasrec_gemm_desc_t* d, int Mmax, int Nmax) {
 int launch_gemm_fast(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, int Nmax, int zdim) {
   bool ones = false;
   for (int q = 0; q < d->nseg; ++q) ones = ones || d->seg[q].ones_col != 0;
-  if (d->amode == NASREC_AM_KC && d->bmode == NASREC_AM_KC)
-    launch_fast_t<NASREC_AM_KC, NASREC_AM_KC>(st, d, Mmax, Nmax, zdim, ones);
-  else if (d->amode == NASREC_AM_KC && d->bmode == NASREC_AM_RC)
-    launch_fast_t<NASREC_AM_KC, NASREC_AM_RC>(st, d, Mmax, Nmax, zdim, ones);
-  else
-    launch_fast_t<NASREC_AM_RC, NASREC_AM_RC>(st, d, Mmax, Nmax, zdim, ones);
-  return 0;
+  if (d->amode == NASREC_AM_KC && d->bmode == NASREC_AM_KC) return launch_fast_t<NASREC_AM_KC, NASREC_AM_KC>(st, d, Mmax, Nmax, zdim, ones);
+  if (d->amode == NASREC_AM_KC && d->bmode == NASREC_AM_RC) return launch_fast_t<NASREC_AM_KC, NASREC_AM_RC>(st, d, Mmax, Nmax, zdim, ones);
+  return launch_fast_t<NASREC_AM_RC, NASREC_AM_RC>(st, d, Mmax, Nmax, zdim, ones);
 }

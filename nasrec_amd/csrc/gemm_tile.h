@@ -29,6 +29,10 @@
 #endif
 bool gemm_fast_eligible(const nasrec_gemm_desc_t* d, int Mmax, int Nmax);
 int launch_gemm_fast(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, int Nmax, int zdim);
+bool token_linear_eligible(const nasrec_gemm_desc_t* d);  // token_linear.hip: token-axis Linear at large batch
+int launch_token_linear(hipStream_t st, const nasrec_gemm_desc_t* d);
+bool token_dw_eligible(const nasrec_gemm_desc_t* d);      // token-axis weight gradient at large batch (main pass; slabs -> gemm_splitk_epilogue)
+int launch_token_dw(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, int Nmax);
 // Tile configurations (template parameters NT threads, TK staged k depth, TBM x TBN block tile):
 //   256 thr, 32, 64x64  4 waves 2x2, 32x32 each — large products, throughput regime (>= 4 workgroups per CU);
 //   1024 thr, TK, 64x64  16 waves 4x4, one 16x16 MFMA tile each — four waves per SIMD, one wave's waits hide under

@@ -273,6 +273,7 @@ class SupernetEngine:
             cp = CompiledPlan()
             cp.arena, cp.evicted = arena, False
             ctx = P.Ctx(B, self.device, self.params, self.grads, shape_only=False, train=train)
+            ctx.sk_workspace = self._sk_workspace
             ctx.defer_dw = defer_dw
             ctx.arena = arena
             cp.ctx = ctx
@@ -469,6 +470,13 @@ class SupernetEngine:
                 return [red, app]
             return [dd, sq, app]  # global batch of a data-parallel step: chunked dedup + merge (two launches), then the same apply
         return descs
+
+    def _sk_workspace(self):
+        """partial-tile workspace of the balanced GEMM schedule (100 MB): one per engine — the launches of a program run in
+        stream order, and each one's second pass has consumed the buffer before the next launch writes it"""
+        if getattr(self, "_sk_ws", None) is None:
+            self._sk_ws = torch.empty(L.SK_WORKSPACE_FLOATS, dtype=torch.float32, device=self.device)
+        return self._sk_ws
 
     # -------------------------------------------------------------------------------------------------------
     def _sp(self):

@@ -166,6 +166,7 @@ class Ctx:
         self.lane = 0        # lane of the forward descriptors being emitted (0 = main, 1 = the block's sparse branch)
         self.fwd_sched: List = []  # [(lane | LANE_FORK | LANE_JOIN, index into self.fwd)] in emission order
         self.arena = None  # optional Arena (engine.py): where alloc() takes its buffers from
+        self.sk_workspace = None  # optional callable -> tensor of L.SK_WORKSPACE_FLOATS floats shared by the plan's balanced GEMM launches
         self.block_marks: List = []  # (block index, length of the backward program once that block's gradients are complete)
 
     # -- memory -----------------------------------------------------------------------------------------------
@@ -355,10 +356,43 @@ def _fast_gemm_splitk(amode, bmode, cmode, segs, zmode):
     return S if tiles * S >= GEMM_FAST_MIN_TILES else None
 
 
+BALANCED_MIN_SAVING_US = 80.0
+
+
+def _balanced_schedule_pays(segs, zmode):
+    """gemm_fast's balanced schedule (NASREC_SPLITK_BALANCED, csrc/gemm_fast.hip).  Measured model of the plain schedule: a CU
+    holds two 128x128 tiles, the chip runs "rounds" of 512 tiles, a round takes k-tiles x 3.8 us (8 x 1024^2 x 4096: 512 tiles
+    in 485 us) however full it is — 256 leftover tiles, one per CU, take as long as 512 (1280 tiles: 1878 us against 1582 us at
+    the 1536-tile rate) — except that a handful of leftover tiles runs in about half a round (528 tiles: 736 us).  Sharing the
+    k-iterations equally costs tiles / 512 rounds plus a second pass of ~35 us (<= 1024 partial tiles of 64 KB out and back):
+    take it when the model saves clearly more than that.  Needs the same K in every problem of a batch."""
+    live = [sd for sd in segs if sd.get("A")]
+    if not live or len(live) != len(segs):
+        return False
+    if zmode:
+        kts = {(sd["K"] + 31) // 32 for sd in segs}
+        if len(kts) != 1:
+            return False
+        T = kts.pop()
+        probs = segs
+    else:
+        T = sum((sd["K"] + 31) // 32 for sd in segs)
+        probs = segs[:1]
+    tiles = sum(((sd["M"] + 127) // 128) * ((sd["N"] + 127) // 128) for sd in probs)
+    left = tiles % 512
+    if left == 0:
+        return False
+    rounds = tiles // 512 + (1.0 if left > 64 else 0.55)
+    return (rounds - tiles / 512.0) * T * 3.8 >= BALANCED_MIN_SAVING_US
+
+
 def gemm_kernel_name(d) -> str:
     """which kernel family launch_gemm picks for this descriptor (mirror of csrc/gemm.hip / gemm_fast.hip)"""
     segs = [dict(A=d.seg[q].A, Aaux=d.seg[q].Aaux, Baux=d.seg[q].Baux, M=d.seg[q].M, N=d.seg[q].N, K=d.seg[q].K) for q in range(d.nseg)]
     live = [sd for sd in segs if sd["A"]]
+    if (d.cmode == L.CM_TOKJ and d.bmode == L.AM_TOKR and d.amode in (L.AM_KC, L.AM_RC) and d.splitk <= 1 and not d.pre_add
+            and not d.save_act and d.mul_nseg == 0 and all(sd["M"] <= 80 and sd["N"] >= 16 * 1024 and not sd["Aaux"] and not sd["Baux"] for sd in segs)):
+        return "token_linear_kernel"  # (csrc/token_linear.hip `token_linear_eligible` has the complete rule)
     if d.cmode != L.CM_PLAIN or (d.amode, d.bmode) not in ((L.AM_KC, L.AM_KC), (L.AM_KC, L.AM_RC), (L.AM_RC, L.AM_RC)) or not live:
         return "gemm_kernel"
     if any(sd["Aaux"] or sd["Baux"] for sd in segs) or max(sd["K"] for sd in live) < 64:
@@ -414,8 +448,16 @@ def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, **kw):
     fast = _fast_gemm_splitk(amode, bmode, cmode, segs, zmode)
     if fast is not None:
         S = fast
+    if (amode == L.AM_TOKK and zmode and ctx.B >= 1024 and all(sd["M"] <= 80 and sd["N"] <= 80 and not sd.get("Aaux") and not sd.get("Baux")
+                                                              for sd in segs)):
+        # token-axis weight gradients at large batch (csrc/token_linear.hip `token_dw_kernel`): S workgroups of 16 wavefronts per
+        # problem, a wavefront per sample — one workgroup per CU, few slabs for the second pass
+        S = max(4, min(32, 256 // len(segs), ctx.B // 64))
     S = kw.get("splitk", S)
     d.splitk = 1
+    if fast == 1 and S == 1 and ctx.B > 256 and ctx.sk_workspace is not None and _balanced_schedule_pays(segs, zmode):
+        d.splitk = L.SPLITK_BALANCED
+        d.workspace = ctx.sk_workspace().data_ptr()
     if S > 1:
         d.splitk = S
         nprob = len(segs) if zmode else 1

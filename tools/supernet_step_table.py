@@ -53,3 +53,15 @@ for phase, prog in (("fwd", cp.fwd), ("bwd", cp.bwd), ("opt", cp.opt)):
 print("sum of isolated launches: %.1f us over %d launches" % (tot, len(rows)))
 for us, phase, name, info in sorted(rows, reverse=True)[:int(os.environ.get("TOP", "40"))]:
     print("%9.1f us  %s %-14s %s" % (us, phase, name, info))
+# per-category totals
+cat = {}
+for us, phase, name, info in rows:
+    key = name + (" " + info.split()[0] if name == "GEMM" else "")
+    if name == "GEMM" and " cm=1" in info or "am=3" in info:
+        key = "GEMM token-axis"
+    c = cat.setdefault(key, [0.0, 0])
+    c[0] += us
+    c[1] += 1
+print("by kind:")
+for k, (us, n) in sorted(cat.items(), key=lambda kv: -kv[1][0]):
+    print("  %-28s %9.1f us  %4d launches" % (k, us, n))
