@@ -309,6 +309,10 @@ typedef struct nasrec_final_desc {
   const float* y;
   float* loss;
   float* dlogits_out;
+  /* bwd, large batches: nsplit > 1 cuts the batch into nsplit slices, one set of workgroups each; dw is then a partial buffer
+     [nsplit, K + 1] (column K = the bias gradient, dbias is unused) that a NASREC_OP_REDUCE_ROWS launch sums in fixed order */
+  int32_t nsplit;
+  int32_t _pad;
 } nasrec_final_desc_t;
 
 /* BCEWithLogitsLoss(mean) forward + dlogits (main_train.py:122; train_utils.py:266):

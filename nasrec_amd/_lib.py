@@ -100,7 +100,7 @@ class FinalDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("nseg", i32), ("grad_scale", f32), ("w", vp), ("bias", vp), ("logits", vp), ("dlogits", vp),
                 ("dw", vp), ("dbias", vp), ("seg", vp * MAX_SEGS), ("dseg", vp * MAX_SEGS), ("width", i32 * MAX_SEGS),
                 ("ld", i32 * MAX_SEGS), ("off", i32 * MAX_SEGS), ("dseg_accumulate", i32 * MAX_SEGS), ("y", vp), ("loss", vp),
-                ("dlogits_out", vp)]
+                ("dlogits_out", vp), ("nsplit", i32), ("_pad", i32)]
 
 
 class BceDesc(C.Structure):
@@ -235,8 +235,8 @@ def load():
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
                  "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_sample_chain"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 8:
-        raise EngineError("ABI version mismatch: library %d, binding 8" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 9:
+        raise EngineError("ABI version mismatch: library %d, binding 9" % lib.nasrec_abi_version())
     sizes = (i32 * 32)()
     n = lib.nasrec_desc_sizes(sizes, 32)
     for kind, cls in DESC_BY_KIND.items():

@@ -65,6 +65,41 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const nasrec_final_desc_
     if (threadIdx.x == 0 && d.loss) d.loss[0] = redl[0] / (float)d.B;
     return;
   }
+  if (d.nsplit > 1) {
+    // large batch: workgroup = 64 columns (256-byte coalesced rows) x one of nsplit batch slices; 4 waves take every 4th row
+    __shared__ float reds[4][64];
+    const int nBk = nB / d.nsplit;
+    const int blk = (int)blockIdx.x - nA, slice = blk / nBk, kl = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k = (blk - slice * nBk) * 64 + kl;
+    const int b0 = (int)((long)d.B * slice / d.nsplit), b1 = (int)((long)d.B * (slice + 1) / d.nsplit);
+    float s0 = 0.f, s1 = 0.f;
+    if (k <= K) {
+      const float* src = nullptr;
+      int ld = 0, jj = 0;
+      if (k < K) {
+        for (int q = 0; q < d.nseg; ++q) {
+          jj = k - d.off[q];
+          if (jj >= 0 && jj < d.width[q]) {
+            src = d.seg[q];
+            ld = d.ld[q];
+            break;
+          }
+        }
+      }
+      int b = b0 + w;
+      for (; b + 4 < b1; b += 8) {
+        const float f0 = (k == K) ? 1.f : (src ? src[(long)b * ld + jj] : 0.f);
+        const float f1 = (k == K) ? 1.f : (src ? src[(long)(b + 4) * ld + jj] : 0.f);
+        s0 = fmaf(dl(b), f0, s0);
+        s1 = fmaf(dl(b + 4), f1, s1);
+      }
+      for (; b < b1; b += 4) s0 = fmaf(dl(b), (k == K) ? 1.f : (src ? src[(long)b * ld + jj] : 0.f), s0);
+    }
+    reds[w][kl] = s0 + s1;
+    __syncthreads();
+    if (w == 0 && k <= K) d.dw[(long)slice * (K + 1) + k] = (reds[0][kl] + reds[1][kl]) + (reds[2][kl] + reds[3][kl]);
+    return;
+  }
   __shared__ float red[16][17];
   const int kl = threadIdx.x & 15, bq = threadIdx.x >> 4;
   const int k = ((int)blockIdx.x - nA) * 16 + kl;  // k == K is the bias column
@@ -110,6 +145,7 @@ int launch_final(hipStream_t st, const nasrec_final_desc_t* d) {
     long tA = (long)d->B * K;
     int nA = (int)((tA + 255) / 256);
     int nB = (K + 1 + 15) / 16;
+    if (d->nsplit > 1) nB = ((K + 1 + 63) / 64) * d->nsplit;
     if (d->y != nullptr && d->logits == nullptr) return nasrec_set_error(-2, "final_bwd: fused BCE needs desc.logits");
     hipLaunchKernelGGL(final_bwd_kernel, dim3(nA + nB + (d->y != nullptr ? 1 : 0)), dim3(256), 0, st, *d, K, nA, nB);
   }
@@ -608,6 +644,166 @@ __global__ __launch_bounds__(256) void ln_bwd_tokr_reg_kernel(const nasrec_layer
   }
 }
 
+// token-axis rows, a wavefront per SAMPLE: the sample's [D, 16] block is contiguous, so the wave reads it with up to four 16-byte
+// loads per lane (1 KB per instruction, every byte used once) instead of D 4-byte loads per thread 64 bytes apart.  float4 #q of
+// lane l covers token q * 16 + (l >> 2), columns e = 4 (l & 3) .. + 3: the per-(sample, e) statistics are sums over the lanes
+// with equal l & 3 (shuffles over lane bits 2..5), the per-token parameter gradients sums over lane bits 0..1 and the samples.
+__device__ __forceinline__ float tok_col_sum(float v) {  // over the 16 lanes that hold the same columns
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_tok_wave_kernel(const nasrec_layernorm_desc_t d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave, B = d.R >> 4, n4 = d.D * 4;
+  if (b >= B) return;
+  const float* x = d.x + (long)b * d.ldx;
+  f32x4 v[4];
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = q * 64 + lane;
+    v[q] = f < n4 ? *reinterpret_cast<const f32x4*>(x + 4 * f) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    s = s + v[q];
+  }
+  f32x4 mu, rstd;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) mu[c] = tok_col_sum(s[c]) / (float)d.D;
+  f32x4 qq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (q * 64 + lane < n4) {
+      const f32x4 t = v[q] - mu;
+      qq = qq + t * t;
+    }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rstd[c] = 1.f / sqrtf(tok_col_sum(qq[c]) / (float)d.D + d.eps);
+  if (lane < 4) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r = b * 16 + 4 * lane + c;
+      d.stats[2 * r] = mu[c];
+      d.stats[2 * r + 1] = rstd[c];
+    }
+  }
+  float* y = d.y + (long)b * d.ldy;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = q * 64 + lane;
+    if (f < n4) {
+      const int i = f >> 2;
+      const float w = d.w[i], bb = d.b[i];
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float u = fmaf((v[q][c] - mu[c]) * rstd[c], w, bb);
+        u = act_apply(u, d.act);
+        if (d.dims_in_use >= 0 && i >= d.dims_in_use) u = 0.f;
+        o[c] = u;
+      }
+      f32x4* yp = reinterpret_cast<f32x4*>(y + 4 * f);
+      if (d.accumulate) o = o + *yp;
+      *yp = o;
+    }
+  }
+}
+
+// backward: workgroup blk owns the 16 samples [16 blk, 16 blk + 16) (= the 256 rows the plan sized dwb_partial for), 4 per wave
+__global__ __launch_bounds__(256) void ln_bwd_tok_wave_kernel(const nasrec_layernorm_desc_t d) {
+  __shared__ float red[4][2][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int B = d.R >> 4, n4 = d.D * 4;
+  float w[4], bb[4], pdw[4], pdb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = q * 16 + (lane >> 2);
+    w[q] = i < d.D ? d.w[i] : 0.f;
+    bb[q] = (i < d.D && d.act != NASREC_ACT_NONE) ? d.b[i] : 0.f;
+    pdw[q] = 0.f;
+    pdb[q] = 0.f;
+  }
+  for (int sidx = 0; sidx < 4; ++sidx) {
+    const int b = blockIdx.x * 16 + sidx * 4 + wave;  // (uniform per wave)
+    if (b >= B) break;
+    const float* x = d.x + (long)b * d.ldx;
+    const float* dy = d.dy + (long)b * d.ldy;
+    f32x4 mu, rstd;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r = b * 16 + 4 * (lane & 3) + c;
+      mu[c] = d.stats[2 * r];
+      rstd[c] = d.stats[2 * r + 1];
+    }
+    f32x4 xh[4], g[4];
+    f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = q * 64 + lane;
+      xh[q] = g[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (f < n4) {
+        const int i = f >> 2;
+        xh[q] = (*reinterpret_cast<const f32x4*>(x + 4 * f) - mu) * rstd;
+        f32x4 gg = *reinterpret_cast<const f32x4*>(dy + 4 * f);
+        if (d.dims_in_use >= 0 && i >= d.dims_in_use) gg = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (d.act != NASREC_ACT_NONE) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) gg[c] *= act_grad(fmaf(xh[q][c], w[q], bb[q]), d.act);
+        }
+        g[q] = gg;
+        pdw[q] += (gg[0] * xh[q][0] + gg[1] * xh[q][1]) + (gg[2] * xh[q][2] + gg[3] * xh[q][3]);
+        pdb[q] += (gg[0] + gg[1]) + (gg[2] + gg[3]);
+        const f32x4 gw = gg * w[q];
+        c1 = c1 + gw;
+        c2 = c2 + gw * xh[q];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      c1[c] = tok_col_sum(c1[c]) / (float)d.D;
+      c2[c] = tok_col_sum(c2[c]) / (float)d.D;
+    }
+    float* dx = d.dx + (long)b * d.ldx;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = q * 64 + lane;
+      if (f < n4) {
+        f32x4 o = rstd * (g[q] * w[q] - c1 - xh[q] * c2);
+        f32x4* dp = reinterpret_cast<f32x4*>(dx + 4 * f);
+        if (d.accumulate) o = o + *dp;
+        *dp = o;
+      }
+    }
+  }
+  // per-token parameter gradients: the 4 lanes of a token, then the 4 waves in fixed order
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float sw = pdw[q], sb = pdb[q];
+    sw += __shfl_xor(sw, 1, 64);
+    sw += __shfl_xor(sw, 2, 64);
+    sb += __shfl_xor(sb, 1, 64);
+    sb += __shfl_xor(sb, 2, 64);
+    if ((lane & 3) == 0) {
+      red[wave][0][q * 16 + (lane >> 2)] = sw;
+      red[wave][1][q * 16 + (lane >> 2)] = sb;
+    }
+  }
+  __syncthreads();
+  float* out = d.dwb_partial + (long)blockIdx.x * 2 * d.D;
+  for (int i = threadIdx.x; i < d.D; i += 256) {
+    out[i] = (red[0][0][i] + red[1][0][i]) + (red[2][0][i] + red[3][0][i]);
+    out[d.D + i] = (red[0][1][i] + red[1][1][i]) + (red[2][1][i] + red[3][1][i]);
+  }
+}
+
+static bool ln_tok_wave_ok(const nasrec_layernorm_desc_t* d, bool fwd) {
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  if ((d->R & 15) || (d->ldx & 3) || (d->ldy & 3) || !al(d->x)) return false;
+  return fwd ? al(d->y) : (al(d->dy) && al(d->dx));
+}
+
 static bool ln_vec_ok(const nasrec_layernorm_desc_t* d, bool fwd) {
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   if ((d->D & 3) || (d->ldx & 3) || (d->ldy & 3)) return false;
@@ -639,14 +835,17 @@ int launch_layernorm(hipStream_t st, const nasrec_layernorm_desc_t* d) {
   } else if (d->mode == NASREC_AM_TOKR) {
     if (d->D > 64) return nasrec_set_error(-2, "layernorm(tok): D=%d > 64", d->D);
     const int nb = (d->R + 255) / 256;
+    const bool wave_form = ln_tok_wave_ok(d, fwd);  // a wavefront per sample, 16-byte accesses (needs aligned sample blocks)
     if (fwd) {
-      if (d->D <= 16) hipLaunchKernelGGL(ln_fwd_tokr_reg_kernel<16>, dim3(nb), dim3(256), 0, st, *d);
+      if (wave_form) hipLaunchKernelGGL(ln_fwd_tok_wave_kernel, dim3(((d->R >> 4) + 3) / 4), dim3(256), 0, st, *d);
+      else if (d->D <= 16) hipLaunchKernelGGL(ln_fwd_tokr_reg_kernel<16>, dim3(nb), dim3(256), 0, st, *d);
       else if (d->D <= 32) hipLaunchKernelGGL(ln_fwd_tokr_reg_kernel<32>, dim3(nb), dim3(256), 0, st, *d);
       else if (d->D <= 48) hipLaunchKernelGGL(ln_fwd_tokr_reg_kernel<48>, dim3(nb), dim3(256), 0, st, *d);
       else hipLaunchKernelGGL(ln_fwd_tokr_reg_kernel<64>, dim3(nb), dim3(256), 0, st, *d);
     } else {
       if (d->nblk != nb) return nasrec_set_error(-2, "layernorm(tok) bwd: nblk=%d, want %d", d->nblk, nb);
-      if (d->D <= 16) hipLaunchKernelGGL(ln_bwd_tokr_reg_kernel<16>, dim3(nb), dim3(256), 0, st, *d);
+      if (wave_form) hipLaunchKernelGGL(ln_bwd_tok_wave_kernel, dim3(nb), dim3(256), 0, st, *d);
+      else if (d->D <= 16) hipLaunchKernelGGL(ln_bwd_tokr_reg_kernel<16>, dim3(nb), dim3(256), 0, st, *d);
       else if (d->D <= 32) hipLaunchKernelGGL(ln_bwd_tokr_reg_kernel<32>, dim3(nb), dim3(256), 0, st, *d);
       else if (d->D <= 48) hipLaunchKernelGGL(ln_bwd_tokr_reg_kernel<48>, dim3(nb), dim3(256), 0, st, *d);
       else hipLaunchKernelGGL(ln_bwd_tokr_reg_kernel<64>, dim3(nb), dim3(256), 0, st, *d);

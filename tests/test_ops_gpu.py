@@ -565,7 +565,7 @@ def test_mha_ffn(lib, N, dims, use_saved):
         close(grads[q], pd[q].grad, 2e-5)
 
 
-@pytest.mark.parametrize("mode", ["dense", "token"])
+@pytest.mark.parametrize("mode", ["dense", "token", "token-b37-d64", "token-b20-d7", "token-b130-d26"])
 @pytest.mark.parametrize("act", [L.ACT_NONE, L.ACT_RELU, L.ACT_SILU])
 def test_layernorm(lib, mode, act):
     torch.manual_seed(8)
@@ -573,7 +573,8 @@ def test_layernorm(lib, mode, act):
         R, D, dims = 37, 300, 200
         x = torch.randn(R, D) * 2 + 0.5
     else:
-        B, D, dims = 5, 45, 30
+        B, D, dims = {"token": (5, 45, 30), "token-b37-d64": (37, 64, 64), "token-b20-d7": (20, 7, 5), "token-b130-d26": (130, 26, -1)}[mode]
+        mode = "token"
         x3 = torch.randn(B, D, 16) * 2 + 0.5  # [B, N', 16]; LN over N' per (b,e)
         R = B * 16
         x = x3.permute(0, 2, 1).reshape(R, D)
@@ -581,7 +582,7 @@ def test_layernorm(lib, mode, act):
     xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
     u = torch.nn.functional.layer_norm(xd, (D,), wd, bd, 1e-5)
     u = {L.ACT_NONE: u, L.ACT_RELU: u.clamp_min(0), L.ACT_SILU: u * torch.sigmoid(u)}[act]
-    ref = u * (torch.arange(D) < dims).double()
+    ref = u * (torch.arange(D) < (dims if dims >= 0 else D)).double()
     dy = torch.randn(R, D)
     ref.backward(dy.double())
 
@@ -664,6 +665,21 @@ def test_final_bce_and_dense_optimizer(lib):
     launch(lib, f2)
     assert torch.equal(dlog2, dlog) and torch.equal(ddl2, ddl) and torch.equal(dsl2, dsl) and torch.equal(dw2, dw) and torch.equal(db2, db)
     close(loss2, ref_loss.reshape(1), 1e-6)
+    # large-batch form: the batch in nsplit slices -> partial [nsplit, K + 1] (column K = bias gradient), summed by REDUCE_ROWS
+    for nsplit in (2, 5):
+        part = dev(torch.full((nsplit * (K + 1),), float("nan")))
+        f3 = L.FinalDesc.from_buffer_copy(f2)
+        ddl3, dsl3, dw3, db3 = dev(torch.zeros(B, D)), dev(torch.ones(B, N, 16)), dev(torch.zeros(K)), dev(torch.zeros(1))
+        f3.nsplit, f3.dw, f3.dbias, f3.dseg[0], f3.dseg[1] = nsplit, part.data_ptr(), None, ddl3.data_ptr(), dsl3.data_ptr()
+        launch(lib, f3)
+        r = L.ReduceRowsDesc()
+        r.kind, r.R, r.C, r.ld, r.in_, r.ndst = L.OP_REDUCE_ROWS, nsplit, K + 1, K + 1, part.data_ptr(), 2
+        r.dst[0], r.dst_off[0], r.dst_len[0] = dw3.data_ptr(), 0, K
+        r.dst[1], r.dst_off[1], r.dst_len[1] = db3.data_ptr(), K, 1
+        launch(lib, r)
+        assert torch.equal(ddl3, ddl) and torch.equal(dsl3, dsl)
+        close(dw3, wd.grad[0], 1e-5)
+        close(db3, bd.grad, 1e-5)
     # flat clip + Adagrad vs torch
     n = 100003
     p0, gr = torch.randn(n), torch.randn(n) * 0.01

@@ -47,6 +47,8 @@ for phase, prog in (("fwd", cp.fwd), ("bwd", cp.bwd), ("opt", cp.opt)):
             info = "%s am=%d bm=%d cm=%d z=%d splitk=%d act=%d %.1f TF/s  %s" % (
                 P.gemm_kernel_name(d), d.amode, d.bmode, d.cmode, d.zmode, d.splitk, d.act, fl / us / 1e6,
                 " ".join("%dx%dx%d%s" % (s[0], s[1], s[2], "+1" if s[3] else "") for s in segs))
+        elif isinstance(d, L.MhaDesc):
+            info = "N=%d dims=%d" % (d.N, d.dims_in_use)
         elif isinstance(d, L.LayerNormDesc):
             info = "mode=%d R=%d D=%d" % (d.mode, d.R, d.D)
         rows.append((us, phase, names.get(d.kind, str(d.kind)), info))
