@@ -66,7 +66,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ft_rsrc(const float* base, lon
 #define FT_SK_PIECES 3           // a share of < 2 tiles touches at most 3 tiles
 #define FT_PIECE_FLOATS (FT_BM * FT_BN)
 
-// tile index (live tiles, problem-major, then k-split, m, n) -> problem z, k-split ks, tile row / column; false: no such tile
+// Order of the tiles of one problem: groups of FT_GROUP_M tile rows, inside a group column by column.  The ~64 workgroups an
+// XCD runs at a time then cover 8 rows x 8 columns (8 A panels + 8 B panels in its 4 MB L2) instead of 1.5 rows x 41 columns,
+// and an XCD's contiguous run re-reads the B panels once per group instead of once per row: fabric reads of the
+// 4096 x 5133 x 1024 product 634 MB -> (see profiles/) against 122 MB of operands.
+#define FT_GROUP_M 8
+__device__ __forceinline__ void ft_grouped(int t, int tm, int tn, int& by, int& bx) {
+  const int per_group = FT_GROUP_M * tn;
+  const int grp = t / per_group, first = grp * FT_GROUP_M;
+  const int rows = tm - first < FT_GROUP_M ? tm - first : FT_GROUP_M;
+  const int r = t - grp * per_group;
+  bx = r / rows;
+  by = first + (r - bx * rows);
+}
+
+// tile index (live tiles, problem-major, then k-split, grouped (m, n) order) -> problem z, k-split ks, tile row / column; false: no such tile
 __device__ __forceinline__ bool ft_decode(const nasrec_gemm_desc_t& d, int lin, int S, int tiles_m, int tiles_n, int& z, int& ks, int& by,
                                           int& bx) {
   z = 0;
@@ -83,15 +97,11 @@ __device__ __forceinline__ bool ft_decode(const nasrec_gemm_desc_t& d, int lin, 
       rem -= per * S;
     }
     ks = rem / per;
-    const int t2 = rem - ks * per;
-    by = t2 / tn;
-    bx = t2 - by * tn;
+    ft_grouped(rem - ks * per, per / tn, tn, by, bx);
   } else {
     const int per_z = tiles_m * tiles_n;
     ks = lin / per_z;
-    const int t2 = lin - ks * per_z;
-    by = t2 / tiles_n;
-    bx = t2 - by * tiles_n;
+    ft_grouped(lin - ks * per_z, tiles_m, tiles_n, by, bx);
   }
   return true;
 }
