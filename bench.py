@@ -262,13 +262,14 @@ def main():
         allg = [d for d in P.iter_ops(cp.fwd.descs + cp.bwd.descs) if isinstance(d, L.GemmDesc)]
         if fixed:
             # ---- forward-only throughput (eval path) ---------------------------------------------------------------
-            eng.compile(choice, B, train=False, graph=True)
+            fgraph = not args.no_graph  # (--no-graph: nothing is graph-replayed — counter collection hangs on replays now and then)
+            eng.compile(choice, B, train=False, graph=fgraph)
             for _ in range(20):
-                eng.forward(batches[0][0], batches[0][1], graph=True)
+                eng.forward(batches[0][0], batches[0][1], graph=fgraph)
             torch.cuda.synchronize(device)
             t1 = time.perf_counter()
             for i in range(200):
-                eng.forward(batches[i % 16][0], batches[i % 16][1], graph=True)
+                eng.forward(batches[i % 16][0], batches[i % 16][1], graph=fgraph)
             torch.cuda.synchronize(device)
             result["forward_only_samples_per_s"] = B * 200 / (time.perf_counter() - t1)
 
