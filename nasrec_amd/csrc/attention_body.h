@@ -198,11 +198,51 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
   for (int r = 0; r < S; ++r) q4[r] *= MHA_SCALE;
   const Vec<S> k4 = mv_slice<S>(Wsh + OFF_WIN + 256, Wsh + OFF_BIN + 16, c0, x);
   const Vec<S> v4 = mv_slice<S>(Wsh + OFF_WIN + 512, Wsh + OFF_BIN + 32, c0, x);
+  float mx[HP], ls[HP], li[HP];
+  Vec<S> o4 = vzero<S>();
+  if (S == 4) {
+    // Two heads per wave = one packed-fp32 lane pair: K and V rows are parked as (h0c0, h1c0, h0c1, h1c1), so one ds_read_b128
+    // yields the operand pairs of v_pk_mul / v_pk_fma (2 heads per instruction; the attention core is ~3/4 of this kernel's
+    // vector instructions).  Scores are kept in log2 units (q pre-scaled by log2 e): exp(s - max) = v_exp_f32(s' - max').
+    constexpr float LOG2E = 1.44269504088896340736f;
+    *reinterpret_cast<f32x4*>(Ks + lane * 16 + c0) = (f32x4){k4[0], k4[2 % S], k4[1], k4[3 % S]};
+    *reinterpret_cast<f32x4*>(Vs + lane * 16 + c0) = (f32x4){v4[0], v4[2 % S], v4[1], v4[3 % S]};
+    __syncthreads();
+    const f32x2 qa = {q4[0] * LOG2E, q4[2 % S] * LOG2E}, qb = {q4[1] * LOG2E, q4[3 % S] * LOG2E};
+    f32x2 m2 = {-INFINITY, -INFINITY};
+#pragma unroll 8
+    for (int j = 0; j < N; ++j) {
+      const f32x4 kj = ld4(Ks + j * 16 + c0);
+      const f32x2 s2 = qa * (f32x2){kj[0], kj[1]} + qb * (f32x2){kj[2], kj[3]};
+      m2[0] = fmaxf(m2[0], s2[0]);
+      m2[1] = fmaxf(m2[1], s2[1]);
+    }
+    f32x2 l2 = {0.f, 0.f}, oa = {0.f, 0.f}, ob = {0.f, 0.f};
+#pragma unroll 8
+    for (int j = 0; j < N; ++j) {
+      const f32x4 kj = ld4(Ks + j * 16 + c0);
+      const f32x4 vj = ld4(Vs + j * 16 + c0);
+      const f32x2 t2 = qa * (f32x2){kj[0], kj[1]} + qb * (f32x2){kj[2], kj[3]} - m2;
+      const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+      l2 = l2 + p2;
+      oa = p2 * (f32x2){vj[0], vj[1]} + oa;
+      ob = p2 * (f32x2){vj[2], vj[3]} + ob;
+    }
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+      mx[h] = m2[h] * (1.f / LOG2E);  // the backward works in natural units
+      ls[h] = l2[h];
+      li[h] = 1.f / ls[h];
+    }
+    o4[0] = oa[0] * li[0];
+    o4[1] = ob[0] * li[0];
+    o4[2 % S] = oa[1] * li[1 % HP];
+    o4[3 % S] = ob[1] * li[1 % HP];
+  } else {
   stv<S>(Ks + lane * 16 + c0, k4);
   stv<S>(Vs + lane * 16 + c0, v4);
   __syncthreads();
   // attention, the wave's HP heads (head h = columns c0+2h, c0+2h+1)
-  float mx[HP], ls[HP];
 #pragma unroll
   for (int h = 0; h < HP; ++h) {
     mx[h] = -INFINITY;
@@ -214,7 +254,6 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
 #pragma unroll
     for (int h = 0; h < HP; ++h) mx[h] = fmaxf(mx[h], fmaf(q4[2 * h], kj[2 * h], q4[2 * h + 1] * kj[2 * h + 1]));
   }
-  Vec<S> o4 = vzero<S>();
 #pragma unroll 4
   for (int j = 0; j < N; ++j) {
     const Vec<S> kj = ldv<S>(Ks + j * 16 + c0);
@@ -227,12 +266,12 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
       o4[2 * h + 1] = fmaf(p, vj[2 * h + 1], o4[2 * h + 1]);
     }
   }
-  float li[HP];
 #pragma unroll
   for (int h = 0; h < HP; ++h) {
     li[h] = 1.f / ls[h];
     o4[2 * h] *= li[h];
     o4[2 * h + 1] *= li[h];
+  }
   }
   stv<S>(Ob + lane * 16 + c0, o4);
   __syncthreads();
