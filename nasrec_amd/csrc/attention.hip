@@ -83,6 +83,29 @@ __global__ __launch_bounds__(1024 / S) void mha_bwd_kernel(const nasrec_mha_desc
   const bool active = lane < N;
   float* gp = d.dparams_partial + (long)b * (d.partial_ld > 0 ? d.partial_ld : NASREC_MHA_PARAMS);
   stage_params<NT>(d, Wsh, tid);
+  // ---- the sample's planes: global -> LDS with contiguous 16-byte accesses (x and the forward state are [token][16] planes) -----
+  {
+    const int n4 = N * 4;
+    auto plane_in = [&](float* lds, const float* src) {
+      for (int t = tid; t < n4; t += NT) *reinterpret_cast<f32x4*>(lds + 4 * t) = *reinterpret_cast<const f32x4*>(src + 4 * t);
+    };
+    plane_in(Xb, d.x + (long)b * d.ldx);
+    plane_in(Qb, sv_plane(d.saved, b, N, SV_Q));
+    plane_in(Kb, sv_plane(d.saved, b, N, SV_K));
+    plane_in(Vb, sv_plane(d.saved, b, N, SV_V));
+    plane_in(Ob, sv_plane(d.saved, b, N, SV_O));
+    plane_in(H1b, sv_plane(d.saved, b, N, SV_H1));
+    plane_in(F1b, sv_plane(d.saved, b, N, SV_F1));
+    plane_in(Bf[7], sv_plane(d.saved, b, N, SV_XH1));  // x-hats: only on their way to registers
+    plane_in(Bf[8], sv_plane(d.saved, b, N, SV_XH2));
+    const float* ml = sv_plane(d.saved, b, N, SV_M);
+    for (int t = tid; t < n4; t += NT) {  // [token][8 max | 8 1/sum] -> Mb, Lb
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ml + 4 * t);
+      float* dst = ((t & 2) ? Lb : Mb) + (t >> 2) * 8 + (t & 1) * 4;
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  }
+  __syncthreads();  // parameters and the token rows are in LDS
   Vec<S> x4 = vzero<S>(), q4 = vzero<S>(), k4 = vzero<S>(), v4 = vzero<S>(), o4 = vzero<S>(), h1 = vzero<S>(), xh1 = vzero<S>(),
          f1 = vzero<S>(), xh2 = vzero<S>(), dout = vzero<S>();
   float mx[HP], li[HP];
@@ -93,41 +116,29 @@ __global__ __launch_bounds__(1024 / S) void mha_bwd_kernel(const nasrec_mha_desc
   }
   float rstd1 = 1.f, rstd2 = 1.f;
   if (active) {
-    const float* sv = d.saved + ((long)b * N + lane) * NASREC_MHA_SAVED;
-    x4 = ldv<S>(d.x + (long)b * d.ldx + lane * 16 + c0);
-    q4 = ldv<S>(sv + SV_Q + c0);
-    k4 = ldv<S>(sv + SV_K + c0);
-    v4 = ldv<S>(sv + SV_V + c0);
-    o4 = ldv<S>(sv + SV_O + c0);
-    h1 = ldv<S>(sv + SV_H1 + c0);
-    xh1 = ldv<S>(sv + SV_XH1 + c0);
-    f1 = ldv<S>(sv + SV_F1 + c0);
-    xh2 = ldv<S>(sv + SV_XH2 + c0);
+    const int o = lane * 16 + c0;
+    x4 = ldv<S>(Xb + o);
+    q4 = ldv<S>(Qb + o);
+    k4 = ldv<S>(Kb + o);
+    v4 = ldv<S>(Vb + o);
+    o4 = ldv<S>(Ob + o);
+    h1 = ldv<S>(H1b + o);
+    f1 = ldv<S>(F1b + o);
+    xh1 = ldv<S>(Bf[7] + o);
+    xh2 = ldv<S>(Bf[8] + o);
 #pragma unroll
     for (int h = 0; h < HP; ++h) {
-      mx[h] = sv[SV_M + HP * w + h];
-      li[h] = sv[SV_M + 8 + HP * w + h];
+      mx[h] = Mb[lane * 8 + HP * w + h];
+      li[h] = Lb[lane * 8 + HP * w + h];
     }
-    rstd1 = sv[SV_RSTD];
-    rstd2 = sv[SV_RSTD + 1];
+    const float* rs = sv_plane(d.saved, b, N, SV_RSTD) + lane * 4;
+    rstd1 = rs[0];
+    rstd2 = rs[1];
     if (!(d.dims_in_use >= 0 && lane >= d.dims_in_use)) dout = ldv<S>(d.dout + (long)b * d.ldo + lane * 16 + c0);
-  }
-  stv<S>(Xb + lane * 16 + c0, x4);
-  stv<S>(Qb + lane * 16 + c0, q4);
-  stv<S>(Kb + lane * 16 + c0, k4);
-  stv<S>(Vb + lane * 16 + c0, v4);
-  stv<S>(Ob + lane * 16 + c0, o4);
-  stv<S>(F1b + lane * 16 + c0, f1);
-  stv<S>(H1b + lane * 16 + c0, h1);
-#pragma unroll
-  for (int h = 0; h < HP; ++h) {
-    Mb[lane * 8 + HP * w + h] = mx[h];
-    Lb[lane * 8 + HP * w + h] = li[h];
   }
   // ---- LayerNorm 2 ----
   bgrad_slice<S>(vmul<S>(dout, xh2), c0, lane, gp + OFF_L2W);
   bgrad_slice<S>(dout, c0, lane, gp + OFF_L2B);
-  __syncthreads();  // parameters and the token rows are in LDS
   Vec<S> gw;
   float sa = 0.f, sb = 0.f;
 #pragma unroll

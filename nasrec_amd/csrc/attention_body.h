@@ -19,17 +19,29 @@
 #define OFF_L2W 1664
 #define OFF_L2B 1680
 
-// layout of the per-token forward state kept for the backward (NASREC_MHA_SAVED floats)
-#define SV_Q 0      // scaled query
-#define SV_K 16
-#define SV_V 32
-#define SV_O 48     // attention output (before the out-projection)
-#define SV_H1 64    // LayerNorm-1 output
-#define SV_XH1 80   // LayerNorm-1 x-hat
-#define SV_F1 96    // FFN hidden (post-ReLU)
-#define SV_XH2 112  // LayerNorm-2 x-hat
-#define SV_M 128    // per-head softmax max (8) and 1/sum (8)
-#define SV_RSTD 144 // 1/std of both LayerNorms
+// Forward state kept for the backward: N * NASREC_MHA_SAVED floats per sample, as PLANES [token][16] (one per vector) so that a
+// plane is 64 N contiguous bytes: the forward copies each plane out of LDS with one fully coalesced 16-byte store per thread
+// (token records of 148 floats made every 16-byte piece of a wave's store land in a different cache line: +34 us per launch at
+// B = 4096, +4 us at B = 256), and as early as the plane is final, so the store latency hides under the rest of the kernel.
+#define SV_Q 0      // plane index: scaled query
+#define SV_K 1
+#define SV_V 2
+#define SV_O 3      // attention output (before the out-projection)
+#define SV_H1 4     // LayerNorm-1 output
+#define SV_XH1 5    // LayerNorm-1 x-hat
+#define SV_F1 6     // FFN hidden (post-ReLU)
+#define SV_XH2 7    // LayerNorm-2 x-hat
+#define SV_M 8      // per-head softmax max (8) and 1/sum (8)
+#define SV_RSTD 9   // [token][4]: 1/std of both LayerNorms, 2 unused
+__device__ __forceinline__ float* sv_plane(float* saved, int b, int N, int p) { return saved + ((long)b * N) * NASREC_MHA_SAVED + (long)p * N * 16; }
+__device__ __forceinline__ const float* sv_plane(const float* saved, int b, int N, int p) {
+  return saved + ((long)b * N) * NASREC_MHA_SAVED + (long)p * N * 16;
+}
+// LDS plane [token][16] -> global plane, all NT threads, 16 bytes each, contiguous
+template <int NT>
+__device__ __forceinline__ void sv_copy_out(float* dst, const float* lds, int N, int tid) {
+  for (int t = tid; t < N * 4; t += NT) *reinterpret_cast<f32x4*>(dst + 4 * t) = *reinterpret_cast<const f32x4*>(lds + 4 * t);
+}
 
 // All 1696 parameters of the node are staged once per workgroup into LDS (6.8 KB) and read back with
 // wave-uniform (broadcast) ds_reads: keeping them in SGPRs instead blows the scalar register file.
@@ -183,6 +195,7 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c0 = S * w;
   const int N = d.N;
   const bool active = lane < N;
+  const bool saving = d.saved != nullptr;  // training: keep what the backward needs instead of recomputing it there
   stage_params<NT>(d, Wsh, tid);
   float x[16];
   if (active) {
@@ -207,7 +220,18 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
     constexpr float LOG2E = 1.44269504088896340736f;
     *reinterpret_cast<f32x4*>(Ks + lane * 16 + c0) = (f32x4){k4[0], k4[2 % S], k4[1], k4[3 % S]};
     *reinterpret_cast<f32x4*>(Vs + lane * 16 + c0) = (f32x4){v4[0], v4[2 % S], v4[1], v4[3 % S]};
+    if (saving) {  // q, k, v planes in natural column order (Hb, Fb, Ob are free until later stages)
+      stv<S>(Hb + lane * 16 + c0, q4);
+      stv<S>(Fb + lane * 16 + c0, k4);
+      stv<S>(Ob + lane * 16 + c0, v4);
+    }
     __syncthreads();
+    if (saving) {
+      sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_Q), Hb, N, tid);
+      sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_K), Fb, N, tid);
+      sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_V), Ob, N, tid);
+      __syncthreads();  // Ob is rewritten right after the attention loop (another wave may get there first)
+    }
     const f32x2 qa = {q4[0] * LOG2E, q4[2 % S] * LOG2E}, qb = {q4[1] * LOG2E, q4[3 % S] * LOG2E};
     f32x2 m2 = {-INFINITY, -INFINITY};
 #pragma unroll 8
@@ -241,7 +265,13 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
   } else {
   stv<S>(Ks + lane * 16 + c0, k4);
   stv<S>(Vs + lane * 16 + c0, v4);
+  if (saving) stv<S>(Hb + lane * 16 + c0, q4);
   __syncthreads();
+  if (saving) {
+    sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_Q), Hb, N, tid);
+    sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_K), Ks, N, tid);
+    sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_V), Vs, N, tid);
+  }
   // attention, the wave's HP heads (head h = columns c0+2h, c0+2h+1)
 #pragma unroll
   for (int h = 0; h < HP; ++h) {
@@ -275,6 +305,7 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
   }
   stv<S>(Ob + lane * 16 + c0, o4);
   __syncthreads();
+  if (saving) sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_O), Ob, N, tid);
   // out-projection + residual + LayerNorm 1
   float row[16];
   ld_row(Ob + lane * 16, row);
@@ -290,7 +321,12 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
     h1[r] = xh1[r] * Wsh[OFF_L1W + c0 + r] + Wsh[OFF_L1B + c0 + r];
   }
   stv<S>(Hb + lane * 16 + c0, h1);
+  if (saving) stv<S>(Ks + lane * 16 + c0, xh1);  // (K rows are dead since the barrier behind the attention loops)
   __syncthreads();
+  if (saving) {
+    sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_H1), Hb, N, tid);
+    sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_XH1), Ks, N, tid);
+  }
   // FFN
   ld_row(Hb + lane * 16, row);
   Vec<S> f1 = mv_slice<S>(Wsh + OFF_W1, Wsh + OFF_C1, c0, row);
@@ -298,6 +334,7 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
   for (int r = 0; r < S; ++r) f1[r] = fmaxf(f1[r], 0.f);
   stv<S>(Fb + lane * 16 + c0, f1);
   __syncthreads();
+  if (saving) sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_F1), Fb, N, tid);
   ld_row(Fb + lane * 16, row);
   Vec<S> r2 = mv_slice<S>(Wsh + OFF_W2, Wsh + OFF_C2, c0, row);
 #pragma unroll
@@ -312,27 +349,19 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
     out[r] = masked ? 0.f : xh2[r] * Wsh[OFF_L2W + c0 + r] + Wsh[OFF_L2B + c0 + r];
   }
   if (active) stv<S>(d.out + (long)b * d.ldo + lane * 16 + c0, out);
-  if (d.saved != nullptr && active) {  // training: keep what the backward needs instead of recomputing it there
-    float* sv = d.saved + ((long)b * N + lane) * NASREC_MHA_SAVED;
-    stv<S>(sv + SV_Q + c0, q4);
-    stv<S>(sv + SV_K + c0, k4);
-    stv<S>(sv + SV_V + c0, v4);
-    stv<S>(sv + SV_O + c0, o4);
-    stv<S>(sv + SV_H1 + c0, h1);
-    stv<S>(sv + SV_XH1 + c0, xh1);
-    stv<S>(sv + SV_F1 + c0, f1);
-    stv<S>(sv + SV_XH2 + c0, xh2);
+  if (saving) {
+    // x-hat of LayerNorm 2 and the softmax statistics: through the dead V / O rows (every wave is past its reads of them: the
+    // LayerNorm barriers above), then planes like the rest
+    stv<S>(Vs + lane * 16 + c0, xh2);
 #pragma unroll
     for (int h = 0; h < HP; ++h) {
-      sv[SV_M + HP * w + h] = mx[h];
-      sv[SV_M + 8 + HP * w + h] = li[h];
+      Ob[lane * 16 + HP * w + h] = mx[h];
+      Ob[lane * 16 + 8 + HP * w + h] = li[h];
     }
-    if (w == 0) {
-      sv[SV_RSTD] = rstd1;
-      sv[SV_RSTD + 1] = rstd2;
-      sv[SV_RSTD + 2] = 0.f;
-      sv[SV_RSTD + 3] = 0.f;
-    }
+    if (w == 0 && active) *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_RSTD) + lane * 4) = (f32x4){rstd1, rstd2, 0.f, 0.f};
+    __syncthreads();
+    sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_XH2), Vs, N, tid);
+    sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_M), Ob, N, tid);
   }
 }
 
