@@ -207,6 +207,7 @@ def main():
             model(batches[0][0][:64], batches[0][1][:64])
         eng = model._engine
         eng.init_weights(seed=0)
+        eng.reserve(B)  # plan slots sized for the largest path: no allocator call inside a step
         model.configure_path_sampling_strategy("default")
         np.random.seed(0)
         dp = DataParallelStep(eng, None, B, clip=5.0, eps=1e-2, graph=False, force_exchange=args.force_dp_path)

@@ -106,6 +106,14 @@ class Arena:
         item = torch.empty((), dtype=dtype).element_size()
         return self.alloc_bytes(int(numel) * item)[:int(numel) * item].view(dtype)
 
+    def used_bytes(self) -> int:
+        return sum(c.numel() for c in self.chunks[:self.cur]) + self.off
+
+    def reserve(self, nbytes: int):
+        """grow to at least nbytes now (one allocator call per chunk, outside any timed or latency-sensitive region)"""
+        while sum(c.numel() for c in self.chunks) < nbytes:
+            self.chunks.append(torch.empty(self.CHUNK, dtype=torch.uint8, device=self.device))
+
 
 def _on_device(fn):
     """run an engine entry point with the engine's device current: raw kernel launches, memsets, graph capture and event
@@ -486,6 +494,33 @@ class SupernetEngine:
                 return [red, app]
             return [dd, sq, app]  # global batch of a data-parallel step: chunked dedup + merge (two launches), then the same apply
         return descs
+
+    @_on_device
+    def reserve(self, B: int, train: bool = True, choice=None):
+        """Size every plan slot for the LARGEST path at batch B (default: the warm-up choice = the full path) and allocate the
+        engine-level workspaces, so that no sampled path of a run has to grow an arena (an allocator call + device
+        synchronisation in the middle of a step: 1-2 ms spikes in the per-step times).  Host work only; nothing is launched."""
+        if self.cfg.fixed:
+            return 0
+        cp = self.compile(choice if choice is not None else self.warm_choice, B, train)
+        need = cp.arena.used_bytes() + Arena.CHUNK
+        key = next(k for k, v in self._plans.items() if v is cp)
+        self._plans.pop(key)
+        cp.evicted = True
+        self._last_plan = None
+        arenas = [cp.arena] + list(self._spare_arenas)
+        cp.arena = None
+        live = len(self._plans)
+        while len(arenas) + live < 4:
+            arenas.append(Arena(self.device))
+        for a in arenas:
+            a.reserve(need)
+        for v in self._plans.values():
+            if v.arena is not None:
+                v.arena.reserve(need)
+        self._spare_arenas = arenas
+        self._sk_workspace()
+        return need
 
     def _sk_workspace(self):
         """partial-tile workspace of the balanced GEMM schedule (100 MB): one per engine — the launches of a program run in

@@ -242,6 +242,9 @@ def warmup_supernet_model(model: nn.Module, train_loader, gpu):
     int_x, cat_x, _ = next(iter(train_loader))
     model.configure_path_sampling_strategy("full-path")
     model(int_x.to(gpu), cat_x.to(gpu))
+    eng = getattr(model, "_engine", None)
+    if eng is not None and hasattr(eng, "reserve") and not getattr(eng, "host_embedding", False):
+        eng.reserve(int(int_x.shape[0]))  # plan slots sized for the full path: sampled paths never grow an arena mid-step
     return model
 
 
