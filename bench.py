@@ -257,11 +257,11 @@ def main():
         "final_loss": loss,
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0:  # (N > 1: the roofline of the dominant launch and the step accounting are rank 0's; forward-only and the CPU baseline are N = 1 legs)
         sp = torch.cuda.current_stream(device).cuda_stream
         cp = dp.last_plan()
         allg = [d for d in P.iter_ops(cp.fwd.descs + cp.bwd.descs) if isinstance(d, L.GemmDesc)]
-        if fixed:
+        if fixed and world == 1:
             # ---- forward-only throughput (eval path) ---------------------------------------------------------------
             fgraph = not args.no_graph  # (--no-graph: nothing is graph-replayed — counter collection hangs on replays now and then)
             eng.compile(choice, B, train=False, graph=fgraph)
@@ -310,7 +310,7 @@ def main():
                                                   "row-sparse embedding semantics" % (n_used, step_bytes / 1e6),
                                    "launches_per_step": len(cp.fwd.descs) + len(cp.bwd.descs) + len(cp.opt.descs) + 1,
                                    "launch_floor_ms": (len(cp.fwd.descs) + len(cp.bwd.descs) + len(cp.opt.descs) + 1) * 1.65e-3}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             # torch CPU ops stop scaling (and start thrashing) far below this box's logical core count: use one
             # socket's worth of threads at most, and state the number
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -320,6 +320,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 
