@@ -12,6 +12,8 @@ local forward/backward:
     instead of all-reducing 2.16 GB of dense table gradient — then every rank runs the same row-sparse
     dedup + clip + Adagrad over the global batch, so the replicated tables stay bit-identical across ranks;
   * the global-norm clip coefficient comes out identical on every rank because it is computed from identical data.
+Fixed sub-networks (batch 256, a 0.6 ms step) issue the three collectives back to back behind the backward with the plain
+(handle-free) API: at that step size the host cost of asynchronous work handles outweighs what their overlap could hide.
 Path sampling under DP: the reference draws ONE path per step from the global `np.random` stream (supernet.py:525-529); all
 ranks share the seed, hence the same path, hence a step that equals a single process at the global batch (`choice=` of
 `DataParallelStep.step`).  The collectives are asynchronous: the ids go out right after staging, the row gradients when the
@@ -128,6 +130,20 @@ class DataParallelStep:
             return loss
         plan = self._plan(choice)
         plan.stage(int_x, cat_x, y, lr)
+        if self.fixed:
+            # Batch-256 regime: the step is a few hundred microseconds and the HOST is what the exchange competes with.  Work
+            # handles (async_op=True) cost ~40 us of host time per collective and made the step host-bound (757 us against 609 us
+            # for the plain step on one GPU); the plain calls, issued back to back behind the backward, cost 46 us in all
+            # (tools/scratch/dp_overhead.py).  They still run on RCCL's stream: the compute stream just waits for them in order.
+            plan.forward()
+            for run, _ in plan.segments:
+                run()
+            all_gather_rows(self.cat_all, plan.cat_local)
+            all_gather_rows(self.sg_all, plan.sparse_grad)
+            dist.all_reduce(eng.flat_g, op=dist.ReduceOp.SUM)
+            self.opt(plan)
+            self._last = ("dp", plan)
+            return plan.loss
         pending = [all_gather_rows_async(self.cat_all, plan.cat_local)]
         plan.forward()
         flat_g = eng.flat_g
