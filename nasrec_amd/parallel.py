@@ -220,10 +220,10 @@ class EngineDP:
         descs = cp.bwd.descs
         with torch.cuda.stream(eng.stream):
             if fixed:
-                # forward + backward chain | parked weight-gradient products: the row-gradient all-gather runs under the latter
-                cut = cp.bwd_tail_start
-                fb = Program(cp.fwd.descs + descs[:cut])
-                tail = Program(descs[cut:]) if cut < len(descs) else None
+                # forward + whole backward (the parked weight-gradient products included) as ONE graph: the collectives of the
+                # batch-256 step are issued behind it (DataParallelStep.step), so a second segment would only add a graph launch
+                fb = Program(cp.fwd.descs + descs)
+                tail = None
                 if graph:
                     fb.capture(eng.stream.cuda_stream)
                     if tail is not None:
