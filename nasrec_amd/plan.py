@@ -85,8 +85,9 @@ class Buf:
 class DV:
     """dense view [B, width], row stride ld, starting `off` floats into buf"""
 
-    def __init__(self, buf, off, width, ld):
+    def __init__(self, buf, off, width, ld, padded=False):
         self.buf, self.off, self.width, self.ld = buf, off, width, ld
+        self.padded = padded  # ld > width only to align the rows: the view still covers every column anybody reads
 
     @property
     def ptr(self):
@@ -97,6 +98,8 @@ class DV:
         return self.buf.grad_tensor().data_ptr() + 4 * self.off
 
     def full(self, B):
+        if self.padded:
+            return self.off == 0 and self.ld * B == self.buf.numel
         return self.off == 0 and self.width == self.ld and self.width * B == self.buf.numel
 
     def cols(self):
@@ -1023,12 +1026,16 @@ def op_sigmoid_gating(ctx, cfg, pre, lsegs, Ltot, rsegs, Rtot, max_dims, dims, t
     mask = -1 if cfg.fixed else dims
     sl = pre + "._left_self_linear._linear"
     need_proj = D != max_dims
-    gbuf = ctx.buf(B * D, need_grad=False)
-    g = DV(gbuf, 0, D, D)
+    # rows of the [B, D] temporaries start on 128-byte boundaries (D = 13 + 1024 i: unaligned rows made the gated product write
+    # 2.5x its output bytes — every 128-byte row segment a wave stores straddled two 64-byte granules)
     masked_plain = (not need_proj) and (not use_ln) and 0 <= mask < D  # the mask is all that follows the gating product
-    if need_proj or use_ln or masked_plain:
-        pbuf = ctx.buf(B * D)
-        prod = DV(pbuf, 0, D, D)
+    own = need_proj or use_ln or masked_plain  # the product lands in a temporary of this operator (else straight in the target)
+    Dp = (D + 31) // 32 * 32 if (own and B > 256) else D  # (the saved sigmoid is addressed like the product: same row stride)
+    gbuf = ctx.buf(B * Dp, need_grad=False)
+    g = DV(gbuf, 0, D, Dp, padded=True)
+    if own:
+        pbuf = ctx.buf(B * Dp)
+        prod = DV(pbuf, 0, D, Dp, padded=True)
         ptgt = Target(prod, 0)
     else:
         prod = tgt.view
@@ -1038,11 +1045,11 @@ def op_sigmoid_gating(ctx, cfg, pre, lsegs, Ltot, rsegs, Rtot, max_dims, dims, t
     def pre_dz():
         if not ctx.live(prod):
             return None
-        dz = ctx.alloc(B * D)
+        dz = ctx.alloc(B * Dp)
         e = L.GateBwdDesc()
         e.kind = L.OP_GATE_BWD
         e.B, e.D = B, D
-        e.ld_dout, e.ld_g, e.ld_dz = prod.ld, D, D
+        e.ld_dout, e.ld_g, e.ld_dz = prod.ld, Dp, Dp
         e.dout, e.g, e.dz = prod.gptr, g.ptr, dz.data_ptr()
         n = 0
         for s in _live_segs(rsegs):
@@ -1052,7 +1059,7 @@ def op_sigmoid_gating(ctx, cfg, pre, lsegs, Ltot, rsegs, Rtot, max_dims, dims, t
             n += 1
         e.nseg = n
         ctx.emit(e)
-        return dz.data_ptr(), D
+        return dz.data_ptr(), Dp
 
     # the D x D self-linear consumes the zero-padded left operand: K range = Ltot (padding contributes nothing)
     linear_dense(ctx, lsegs, D, sl, D, True, prod, L.ACT_SIGMOID, -1, ptgt.accumulate, mul=rsegs, save_act=g, pre_dz_cb=pre_dz)
