@@ -510,11 +510,11 @@ def _mha_ref(x, p, dims):
 
 
 @pytest.mark.parametrize("use_saved", [False, True])
-@pytest.mark.parametrize("N,dims", [(16, -1), (64, -1), (48, 32), (7, -1)])
-def test_mha_ffn(lib, N, dims, use_saved):
-    """the forward runs with or without saving its per-token state; the backward always consumes a saved state"""
+@pytest.mark.parametrize("N,dims,B", [(16, -1, 13), (64, -1, 13), (48, 32, 13), (7, -1, 13), (64, 40, 1030), (26, -1, 1024)])
+def test_mha_ffn(lib, N, dims, use_saved, B):
+    """the forward runs with or without saving its per-token state; the backward always consumes a saved state.  Batches >= 1024
+    take the 4-wave backward (two heads per wave), smaller ones the 8-wave form"""
     torch.manual_seed(7 + N)
-    B = 13
     shapes = [(48, 16), (48,), (16, 16), (16,), (16,), (16,), (16, 16), (16,), (16, 16), (16,), (16,), (16,)]
     p = [torch.randn(s) * (0.3 if len(s) == 2 else 0.1) for s in shapes]
     p[4] = 0.17 + 0.02 * torch.randn(16)
