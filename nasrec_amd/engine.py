@@ -273,6 +273,15 @@ class SupernetEngine:
                 arena = old.arena
                 old.arena = None
                 self._last_plan = None
+                # a plan is a web of closures over its context: cut it open so reference counting frees the ~10^4 objects now
+                # instead of leaving them to the cyclic collector (whose full passes stalled a step for 17-56 ms)
+                octx = getattr(old, "ctx", None)
+                if octx is not None:
+                    octx.closures = []
+                    octx.deferred = []
+                    octx.mha_reduce = []
+                    octx.keep = []
+                    octx.sk_workspace = None
             if arena is None:
                 arena = self._spare_arenas.pop() if self._spare_arenas else Arena(self.device)
             arena.reset()
@@ -520,6 +529,11 @@ class SupernetEngine:
                 v.arena.reserve(need)
         self._spare_arenas = arenas
         self._sk_workspace()
+        # everything alive now (modules, parameters, the interpreter's own structures) lives as long as the run: take it out of
+        # the cyclic collector's reach, so that its full passes walk the few plans in flight instead of ~10^6 objects
+        import gc
+        gc.collect()
+        gc.freeze()
         return need
 
     def _sk_workspace(self):
