@@ -497,10 +497,30 @@ def _cover_pieces(live: List[Seg]):
     return out
 
 
+def _split_column_remainder(ctx, bm, cm, d):
+    """[problem] or [its first 128 n columns, its last <= 16 columns].  A [B, 1035] input gradient or a [1024, 1035 (+1)] weight
+    gradient (13 dense features + 1024) has a ninth column of 128-wide tiles that is 8 % full: 576 tiles instead of 512 put a
+    second, almost empty round on the chip (8192 x 1035 x 1024: 200 us against 123 us for 8192 x 1024 x 1024).  The remainder
+    columns become a problem of their own, which the shape classes send to the small-tile kernel."""
+    if ctx.B <= 256 or cm != L.CM_PLAIN or bm not in (L.AM_KC, L.AM_RC) or not d.get("A"):
+        return [d]
+    N, ones = d["N"], int(bool(d.get("ones_col")))
+    r = N % 128
+    if N <= 128 or r == 0 or r > 16 or r - ones < 1 or d["M"] < 128:
+        return [d]
+    Nm = N - r
+    step = 4 * Nm * (d["ldb"] if bm == L.AM_KC else 1)
+    main = dict(d, N=Nm, ones_col=0, rowsum=None)
+    rem = dict(d, N=r, B=d["B"] + step, C=d["C"] + 4 * Nm)
+    if d.get("Baux"):
+        rem["Baux"] = d["Baux"] + step
+    return [main, rem]
+
+
 def _emit_z_groups(ctx, am, bm, cm, items, rowsum_out=None):
     """items: [(group_index, seg_dict)] -> one launch per group (in order), <= MAX_SEGS problems per launch.
     rowsum_out: fuse the bias gradient into the first problem as a virtual ones-column (B(N-1,k) = 1)."""
-    items = _with_rowsum(items, rowsum_out)
+    items = [(g, p) for g, d in _with_rowsum(items, rowsum_out) for p in _split_column_remainder(ctx, bm, cm, d)]
     for gi in sorted({g for g, _ in items}):
         grp = [d for g, d in items if g == gi]
         for cls in sorted({_shape_class(ctx, d) for d in grp}):
@@ -535,7 +555,8 @@ def _weight_grad_products(ctx, am, bm, cm, items, rowsum_out=None):
     if not ctx.defer_dw:
         return _emit_z_groups(ctx, am, bm, cm, items, rowsum_out)
     for rank, d in _with_rowsum(items, rowsum_out):
-        ctx.deferred.append((am, bm, cm, rank, d))
+        for p in _split_column_remainder(ctx, bm, cm, d):
+            ctx.deferred.append((am, bm, cm, rank, p))
 
 
 def _flush_mha_reduce(ctx):
