@@ -76,6 +76,10 @@ static void launch_ring(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, i
   for (int q = 0; q < d->nseg; ++q) {
     aux = aux || d->seg[q].Aaux || d->seg[q].Baux;
     if (!d->zmode && (d->seg[q].ones_col != d->seg[0].ones_col || d->seg[q].Mvalid != d->seg[0].Mvalid)) uniform = false;
+    // (the ring keeps one "masked operand" flag per launch segment in flight, not per staged slot: k-segments that disagree on
+    // having a ReLU-mask operand — contributions of different Linears concatenated along K — take the plain template)
+    if (!d->zmode && d->seg[q].A && ((d->seg[q].Aaux != nullptr) != (d->seg[0].Aaux != nullptr) || (d->seg[q].Baux != nullptr) != (d->seg[0].Baux != nullptr)))
+      uniform = false;
   }
   if (!uniform || !GEMM_RING) {
     launch_cfg<AM, BMODE, CM, NT, TK, TBM, TBN>(st, d, Mmax, Nmax, zdim);

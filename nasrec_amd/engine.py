@@ -307,6 +307,7 @@ class SupernetEngine:
             sbuf = ctx.buf(B * self.Fs * E)
             sparse0 = P.SV(sbuf, 0, self.Fs, self.Fs * E)
             cp.sparse0 = sbuf
+            ctx.raw_sparse = sbuf
             g = L.EmbedDesc()
             g.kind = L.OP_EMBED_GATHER
             g.B, g.Fs = B, self.Fs

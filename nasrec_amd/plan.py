@@ -169,6 +169,8 @@ class Ctx:
         self.lane = 0        # lane of the forward descriptors being emitted (0 = main, 1 = the block's sparse branch)
         self.fwd_sched: List = []  # [(lane | LANE_FORK | LANE_JOIN, index into self.fwd)] in emission order
         self.arena = None  # optional Arena (engine.py): where alloc() takes its buffers from
+        self.raw_sparse = None  # Buf of the embedding stem's output [B, Fs, 16] (set by the engine): see _flush_raw_dx
+        self.deferred_raw: List = []
         self.sk_workspace = None  # optional callable -> tensor of L.SK_WORKSPACE_FLOATS floats shared by the plan's balanced GEMM launches
         self.block_marks: List = []  # (block index, length of the backward program once that block's gradients are complete)
 
@@ -237,6 +239,7 @@ class Ctx:
         self.out = self.bwd
         for fn in reversed(self.closures):
             fn()
+        _flush_raw_dx(self)
         _flush_mha_reduce(self)
         self.bwd_tail_start = len(self.bwd)  # from here on: only the parked weight-gradient products
         _flush_deferred(self)
@@ -247,7 +250,7 @@ class Ctx:
         buf = view.buf
         if not buf.need_grad:
             return None, 0
-        if self.deferred and buf.g is not None and not self.shape_only:
+        if (self.deferred or self.deferred_raw) and buf.g is not None and not self.shape_only:
             # A parked weight-gradient product reads this gradient storage as its dz operand, and a write is about to
             # land in it (gradient storage shared through _alias_add: the pre-FM block output takes further
             # contributions after the FM projection consumed the sum): issue those products first.
@@ -257,6 +260,8 @@ class Ctx:
             if hit:
                 self.deferred = [e for e in self.deferred if not (lo <= e[4]["A"] < hi)]
                 _flush_deferred(self, hit)
+            if any(lo <= e["B"] < hi for e in self.deferred_raw):
+                _flush_raw_dx(self)
         acc = buf.grad_written
         if not acc and not view.full(self.B):
             self.emit(memset_desc(buf.grad_tensor()))
@@ -594,6 +599,32 @@ def _flush_deferred(ctx, todo=None):
                 ctx.emit(g)
 
 
+def _flush_raw_dx(ctx):
+    """Gradients into the raw embedding tokens have no consumer inside the backward (the stem's output is a leaf: only the
+    row-sparse optimizer reads its gradient), and every block's token-axis Linear that reads the raw tokens contributes
+    dx = W_l^T dz_l to the SAME [B, Fs, 16] buffer.  Instead of one accumulating launch per contributor, in backward order, they are
+    parked and issued as ONE K-concatenated product [W_1^T | W_2^T | ...] [dz_1; dz_2; ...] at the end of the backward chain
+    (batch 256: five 5.6-10.8 us launches -> one)."""
+    items, ctx.deferred_raw = ctx.deferred_raw, []
+    if not items:
+        return
+    view = items[0]["view"]
+    gp, acc = ctx.gtarget(view)
+    if gp is None:
+        return
+    for i in range(0, len(items), L.MAX_SEGS):
+        segs = [dict(A=e["A"], B=e["B"], Baux=e["Baux"], C=gp, M=e["M"], N=e["N"], K=e["K"], lda=e["lda"], ldb=e["ldb"], ldc=view.ld)
+                for e in items[i:i + L.MAX_SEGS]]
+        for d in gemm_descs(ctx, L.AM_RC, L.AM_TOKR, L.CM_TOKJ, segs, 0, beta=int(acc or i > 0)):
+            ctx.emit(d)
+
+
+def _is_whole_raw(ctx, s):
+    """segment = all tokens of the embedding stem's output?"""
+    v = s.view
+    return ctx.defer_dw and ctx.raw_sparse is not None and v.buf is ctx.raw_sparse and v.off == 0 and v.N * E == v.ld and s.width == v.N
+
+
 def _dx_groups(ctx, live, mk):
     """gradient products towards the input segments; two segments that alias the same buffer (Sum/gating with
     left == right) must not race inside one launch -> they go to consecutive launches."""
@@ -790,7 +821,11 @@ def linear_tokens(ctx, segs: List[Seg], Ntot, wname, nout, bias: bool, out: SV, 
 
     def backward_products(dz_ptr, dz_ld, aux_ptr, kdims):
         kd = nout if kdims < 0 else min(kdims, nout)
-        _emit_z_groups(ctx, L.AM_RC, L.AM_TOKR, L.CM_TOKJ, _dx_groups(ctx, live, lambda s, gp, acc: dict(
+        for s in live:
+            if _is_whole_raw(ctx, s) and s.view.buf.need_grad:  # parked: one K-concatenated launch for all of them (_flush_raw_dx)
+                ctx.deferred_raw.append(dict(A=W + 4 * s.koff, B=dz_ptr, Baux=aux_ptr, M=s.width, N=B * E, K=kd, lda=Ntot, ldb=dz_ld, view=s.view))
+        rest = [s for s in live if not (_is_whole_raw(ctx, s) and s.view.buf.need_grad)]
+        _emit_z_groups(ctx, L.AM_RC, L.AM_TOKR, L.CM_TOKJ, _dx_groups(ctx, rest, lambda s, gp, acc: dict(
             A=W + 4 * s.koff, B=dz_ptr, Baux=aux_ptr, C=gp, M=s.width, N=B * E, K=kd, lda=Ntot, ldb=dz_ld, ldc=s.view.ld, accumulate=acc)))
         gW = ctx.gparam(wname + ".weight")
         _weight_grad_products(ctx, L.AM_TOKK, L.AM_TOKK, L.CM_PLAIN, [(rank, dict(

@@ -176,6 +176,39 @@ def test_gemm_dense_backward_products(lib):
     close(db, dz.sum(0))
 
 
+@pytest.mark.parametrize("B", [8, 256])
+@pytest.mark.parametrize("specs", [[(48, 0, False), (45, 0, False)], [(48, 192, True), (45, 128, False)], [(48, 0, True), (45, 0, True)],
+                                   [(32, 5, False), (39, 7, True), (64, 0, False), (8, 0, True)]])
+def test_gemm_token_input_gradients_concatenated_along_k(lib, B, specs):
+    """dx[b, n, e] = sum over several token-axis Linears l of sum_n' W_l[n', n] dz_l[b, n', e] as ONE launch: binding RC / TOKR / TOKJ with
+    k-segments that differ in K, in the row stride of their weights and in having a ReLU-mask operand (the parked gradients into the raw
+    embedding tokens, plan._flush_raw_dx).  (k-segments that disagree on the mask operand once went through the staged ring, which keeps
+    that flag per launch segment in flight: wrong results.)"""
+    torch.manual_seed(30)
+    M, N = 10, B * 16
+    out = dev(torch.zeros(B, M, 16))
+    d = L.GemmDesc()
+    d.kind = L.OP_GEMM
+    d.amode, d.bmode, d.cmode, d.nseg, d.zmode, d.dims_in_use, d.splitk = L.AM_RC, L.AM_TOKR, L.CM_TOKJ, len(specs), 0, -1, 1
+    want = torch.zeros(B, M, 16, dtype=torch.float64)
+    keep = []
+    for q, (K, extra, aux) in enumerate(specs):
+        lda = M + extra
+        W, dz, y = torch.randn(K, lda), torch.randn(B, K + 3, 16), torch.randn(B, K + 3, 16)
+        gW, gdz, gy = dev(W), dev(dz), dev(y)
+        keep += [gW, gdz, gy]
+        s = d.seg[q]
+        s.A, s.B, s.C = gW.data_ptr(), gdz.data_ptr(), out.data_ptr()
+        s.M, s.N, s.K, s.lda, s.ldb, s.ldc, s.Mvalid = M, N, K, lda, (K + 3) * 16, M * 16, M
+        g = dz[:, :K].double()
+        if aux:
+            s.Baux = gy.data_ptr()
+            g = g * (y[:, :K] > 0).double()
+        want += torch.einsum("ki,bke->bie", W[:, :M].double(), g)
+    launch(lib, d)
+    close(out, want, 2e-5)
+
+
 @pytest.mark.parametrize("splitk", [1, 4])
 def test_gemm_token_axis_all_products(lib, splitk):
     """token-axis Linear over [B,N,16] with two token segments living inside larger slabs, + both gradients."""
