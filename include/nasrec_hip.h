@@ -78,7 +78,8 @@ enum {
   NASREC_OP_OPT_REDUCE = 28,
   NASREC_OP_OPT_APPLY = 29,
   NASREC_OP_SAMPLE_CHAIN = 30,
-  NASREC_OP_CONST_I64 = 31
+  NASREC_OP_CONST_I64 = 31,
+  NASREC_OP_SPLITK_EPILOGUES = 32
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -130,7 +131,9 @@ typedef struct nasrec_gemm_desc {
   const float* mul_ptr[NASREC_MAX_SEGS];
   int32_t mul_off[NASREC_MAX_SEGS], mul_width[NASREC_MAX_SEGS], mul_ld[NASREC_MAX_SEGS];
   int32_t mul_nseg;
-  int32_t _pad;
+  int32_t defer_second_pass; /* splitk > 1 only: this launch just writes its slabs; a NASREC_OP_SPLITK_EPILOGUES launch runs the
+                                second passes of up to NASREC_EPILOGUES_MAX such launches at once (batch 256: every launch on
+                                the critical path costs ~5 us whatever it does) */
   float* workspace;  /* splitk slabs: splitk*M*N floats */
   int32_t* counters; /* reserved (must be NULL) */
   float* rowsum_out; /* destination of the ones_col row sums */
@@ -422,6 +425,15 @@ typedef struct nasrec_memset_desc {
   const int64_t* chunks; /* optional chunk table: zero only these ranges of ptr (4-byte elements) */
   int64_t nchunks;
 } nasrec_memset_desc_t;
+
+/* the second passes (fixed-order slab sums + epilogue) of up to 3 split-K GEMM launches whose descriptors carry
+ * defer_second_pass = 1 (CM_PLAIN outputs), as ONE launch: g[] are copies of those descriptors */
+#define NASREC_EPILOGUES_MAX 3
+typedef struct nasrec_splitk_epilogues_desc {
+  int32_t kind; /* NASREC_OP_SPLITK_EPILOGUES */
+  int32_t n;
+  nasrec_gemm_desc_t g[NASREC_EPILOGUES_MAX];
+} nasrec_splitk_epilogues_desc_t;
 
 /* dst[0, n) = vals[0, n): small integer tables (chunk tables) travel in the kernel arguments */
 typedef struct nasrec_const_i64_desc {

@@ -32,7 +32,7 @@ ACT_BY_NAME = {"identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
 (OP_GEMM, OP_EMBED_GATHER, OP_DOT_TRI_FWD, OP_DOT_TRI_BWD, OP_FM_FWD, OP_FM_BWD, OP_MHA_FWD, OP_MHA_BWD, OP_REDUCE_ROWS,
  OP_COPY_SEGS, OP_GATE_BWD, OP_ROWSUM, OP_FINAL_FWD, OP_BCE, OP_FINAL_BWD, OP_EMB_DEDUP, OP_SUMSQ, OP_CLIP_COEF,
  OP_ADAGRAD_DENSE, OP_ADAGRAD_ROWS, OP_MEMSET, OP_LAYERNORM_FWD, OP_LAYERNORM_BWD, OP_ADD_SEGS, OP_SCALE,
- OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY, OP_SAMPLE_CHAIN, OP_CONST_I64) = range(1, 32)
+ OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY, OP_SAMPLE_CHAIN, OP_CONST_I64, OP_SPLITK_EPILOGUES) = range(1, 33)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -46,8 +46,15 @@ class GemmDesc(C.Structure):
     _fields_ = [("kind", i32), ("amode", i32), ("bmode", i32), ("cmode", i32), ("nseg", i32), ("zmode", i32), ("act", i32),
                 ("bias_on_rows", i32), ("mask_on_rows", i32), ("dims_in_use", i32), ("beta", i32), ("splitk", i32),
                 ("bias", vp), ("save_z", vp), ("save_act", vp), ("mul_ptr", vp * MAX_SEGS), ("mul_off", i32 * MAX_SEGS),
-                ("mul_width", i32 * MAX_SEGS), ("mul_ld", i32 * MAX_SEGS), ("mul_nseg", i32), ("_pad", i32),
+                ("mul_width", i32 * MAX_SEGS), ("mul_ld", i32 * MAX_SEGS), ("mul_nseg", i32), ("defer_second_pass", i32),
                 ("workspace", vp), ("counters", vp), ("rowsum_out", vp), ("pre_add", vp), ("seg", GemmSeg * MAX_SEGS)]
+
+
+EPILOGUES_MAX = 3  # NASREC_EPILOGUES_MAX
+
+
+class SplitkEpiloguesDesc(C.Structure):
+    _fields_ = [("kind", i32), ("n", i32), ("g", GemmDesc * EPILOGUES_MAX)]
 
 
 class EmbedDesc(C.Structure):
@@ -183,7 +190,7 @@ DESC_BY_KIND = {
     OP_EMB_DEDUP: EmbDedupDesc, OP_SUMSQ: SumsqDesc, OP_CLIP_COEF: ClipCoefDesc, OP_ADAGRAD_DENSE: AdagradDenseDesc,
     OP_ADAGRAD_ROWS: AdagradRowsDesc, OP_MEMSET: MemsetDesc, OP_LAYERNORM_FWD: LayerNormDesc, OP_LAYERNORM_BWD: LayerNormDesc,
     OP_SCALE: ScaleDesc, OP_ACT_BWD: ActBwdDesc, OP_STAGE_INPUTS: StageDesc, OP_OPT_REDUCE: OptReduceDesc, OP_OPT_APPLY: OptApplyDesc,
-    OP_SAMPLE_CHAIN: ChainDesc, OP_CONST_I64: ConstI64Desc,
+    OP_SAMPLE_CHAIN: ChainDesc, OP_CONST_I64: ConstI64Desc, OP_SPLITK_EPILOGUES: SplitkEpiloguesDesc,
 }
 
 LANE_FORK, LANE_JOIN = -1, -2  # nasrec_graph_create_lanes markers
@@ -235,10 +242,10 @@ def load():
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
                  "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_sample_chain"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 9:
-        raise EngineError("ABI version mismatch: library %d, binding 9" % lib.nasrec_abi_version())
-    sizes = (i32 * 32)()
-    n = lib.nasrec_desc_sizes(sizes, 32)
+    if lib.nasrec_abi_version() != 10:
+        raise EngineError("ABI version mismatch: library %d, binding 10" % lib.nasrec_abi_version())
+    sizes = (i32 * 40)()
+    n = lib.nasrec_desc_sizes(sizes, 40)
     for kind, cls in DESC_BY_KIND.items():
         if kind >= n or sizes[kind] != C.sizeof(cls):
             raise EngineError("struct layout mismatch for op kind %d: library %d bytes, binding %d bytes"

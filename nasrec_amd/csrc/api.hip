@@ -60,6 +60,7 @@ static int dispatch(hipStream_t st, const void* desc) {
     case NASREC_OP_ACT_BWD: return launch_act_bwd(st, (const nasrec_act_bwd_desc_t*)desc);
     case NASREC_OP_STAGE_INPUTS: return launch_stage(st, (const nasrec_stage_desc_t*)desc);
     case NASREC_OP_CONST_I64: return launch_const_i64(st, (const nasrec_const_i64_desc_t*)desc);
+    case NASREC_OP_SPLITK_EPILOGUES: return launch_splitk_epilogues(st, (const nasrec_splitk_epilogues_desc_t*)desc);
     case NASREC_OP_OPT_REDUCE: return launch_opt_reduce(st, (const nasrec_opt_reduce_desc_t*)desc);
     case NASREC_OP_OPT_APPLY: return launch_opt_apply(st, (const nasrec_opt_apply_desc_t*)desc);
     case NASREC_OP_SAMPLE_CHAIN: return launch_sample_chain(st, (const nasrec_chain_desc_t*)desc);
@@ -251,7 +252,7 @@ int nasrec_event_destroy(void* ev) {
 
 const char* nasrec_last_error(void) { return g_err; }
 
-int nasrec_abi_version(void) { return 9; }
+int nasrec_abi_version(void) { return 10; }
 
 int nasrec_desc_sizes(int32_t* out, int n) {
   static const int32_t sizes[] = {
@@ -287,6 +288,7 @@ int nasrec_desc_sizes(int32_t* out, int n) {
       (int32_t)sizeof(nasrec_opt_apply_desc_t),     // 29
       (int32_t)sizeof(nasrec_chain_desc_t),         // 30
       (int32_t)sizeof(nasrec_const_i64_desc_t),     // 31
+      (int32_t)sizeof(nasrec_splitk_epilogues_desc_t), // 32
   };
   const int total = (int)(sizeof(sizes) / sizeof(sizes[0]));
   int w = 0;

@@ -26,14 +26,12 @@ __global__ __launch_bounds__(NT) void gemm_ring_kernel(const nasrec_gemm_desc_t 
   gemm_tile_ring<AM, BMODE, CM, NT, TK, TBM, TBN, AUX, AUX ? 2 : GEMM_RING>(d, Mmax, Nmax, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// second pass of split-K: fixed-order sum of the partial slabs, then the same epilogue
+// second pass of split-K: fixed-order sum of the partial slabs, then the same epilogue (element e of problem z)
 template <int CM>
-__global__ __launch_bounds__(256) void gemm_splitk_epilogue(const nasrec_gemm_desc_t d, int Mmax, int Nmax) {
+__device__ __forceinline__ void splitk_second_pass(const nasrec_gemm_desc_t& d, int Mmax, int Nmax, int z, long e) {
   const int S = d.splitk;
-  const int z = blockIdx.z;
   const nasrec_gemm_seg_t& sg = d.seg[d.zmode ? z : 0];
   const int M = sg.M, N = sg.N;
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long)M * N) return;
   int i, j;
   if (CM == NASREC_CM_TOKJ) {  // token-axis outputs: consecutive threads walk e (16 contiguous floats), then i
@@ -61,6 +59,50 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue(const nasrec_gemm_de
   }
   for (; q < S; ++q) v0 += slab[(long)q * stride];
   epilogue_store<CM>(d, sg, i, j, (v0 + v1) + (v2 + v3));
+}
+
+template <int CM>
+__global__ __launch_bounds__(256) void gemm_splitk_epilogue(const nasrec_gemm_desc_t d, int Mmax, int Nmax) {
+  splitk_second_pass<CM>(d, Mmax, Nmax, blockIdx.z, (long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// NASREC_OP_SPLITK_EPILOGUES: the second passes of up to three launches (defer_second_pass = 1, CM_PLAIN) in one
+struct EpiGeom {
+  int first[NASREC_EPILOGUES_MAX + 1];  // first workgroup of each descriptor's share
+  int per[NASREC_EPILOGUES_MAX];        // workgroups per problem
+  int Mmax[NASREC_EPILOGUES_MAX], Nmax[NASREC_EPILOGUES_MAX];
+};
+
+__global__ __launch_bounds__(256) void gemm_splitk_epilogues_kernel(const nasrec_splitk_epilogues_desc_t b, const EpiGeom g) {
+  int k = 0;
+  while (k + 1 < b.n && (int)blockIdx.x >= g.first[k + 1]) ++k;
+  const int local = (int)blockIdx.x - g.first[k];
+  const int z = local / g.per[k];
+  splitk_second_pass<NASREC_CM_PLAIN>(b.g[k], g.Mmax[k], g.Nmax[k], z, (long)(local - z * g.per[k]) * 256 + threadIdx.x);
+}
+
+int launch_splitk_epilogues(hipStream_t st, const nasrec_splitk_epilogues_desc_t* b) {
+  if (b->n < 1 || b->n > NASREC_EPILOGUES_MAX) return nasrec_set_error(-2, "splitk_epilogues: n=%d outside [1,%d]", b->n, NASREC_EPILOGUES_MAX);
+  EpiGeom g;
+  g.first[0] = 0;
+  for (int k = 0; k < b->n; ++k) {
+    const nasrec_gemm_desc_t& d = b->g[k];
+    if (d.cmode != NASREC_CM_PLAIN || d.splitk < 2 || !d.workspace)
+      return nasrec_set_error(-2, "splitk_epilogues: descriptor %d is not a split CM_PLAIN launch", k);
+    const int nprob = d.zmode ? d.nseg : 1;
+    int Mm = 0, Nm = 0;
+    for (int q = 0; q < nprob; ++q) {
+      if (d.seg[q].M > Mm) Mm = d.seg[q].M;
+      if (d.seg[q].N > Nm) Nm = d.seg[q].N;
+    }
+    g.Mmax[k] = Mm;
+    g.Nmax[k] = Nm;
+    g.per[k] = (int)(((long)Mm * Nm + 255) / 256);
+    g.first[k + 1] = g.first[k] + g.per[k] * nprob;
+  }
+  if (g.first[b->n] < 1) return 0;
+  hipLaunchKernelGGL(gemm_splitk_epilogues_kernel, dim3((unsigned)g.first[b->n]), dim3(256), 0, st, *b, g);
+  return nasrec_check_launch("splitk_epilogues");
 }
 
 template <int AM, int BMODE, int CM, int NT, int TK, int TBM, int TBN>
@@ -138,7 +180,7 @@ static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
     if (deep) launch_ring<AM, BMODE, CM, 256, GEMM_TK_DEEP, 16, 64>(st, d, Mmax, Nmax, zdim);
     else launch_ring<AM, BMODE, CM, 256, 32, 16, 64>(st, d, Mmax, Nmax, zdim);
   }
-  if (S > 1) {
+  if (S > 1 && !d->defer_second_pass) {
     long elems = (long)Mmax * Nmax;
     dim3 g2((unsigned)((elems + 255) / 256), 1, nprob);
     hipLaunchKernelGGL((gemm_splitk_epilogue<CM>), g2, dim3(256), 0, st, *d, Mmax, Nmax);

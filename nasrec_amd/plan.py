@@ -588,15 +588,39 @@ def _flush_mha_reduce(ctx):
 
 
 def _flush_deferred(ctx, todo=None):
+    final = todo is None  # the flush at the end of the backward program (not an early flush of a few products)
     if todo is None:
         todo, ctx.deferred = ctx.deferred, []
     keys = sorted({(rank, am, bm, cm, d["K"], _shape_class(ctx, d)) for am, bm, cm, rank, d in todo})  # rank r accumulates over rank r-1: later launch
+    split = []
+
+    def second_passes():
+        # Batch 256: the parked launches have no consumers before the optimizer, so their split-K second passes need not follow
+        # them one by one — up to three run as ONE launch behind the last of them (each launch on the critical path costs ~5 us).
+        # Rank-0 products only, and before any rank-1 product (which accumulates over what a rank-0 second pass wrote).
+        if len(split) > 1:
+            for g in split:
+                g.defer_second_pass = 1
+            for i in range(0, len(split), L.EPILOGUES_MAX):
+                chunk = split[i:i + L.EPILOGUES_MAX]
+                e = L.SplitkEpiloguesDesc()
+                e.kind, e.n = L.OP_SPLITK_EPILOGUES, len(chunk)
+                for q, g in enumerate(chunk):
+                    C.memmove(C.addressof(e.g[q]), C.addressof(g), C.sizeof(L.GemmDesc))
+                ctx.emit(e)
+        del split[:]
+
     for key in keys:
+        if key[0] > 0:
+            second_passes()
         grp = [d for am, bm, cm, rank, d in todo if (rank, am, bm, cm, d["K"], _shape_class(ctx, d)) == key]
         grp.sort(key=lambda d: -d["M"] * d["N"])  # problems of similar size share a launch (its grid is Mmax x Nmax)
         for i in range(0, len(grp), L.MAX_SEGS):
             for g in gemm_descs(ctx, key[1], key[2], key[3], grp[i:i + L.MAX_SEGS], 1):
                 ctx.emit(g)
+                if final and ctx.B <= 256 and g.splitk > 1 and g.cmode == L.CM_PLAIN and key[0] == 0 and not ctx.shape_only:
+                    split.append(g)
+    second_passes()
 
 
 def _flush_raw_dx(ctx):
