@@ -859,6 +859,56 @@ def test_gemm_splitk_stress(lib):
                 assert torch.equal(first, y)  # same inputs -> same bits
 
 
+def test_splitk_second_passes_of_several_launches_as_one(lib):
+    """NASREC_OP_SPLITK_EPILOGUES: three split-K weight-gradient launches (ReLU-mask operand, bias column, accumulation, different
+    split factors and problem counts) write only their slabs (defer_second_pass); one launch then runs all three second passes —
+    bit-identical to every launch running its own"""
+    torch.manual_seed(31)
+    B = 256
+    specs = [([(96, 130, 1), (40, 37, 0)], 4), ([(64, 64, 0)], 7), ([(13, 14, 1), (200, 129, 0), (32, 16, 0)], 3)]  # [(nout, nin, ones)], S
+    keep = []
+
+    def build(defer):
+        descs, outs = [], []
+        g = torch.Generator().manual_seed(5)
+        for probs, S in specs:
+            segs = []
+            for q, (nout, nin, ones) in enumerate(probs):
+                dy, y, x = torch.randn(B, nout, generator=g) * 0.3, torch.randn(B, nout, generator=g), torch.randn(B, nin, generator=g)
+                dw, db = dev(torch.randn(nout, nin, generator=g)), dev(torch.zeros(nout))
+                t = [dev(dy), dev(y), dev(x)]
+                keep.extend(t + [dw, db])
+                segs.append(dict(A=t[0].data_ptr(), Aaux=t[1].data_ptr(), B=t[2].data_ptr(), C=dw.data_ptr(), M=nout, N=nin + ones, K=B, lda=nout, ldb=nin,
+                                 ldc=nin, Mvalid=nout - 3, accumulate=q % 2, ones_col=ones, rowsum=db.data_ptr() if ones else None))
+                outs += [dw, db]
+            Mm, Nm = max(sd["M"] for sd in segs), max(sd["N"] for sd in segs)
+            ws = dev(torch.full((S * Mm * Nm * len(segs),), float("nan")))
+            keep.append(ws)
+            d = gemm_desc(L.AM_RC, L.AM_RC, L.CM_PLAIN, segs, 1, splitk=S, workspace=ws.data_ptr())
+            d.defer_second_pass = int(defer)
+            descs.append(d)
+        return descs, outs
+
+    plain, want = build(False)
+    for d in plain:
+        launch(lib, d)
+    deferred, got = build(True)
+    for d in deferred:
+        launch(lib, d)
+    e = L.SplitkEpiloguesDesc()
+    e.kind, e.n = L.OP_SPLITK_EPILOGUES, len(deferred)
+    for q, d in enumerate(deferred):
+        C.memmove(C.addressof(e.g[q]), C.addressof(d), C.sizeof(L.GemmDesc))
+    launch(lib, e)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert float(want[0].abs().max()) > 0
+    bad = L.SplitkEpiloguesDesc()
+    bad.kind, bad.n = L.OP_SPLITK_EPILOGUES, 4
+    with pytest.raises(L.EngineError):
+        launch(lib, bad)
+
+
 def test_gemm_bias_gradient_as_ones_column(lib):
     """db = column sums of dz come out of the dW product as a virtual ones-column (dense and token bindings)"""
     torch.manual_seed(12)
