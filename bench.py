@@ -46,17 +46,55 @@ WORKLOADS = {
 }
 
 
-def synthetic_batches(n, B, Fd, tables, device, seed, zero_dense=False):
-    """int_x = log(U_int[0,1000)+1) (Avazu: zeros, data_pipes.py:181), ids uniform per table (cache-hostile),
-    y ~ Bernoulli(0.25)."""
+def synthetic_ids(B, tables, g, dist_name="uniform"):
+    """ids of one batch, [B, Fs] int64.  uniform: U_int[0, n_f) per table — the cache-hostile primary case of SURVEY §8d;
+    zipf: Zipf(alpha = 1.05) over the ranks 1 .. n_f - 1 (bounded, by inverse CDF) with 2 % zeros (0 = missing id,
+    data_pipes.py:141,164); rank r lands on id 1 + (r * 2654435761) mod (n_f - 1), as the reference's hash of the raw token does."""
+    if dist_name == "uniform":
+        return torch.stack([torch.randint(0, int(t), (B,), generator=g) for t in tables], dim=1)
+    cols = []
+    a = 1.05
+    for t in tables:
+        n = max(int(t) - 1, 1)
+        u = torch.rand(B, generator=g, dtype=torch.float64)
+        rank = torch.floor(((float(n) ** (1.0 - a) - 1.0) * u + 1.0) ** (1.0 / (1.0 - a))).clamp_(1, n).to(torch.int64)
+        ids = 1 + (rank * 2654435761) % n
+        ids[torch.rand(B, generator=g) < 0.02] = 0
+        cols.append(ids.clamp_(0, int(t) - 1))
+    return torch.stack(cols, dim=1)
+
+
+def synthetic_batches(n, B, Fd, tables, device, seed, zero_dense=False, ids="uniform"):
+    """int_x = log(U_int[0,1000)+1) (Avazu: zeros, data_pipes.py:181), ids per `synthetic_ids`, y ~ Bernoulli(0.25)."""
     g = torch.Generator().manual_seed(seed)
     out = []
     for _ in range(n):
         int_x = torch.zeros(B, Fd) if zero_dense else torch.log(torch.randint(0, 1000, (B, Fd), generator=g).float() + 1.0)
-        cat_x = torch.stack([torch.randint(0, int(t), (B,), generator=g) for t in tables], dim=1)
+        cat_x = synthetic_ids(B, tables, g, ids)
         y = (torch.rand(B, generator=g) < 0.25).float()
         out.append((int_x.to(device), cat_x.to(device), y.to(device)))
     return out
+
+
+class BatchPool:
+    """Pre-generated synthetic batches resident in HBM.  The ids come from a pool large enough that the set of table rows touched
+    between two uses of the same id batch exceeds the 256 MB Infinity Cache (cfg 2: 1024 id batches x 256 x 26 rows x 64 B = 436 MB
+    of rows, 54 MB of ids; the supernets: 64 batches x 4096 x Fs x 64 B >= 250 MB), so that the gather / dedup / row-Adagrad kernels
+    see HBM latency on every step; dense features and labels (a few KB) cycle through a small pool."""
+
+    def __init__(self, n_ids, n_dense, B, Fd, tables, device, seed, zero_dense, ids):
+        g = torch.Generator().manual_seed(seed)
+        self.dense = synthetic_batches(n_dense, B, Fd, tables[:1], "cpu", seed + 7, zero_dense)
+        self.dense = [(a.to(device), c.to(device)) for a, _, c in self.dense]
+        self.ids = torch.stack([synthetic_ids(B, tables, g, ids) for _ in range(n_ids)]).to(device)  # [n_ids, B, Fs]
+        self.n = n_ids
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        d = self.dense[i % len(self.dense)]
+        return d[0], self.ids[i % self.n], d[1]
 
 
 def gemm_flops(d):
@@ -144,12 +182,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-dp-path", action="store_true", help="run the N>1 exchange code path on a single rank")
+    ap.add_argument("--ids", choices=["uniform", "zipf"], default="uniform",
+                    help="id distribution (SURVEY 8d): uniform over each table = the cache-hostile primary case; zipf = Zipf(1.05) with 2 %% zeros")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: the config's batch PER GPU (global batch grows with N); strong: the config's batch is the GLOBAL batch")
+    ap.add_argument("--id-pool", type=int, default=None, help="number of pre-generated id batches (default: enough to overflow the Infinity Cache)")
     args = ap.parse_args()
     w = WORKLOADS[args.config]
     fixed = w["mode"] == "fixed"
     steps = args.steps if args.steps is not None else (300 if fixed else 60)
     warmup = args.warmup if args.warmup is not None else (30 if fixed else 10)
     B = w["B"]
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.scaling == "strong":
+        if B % world_env:
+            raise SystemExit("--scaling strong: the config's batch %d does not divide over %d GPUs" % (B, world_env))
+        B = B // world_env  # per-GPU share of the config's (global) batch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -177,7 +225,8 @@ def main():
     ds = DATASETS[w["dataset"]]
     tables = [min(n, w["cap"]) if w.get("cap") else n for n in ds["tables"]]
     Fd, Fs = ds["Fd"], ds["Fs"]
-    batches = synthetic_batches(16 if fixed else 4, B, Fd, tables, device, 1234 + rank, zero_dense=(w["dataset"] == "avazu"))
+    n_pool = args.id_pool if args.id_pool is not None else max(4, -(-(280 << 20) // (B * Fs * 64)))  # touched rows > 256 MiB per lap
+    batches = BatchPool(n_pool, 16 if fixed else 4, B, Fd, tables, device, 1234 + rank, w["dataset"] == "avazu", args.ids)
     steps_per_epoch = w["train_limit"] // B
     sched = CosineAnnealingWarmupRestarts(steps_per_epoch, max_lr=LR_MAX if fixed else 0.12, min_lr=LR_MIN, warmup_steps=steps_per_epoch // 10)
 
@@ -207,7 +256,7 @@ def main():
             model(batches[0][0][:64], batches[0][1][:64])
         eng = model._engine
         eng.init_weights(seed=0)
-        eng.reserve(B)  # plan slots sized for the largest path: no allocator call inside a step
+        eng.reserve(B, freeze_gc=True)  # plan slots sized for the largest path: no allocator call inside a step; one engine per process
         model.configure_path_sampling_strategy("default")
         np.random.seed(0)
         dp = DataParallelStep(eng, None, B, clip=5.0, eps=1e-2, graph=False, force_exchange=args.force_dp_path)
@@ -249,10 +298,12 @@ def main():
     result = {
         "metric": "supernet samples/sec at batch 256 (Criteo-shape), 1/2/4/8 MI355X",
         "value": B * world * steps / dt, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": dt / steps * 1e3, "median_ms_per_step": float(np.median(per_step)), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": dt / steps * 1e3, "median_ms_per_step": float(np.median(per_step)), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": w["name"], "baseline_config": args.config, "per_gpu_batch": B, "global_batch": B * world, "graph": dp.graph,
                    "parallelism": parallelism,
+                   "ids": "%s over each table; %d pre-generated id batches = %.0f MB of distinct-ish table rows per lap of the pool (Infinity Cache: 256 MB)"
+                          % (args.ids, len(batches), len(batches) * B * Fs * 64 / 1e6),
                    "embedding_update": "row-sparse clip+Adagrad (== dense reference update for weight_decay 0)"},
         "final_loss": loss,
     }
@@ -270,9 +321,26 @@ def main():
             torch.cuda.synchronize(device)
             t1 = time.perf_counter()
             for i in range(200):
-                eng.forward(batches[i % 16][0], batches[i % 16][1], graph=fgraph)
+                eng.forward(batches[i][0], batches[i][1], graph=fgraph)
             torch.cuda.synchronize(device)
             result["forward_only_samples_per_s"] = B * 200 / (time.perf_counter() - t1)
+
+        if world == 1:
+            # ---- embedding stem on COLD rows: the staging launch (batch copy + gather of B x Fs 64-byte rows, a1 of SURVEY 8a) over
+            # distinct id batches of the pool — random 64-B rows out of HBM, HBM-latency bound -----------------------------------
+            ng = min(200, len(batches))
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(5):
+                eng._stage_inputs(sp, cp, *batches[len(batches) - 1 - i], 1e-3)
+            ea.record()
+            for i in range(ng):
+                eng._stage_inputs(sp, cp, *batches[i], 1e-3)
+            eb.record()
+            torch.cuda.synchronize(device)
+            us = ea.elapsed_time(eb) / ng * 1e3
+            result["embedding_gather_cold"] = {"avg_launch_us": us, "rows": B * Fs, "bytes": B * Fs * 128,
+                                               "achieved_GBps": B * Fs * 128 / us / 1e3, "bound": "hbm latency (random 64-B rows: read + write)",
+                                               "frac_of_hbm_peak": B * Fs * 128 / us / 1e3 / HBM_PEAK_GBS}
 
         # ---- roofline of the dominant kernel: the largest GEMM launch of the (last) step's plan, fp32 MFMA bound ---------
         dom = max(allg, key=gemm_flops)

@@ -140,6 +140,14 @@ class SupernetEngine:
             raise L.EngineError("SupernetEngine needs a GPU: there is no CPU fallback")
         self.cfg, self.Fd, self.Fs = cfg, Fd, Fs
         self.num_embeddings = [int(n) for n in num_embeddings[:Fs]]
+        # hard limits of the kernels, raised here instead of corrupting later: the row-gradient dedup packs ids into 32 bits
+        # (csrc/embedding.hip; ids are range-checked against the table by the gather, so rows < 2^31 makes the cast exact), a
+        # descriptor carries at most MAX_TABLES table pointers
+        for f, n in enumerate(self.num_embeddings):
+            if not 0 < n < (1 << 31):
+                raise ValueError("embedding table %d has %d rows: the engine supports 1 .. 2^31 - 1 rows per table" % (f, n))
+        if Fs > L.MAX_TABLES:
+            raise ValueError("%d sparse fields: the engine supports at most %d" % (Fs, L.MAX_TABLES))
         self.device = torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
@@ -506,10 +514,14 @@ class SupernetEngine:
         return descs
 
     @_on_device
-    def reserve(self, B: int, train: bool = True, choice=None):
+    def reserve(self, B: int, train: bool = True, choice=None, freeze_gc: bool = False):
         """Size every plan slot for the LARGEST path at batch B (default: the warm-up choice = the full path) and allocate the
         engine-level workspaces, so that no sampled path of a run has to grow an arena (an allocator call + device
-        synchronisation in the middle of a step: 1-2 ms spikes in the per-step times).  Host work only; nothing is launched."""
+        synchronisation in the middle of a step: 1-2 ms spikes in the per-step times).  Host work only; nothing is launched.
+        freeze_gc (opt-in, for a process that keeps ONE engine for its whole life — bench.py, the train_supernet CLI): move
+        everything alive now into the cyclic collector's permanent generation, so that its full passes walk the few plans in flight
+        instead of ~10^6 long-lived objects (17-56 ms stalls per step otherwise).  Frozen objects are never collected: a process that
+        builds engine after engine (eval_subnet_from_supernet: one SuperNet per candidate) must leave it off."""
         if self.cfg.fixed:
             return 0
         cp = self.compile(choice if choice is not None else self.warm_choice, B, train)
@@ -520,6 +532,16 @@ class SupernetEngine:
         self._last_plan = None
         arenas = [cp.arena] + list(self._spare_arenas)
         cp.arena = None
+        # the warm plan is a web of closures over its context, which holds the parameter / gradient dicts, the arena and a bound
+        # method of this engine: cut it open so that reference counting frees it now (and nothing of it is frozen below)
+        wctx = getattr(cp, "ctx", None)
+        if wctx is not None:
+            wctx.closures, wctx.deferred, wctx.mha_reduce, wctx.keep = [], [], [], []
+            wctx.sk_workspace = None
+            wctx.arena = None
+            wctx.params = wctx.grads = None
+        cp.ctx = None
+        del cp, wctx
         live = len(self._plans)
         while len(arenas) + live < 4:
             arenas.append(Arena(self.device))
@@ -530,11 +552,10 @@ class SupernetEngine:
                 v.arena.reserve(need)
         self._spare_arenas = arenas
         self._sk_workspace()
-        # everything alive now (modules, parameters, the interpreter's own structures) lives as long as the run: take it out of
-        # the cyclic collector's reach, so that its full passes walk the few plans in flight instead of ~10^6 objects
-        import gc
-        gc.collect()
-        gc.freeze()
+        if freeze_gc:
+            import gc
+            gc.collect()
+            gc.freeze()
         return need
 
     def _sk_workspace(self):

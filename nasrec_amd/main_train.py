@@ -84,6 +84,9 @@ def train_and_eval_one_model(model, args):
     num_warmup_steps = steps_per_epoch // 10 // args.num_epochs
     lr_scheduler = build_lr_scheduler(args.lr_schedule, optimizer, num_train_steps, num_warmup_steps, args.learning_rate)
     model.apply(init_weights)
+    from nasrec_amd.utils.dist import assert_replicas_identical, broadcast_replica_state
+    broadcast_replica_state(model)  # data parallel: rank 0's weights, tables and accumulators are THE model
+    assert_replicas_identical(model)
     print(model)
     create_dir(args.logging_dir)
     with open(os.path.join(args.logging_dir, "configs_args.json"), "w") as f:
@@ -99,7 +102,7 @@ def train_and_eval_one_model(model, args):
         epoch_logs.append(logs)
     print("Dumping logs to {}!".format(args.logging_dir))
     from nasrec_amd.utils.dist import world_info
-    if world_info()[0] == 0:  # replicas are identical: rank 0 writes the artefacts
+    if world_info()[0] == 0:  # replicas are identical (broadcast at start, same global-batch update on every rank): rank 0 writes the artefacts
         save_model_checkpoint(model, os.path.join(args.logging_dir, "{}_checkpoint.pt".format(args.net)), optimizer)
         dump_pickle_data(os.path.join(args.logging_dir, "train_test_logs.pickle"), epoch_logs)
     return epoch_logs

@@ -236,17 +236,46 @@ class EngineDP:
                 plan.forward = lambda: cp.fwd.run(eng._sp())
                 marks = sorted(cp.bwd_marks, key=lambda m: m[1])  # (block, end index in the backward program), ascending position
                 used = [n for n in list(cp.ctx.grad_params) + ["_final.weight", "_final.bias"] if not n.startswith("_embedding.")]
-                segs, start, sent = [], 0, set()
+                groups, sent = [], set()
                 for blk, end in marks:
                     names = [n for n in used if n not in sent and (n.startswith("_blocks.%d." % blk) or n.startswith("_final."))]
                     sent.update(names)
-                    ranges = coalesce_ranges([(eng.offsets[n], eng.params[n].numel()) for n in names])
-                    prog = Program(descs[start:end])
+                    groups.append((end, names))
+                groups.append((len(descs), [n for n in used if n not in sent]))
+                span = lambda n: (eng.offsets[n], eng.params[n].numel())
+                buckets = [coalesce_ranges([span(n) for n in names]) for _, names in groups]
+                # A merged range also covers the gaps between its members.  (1) No parameter that ANOTHER bucket sends may sit in such
+                # a gap (it would be reduced twice, or while its backward is still writing it).  (2) What does sit there are gradients
+                # of parameters off this path: nothing of this step writes or reads them, but summing leftovers of earlier paths in
+                # place, step after step, grows without bound — they are zeroed at the start of every backward.
+                gaps = []
+                for bi, ranges in enumerate(buckets):
+                    own = sorted(span(n) for n in groups[bi][1])
+                    others = [span(n) for bj, (_, names) in enumerate(groups) if bj != bi for n in names]
+                    for off, n in ranges:
+                        assert not any(o < off + n and off < o + m for o, m in others), "a gradient bucket's gap spans a parameter of another bucket"
+                        pos = off
+                        for o, m in own:
+                            if off <= o < off + n:
+                                if o > pos:
+                                    gaps.append((pos, o - pos))
+                                pos = max(pos, o + m)
+                        if off + n > pos:
+                            gaps.append((pos, off + n - pos))
+                head = []
+                if gaps:
+                    from . import plan as P
+                    flat = P.path_chunks(gaps)
+                    plan.gap_tab = torch.empty(len(flat), dtype=torch.int64, device=eng.device)
+                    ms = P.memset_desc(eng.flat_g)
+                    ms.chunks, ms.nchunks = plan.gap_tab.data_ptr(), len(flat) // 2
+                    head = P.const_i64_descs(plan.gap_tab.data_ptr(), flat) + [ms]
+                segs, start = [], 0
+                for (end, _), ranges in zip(groups, buckets):
+                    prog = Program(head + descs[start:end])
+                    head = []
                     segs.append(((lambda p: (lambda: p.run(eng._sp())))(prog), ranges))
                     start = end
-                rest = [n for n in used if n not in sent]
-                prog = Program(descs[start:])
-                segs.append(((lambda p: (lambda: p.run(eng._sp())))(prog), coalesce_ranges([(eng.offsets[n], eng.params[n].numel()) for n in rest])))
                 plan.segments = segs
         eng.stream.synchronize()
         return plan

@@ -353,6 +353,10 @@ def _fast_gemm_splitk(amode, bmode, cmode, segs, zmode):
         return None
     if max(sd["K"] for sd in live) < 64:
         return None
+    for sd in live:  # 31-bit byte offsets of the staging loads: operand extents stay below 2^29 floats (gemm_fast.hip:623-625)
+        r, ld = max(sd["M"], sd["N"]), max(sd.get("lda", 0), sd.get("ldb", 0))
+        if r * ld + sd["K"] >= (1 << 29) or sd["K"] * ld + r >= (1 << 29):
+            return None
     probs = segs if zmode else segs[:1]
     tiles = sum(((sd["M"] + 127) // 128) * ((sd["N"] + 127) // 128) for sd in probs)
     if 2 * sum(sd["M"] * sd["N"] for sd in probs) < tiles * 128 * 128:

@@ -25,7 +25,7 @@ from nasrec_amd.utils.train_utils import (get_l2_loss, get_model_flops_and_param
 def train_and_eval_one_model(model, args):
     train_loader, test_loader = make_loaders(args)
     with torch.no_grad():
-        model = warmup_supernet_model(model, train_loader, args.gpu)
+        model = warmup_supernet_model(model, train_loader, args.gpu, freeze_gc=True)  # this process trains this one model
     flops, params = get_model_flops_and_params(model, train_loader, args.gpu)
     print("FLOPS: {:.4f} M \t Params: {:.4f} M".format(flops / 1e6, params / 1e6))
     model.configure_path_sampling_strategy(args.strategy)
@@ -47,6 +47,9 @@ def train_and_eval_one_model(model, args):
             optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
     else:
         model.apply(init_weights)
+    from nasrec_amd.utils.dist import assert_replicas_identical, broadcast_replica_state
+    broadcast_replica_state(model)  # data parallel: rank 0's weights, tables and accumulators are THE model
+    assert_replicas_identical(model)
     print(model)
     strategy_name = args.strategy if args.strategy == "single-path" else args.strategy + "-" + args.anypath_choice
     logging_dir = os.path.join(args.logging_dir, "supernet_{}blocks_layernorm{:d}_{}_lr{:.2f}_supernetwarmup_{}".format(
@@ -63,7 +66,7 @@ def train_and_eval_one_model(model, args):
         epoch_logs.append(logs)
     print("Dumping logs to {}!".format(logging_dir))
     from nasrec_amd.utils.dist import world_info
-    if world_info()[0] == 0:  # replicas are identical: rank 0 writes the artefacts
+    if world_info()[0] == 0:  # replicas are identical (broadcast at start, same global-batch update on every rank): rank 0 writes the artefacts
         dump_pickle_data(os.path.join(logging_dir, "train_test_logs.pickle"), logs)  # the last epoch only, as the reference does
         save_model_checkpoint(model, os.path.join(logging_dir, "supernet_checkpoint.pt"), optimizer)
     return epoch_logs

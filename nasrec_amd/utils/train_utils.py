@@ -112,6 +112,37 @@ def _fused_step_applies(model, optimizer, l2_loss_fn, use_amp):
         return float(l2_loss_fn(model)) == 0.0
 
 
+def _agreed_batches(train_loader, train_batch_size: int, world: int, gpu):
+    """The batches of one epoch.  Single process: the loader as it is (incl. its short last batch, which the reference evaluates
+    without training on it).  Data parallel: every rank reads its own shards, which differ in length — the ranks agree one step
+    ahead (utils/dist.StepAgreement, off the compute stream) on whether ALL of them hold a FULL batch for the next step, and the
+    epoch ends for everybody at the first step some rank cannot take: no rank enters a collective the others skip."""
+    if world <= 1:
+        yield from train_loader
+        return
+    from .dist import StepAgreement
+    agree = StepAgreement(gpu)
+    it = iter(train_loader)
+
+    def fetch():
+        try:
+            b = next(it)
+        except StopIteration:
+            return None
+        return b
+
+    nxt = fetch()
+    agree.post(nxt is not None and len(nxt[2]) == train_batch_size)
+    while True:
+        ok = agree.take()
+        if not ok:
+            return
+        cur = nxt
+        nxt = fetch()
+        agree.post(nxt is not None and len(nxt[2]) == train_batch_size)  # travels while the step on `cur` runs
+        yield cur
+
+
 def train_and_test_one_epoch(model, epoch: int, optimizer: Any, lr_scheduler, train_loader, test_loader, loss_fn, l2_loss_fn,
                              train_batch_size: int, gpu: Union[int, None], display_interval: int = 100, test_interval: int = 2000,
                              max_train_steps: int = -1, max_eval_steps: int = -1, test_only_at_last_step: bool = False,
@@ -127,7 +158,9 @@ def train_and_test_one_epoch(model, epoch: int, optimizer: Any, lr_scheduler, tr
     best_model, best_test_loss = None, 9999.99
     t_data0 = time.time()
     batch_num = -1
-    for batch_num, (int_x, cat_x, y) in enumerate(train_loader):
+    from .dist import StepAgreement, allreduce_grads, any_rank, world_info
+    world = world_info()[1]
+    for batch_num, (int_x, cat_x, y) in enumerate(_agreed_batches(train_loader, train_batch_size, world, gpu)):
         t_data1 = time.time()
         int_x, cat_x, y = int_x.to(gpu, non_blocking=True), cat_x.to(gpu, non_blocking=True), y.to(gpu, non_blocking=True)
         t_gpu0 = time.time()
@@ -151,12 +184,16 @@ def train_and_test_one_epoch(model, epoch: int, optimizer: Any, lr_scheduler, tr
                 if use_amp:
                     scaler.scale(total_loss).backward()
                     scaler.unscale_(optimizer)
+                    if world > 1:
+                        allreduce_grads(model)
                     if grad_clip_value is not None:
                         torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip_value)
                     scaler.step(optimizer)
                     scaler.update()
                 else:
                     total_loss.backward()
+                    if world > 1:  # the torch route has no exchange of its own: average the gradients over the ranks
+                        allreduce_grads(model)
                     if grad_clip_value is not None:
                         torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip_value)
                     optimizer.step()
@@ -165,7 +202,7 @@ def train_and_test_one_epoch(model, epoch: int, optimizer: Any, lr_scheduler, tr
 
         if batch_num % display_interval == 0 or last:
             y_pred, y_true = res.detach(), y.detach()
-            if torch.isnan(loss):  # happens on KDD: report a diverged model
+            if any_rank(bool(torch.isnan(loss)), gpu):  # happens on KDD: report a diverged model (every rank leaves together)
                 print("Loss NaN. Exiting...")
                 logs["test_loss"].append(999.99)
                 logs["test_AUROC"].append(-1)
@@ -235,8 +272,9 @@ def warmup_model(model: nn.Module, train_loader, gpu: Union[int, None]):
     return model
 
 
-def warmup_supernet_model(model: nn.Module, train_loader, gpu):
-    """full-path forward so that every candidate operator materialises (train_utils.py:413-433)"""
+def warmup_supernet_model(model: nn.Module, train_loader, gpu, freeze_gc: bool = False):
+    """full-path forward so that every candidate operator materialises (train_utils.py:413-433).  freeze_gc: see
+    SupernetEngine.reserve — only for a process that keeps this one model for its whole life (the train_supernet CLI)"""
     assert isinstance(model, SuperNet), NotImplementedError("For 'warmup_supernet_model', the passed in model must be a 'SuperNet' object.")
     model = model.to(gpu)
     int_x, cat_x, _ = next(iter(train_loader))
@@ -244,7 +282,7 @@ def warmup_supernet_model(model: nn.Module, train_loader, gpu):
     model(int_x.to(gpu), cat_x.to(gpu))
     eng = getattr(model, "_engine", None)
     if eng is not None and hasattr(eng, "reserve") and not getattr(eng, "host_embedding", False):
-        eng.reserve(int(int_x.shape[0]))  # plan slots sized for the full path: sampled paths never grow an arena mid-step
+        eng.reserve(int(int_x.shape[0]), freeze_gc=freeze_gc)  # plan slots sized for the full path: sampled paths never grow an arena mid-step
     return model
 
 

@@ -141,7 +141,9 @@ def _layernorm(P: Params, name: str, x: torch.Tensor, eps: float = LN_EPS) -> to
 def _act(x: torch.Tensor, activation: str) -> torch.Tensor:
     """modules.py:28-36."""
     if activation == "relu":
-        return torch.clamp_min(x, 0.0)
+        # F.relu as the reference calls it: the (sub)gradient AT exactly 0 is 0 (clamp_min would pass 1 there — a tie that real
+        # batches do hit: an all-zero dense input (Avazu, data_pipes.py:181) through LayerNorm with bias 0 lands on 0 exactly)
+        return torch.relu(x)
     if activation == "silu":
         return x * torch.sigmoid(x)
     if activation == "identity":
@@ -303,7 +305,7 @@ def transformer(P, pre, x, dims_in_use, max_dims, use_ln, emb_dim, fixed):
     a = multihead_self_attention(P, pre + "._mha", t, emb_dim)  # :664
     a = _layernorm(P, pre + "._attn_ln", a + t)  # :666-668
     f = _linear(P, pre + ".attn_fc1", a, emb_dim, bias=True)  # :671
-    f = torch.clamp_min(f, 0.0)
+    f = _act(f, "relu")  # F.relu, modules.py:671 (gradient 0 at exactly 0)
     f = _linear(P, pre + ".attn_fc2", f, emb_dim, bias=True)  # :672
     out = _layernorm(P, pre + "._attn_fc_ln", a + f)  # :673-675
     if not fixed:  # :678-686
@@ -608,8 +610,9 @@ def full_path_choice(cfg: NetCfg) -> dict:
 # Step body (train_utils.py:255-287; main_train.py:122,152-154)
 # ----------------------------------------------------------------------------------------------
 def bce_with_logits_mean(z: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-    """torch.nn.BCEWithLogitsLoss() (main_train.py:122), numerically stable form."""
-    return (torch.clamp_min(z, 0.0) - z * y + torch.log1p(torch.exp(-torch.abs(z)))).mean()
+    """torch.nn.BCEWithLogitsLoss() (main_train.py:122), numerically stable form: max(z, 0) - z y + log(1 + exp(-|z|)).  Written with
+    softplus so that the gradient is sigmoid(z) - y everywhere, z = 0 included (clamp / abs would give 1 - y there)."""
+    return (torch.nn.functional.softplus(z) - z * y).mean()
 
 
 def clip_grad_norm_(grads: List[torch.Tensor], max_norm: float) -> torch.Tensor:

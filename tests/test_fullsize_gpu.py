@@ -87,7 +87,9 @@ def test_embedding_stem_bit_exact_on_full_tables(setup):
 def test_logits_against_the_oracle_on_the_engines_weights(setup):
     eng, choice, ca, int_x, cat_x, _ = setup
     n = 16
-    logits = eng.forward(int_x[:n], cat_x[:n], choice).double().cpu().view(-1)
+    # the B = 256 plan (the launches bench.py times), sliced — not a 16-sample plan with other tile / split-K choices; the whole
+    # batch incl. the backward is checked in tests/test_operating_point_parity_gpu.py
+    logits = eng.forward(int_x, cat_x, choice)[:n].double().cpu().view(-1)
     Pm = O.Params(torch.float64)
     torch.cuda.synchronize()
     for k, v in eng.params.items():

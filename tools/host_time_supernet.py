@@ -21,7 +21,7 @@ model = SuperNet(num_blocks=7, ops_config=ops_config_lib[w["space"]], use_layern
 with torch.no_grad():
     model(batches[0][0][:64], batches[0][1][:64])
 model._engine.init_weights(0)
-model._engine.reserve(B)
+model._engine.reserve(B, freeze_gc=True)
 model.configure_path_sampling_strategy("default")
 np.random.seed(0)
 for i in range(8):
