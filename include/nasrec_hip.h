@@ -77,7 +77,7 @@ enum {
   NASREC_OP_STAGE_INPUTS = 27,
   NASREC_OP_OPT_REDUCE = 28,
   NASREC_OP_OPT_APPLY = 29,
-  NASREC_OP_SAMPLE_CHAIN = 30,
+  NASREC_OP_WORKLIST = 30,
   NASREC_OP_CONST_I64 = 31,
   NASREC_OP_SPLITK_EPILOGUES = 32
 };
@@ -505,28 +505,45 @@ typedef struct nasrec_stage_desc {
 } nasrec_stage_desc_t;
 
 /* ------------------------------------------------------------------------------------------------
- * Per-sample chain (forward).  Every operator between two block-level products is sample-local: the token-axis Linear of
- * sample b reads only x[b], and so do the Transformer body, the FM and DotProduct cores and segmented copies.  A run of up
- * to NASREC_CHAIN_MAX such launches that follow each other in the program can therefore execute as ONE launch in which
- * workgroup b runs the stages for sample b back to back (workgroup barrier + workgroup-scope fence in between) — each stage
- * saved is one ~5 us cold-L2 kernel start at batch 256.  Results are bit-identical to the separate launches (same bodies,
- * same per-sample work split).  Constraints (checked by the launcher): at most one stage of each kind; the GEMM stage is a
- * forward token-axis Linear (amode KC, bmode TOKR, cmode TOKJ, zmode 0, no split-K) with M <= 64 output tokens and N = 16·B
- * columns, i.e. exactly one 64x16 tile per sample; mha/fm/tri/copy have B samples.
+ * Heterogeneous launch (batch <= 256).  Inside a choice block the dense nodes and the sparse nodes are independent
+ * (supernet.py:1113-1134), blocks depend on a few earlier blocks only, weight-gradient products and split-K second passes have no
+ * consumer nearby: nasrec_amd/schedule.py puts the operators of a step that do not depend on each other into LEVELS, and one
+ * NASREC_OP_WORKLIST launch runs a level — item k owns the workgroups [first_k, first_k + nblk_k) and executes the very body of its
+ * stand-alone kernel on them (bit-identical results; at batch 256 every launch costs ~5 us whatever it does, so a step is as long
+ * as its number of dependent launches).
+ *   item.kind   NASREC_OP_GEMM (part 0 = the whole launch of an unsplit product, 1 = main pass of a split-K product: slabs only,
+ *               2 = its second pass: fixed-order slab sum + epilogue), _DOT_TRI_FWD/_BWD, _FM_FWD/_BWD, _MHA_FWD/_BWD,
+ *               _COPY_SEGS, _GATE_BWD, _REDUCE_ROWS (compact form nasrec_wl_reduce_t, <= NASREC_WL_REDUCE_DST destinations);
+ *   item.off    byte offset (multiple of 16) of the item's descriptor inside `blob`; a GEMM descriptor may be truncated behind its
+ *               last used segment (offsetof(seg) + nseg * sizeof(seg) bytes);
+ *   first / nblk / geom are filled in by the launcher (callers leave them 0).
+ * All workgroups have 256 threads; GEMM items run the run-time-binding body (csrc/gemm_rt.h) on 64x64 / 32x32 / 64x16 / 16x64 tiles.
  * ---------------------------------------------------------------------------------------------- */
-#define NASREC_CHAIN_MAX 4
-typedef struct nasrec_chain_desc {
-  int32_t kind;   /* NASREC_OP_SAMPLE_CHAIN */
-  int32_t B;      /* samples (= workgroups) */
-  int32_t n;      /* number of stages */
-  int32_t stage[NASREC_CHAIN_MAX]; /* NASREC_OP_GEMM / MHA_FWD / FM_FWD / DOT_TRI_FWD / COPY_SEGS, executed in this order */
+#define NASREC_WL_MAX_ITEMS 12
+#define NASREC_WL_BLOB_BYTES 3680
+#define NASREC_WL_REDUCE_DST 16
+typedef struct nasrec_wl_item {
+  int32_t kind, part, off;
+  int32_t first, nblk;  /* launcher: workgroup range of the item */
+  int32_t geom[3];      /* launcher: grid geometry of the item (GEMM: tiles along n, tiles along m, tile configuration) */
+} nasrec_wl_item_t;
+
+typedef struct nasrec_wl_reduce {   /* NASREC_OP_REDUCE_ROWS with few destinations, as a worklist item */
+  int32_t kind, R, C, ld;
+  const float* in;
+  int32_t ndst, _pad;
+  float* dst[NASREC_WL_REDUCE_DST];
+  int32_t dst_off[NASREC_WL_REDUCE_DST], dst_len[NASREC_WL_REDUCE_DST];
+} nasrec_wl_reduce_t;
+
+typedef struct nasrec_worklist_desc {
+  int32_t kind; /* NASREC_OP_WORKLIST */
+  int32_t n;    /* items, <= NASREC_WL_MAX_ITEMS */
+  int32_t total_blocks; /* launcher */
   int32_t _pad;
-  nasrec_gemm_desc_t gemm;
-  nasrec_mha_desc_t mha;
-  nasrec_fm_desc_t fm;
-  nasrec_dot_tri_desc_t tri;
-  nasrec_copy_segs_desc_t copy;
-} nasrec_chain_desc_t;
+  nasrec_wl_item_t item[NASREC_WL_MAX_ITEMS];
+  char blob[NASREC_WL_BLOB_BYTES] __attribute__((aligned(16)));
+} nasrec_worklist_desc_t;
 
 /* ------------------------------------------------------------------------------------------------
  * Entry points
@@ -538,10 +555,6 @@ int nasrec_program_run(void* stream, const void* const* descs, int n);
 
 /* hipGraph capture of a program: capture once, replay many times (launch-bound B=256 step). */
 int nasrec_graph_create(void* stream, const void* const* descs, int n, void** graph_out);
-/* Two-lane capture (dense branch || sparse branch of a choice block): lanes[i] = 0 / 1, or a marker (descs[i] ignored). */
-#define NASREC_LANE_FORK (-1) /* lane 1 continues from lane 0's current position */
-#define NASREC_LANE_JOIN (-2) /* lane 0 waits for lane 1 */
-int nasrec_graph_create_lanes(void* stream, const void* const* descs, const int32_t* lanes, int n, void** graph_out);
 int nasrec_graph_launch(void* graph, void* stream);
 int nasrec_graph_destroy(void* graph);
 
@@ -559,7 +572,7 @@ int nasrec_adagrad_dense(void* stream, const nasrec_adagrad_dense_desc_t* d);
 int nasrec_adagrad_rows(void* stream, const nasrec_adagrad_rows_desc_t* d);
 int nasrec_opt_reduce(void* stream, const nasrec_opt_reduce_desc_t* d);
 int nasrec_opt_apply(void* stream, const nasrec_opt_apply_desc_t* d);
-int nasrec_sample_chain(void* stream, const nasrec_chain_desc_t* d);
+int nasrec_worklist(void* stream, const nasrec_worklist_desc_t* d);
 
 /* HIP-event timing on an arbitrary stream (bench.py measures kernels on the engine's own stream). */
 int nasrec_event_create(void** ev);

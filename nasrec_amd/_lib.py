@@ -32,7 +32,7 @@ ACT_BY_NAME = {"identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
 (OP_GEMM, OP_EMBED_GATHER, OP_DOT_TRI_FWD, OP_DOT_TRI_BWD, OP_FM_FWD, OP_FM_BWD, OP_MHA_FWD, OP_MHA_BWD, OP_REDUCE_ROWS,
  OP_COPY_SEGS, OP_GATE_BWD, OP_ROWSUM, OP_FINAL_FWD, OP_BCE, OP_FINAL_BWD, OP_EMB_DEDUP, OP_SUMSQ, OP_CLIP_COEF,
  OP_ADAGRAD_DENSE, OP_ADAGRAD_ROWS, OP_MEMSET, OP_LAYERNORM_FWD, OP_LAYERNORM_BWD, OP_ADD_SEGS, OP_SCALE,
- OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY, OP_SAMPLE_CHAIN, OP_CONST_I64, OP_SPLITK_EPILOGUES) = range(1, 33)
+ OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY, OP_WORKLIST, OP_CONST_I64, OP_SPLITK_EPILOGUES) = range(1, 33)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -175,12 +175,22 @@ class OptApplyDesc(C.Structure):
     _fields_ = [("kind", i32), ("dense_blocks", i32), ("clip", ClipCoefDesc), ("dense", AdagradDenseDesc), ("rows", AdagradRowsDesc)]
 
 
-CHAIN_MAX = 4
+WL_MAX_ITEMS, WL_BLOB_BYTES, WL_REDUCE_DST = 12, 3680, 16  # NASREC_WL_*
+WL_WHOLE, WL_MAIN, WL_EPI = 0, 1, 2                      # nasrec_wl_item_t.part of a GEMM item
 
 
-class ChainDesc(C.Structure):
-    _fields_ = [("kind", i32), ("B", i32), ("n", i32), ("stage", i32 * CHAIN_MAX), ("_pad", i32), ("gemm", GemmDesc), ("mha", MhaDesc),
-                ("fm", FmDesc), ("tri", DotTriDesc), ("copy", CopySegsDesc)]
+class WlItem(C.Structure):
+    _fields_ = [("kind", i32), ("part", i32), ("off", i32), ("first", i32), ("nblk", i32), ("geom", i32 * 3)]
+
+
+class WlReduce(C.Structure):
+    _fields_ = [("kind", i32), ("R", i32), ("C", i32), ("ld", i32), ("in_", vp), ("ndst", i32), ("_pad", i32), ("dst", vp * WL_REDUCE_DST),
+                ("dst_off", i32 * WL_REDUCE_DST), ("dst_len", i32 * WL_REDUCE_DST)]
+
+
+class WorklistDesc(C.Structure):
+    _fields_ = [("kind", i32), ("n", i32), ("total_blocks", i32), ("_pad", i32), ("item", WlItem * WL_MAX_ITEMS),
+                ("blob", C.c_char * WL_BLOB_BYTES)]
 
 
 DESC_BY_KIND = {
@@ -190,17 +200,15 @@ DESC_BY_KIND = {
     OP_EMB_DEDUP: EmbDedupDesc, OP_SUMSQ: SumsqDesc, OP_CLIP_COEF: ClipCoefDesc, OP_ADAGRAD_DENSE: AdagradDenseDesc,
     OP_ADAGRAD_ROWS: AdagradRowsDesc, OP_MEMSET: MemsetDesc, OP_LAYERNORM_FWD: LayerNormDesc, OP_LAYERNORM_BWD: LayerNormDesc,
     OP_SCALE: ScaleDesc, OP_ACT_BWD: ActBwdDesc, OP_STAGE_INPUTS: StageDesc, OP_OPT_REDUCE: OptReduceDesc, OP_OPT_APPLY: OptApplyDesc,
-    OP_SAMPLE_CHAIN: ChainDesc, OP_CONST_I64: ConstI64Desc, OP_SPLITK_EPILOGUES: SplitkEpiloguesDesc,
+    OP_WORKLIST: WorklistDesc, OP_CONST_I64: ConstI64Desc, OP_SPLITK_EPILOGUES: SplitkEpiloguesDesc,
 }
-
-LANE_FORK, LANE_JOIN = -1, -2  # nasrec_graph_create_lanes markers
 
 # every symbol include/nasrec_hip.h declares
 SYMBOLS = [
-    "nasrec_launch", "nasrec_program_run", "nasrec_graph_create", "nasrec_graph_create_lanes", "nasrec_graph_launch", "nasrec_graph_destroy", "nasrec_gemm",
+    "nasrec_launch", "nasrec_program_run", "nasrec_graph_create", "nasrec_graph_launch", "nasrec_graph_destroy", "nasrec_gemm",
     "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm", "nasrec_mha_ffn", "nasrec_layernorm",
     "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense", "nasrec_adagrad_rows", "nasrec_opt_reduce",
-    "nasrec_opt_apply", "nasrec_sample_chain", "nasrec_event_create",
+    "nasrec_opt_apply", "nasrec_worklist", "nasrec_event_create",
     "nasrec_event_record", "nasrec_event_elapsed_ms", "nasrec_event_destroy", "nasrec_last_error", "nasrec_abi_version",
     "nasrec_desc_sizes", "nasrec_tsv_parse",
 ]
@@ -228,7 +236,6 @@ def load():
     lib.nasrec_launch.argtypes = [vp, vp]
     lib.nasrec_program_run.argtypes = [vp, C.POINTER(vp), C.c_int]
     lib.nasrec_graph_create.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp)]
-    lib.nasrec_graph_create_lanes.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.c_int, C.POINTER(vp)]
     lib.nasrec_graph_launch.argtypes = [vp, vp]
     lib.nasrec_graph_destroy.argtypes = [vp]
     lib.nasrec_event_create.argtypes = [C.POINTER(vp)]
@@ -240,10 +247,10 @@ def load():
     lib.nasrec_tsv_parse.restype = i64
     for name in ("nasrec_gemm", "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm",
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
-                 "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_sample_chain"):
+                 "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_worklist"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 10:
-        raise EngineError("ABI version mismatch: library %d, binding 10" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 11:
+        raise EngineError("ABI version mismatch: library %d, binding 11" % lib.nasrec_abi_version())
     sizes = (i32 * 40)()
     n = lib.nasrec_desc_sizes(sizes, 40)
     for kind, cls in DESC_BY_KIND.items():

@@ -63,7 +63,7 @@ static int dispatch(hipStream_t st, const void* desc) {
     case NASREC_OP_SPLITK_EPILOGUES: return launch_splitk_epilogues(st, (const nasrec_splitk_epilogues_desc_t*)desc);
     case NASREC_OP_OPT_REDUCE: return launch_opt_reduce(st, (const nasrec_opt_reduce_desc_t*)desc);
     case NASREC_OP_OPT_APPLY: return launch_opt_apply(st, (const nasrec_opt_apply_desc_t*)desc);
-    case NASREC_OP_SAMPLE_CHAIN: return launch_sample_chain(st, (const nasrec_chain_desc_t*)desc);
+    case NASREC_OP_WORKLIST: return launch_worklist(st, (const nasrec_worklist_desc_t*)desc);
     default: return nasrec_set_error(-1, "unknown op kind %d", kind);
   }
 }
@@ -114,75 +114,6 @@ int nasrec_graph_create(void* stream, const void* const* descs, int n, void** gr
   return 0;
 }
 
-// Two-lane capture: the dense branch and the sparse branch of a choice block are independent until the block's merge, so the
-// forward program carries a lane tag per descriptor (plan.py): lane 0 = the capturing stream, lane 1 = a side stream that is
-// forked from / joined to it with events.  In the captured graph these become plain dependency edges: the two branches of a
-// block are siblings the hardware queues may overlap, instead of a chain of ~5 us cold-start kernels.
-//   lanes[i] >= 0: descriptor i runs on that lane;  NASREC_LANE_FORK: lane 1 continues from lane 0's current position;
-//   NASREC_LANE_JOIN: lane 0 waits for lane 1 (descs[i] is ignored for the two markers).
-int nasrec_graph_create_lanes(void* stream, const void* const* descs, const int32_t* lanes, int n, void** graph_out) {
-  hipStream_t st = (hipStream_t)stream;
-  if (graph_out == nullptr || lanes == nullptr) return nasrec_set_error(-1, "graph_out / lanes is null");
-  static hipStream_t side = nullptr;
-  if (side == nullptr) {
-    hipError_t e0 = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
-    if (e0 != hipSuccess) return nasrec_set_error((int)e0, "hipStreamCreate: %s", hipGetErrorString(e0));
-  }
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  (void)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
-  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) return nasrec_set_error((int)e, "hipStreamBeginCapture: %s", hipGetErrorString(e));
-  int rc = 0;
-  bool side_open = false;  // lane 1 holds work not yet joined
-  for (int i = 0; i < n && rc == 0; ++i) {
-    if (lanes[i] == NASREC_LANE_FORK) {
-      if (side_open) {  // re-fork: the side lane first rejoins (keeps the event dependencies a simple fork/join nest)
-        (void)hipEventRecord(ev_join, side);
-        (void)hipStreamWaitEvent(st, ev_join, 0);
-      }
-      (void)hipEventRecord(ev_fork, st);
-      (void)hipStreamWaitEvent(side, ev_fork, 0);
-      side_open = true;
-    } else if (lanes[i] == NASREC_LANE_JOIN) {
-      if (side_open) {
-        (void)hipEventRecord(ev_join, side);
-        (void)hipStreamWaitEvent(st, ev_join, 0);
-        side_open = false;
-      }
-    } else {
-      hipStream_t target = (lanes[i] == 1 && side_open) ? side : st;
-      rc = dispatch(target, descs[i]);
-      if (rc != 0) {
-        char tmp[400];
-        snprintf(tmp, sizeof(tmp), "%s", g_err);
-        rc = nasrec_set_error(rc, "program op %d (kind %d): %s", i, descs[i] ? *(const int32_t*)descs[i] : -1, tmp);
-      }
-    }
-  }
-  if (side_open) {
-    (void)hipEventRecord(ev_join, side);
-    (void)hipStreamWaitEvent(st, ev_join, 0);
-  }
-  hipGraph_t g = nullptr;
-  e = hipStreamEndCapture(st, &g);
-  (void)hipEventDestroy(ev_fork);
-  (void)hipEventDestroy(ev_join);
-  if (rc != 0) {
-    if (g) (void)hipGraphDestroy(g);
-    return rc;
-  }
-  if (e != hipSuccess) return nasrec_set_error((int)e, "hipStreamEndCapture: %s", hipGetErrorString(e));
-  hipGraphExec_t ex = nullptr;
-  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-  if (e != hipSuccess) {
-    (void)hipGraphDestroy(g);
-    return nasrec_set_error((int)e, "hipGraphInstantiate: %s", hipGetErrorString(e));
-  }
-  *graph_out = new nasrec_graph{g, ex};
-  return 0;
-}
-
 int nasrec_graph_launch(void* graph, void* stream) {
   nasrec_graph* h = (nasrec_graph*)graph;
   if (!h) return nasrec_set_error(-1, "null graph");
@@ -221,7 +152,7 @@ TYPED(nasrec_adagrad_dense, nasrec_adagrad_dense_desc_t, kind == NASREC_OP_ADAGR
 TYPED(nasrec_adagrad_rows, nasrec_adagrad_rows_desc_t, kind == NASREC_OP_ADAGRAD_ROWS)
 TYPED(nasrec_opt_reduce, nasrec_opt_reduce_desc_t, kind == NASREC_OP_OPT_REDUCE)
 TYPED(nasrec_opt_apply, nasrec_opt_apply_desc_t, kind == NASREC_OP_OPT_APPLY)
-TYPED(nasrec_sample_chain, nasrec_chain_desc_t, kind == NASREC_OP_SAMPLE_CHAIN)
+TYPED(nasrec_worklist, nasrec_worklist_desc_t, kind == NASREC_OP_WORKLIST)
 
 int nasrec_event_create(void** ev) {
   hipEvent_t e;
@@ -252,7 +183,7 @@ int nasrec_event_destroy(void* ev) {
 
 const char* nasrec_last_error(void) { return g_err; }
 
-int nasrec_abi_version(void) { return 10; }
+int nasrec_abi_version(void) { return 11; }
 
 int nasrec_desc_sizes(int32_t* out, int n) {
   static const int32_t sizes[] = {
@@ -286,7 +217,7 @@ int nasrec_desc_sizes(int32_t* out, int n) {
       (int32_t)sizeof(nasrec_stage_desc_t),         // 27
       (int32_t)sizeof(nasrec_opt_reduce_desc_t),    // 28
       (int32_t)sizeof(nasrec_opt_apply_desc_t),     // 29
-      (int32_t)sizeof(nasrec_chain_desc_t),         // 30
+      (int32_t)sizeof(nasrec_worklist_desc_t),      // 30
       (int32_t)sizeof(nasrec_const_i64_desc_t),     // 31
       (int32_t)sizeof(nasrec_splitk_epilogues_desc_t), // 32
   };

@@ -68,4 +68,4 @@ int launch_opt_apply(hipStream_t s, const nasrec_opt_apply_desc_t* d);
 int launch_memset_chunks(hipStream_t s, const nasrec_memset_desc_t* d);
 int launch_const_i64(hipStream_t s, const nasrec_const_i64_desc_t* d);
 int launch_splitk_epilogues(hipStream_t s, const nasrec_splitk_epilogues_desc_t* d);
-int launch_sample_chain(hipStream_t s, const nasrec_chain_desc_t* d);
+int launch_worklist(hipStream_t s, const nasrec_worklist_desc_t* d);

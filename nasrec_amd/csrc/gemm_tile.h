@@ -92,6 +92,41 @@ __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, cons
   sg.C[o] = v;
 }
 
+// second pass of split-K: fixed-order sum of the partial slabs, then the same epilogue (element e of problem z)
+template <int CM>
+__device__ __forceinline__ void splitk_second_pass(const nasrec_gemm_desc_t& d, int Mmax, int Nmax, int z, long e) {
+  const int S = d.splitk;
+  const nasrec_gemm_seg_t& sg = d.seg[d.zmode ? z : 0];
+  const int M = sg.M, N = sg.N;
+  if (e >= (long)M * N) return;
+  int i, j;
+  if (CM == NASREC_CM_TOKJ) {  // token-axis outputs: consecutive threads walk e (16 contiguous floats), then i
+    int jb = (int)(e / ((long)M * 16));
+    int rem = (int)(e % ((long)M * 16));
+    i = rem >> 4;
+    j = jb * 16 + (rem & 15);
+  } else {
+    i = (int)(e / N);
+    j = (int)(e % N);
+  }
+  const float* slab = d.workspace + ((long)z * S) * Mmax * Nmax + (long)i * N + j;
+  const long stride = (long)Mmax * Nmax;
+  // four independent partial sums keep several slab loads in flight (every kernel starts on a cold L2); the
+  // association order is still a fixed function of S, so results stay reproducible
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int q = 0;
+  for (; q + 4 <= S; q += 4) {
+    const float a0 = slab[(long)q * stride], a1 = slab[(long)(q + 1) * stride];
+    const float a2 = slab[(long)(q + 2) * stride], a3 = slab[(long)(q + 3) * stride];
+    v0 += a0;
+    v1 += a1;
+    v2 += a2;
+    v3 += a3;
+  }
+  for (; q < S; ++q) v0 += slab[(long)q * stride];
+  epilogue_store<CM>(d, sg, i, j, (v0 + v1) + (v2 + v3));
+}
+
 // One workgroup's share of a GEMM launch: block tile (bx, by) of problem / k-split bz.  Called by gemm_kernel with the
 // hardware block index, and by the per-sample chain kernel (chain.hip) with bx = the sample.
 template <int AM, int BMODE, int CM, int NT, int TK, int TBM, int TBN>

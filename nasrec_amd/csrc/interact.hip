@@ -24,33 +24,7 @@ __global__ __launch_bounds__(256) void dot_tri_bwd_kernel(const nasrec_dot_tri_d
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + wave;
   if (b >= d.B) return;
-  const int k1 = d.k1;
-  const int P = k1 * (k1 - 1) / 2;
-  const float* Tb = d.T + (long)b * k1 * 16;
-  const float* dob = d.dout + (long)b * d.ld_out;
-  float* ts = Ts[wave];
-  float* ds = Ds[wave];
-  for (int q = lane; q < k1 * 16; q += 64) ts[(q >> 4) * TRI_LD + (q & 15)] = Tb[q];
-  for (int q = lane; q < P; q += 64) ds[q] = dob[q];
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0);
-  float* dTb = d.dT + (long)b * k1 * 16;
-  for (int item = lane; item < k1 * 4; item += 64) {
-    const int i = item >> 2, q = item & 3;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int rowbase = i * (i - 1) / 2;
-    for (int j = 0; j < i; ++j) {
-      const float w = ds[rowbase + j];
-      f32x4 t = *reinterpret_cast<const f32x4*>(ts + j * TRI_LD + 4 * q);
-      acc += w * t;
-    }
-    for (int j = i + 1; j < k1; ++j) {
-      const float w = ds[j * (j - 1) / 2 + i];
-      f32x4 t = *reinterpret_cast<const f32x4*>(ts + j * TRI_LD + 4 * q);
-      acc += w * t;
-    }
-    *reinterpret_cast<f32x4*>(dTb + i * 16 + 4 * q) = acc;
-  }
+  dot_tri_bwd_sample(d, b, lane, Ts[wave], Ds[wave]);
 }
 
 int launch_dot_tri(hipStream_t st, const nasrec_dot_tri_desc_t* d) {
@@ -80,18 +54,7 @@ __global__ __launch_bounds__(256) void fm_bwd_kernel(const nasrec_fm_desc_t d) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + wave;
   if (b >= d.B) return;
-  const int g = lane >> 4, e = lane & 15;
-  const float* x = d.x + (long)b * d.ldx + e;
-  float* dx = d.dx + (long)b * d.ldx + e;
-  float s = 0.f;
-  for (int n = g; n < d.N; n += 4) s += x[n * 16];
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  const float g2 = 2.f * d.dix[(long)b * d.ld_ix + e];
-  for (int n = g; n < d.N; n += 4) {
-    float r = g2 * (s - x[n * 16]);
-    dx[n * 16] = d.accumulate ? dx[n * 16] + r : r;
-  }
+  fm_bwd_sample(d, b, lane);
 }
 
 int launch_fm(hipStream_t st, const nasrec_fm_desc_t* d) {
@@ -126,25 +89,7 @@ int launch_copy_segs(hipStream_t st, const nasrec_copy_segs_desc_t* d) {
 // SigmoidGating backward, elementwise part (modules.py:578-582)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const nasrec_gate_bwd_desc_t d) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long)d.B * d.D) return;
-  const int b = (int)(t / d.D), j = (int)(t % d.D);
-  const float go = d.dout[(long)b * d.ld_dout + j];
-  const float g = d.g[(long)b * d.ld_g + j];
-  float r = 0.f;
-  for (int q = 0; q < d.nseg; ++q) {
-    const int jj = j - d.r_off[q];
-    if (jj >= 0 && jj < d.r_width[q]) {
-      if (d.r_ptr[q]) r = d.r_ptr[q][(long)b * d.r_ld[q] + jj];
-      if (d.dr_ptr[q]) {
-        float* p = d.dr_ptr[q] + (long)b * d.r_ld[q] + jj;
-        const float v = go * g;
-        *p = d.dr_accumulate[q] ? *p + v : v;
-      }
-      break;
-    }
-  }
-  d.dz[(long)b * d.ld_dz + j] = go * r * g * (1.f - g);
+  gate_bwd_element(d, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
 int launch_gate_bwd(hipStream_t st, const nasrec_gate_bwd_desc_t* d) {
@@ -216,39 +161,8 @@ int launch_rowsum(hipStream_t st, const nasrec_rowsum_desc_t* d) {
 // out[c] = sum_r in[r*ld + c] in fixed order, scattered to destination tensors by column range
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const nasrec_reduce_rows_desc_t d) {
-  __shared__ float red[16][17];
-  const int cl = threadIdx.x & 15, rq = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
-  float s = 0.f;
-  if (c < d.C) {
-    // four independent chains: the loads of a cold [R, C] slab pipeline instead of queueing behind one accumulator
-    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = rq;
-    for (; r + 48 < d.R; r += 64) {
-      const float a0 = d.in[(long)r * d.ld + c], a1 = d.in[(long)(r + 16) * d.ld + c];
-      const float a2 = d.in[(long)(r + 32) * d.ld + c], a3 = d.in[(long)(r + 48) * d.ld + c];
-      s += a0;
-      s1 += a1;
-      s2 += a2;
-      s3 += a3;
-    }
-    for (; r < d.R; r += 16) s += d.in[(long)r * d.ld + c];
-    s = (s + s1) + (s2 + s3);
-  }
-  red[rq][cl] = s;
-  __syncthreads();
-  if (rq == 0 && c < d.C) {
-    float tot = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) tot += red[q][cl];
-    for (int q = 0; q < d.ndst; ++q) {
-      const int cc = c - d.dst_off[q];
-      if (cc >= 0 && cc < d.dst_len[q]) {
-        if (d.dst[q]) d.dst[q][cc] = tot;
-        break;
-      }
-    }
-  }
+  __shared__ float red[16 * 17];
+  reduce_rows_block(d, blockIdx.x, threadIdx.x, red);
 }
 
 int launch_reduce_rows(hipStream_t st, const nasrec_reduce_rows_desc_t* d) {

@@ -79,3 +79,108 @@ __device__ __forceinline__ void copy_segs_element(const nasrec_copy_segs_desc_t&
   }
 }
 
+
+// dT[b,i,:] = sum_{j<i} dO[p(i,j)] T[j] + sum_{j>i} dO[p(j,i)] T[j]; one wavefront = one sample; ts / ds = this wavefront's LDS
+// (k1 * TRI_LD and k1 (k1 - 1) / 2 floats)
+__device__ __forceinline__ void dot_tri_bwd_sample(const nasrec_dot_tri_desc_t& d, int b, int lane, float* ts, float* ds) {
+  const int k1 = d.k1;
+  const int P = k1 * (k1 - 1) / 2;
+  const float* Tb = d.T + (long)b * k1 * 16;
+  const float* dob = d.dout + (long)b * d.ld_out;
+  for (int q = lane; q < k1 * 16; q += 64) ts[(q >> 4) * TRI_LD + (q & 15)] = Tb[q];
+  for (int q = lane; q < P; q += 64) ds[q] = dob[q];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0);
+  float* dTb = d.dT + (long)b * k1 * 16;
+  for (int item = lane; item < k1 * 4; item += 64) {
+    const int i = item >> 2, q = item & 3;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int rowbase = i * (i - 1) / 2;
+    for (int j = 0; j < i; ++j) {
+      const float w = ds[rowbase + j];
+      f32x4 t = *reinterpret_cast<const f32x4*>(ts + j * TRI_LD + 4 * q);
+      acc += w * t;
+    }
+    for (int j = i + 1; j < k1; ++j) {
+      const float w = ds[j * (j - 1) / 2 + i];
+      f32x4 t = *reinterpret_cast<const f32x4*>(ts + j * TRI_LD + 4 * q);
+      acc += w * t;
+    }
+    *reinterpret_cast<f32x4*>(dTb + i * 16 + 4 * q) = acc;
+  }
+}
+
+__device__ __forceinline__ void fm_bwd_sample(const nasrec_fm_desc_t& d, int b, int lane) {
+  const int g = lane >> 4, e = lane & 15;
+  const float* x = d.x + (long)b * d.ldx + e;
+  float* dx = d.dx + (long)b * d.ldx + e;
+  float s = 0.f;
+  for (int n = g; n < d.N; n += 4) s += x[n * 16];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  const float g2 = 2.f * d.dix[(long)b * d.ld_ix + e];
+  for (int n = g; n < d.N; n += 4) {
+    float r = g2 * (s - x[n * 16]);
+    dx[n * 16] = d.accumulate ? dx[n * 16] + r : r;
+  }
+}
+
+// SigmoidGating backward, element t = (b, j) (modules.py:578-582)
+__device__ __forceinline__ void gate_bwd_element(const nasrec_gate_bwd_desc_t& d, long t) {
+  if (t >= (long)d.B * d.D) return;
+  const int b = (int)(t / d.D), j = (int)(t % d.D);
+  const float go = d.dout[(long)b * d.ld_dout + j];
+  const float g = d.g[(long)b * d.ld_g + j];
+  float r = 0.f;
+  for (int q = 0; q < d.nseg; ++q) {
+    const int jj = j - d.r_off[q];
+    if (jj >= 0 && jj < d.r_width[q]) {
+      if (d.r_ptr[q]) r = d.r_ptr[q][(long)b * d.r_ld[q] + jj];
+      if (d.dr_ptr[q]) {
+        float* p = d.dr_ptr[q] + (long)b * d.r_ld[q] + jj;
+        const float v = go * g;
+        *p = d.dr_accumulate[q] ? *p + v : v;
+      }
+      break;
+    }
+  }
+  d.dz[(long)b * d.ld_dz + j] = go * r * g * (1.f - g);
+}
+
+// out[c] = sum_r in[r*ld + c] in fixed order for the 16 columns of workgroup vb, scattered to the destinations by column range.
+// D: nasrec_reduce_rows_desc_t or the compact form a worklist launch carries (same field names).  red = 16 x 17 floats of LDS.
+template <typename D>
+__device__ __forceinline__ void reduce_rows_block(const D& d, int vb, int tid, float* red) {
+  const int cl = tid & 15, rq = tid >> 4;
+  const int c = vb * 16 + cl;
+  float s = 0.f;
+  if (c < d.C) {
+    // four independent chains: the loads of a cold [R, C] slab pipeline instead of queueing behind one accumulator
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = rq;
+    for (; r + 48 < d.R; r += 64) {
+      const float a0 = d.in[(long)r * d.ld + c], a1 = d.in[(long)(r + 16) * d.ld + c];
+      const float a2 = d.in[(long)(r + 32) * d.ld + c], a3 = d.in[(long)(r + 48) * d.ld + c];
+      s += a0;
+      s1 += a1;
+      s2 += a2;
+      s3 += a3;
+    }
+    for (; r < d.R; r += 16) s += d.in[(long)r * d.ld + c];
+    s = (s + s1) + (s2 + s3);
+  }
+  red[rq * 17 + cl] = s;
+  __syncthreads();
+  if (rq == 0 && c < d.C) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q * 17 + cl];
+    for (int q = 0; q < d.ndst; ++q) {
+      const int cc = c - d.dst_off[q];
+      if (cc >= 0 && cc < d.dst_len[q]) {
+        if (d.dst[q]) d.dst[q][cc] = tot;
+        break;
+      }
+    }
+  }
+}

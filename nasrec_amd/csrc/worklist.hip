@@ -1,0 +1,155 @@
+// NASREC_OP_WORKLIST (include/nasrec_hip.h): one launch = the operators of one LEVEL of a batch-256 step (nasrec_amd/schedule.py),
+// side by side on disjoint workgroup ranges.  Every item runs the body of its stand-alone kernel — the run-time-binding GEMM tile
+// (gemm_rt.h), the split-K second pass, the Transformer forward / backward, the FM / DotProduct cores, segmented copies, the gating
+// backward, fixed-order row reductions — so results are bit-identical to the separate launches; what disappears is a kernel
+// boundary (~5 us of cold-L2 start at batch 256) per operator that has an independent neighbour.
+//
+// One LDS buffer is shared by all bodies (the largest wins: 35 KB for a 64x64x64 GEMM tile, 52 KB when a Transformer backward is
+// in the level), so that a CU still holds 3-4 workgroups of different items next to each other.  Descriptors travel in the kernel
+// arguments (a 3.6 KB blob; GEMM descriptors truncated behind their last segment): no dependent global read before the operands.
+#include <stdlib.h>
+
+#include "worklist_body.h"
+
+// host side: geometry of every item, then ONE launch
+static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, int blob_left) {
+  if (g->nseg < 1 || g->nseg > NASREC_MAX_SEGS) return nasrec_set_error(-2, "worklist: gemm nseg=%d", g->nseg);
+  const int need = (int)offsetof(nasrec_gemm_desc_t, seg) + g->nseg * (int)sizeof(nasrec_gemm_seg_t);
+  if (need > blob_left) return nasrec_set_error(-2, "worklist: truncated gemm descriptor (%d bytes) runs past the blob", need);
+  const int nprob = g->zmode ? g->nseg : 1;
+  const int S = g->splitk > 1 ? g->splitk : 1;
+  if (g->splitk == NASREC_SPLITK_BALANCED) return nasrec_set_error(-2, "worklist: the balanced schedule is a throughput-regime launch");
+  if ((it.part == 0) != (S == 1)) return nasrec_set_error(-2, "worklist: gemm part %d with splitk %d", it.part, g->splitk);
+  if (S > 1 && !g->workspace) return nasrec_set_error(-3, "worklist: splitk=%d needs a workspace", S);
+  int Mmax = 0, Nmax = 0, Kmax = 0;
+  long wgs = 0;
+  bool aux = false, uniform = true;
+  for (int q = 0; q < nprob; ++q) {
+    Mmax = g->seg[q].M > Mmax ? g->seg[q].M : Mmax;
+    Nmax = g->seg[q].N > Nmax ? g->seg[q].N : Nmax;
+    wgs += (long)((g->seg[q].M + 63) / 64) * ((g->seg[q].N + 63) / 64) * S;
+  }
+  for (int q = 0; q < g->nseg; ++q) {
+    const nasrec_gemm_seg_t& s = g->seg[q];
+    if (s.A && s.K > Kmax) Kmax = s.K;
+    aux = aux || s.Aaux || s.Baux;
+    if (!g->zmode && (s.ones_col != g->seg[0].ones_col || s.Mvalid != g->seg[0].Mvalid)) uniform = false;
+    if (!g->zmode && s.A && ((s.Aaux != nullptr) != (g->seg[0].Aaux != nullptr) || (s.Baux != nullptr) != (g->seg[0].Baux != nullptr))) uniform = false;
+  }
+  if (!uniform) return nasrec_set_error(-2, "worklist: k-segments that disagree on row predicates / mask operands take the plain template");
+  {
+    const bool kca = g->amode == NASREC_AM_KC || g->amode == NASREC_AM_TOKK, kcb = g->bmode == NASREC_AM_KC || g->bmode == NASREC_AM_TOKK;
+    if (!kca && kcb) return nasrec_set_error(-2, "worklist: operand binding a=%d b=%d has no body", g->amode, g->bmode);
+  }
+  if (Mmax <= 0 || Nmax <= 0) {
+    it.nblk = 0;
+    return 0;
+  }
+  if (it.part == 2) {
+    const int per = (int)(((long)Mmax * Nmax + 255) / 256);
+    it.geom[0] = per;
+    it.nblk = per * nprob;
+    return 0;
+  }
+  // the tile choice of launch_gemm_t (gemm.hip) on 256-thread workgroups
+  int tile, tbm, tbn;
+  if (wgs >= GEMM_SKINNY_BELOW) {
+    tile = WL_T32x32, tbm = 32, tbn = 32;
+  } else if (Nmax >= Mmax) {
+    tile = WL_T64x16, tbm = 64, tbn = 16;
+  } else {
+    tile = WL_T16x64, tbm = 16, tbn = 64;
+  }
+  it.geom[0] = (Nmax + tbn - 1) / tbn;
+  it.geom[1] = (Mmax + tbm - 1) / tbm;
+  const bool kca_ = g->amode == NASREC_AM_KC || g->amode == NASREC_AM_TOKK, kcb_ = g->bmode == NASREC_AM_KC || g->bmode == NASREC_AM_TOKK;
+  it.geom[2] = tile | ((kca_ && kcb_ ? 0 : (kca_ ? 1 : 2)) << 2) | ((aux ? 1 : 0) << 4);
+  it.nblk = it.geom[0] * it.geom[1] * nprob * S;
+  return 0;
+}
+
+int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
+  if (w->n < 1 || w->n > NASREC_WL_MAX_ITEMS) return nasrec_set_error(-2, "worklist: n=%d outside [1,%d]", w->n, NASREC_WL_MAX_ITEMS);
+  nasrec_worklist_desc_t wl = *w;
+  static const bool force_big = getenv("NASREC_WL_BIG") != nullptr && atoi(getenv("NASREC_WL_BIG")) != 0;  // A/B knob
+  bool big = force_big;
+  int first = 0;
+  for (int k = 0; k < wl.n; ++k) {
+    nasrec_wl_item_t& it = wl.item[k];
+    if (it.off < 0 || (it.off & 15) || it.off >= NASREC_WL_BLOB_BYTES) return nasrec_set_error(-2, "worklist: item %d offset %d", k, it.off);
+    const char* blob = wl.blob + it.off;
+    const int left = NASREC_WL_BLOB_BYTES - it.off;
+    it.first = first;
+    it.nblk = 0;
+    it.geom[0] = it.geom[1] = it.geom[2] = 0;
+#define WL_NEED(T) if ((int)sizeof(T) > left) return nasrec_set_error(-2, "worklist: item %d runs past the blob", k)
+    switch (it.kind) {
+      case NASREC_OP_GEMM: {
+        const int rc = wl_gemm_geometry(reinterpret_cast<const nasrec_gemm_desc_t*>(blob), it, left);
+        if (rc) return rc;
+        break;
+      }
+      case NASREC_OP_MHA_FWD:
+      case NASREC_OP_MHA_BWD: {
+        WL_NEED(nasrec_mha_desc_t);
+        const nasrec_mha_desc_t* d = reinterpret_cast<const nasrec_mha_desc_t*>(blob);
+        if (d->N < 1 || d->N > MHA_N) return nasrec_set_error(-2, "worklist: mha N=%d out of range [1,%d]", d->N, MHA_N);
+        if (it.kind == NASREC_OP_MHA_BWD) {
+          if (!d->saved) return nasrec_set_error(-2, "worklist: mha backward needs the state saved by the forward launch");
+          big = true;
+        }
+        it.nblk = d->B;
+        break;
+      }
+      case NASREC_OP_FM_FWD:
+      case NASREC_OP_FM_BWD:
+        WL_NEED(nasrec_fm_desc_t);
+        it.nblk = (reinterpret_cast<const nasrec_fm_desc_t*>(blob)->B + 3) / 4;
+        break;
+      case NASREC_OP_DOT_TRI_FWD:
+      case NASREC_OP_DOT_TRI_BWD: {
+        WL_NEED(nasrec_dot_tri_desc_t);
+        const nasrec_dot_tri_desc_t* d = reinterpret_cast<const nasrec_dot_tri_desc_t*>(blob);
+        const int P4 = (d->k1 * (d->k1 - 1) / 2 + 3) & ~3;
+        if (d->k1 < 2 || 4 * (d->k1 * TRI_LD + P4) > WL_LDS_FLOATS)
+          return nasrec_set_error(-2, "worklist: dot_tri k1=%d does not fit the shared LDS buffer", d->k1);
+        it.nblk = (d->B + 3) / 4;
+        break;
+      }
+      case NASREC_OP_COPY_SEGS: {
+        WL_NEED(nasrec_copy_segs_desc_t);
+        const nasrec_copy_segs_desc_t* d = reinterpret_cast<const nasrec_copy_segs_desc_t*>(blob);
+        int W = 0;
+        for (int q = 0; q < d->nseg; ++q) W = max(W, d->off[q] + d->width[q]);
+        it.geom[0] = W;
+        it.nblk = (int)(((long)d->B * W + 255) / 256);
+        break;
+      }
+      case NASREC_OP_GATE_BWD: {
+        WL_NEED(nasrec_gate_bwd_desc_t);
+        const nasrec_gate_bwd_desc_t* d = reinterpret_cast<const nasrec_gate_bwd_desc_t*>(blob);
+        it.nblk = (int)(((long)d->B * d->D + 255) / 256);
+        break;
+      }
+      case NASREC_OP_REDUCE_ROWS: {
+        WL_NEED(nasrec_wl_reduce_t);
+        const nasrec_wl_reduce_t* d = reinterpret_cast<const nasrec_wl_reduce_t*>(blob);
+        if (d->ndst < 1 || d->ndst > NASREC_WL_REDUCE_DST) return nasrec_set_error(-2, "worklist: reduce_rows ndst=%d", d->ndst);
+        it.nblk = (d->C + 15) / 16;
+        break;
+      }
+      default:
+        return nasrec_set_error(-2, "worklist: item %d has kind %d, which has no body in the worklist kernel", k, it.kind);
+    }
+#undef WL_NEED
+    first += it.nblk;
+  }
+  wl.total_blocks = first;
+  if (first < 1) return 0;
+  if (big) {
+    hipLaunchKernelGGL(worklist_kernel<true>, dim3((unsigned)first), dim3(256), sizeof(float) * WL_LDS_BIG_FLOATS, st, wl);
+  } else {
+    hipLaunchKernelGGL(worklist_kernel<false>, dim3((unsigned)first), dim3(256), sizeof(float) * WL_LDS_FLOATS, st, wl);
+  }
+  return nasrec_check_launch("worklist");
+}

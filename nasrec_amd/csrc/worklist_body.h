@@ -1,0 +1,153 @@
+// Device side of NASREC_OP_WORKLIST (see worklist.hip): the kernel and its item bodies.
+#pragma once
+#include "attention_body.h"
+#include "gemm_rt.h"
+#include "interact_bodies.h"
+
+#define WL_LDS_BIG_FLOATS MHA_BWD_LDS_FLOATS(4)  // 12960 floats = 52 KB
+#define WL_LDS_FLOATS MHA_FWD_LDS_FLOATS(4)  // 7840 floats = 31 KB (5 workgroups per CU): the Transformer forward; a 64x16x64 GEMM tile needs 5568
+
+#define WL_TK 64  // staged k depth of every GEMM item (a product with K <= 32 pads its one tile with zeros: same sums, bit for bit)
+// tile configurations of GEMM items: geom[2] = tile | binding pair << 2 | mask operand << 4
+enum { WL_T32x32 = 1, WL_T64x16 = 2, WL_T16x64 = 3 };
+
+// All bodies share the launch's DYNAMIC LDS buffer (sized by the launcher: 35 KB, or 52 KB when a Transformer backward is in the level).
+extern __shared__ __attribute__((aligned(16))) float wl_lds[];
+
+// Taking the address of the by-value kernel argument (`wl.blob + off` bound to a reference through a cast) makes clang copy all 4 KB of
+// it into scratch, per thread, at kernel entry (a step 8x slower).  The kernel therefore reads the kernel-argument segment pointer
+// itself, items are 64-bit ADDRESSES, and a body turns its address into a uniform pointer to constant memory (scalar loads).
+// Every body is inlined: as real functions each call saved ~100 callee-saved registers in scratch.
+template <typename T>
+__device__ __forceinline__ const T& wl_ref(unsigned long long addr) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr), hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+  return *(const T*)(const __attribute__((address_space(4))) T*)(((unsigned long long)hi << 32) | lo);
+}
+
+template <bool KCA, bool KCB, int TBM, int TBN, bool AUX>
+__device__ __forceinline__ void wl_gemm_cfg(unsigned long long blob, int vb_, int gx_, int gy_) {
+  // ring depth 2: the kernel must fit 128 registers so that FOUR workgroups of different items share a CU (a level's items only run
+  // side by side if they are resident together); a staged k-tile is <= 20 floats per thread on these tiles
+  constexpr int RING = 2;
+  const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
+  const int vb = __builtin_amdgcn_readfirstlane(vb_), gx = __builtin_amdgcn_readfirstlane(gx_), gy = __builtin_amdgcn_readfirstlane(gy_);
+  const int nprob = g.zmode ? g.nseg : 1;
+  int Mmax = 0, Nmax = 0;
+  for (int q = 0; q < nprob; ++q) {
+    Mmax = max(Mmax, g.seg[q].M);
+    Nmax = max(Nmax, g.seg[q].N);
+  }
+  const int bx = vb % gx, by = (vb / gx) % gy, bz = vb / (gx * gy);
+  gemm_tile_rt<KCA, KCB, 256, WL_TK, TBM, TBN, AUX, RING>(g, Mmax, Nmax, bx, by, bz, wl_lds);
+}
+
+template <bool KCA, bool KCB, bool AUX>
+__device__ __forceinline__ void wl_gemm_tile(int tile, unsigned long long off, int vb, int gx, int gy) {
+  switch (tile) {
+    case WL_T32x32: wl_gemm_cfg<KCA, KCB, 32, 32, AUX>(off, vb, gx, gy); break;
+    case WL_T64x16: wl_gemm_cfg<KCA, KCB, 64, 16, AUX>(off, vb, gx, gy); break;
+    default: wl_gemm_cfg<KCA, KCB, 16, 64, AUX>(off, vb, gx, gy); break;
+  }
+}
+
+template <bool AUX>
+__device__ __forceinline__ void wl_gemm_bind(int bind, int tile, unsigned long long off, int vb, int gx, int gy) {
+  // which axis of each operand is contiguous: the six bindings of the step fall into three pairs (the launcher rejects the fourth)
+  if (bind == 0) wl_gemm_tile<true, true, AUX>(tile, off, vb, gx, gy);          // x W^T, token-axis dW
+  else if (bind == 1) wl_gemm_tile<true, false, AUX>(tile, off, vb, gx, gy);    // dy W, token-axis W x
+  else wl_gemm_tile<false, false, AUX>(tile, off, vb, gx, gy);                  // dy^T x, token-axis W^T dy
+}
+
+__device__ __forceinline__ void wl_gemm_second_pass(unsigned long long blob, int vb_, int per_) {
+  const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
+  const int vb = __builtin_amdgcn_readfirstlane(vb_), per = __builtin_amdgcn_readfirstlane(per_);
+  const int nprob = g.zmode ? g.nseg : 1;
+  int Mmax = 0, Nmax = 0;
+  for (int q = 0; q < nprob; ++q) {
+    Mmax = max(Mmax, g.seg[q].M);
+    Nmax = max(Nmax, g.seg[q].N);
+  }
+  const int z = vb / per;
+  const long e = (long)(vb - z * per) * 256 + threadIdx.x;
+  if (g.cmode == NASREC_CM_PLAIN)
+    splitk_second_pass<NASREC_CM_PLAIN>(g, Mmax, Nmax, z, e);
+  else
+    splitk_second_pass<NASREC_CM_TOKJ>(g, Mmax, Nmax, z, e);
+}
+
+__device__ __forceinline__ void wl_mha_fwd(unsigned long long blob, int vb) {
+  mha_fwd_sample<4>(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
+}
+
+// BIG: the variant that also carries the Transformer backward (164 registers, 52 KB of LDS: three workgroups per CU instead of four /
+// five) — used for the levels that contain one, so that the level's other items run beside it instead of before it
+template <bool BIG>
+__global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(const nasrec_worklist_desc_t wl) {
+  float* lds = wl_lds;
+  const int bid = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int k = 0;
+#pragma unroll 1
+  while (k + 1 < wl.n && bid >= wl.item[k + 1].first) ++k;
+  const nasrec_wl_item_t& it = wl.item[k];
+  const int vb = bid - it.first;
+  const unsigned long long blob = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(nasrec_worklist_desc_t, blob) + it.off;
+  switch (it.kind) {
+    case NASREC_OP_GEMM: {
+      if (it.part == 2) {
+        wl_gemm_second_pass(blob, vb, it.geom[0]);
+        break;
+      }
+      const int cfg = it.geom[2];  // tile | binding pair << 2 | mask operand << 4
+      if ((cfg >> 4) & 1) wl_gemm_bind<true>((cfg >> 2) & 3, cfg & 3, blob, vb, it.geom[0], it.geom[1]);
+      else wl_gemm_bind<false>((cfg >> 2) & 3, cfg & 3, blob, vb, it.geom[0], it.geom[1]);
+      break;
+    }
+    case NASREC_OP_MHA_FWD:
+      wl_mha_fwd(blob, vb);
+      break;
+    case NASREC_OP_MHA_BWD:
+      if (BIG) mha_bwd_sample<4>(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
+      break;
+    case NASREC_OP_FM_FWD: {
+      const nasrec_fm_desc_t& d = wl_ref<nasrec_fm_desc_t>(blob);
+      const int b = vb * 4 + wave;
+      if (b < d.B) fm_fwd_sample(d, b, lane);
+      break;
+    }
+    case NASREC_OP_FM_BWD: {
+      const nasrec_fm_desc_t& d = wl_ref<nasrec_fm_desc_t>(blob);
+      const int b = vb * 4 + wave;
+      if (b < d.B) fm_bwd_sample(d, b, lane);
+      break;
+    }
+    case NASREC_OP_DOT_TRI_FWD: {
+      const nasrec_dot_tri_desc_t& d = wl_ref<nasrec_dot_tri_desc_t>(blob);
+      const int b = vb * 4 + wave;
+      if (b < d.B) dot_tri_fwd_sample(d, b, lane, lds + wave * (d.k1 * TRI_LD));
+      break;
+    }
+    case NASREC_OP_DOT_TRI_BWD: {
+      const nasrec_dot_tri_desc_t& d = wl_ref<nasrec_dot_tri_desc_t>(blob);
+      const int b = vb * 4 + wave;
+      const int P4 = (d.k1 * (d.k1 - 1) / 2 + 3) & ~3;
+      if (b < d.B) dot_tri_bwd_sample(d, b, lane, lds + wave * (d.k1 * TRI_LD), lds + 4 * (d.k1 * TRI_LD) + wave * P4);
+      break;
+    }
+    case NASREC_OP_COPY_SEGS: {
+      const nasrec_copy_segs_desc_t& d = wl_ref<nasrec_copy_segs_desc_t>(blob);
+      const int W = it.geom[0];
+      const long t = (long)vb * 256 + tid;
+      if (t < (long)d.B * W) copy_segs_element(d, (int)(t / W), (int)(t % W));
+      break;
+    }
+    case NASREC_OP_GATE_BWD:
+      gate_bwd_element(wl_ref<nasrec_gate_bwd_desc_t>(blob), (long)vb * 256 + tid);
+      break;
+    case NASREC_OP_REDUCE_ROWS:
+      reduce_rows_block(wl_ref<nasrec_wl_reduce_t>(blob), vb, tid, lds);
+      break;
+    default:
+      break;
+  }
+}
+

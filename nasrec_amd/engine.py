@@ -17,6 +17,7 @@ import torch
 
 from . import _lib as L
 from . import plan as P
+from . import schedule as S
 
 E = 16
 
@@ -31,13 +32,11 @@ def _ptr_array(descs):
 class Program:
     """An ordered list of descriptors; runs with one host call (nasrec_program_run) or as a captured hipGraph."""
 
-    def __init__(self, descs: List, sched: Optional[List] = None):
-        """sched: optional two-lane schedule [(lane | LANE_FORK | LANE_JOIN, index into descs)] used when the program is captured"""
+    def __init__(self, descs: List):
         self.descs = list(descs)
         self.arr = _ptr_array(self.descs)
         self.n = len(self.descs)
         self.graph = None
-        self.sched = sched if (sched and os.environ.get("NASREC_LANES", "0") == "1") else None
 
     def run(self, stream_ptr):
         lib = L.load()
@@ -46,15 +45,7 @@ class Program:
     def capture(self, stream_ptr):
         lib = L.load()
         g = C.c_void_p()
-        if self.sched is not None and any(lane < 0 for lane, _ in self.sched):
-            m = len(self.sched)
-            arr, lanes = (C.c_void_p * m)(), (C.c_int32 * m)()
-            for k, (lane, idx) in enumerate(self.sched):
-                arr[k] = C.addressof(self.descs[idx]) if idx >= 0 else None
-                lanes[k] = lane
-            L.check(lib.nasrec_graph_create_lanes(stream_ptr, arr, lanes, m, C.byref(g)))
-        else:
-            L.check(lib.nasrec_graph_create(stream_ptr, self.arr, self.n, C.byref(g)))
+        L.check(lib.nasrec_graph_create(stream_ptr, self.arr, self.n, C.byref(g)))
         self.graph = g
 
     def replay(self, stream_ptr):
@@ -154,8 +145,9 @@ class SupernetEngine:
         self.world_size = world_size
         self.stream = torch.cuda.Stream(device=self.device)
         self._last_plan = None
-        # per-sample chains (plan.fuse_sample_chains) are correct but not faster in the captured step: opt-in
-        self.fuse_chains = os.environ.get("NASREC_CHAINS", "0") == "1"
+        # batch <= 256 (fixed sub-networks): operators that do not depend on each other share heterogeneous launches
+        # (nasrec_amd/schedule.py); NASREC_WORKLIST=0 keeps one launch per operator (A/B runs, bit-identical results)
+        self.level_schedule = os.environ.get("NASREC_WORKLIST", "1") != "0"
         if cfg.fixed:
             assert warm_choice is not None, "fixed mode needs the fixed choice"
             self.warm_choice = warm_choice
@@ -299,7 +291,8 @@ class SupernetEngine:
             cp.arena, cp.evicted = arena, False
             ctx = P.Ctx(B, self.device, self.params, self.grads, shape_only=False, train=train)
             ctx.sk_workspace = self._sk_workspace
-            ctx.defer_dw = defer_dw
+            # parked weight-gradient batches are for one-launch-per-operator plans; the level scheduler places the products itself
+            ctx.defer_dw = defer_dw and getattr(self, "park_weight_grads", True) and not (self.level_schedule and cfg.fixed and B <= 256)
             ctx.arena = arena
             cp.ctx = ctx
             new = (lambda n, dt=torch.float32: arena.alloc(n, dt)) if arena is not None else \
@@ -351,8 +344,13 @@ class SupernetEngine:
             ctx.emit(fd)
             if cfg.use_final_sigmoid:
                 raise NotImplementedError("use_final_sigmoid is never enabled by the reference CLIs")
-            fwd_sched = None if self.fuse_chains else list(ctx.fwd_sched)
-            cp.fwd = Program(P.fuse_sample_chains(ctx.fwd, B) if self.fuse_chains else ctx.fwd, fwd_sched)
+            scheduled = self.level_schedule and cfg.fixed and B <= 256
+            cp.fwd_levels = cp.bwd_levels = None
+            if scheduled:
+                fwd_descs, cp.fwd_levels = S.pack(ctx.fwd)
+            else:
+                fwd_descs = ctx.fwd
+            cp.fwd = Program(fwd_descs)
             cp.used_params = list(ctx.used_params)
             if train:
                 self._ensure_table_state()
@@ -415,7 +413,15 @@ class SupernetEngine:
                 fused.logits, fused.y, fused.loss, fused.dlogits_out = cp.logits.data_ptr(), cp.y.data_ptr(), cp.loss.data_ptr(), cp.dlogits.data_ptr()
                 fused.grad_scale = bd.grad_scale
                 cp.bce = bd
-                cp.bwd = Program(pre[1:] + ctx.bwd[:fi] + [fused] + ctx.bwd[fi + 1:])
+                bwd_descs = pre[1:] + ctx.bwd[:fi] + [fused] + ctx.bwd[fi + 1:]
+                # forward + backward of a training step as ONE scheduled program: what the forward leaves off its critical path (a
+                # block output no later block reads, second passes) runs beside the first backward levels
+                cp.fb = None
+                if scheduled:
+                    fb_descs, cp.fb_levels = S.pack(list(ctx.fwd) + bwd_descs)
+                    cp.fb = Program(fb_descs)
+                    bwd_descs, cp.bwd_levels = S.pack(bwd_descs)
+                cp.bwd = Program(bwd_descs)
                 cp.bwd_tail_start = len(pre) - 1 + ctx.bwd_tail_start  # cp.bwd.descs[this:] = the parked weight-gradient products
                 cp.bwd_marks = [(b, len(pre) - 1 + idx) for b, idx in ctx.block_marks]  # block b's gradients complete after cp.bwd.descs[:idx]
                 cp.bwd_core = Program(pre[1:] + ctx.bwd)  # dlogits supplied by the caller (autograd path)
@@ -429,11 +435,7 @@ class SupernetEngine:
                 cp.opt = Program(self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if (sbuf.grad_written and not self.host_embedding)
                                                        else None, clip, eps))
                 if graph:
-                    nf = len(cp.fwd.descs)
-                    sched = None
-                    if fwd_sched is not None:
-                        sched = fwd_sched + [(0, nf + i) for i in range(len(cp.bwd.descs) + len(cp.opt.descs))]
-                    cp.step = Program(cp.fwd.descs + cp.bwd.descs + cp.opt.descs, sched)
+                    cp.step = Program((cp.fb.descs if cp.fb is not None else cp.fwd.descs + cp.bwd.descs) + cp.opt.descs)
                     cp.step.capture(self.stream.cuda_stream)
             elif graph:
                 cp.fwd.capture(self.stream.cuda_stream)
@@ -638,8 +640,11 @@ class SupernetEngine:
         if graph:
             cp.step.replay(sp)
         else:
-            cp.fwd.run(sp)
-            cp.bwd.run(sp)
+            if getattr(cp, "fb", None) is not None:
+                cp.fb.run(sp)
+            else:
+                cp.fwd.run(sp)
+                cp.bwd.run(sp)
             cp.opt.run(sp)
         return cp.loss
 
@@ -665,8 +670,11 @@ class SupernetEngine:
         cp = self.compile(choice, B, train=True, grad_scale=grad_scale)
         sp = self._sp()
         self._stage_inputs(sp, cp, int_x, cat_x, y)
-        cp.fwd.run(sp)
-        cp.bwd.run(sp)
+        if getattr(cp, "fb", None) is not None:
+            cp.fb.run(sp)
+        else:
+            cp.fwd.run(sp)
+            cp.bwd.run(sp)
         return cp
 
     def check_indices(self):

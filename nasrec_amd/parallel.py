@@ -222,7 +222,7 @@ class EngineDP:
             if fixed:
                 # forward + whole backward (the parked weight-gradient products included) as ONE graph: the collectives of the
                 # batch-256 step are issued behind it (DataParallelStep.step), so a second segment would only add a graph launch
-                fb = Program(cp.fwd.descs + descs)
+                fb = Program(cp.fb.descs if getattr(cp, "fb", None) is not None else cp.fwd.descs + descs)
                 tail = None
                 if graph:
                     fb.capture(eng.stream.cuda_stream)

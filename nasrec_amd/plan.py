@@ -166,8 +166,6 @@ class Ctx:
         self.bwd_tail_start = 0
         self.mha_reduce: List = []  # (MHA backward descriptor, [(grad ptr, column offset, length)]) awaiting the shared reduction
         self.defer_dw = True
-        self.lane = 0        # lane of the forward descriptors being emitted (0 = main, 1 = the block's sparse branch)
-        self.fwd_sched: List = []  # [(lane | LANE_FORK | LANE_JOIN, index into self.fwd)] in emission order
         self.arena = None  # optional Arena (engine.py): where alloc() takes its buffers from
         self.raw_sparse = None  # Buf of the embedding stem's output [B, Fs, 16] (set by the engine): see _flush_raw_dx
         self.deferred_raw: List = []
@@ -217,19 +215,6 @@ class Ctx:
     def emit(self, desc):
         if not self.shape_only:
             self.out.append(desc)
-            if self.out is self.fwd:
-                self.fwd_sched.append((self.lane, len(self.fwd) - 1))
-
-    # Two-lane schedule of the FORWARD program (graph capture only, api.hip nasrec_graph_create_lanes): inside a choice block the
-    # dense nodes and the sparse nodes are independent until the block's merge, so they are captured as sibling branches.
-    def fork(self):
-        if not self.shape_only:
-            self.fwd_sched.append((L.LANE_FORK, -1))
-
-    def join(self):
-        if not self.shape_only:
-            self.fwd_sched.append((L.LANE_JOIN, -1))
-            self.lane = 0
 
     def on_backward(self, fn):
         if self.train and not self.shape_only:
@@ -1303,7 +1288,6 @@ def block_walk(ctx, cfg, pre, ops, choice, d_in, Dtot, s_in, Ntot, l_in, Ltot, r
         dense_out = DV(dbuf, 0, max_dense, max_dense)
     act = L.ACT_BY_NAME[cfg.activation]
 
-    ctx.fork()  # the sparse nodes below (lane 1) only read previous blocks' outputs and write their own rows of the sparse slab
     # ---- dense nodes: sum of node outputs (supernet.py:1133 / 1215) --------------------------------------------
     real_dense = [n for n in dense_nodes if names[n] != "zeros-2d"]
     n_contrib = len(real_dense) + (1 if deep_fm else 0)
@@ -1351,7 +1335,6 @@ def block_walk(ctx, cfg, pre, ops, choice, d_in, Dtot, s_in, Ntot, l_in, Ltot, r
     node_sum = pre_fm if pre_fm is not None else dense_out  # pre-FM value of the block's dense output
 
     # ---- sparse nodes ------------------------------------------------------------------------------------------
-    ctx.lane = 1
     real_sparse = [n for n in sparse_nodes if names[n] != "zeros-3d"]
     wrote_s = False
     for n in range(ops["num_nodes"]):
@@ -1376,7 +1359,6 @@ def block_walk(ctx, cfg, pre, ops, choice, d_in, Dtot, s_in, Ntot, l_in, Ltot, r
     if not wrote_s:
         zero_fill(ctx, sparse_nodes_out.dense())
 
-    ctx.join()  # the merges read both branches
     # ---- dense -> sparse merge (supernet.py:1137-1150 / 1218-1231) --------------------------------------------
     if extra:
         proj_rows = sparse_all.rows(max_sparse, DS_INTERACT_NUM_SPLITS).dense()  # [B,128] view into the sparse slab
@@ -1507,67 +1489,13 @@ def full_path_choice(cfg: NetConfig):
     return {"macro": macro, "micro": micro}
 
 
-# ----------------------------------------------------------------------------------------------------------------
-# per-sample chains (forward): a peephole over the finished descriptor list
-# ----------------------------------------------------------------------------------------------------------------
-def _chain_stage(d, B):
-    """-> (stage kind, field name) if descriptor d is a sample-local forward operator the chain kernel can run, else None"""
-    if isinstance(d, L.GemmDesc):
-        s0 = d.seg[0]
-        if (d.amode, d.bmode, d.cmode, d.zmode) == (L.AM_KC, L.AM_TOKR, L.CM_TOKJ, 0) and d.splitk <= 1 and 1 <= s0.M <= 64 and s0.N == 16 * B:
-            return L.OP_GEMM, "gemm"
-        return None
-    if isinstance(d, L.MhaDesc) and d.kind == L.OP_MHA_FWD and d.B == B:
-        return L.OP_MHA_FWD, "mha"
-    if isinstance(d, L.FmDesc) and d.kind == L.OP_FM_FWD and d.B == B:
-        return L.OP_FM_FWD, "fm"
-    if isinstance(d, L.DotTriDesc) and d.kind == L.OP_DOT_TRI_FWD and d.B == B:
-        return L.OP_DOT_TRI_FWD, "tri"
-    if isinstance(d, L.CopySegsDesc) and d.B == B and not d.reverse:
-        return L.OP_COPY_SEGS, "copy"
-    return None
-
-
-def fuse_sample_chains(descs, B, max_batch=256):
-    """Merge runs of consecutive sample-local forward launches into NASREC_OP_SAMPLE_CHAIN launches (workgroup b runs the
-    stages for sample b back to back).  Program order is kept and no operator in the set reads another sample's data, so
-    any run qualifies; a chain holds at most one stage of each kind and CHAIN_MAX stages.  Only used in the latency
-    regime (B <= max_batch: one 64x16 GEMM tile per sample is what the stand-alone launcher would pick there too)."""
-    if B > max_batch:
-        return list(descs)
-    out, run = [], []
-
-    def flush():
-        if len(run) >= 2:
-            c = L.ChainDesc()
-            c.kind, c.B, c.n = L.OP_SAMPLE_CHAIN, B, len(run)
-            for i, (kind, field, d) in enumerate(run):
-                c.stage[i] = kind
-                setattr(c, field, d)
-            out.append(c)
-        else:
-            out.extend(d for _, _, d in run)
-        run.clear()
-
-    for d in descs:
-        st = _chain_stage(d, B)
-        if st is None:
-            flush()
-            out.append(d)
-            continue
-        if len(run) == L.CHAIN_MAX or any(f == st[1] for _, f, _ in run):
-            flush()
-        run.append((st[0], st[1], d))
-    flush()
-    return out
-
-
 def iter_ops(descs):
-    """the operator descriptors of a program with chains expanded back into their stages (for FLOP counting, reports)"""
-    names = {L.OP_GEMM: "gemm", L.OP_MHA_FWD: "mha", L.OP_FM_FWD: "fm", L.OP_DOT_TRI_FWD: "tri", L.OP_COPY_SEGS: "copy"}
+    """the operator descriptors of a program with worklist launches (nasrec_amd/schedule.py) expanded back into their operators
+    (for FLOP counting, reports): a split-K GEMM appears once (at its main pass)"""
     for d in descs:
-        if isinstance(d, L.ChainDesc):
-            for i in range(d.n):
-                yield getattr(d, names[d.stage[i]])
+        if isinstance(d, L.WorklistDesc):
+            for n in d.nodes:
+                if n.part != "epi":
+                    yield n.desc
         else:
             yield d

@@ -1,0 +1,447 @@
+"""Level scheduling of a launch program (batch <= 256: the latency regime).
+
+At batch 256 every launch costs ~5 us whatever it does (cold L2, dependent round trips: DESIGN.md §3), and a step is a chain of
+~60 of them.  But the step is not a chain: inside a choice block the dense nodes and the sparse nodes are independent
+(supernet.py:1113-1134), a block often depends on a few of the earlier blocks only (macro choice), the backward's weight-gradient
+products have no consumer before the optimizer, split-K second passes are independent of whatever runs beside them.  This module
+
+  * derives each descriptor's read / write footprint from its fields (strided views: a [B, w] window of a row-strided slab),
+  * builds the dependency DAG (RAW, WAR, WAW on overlapping footprints; program order breaks ties),
+  * assigns ASAP levels, and
+  * packs each level into ONE heterogeneous launch (NASREC_OP_WORKLIST, csrc/worklist.hip) whose workgroup ranges run the level's
+    operators side by side; operators the worklist kernel has no body for stay launches of their own inside their level.
+
+A split-K GEMM is cut in two schedulable pieces: the main pass (slabs out) and the second pass (fixed-order sum + epilogue), which
+lands one level later beside unrelated work instead of costing a launch of its own on the critical path.
+
+Results are bit-identical to the unscheduled program: the same bodies run on the same operands, only launch boundaries move."""
+import ctypes as C
+from typing import List, Tuple
+
+from . import _lib as L
+
+E = 16
+MHA_PARAM_FLOATS = [768, 48, 256, 16, 16, 16, 256, 16, 256, 16, 16, 16]
+
+
+class Acc:
+    """footprint: `rows` windows of `width` bytes, `stride` bytes apart, starting at ptr"""
+    __slots__ = ("ptr", "width", "stride", "rows", "end")
+
+    def __init__(self, ptr, rows, width_f, ld_f):
+        self.ptr = int(ptr)
+        self.rows = max(int(rows), 1)
+        self.width = int(width_f) * 4
+        self.stride = int(ld_f) * 4 if self.rows > 1 else self.width
+        if self.stride < self.width:
+            self.stride = self.width
+        self.end = self.ptr + (self.rows - 1) * self.stride + self.width
+
+
+def _flat(ptr, n_floats):
+    return Acc(ptr, 1, n_floats, n_floats)
+
+
+def overlap(a: Acc, b: Acc) -> bool:
+    if a.width <= 0 or b.width <= 0 or a.end <= b.ptr or b.end <= a.ptr:
+        return False
+    if a.stride == b.stride and a.rows > 1 and b.rows > 1:
+        s = a.stride
+        d = (b.ptr - a.ptr) % s  # b's window starts d bytes into a's period
+        return d < a.width or d + b.width > s
+    return True  # extents overlap and the strides differ: assume the worst
+
+
+def _operand(ptr, mode, R, K, ld):
+    """footprint of a GEMM operand P(r, k), r < R, k < K (include/nasrec_hip.h addressing modes)"""
+    if not ptr:
+        return None
+    if mode == L.AM_KC:
+        return Acc(ptr, R, K, ld)
+    if mode == L.AM_RC:
+        return Acc(ptr, K, R, ld)
+    if mode == L.AM_TOKR:
+        return Acc(ptr, (R + 15) // 16, K * E, ld)
+    return Acc(ptr, (K + 15) // 16, R * E, ld)  # TOKK
+
+
+def _cview(ptr, cmode, M, N, ldc):
+    if not ptr:
+        return None
+    if cmode == L.CM_PLAIN:
+        return Acc(ptr, M, N, ldc)
+    return Acc(ptr, (N + 15) // 16, M * E, ldc)
+
+
+def _gemm_io(d, part):
+    """part: 'whole' | 'main' (operands -> split-K slabs) | 'epi' (slabs -> epilogue -> C)"""
+    R, W = [], []
+    nprob = d.nseg if d.zmode else 1
+    S = d.splitk if d.splitk > 1 else 1
+    Mm = max(d.seg[q].M for q in range(nprob))
+    Nm = max(d.seg[q].N for q in range(nprob))
+    ws = _flat(d.workspace, S * Mm * Nm * nprob) if (S > 1 and d.workspace) else None
+    if part in ("whole", "main"):
+        for q in range(d.nseg):
+            s = d.seg[q]
+            if not s.A:
+                continue
+            M, N = (s.M, s.N) if d.zmode else (d.seg[0].M, d.seg[0].N)
+            Nb = N - (1 if s.ones_col else 0)
+            for ptr, mode, rr, ld in ((s.A, d.amode, M, s.lda), (s.Aaux, d.amode, M, s.lda), (s.B, d.bmode, Nb, s.ldb), (s.Baux, d.bmode, Nb, s.ldb)):
+                a = _operand(ptr, mode, rr, s.K, ld)
+                if a is not None:
+                    R.append(a)
+        if part == "main":
+            W.append(ws)
+            return R, W
+    if part == "epi":
+        R.append(ws)
+    for q in range(nprob):
+        s = d.seg[q]
+        N = s.N - (1 if s.ones_col else 0)
+        c = _cview(s.C if d.zmode else d.seg[0].C, d.cmode, s.M, N, s.ldc)
+        if c is not None:
+            W.append(c)
+            if (s.accumulate if d.zmode else d.beta):
+                R.append(c)
+        if s.ones_col:
+            rs = s.rowsum or d.rowsum_out
+            if rs:
+                W.append(_flat(rs, s.M))
+    s0 = d.seg[0]
+    if d.bias:
+        R.append(_flat(d.bias, max(Mm, Nm)))
+    for ptr, tgt in ((d.save_z, W), (d.save_act, W), (d.pre_add, R)):
+        if ptr:
+            tgt.append(_cview(ptr, d.cmode, s0.M, s0.N, s0.ldc))
+    for q in range(d.mul_nseg):
+        if d.mul_ptr[q]:
+            R.append(Acc(d.mul_ptr[q], s0.M, d.mul_width[q], d.mul_ld[q]))
+    return R, W
+
+
+def desc_io(d, part="whole") -> Tuple[List[Acc], List[Acc]]:
+    """(reads, writes) of a descriptor, or None if the kind is not modelled (the scheduler then treats it as a full barrier)"""
+    k = d.kind
+    R, W = [], []
+    if isinstance(d, L.GemmDesc):
+        R, W = _gemm_io(d, part)
+    elif k in (L.OP_DOT_TRI_FWD, L.OP_DOT_TRI_BWD):
+        P = d.k1 * (d.k1 - 1) // 2
+        R.append(_flat(d.T, d.B * d.k1 * E))
+        if k == L.OP_DOT_TRI_FWD:
+            W.append(Acc(d.out, d.B, P, d.ld_out))
+        else:
+            R.append(Acc(d.dout, d.B, P, d.ld_out))
+            W.append(_flat(d.dT, d.B * d.k1 * E))
+    elif k in (L.OP_FM_FWD, L.OP_FM_BWD):
+        R.append(Acc(d.x, d.B, d.N * E, d.ldx))
+        if k == L.OP_FM_FWD:
+            ix = Acc(d.ix, d.B, E, d.ld_ix)
+            W.append(ix)
+            if d.accumulate:
+                R.append(ix)
+            if d.add:
+                R.append(Acc(d.add, d.B, E, d.ld_ix))
+        else:
+            R.append(Acc(d.dix, d.B, E, d.ld_ix))
+            dx = Acc(d.dx, d.B, d.N * E, d.ldx)
+            W.append(dx)
+            if d.accumulate:
+                R.append(dx)
+    elif k in (L.OP_MHA_FWD, L.OP_MHA_BWD):
+        R.append(Acc(d.x, d.B, d.N * E, d.ldx))
+        for q in range(12):
+            R.append(_flat(d.params[q], MHA_PARAM_FLOATS[q]))
+        sv = _flat(d.saved, d.B * d.N * L.MHA_SAVED) if d.saved else None
+        if k == L.OP_MHA_FWD:
+            W.append(Acc(d.out, d.B, d.N * E, d.ldo))
+            if sv:
+                W.append(sv)
+        else:
+            R.append(Acc(d.dout, d.B, d.N * E, d.ldo))
+            if sv:
+                R.append(sv)
+            W.append(Acc(d.dx, d.B, d.N * E, d.ldx))
+            W.append(Acc(d.dparams_partial, d.B, L.MHA_PARAMS, d.partial_ld if d.partial_ld > 0 else L.MHA_PARAMS))
+    elif k == L.OP_REDUCE_ROWS:
+        R.append(Acc(d.in_, d.R, d.C, d.ld))
+        for q in range(d.ndst):
+            if d.dst[q]:
+                W.append(_flat(d.dst[q], d.dst_len[q]))
+    elif k == L.OP_COPY_SEGS:
+        for q in range(d.nseg):
+            win = Acc(d.dst + 4 * d.off[q], d.B, d.width[q], d.ld_dst)
+            seg = Acc(d.seg[q], d.B, d.width[q], d.ld[q]) if d.seg[q] else None
+            if not d.reverse:
+                W.append(win)
+                if d.accumulate:
+                    R.append(win)
+                if seg:
+                    R.append(seg)
+            elif seg:
+                R.append(win)
+                W.append(seg)
+                if d.seg_accumulate[q]:
+                    R.append(seg)
+    elif k == L.OP_GATE_BWD:
+        R += [Acc(d.dout, d.B, d.D, d.ld_dout), Acc(d.g, d.B, d.D, d.ld_g)]
+        W.append(Acc(d.dz, d.B, d.D, d.ld_dz))
+        for q in range(d.nseg):
+            if d.r_ptr[q]:
+                R.append(Acc(d.r_ptr[q], d.B, d.r_width[q], d.r_ld[q]))
+            if d.dr_ptr[q]:
+                a = Acc(d.dr_ptr[q], d.B, d.r_width[q], d.r_ld[q])
+                W.append(a)
+                if d.dr_accumulate[q]:
+                    R.append(a)
+    elif k == L.OP_ROWSUM:
+        R.append(_operand(d.p, d.mode, d.R, d.K, d.ld))
+        if d.aux:
+            R.append(_operand(d.aux, d.mode, d.R, d.K, d.ld))
+        W.append(_flat(d.out, d.R))
+    elif k in (L.OP_FINAL_FWD, L.OP_FINAL_BWD):
+        K = max([d.off[q] + d.width[q] for q in range(d.nseg)] + [0])
+        for q in range(d.nseg):
+            if d.seg[q]:
+                R.append(Acc(d.seg[q], d.B, d.width[q], d.ld[q]))
+        R.append(_flat(d.w, K))
+        if k == L.OP_FINAL_FWD:
+            R.append(_flat(d.bias, 1))
+            W.append(_flat(d.logits, d.B))
+        else:
+            for ptr in (d.dlogits, d.logits, d.y):
+                if ptr:
+                    R.append(_flat(ptr, d.B))
+            for q in range(d.nseg):
+                if d.dseg[q]:
+                    a = Acc(d.dseg[q], d.B, d.width[q], d.ld[q])
+                    W.append(a)
+                    if d.dseg_accumulate[q]:
+                        R.append(a)
+            W.append(_flat(d.dw, (K + 1) * max(d.nsplit, 1)))
+            for ptr, n in ((d.dbias, 1), (d.loss, 1), (d.dlogits_out, d.B)):
+                if ptr:
+                    W.append(_flat(ptr, n))
+    elif k == L.OP_BCE:
+        R += [_flat(d.logits, d.B), _flat(d.y, d.B)]
+        W += [_flat(d.loss, 1), _flat(d.dlogits, d.B)]
+    elif k in (L.OP_LAYERNORM_FWD, L.OP_LAYERNORM_BWD):
+        if d.mode == L.AM_KC:
+            vx = lambda p, ld: Acc(p, d.R, d.D, ld)
+            ndx = d.R * d.ldx
+        else:
+            vx = lambda p, ld: Acc(p, d.R // 16, d.D * E, ld)
+            ndx = (d.R // 16) * d.ldx
+        R += [vx(d.x, d.ldx), _flat(d.w, d.D), _flat(d.b, d.D)]
+        st = _flat(d.stats, d.R * 2)
+        if k == L.OP_LAYERNORM_FWD:
+            y = vx(d.y, d.ldy)
+            W += [y, st]
+            if d.accumulate:
+                R.append(y)
+        else:
+            R += [st, vx(d.dy, d.ldy)]
+            W += [_flat(d.dx, ndx), _flat(d.dwb_partial, d.nblk * 2 * d.D)]
+    elif k == L.OP_ACT_BWD:
+        if d.mode == L.AM_KC:
+            v = lambda p, ld: Acc(p, d.R, d.D, ld)
+        else:
+            v = lambda p, ld: Acc(p, d.R // 16, d.D * E, ld)
+        R += [v(d.dy, d.ld_dy), v(d.z, d.ld_z)]
+        W.append(v(d.dz, d.ld_dz))
+    elif k == L.OP_MEMSET and not d.chunks:
+        W.append(_flat(d.ptr, (d.bytes + 3) // 4))
+    else:
+        return None
+    return [a for a in R if a is not None and a.ptr], [a for a in W if a is not None and a.ptr]
+
+
+class Node:
+    __slots__ = ("desc", "part", "reads", "writes", "level", "index")
+
+    def __init__(self, desc, part="whole"):
+        self.desc, self.part = desc, part
+        io = desc_io(desc, part)
+        self.reads, self.writes = io if io is not None else (None, None)
+        self.level = 0
+        self.index = 0
+
+
+def expand(descs) -> List[Node]:
+    """program -> schedulable nodes: split-K GEMMs become (main pass, second pass)"""
+    nodes = []
+    for d in descs:
+        if isinstance(d, L.GemmDesc) and d.splitk > 1 and not d.defer_second_pass:
+            nodes.append(Node(d, "main"))
+            nodes.append(Node(d, "epi"))
+        else:
+            nodes.append(Node(d))
+    for i, n in enumerate(nodes):
+        n.index = i
+    return nodes
+
+
+def _depends(later: Node, earlier: Node) -> bool:
+    if later.reads is None or earlier.reads is None:
+        return True  # an unmodelled kind orders everything around it
+    for w in earlier.writes:
+        for a in later.reads:
+            if overlap(w, a):
+                return True
+        for a in later.writes:
+            if overlap(w, a):
+                return True
+    for r in earlier.reads:
+        for a in later.writes:
+            if overlap(r, a):
+                return True
+    return False
+
+
+def assign_levels(nodes: List[Node]) -> int:
+    """ASAP level of every node (program order respected between dependent nodes); returns the number of levels"""
+    for i, n in enumerate(nodes):
+        lv = 0
+        for j in range(i - 1, -1, -1):
+            m = nodes[j]
+            if m.level + 1 > lv and _depends(n, m):
+                lv = m.level + 1
+        n.level = lv
+    return (max(n.level for n in nodes) + 1) if nodes else 0
+
+
+def levels_of(descs):
+    nodes = expand(descs)
+    nl = assign_levels(nodes)
+    out = [[] for _ in range(nl)]
+    for n in nodes:
+        out[n.level].append(n)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# packing levels into NASREC_OP_WORKLIST launches
+# ----------------------------------------------------------------------------------------------------------------
+_GEMM_HEAD = L.GemmDesc.seg.offset
+_SEG_BYTES = C.sizeof(L.GemmSeg)
+_PLAIN_KINDS = (L.OP_MHA_FWD, L.OP_MHA_BWD, L.OP_FM_FWD, L.OP_FM_BWD, L.OP_DOT_TRI_FWD, L.OP_DOT_TRI_BWD, L.OP_COPY_SEGS, L.OP_GATE_BWD)
+WL_LDS_FLOATS = 1696 + 5 * 1024 + 1024  # csrc/worklist_body.h WL_LDS_FLOATS
+
+
+def gemm_capable(d) -> bool:
+    """mirror of csrc/worklist.hip wl_gemm_geometry: can this GEMM launch run as a worklist item?"""
+    if d.splitk == L.SPLITK_BALANCED or d.defer_second_pass:
+        return False
+    kca, kcb = d.amode in (L.AM_KC, L.AM_TOKK), d.bmode in (L.AM_KC, L.AM_TOKK)
+    if not kca and kcb:
+        return False
+    if d.splitk > 1 and not d.workspace:
+        return False
+    # one large product (>= 128 workgroups of 64x64, the class launch_gemm_t gives 1024-thread workgroups) fills the chip on its
+    # own and is faster in its own kernel than on the worklist kernel's small tiles
+    nprob = d.nseg if d.zmode else 1
+    S = d.splitk if d.splitk > 1 else 1
+    if nprob == 1 and ((d.seg[0].M + 63) // 64) * ((d.seg[0].N + 63) // 64) * S >= 128:
+        return False
+    s0 = d.seg[0]
+    if not d.zmode:
+        for q in range(d.nseg):
+            s = d.seg[q]
+            if s.ones_col != s0.ones_col or s.Mvalid != s0.Mvalid:
+                return False
+            if s.A and (bool(s.Aaux) != bool(s0.Aaux) or bool(s.Baux) != bool(s0.Baux)):
+                return False
+    return True
+
+
+def item_bytes(node):
+    """the bytes a worklist item carries for this node, or None if the worklist kernel has no body for it"""
+    d = node.desc
+    k = d.kind
+    if isinstance(d, L.GemmDesc):
+        if not gemm_capable(d):
+            return None
+        return C.string_at(C.addressof(d), _GEMM_HEAD + d.nseg * _SEG_BYTES)
+    if k in (L.OP_DOT_TRI_FWD, L.OP_DOT_TRI_BWD):
+        P4 = (d.k1 * (d.k1 - 1) // 2 + 3) & ~3
+        if d.k1 < 2 or 4 * (d.k1 * 20 + P4) > WL_LDS_FLOATS:
+            return None
+    if k in (L.OP_MHA_FWD, L.OP_MHA_BWD) and (d.N < 1 or d.N > 64 or (k == L.OP_MHA_BWD and not d.saved)):
+        return None
+    if k in _PLAIN_KINDS:
+        return C.string_at(C.addressof(d), C.sizeof(d))
+    if k == L.OP_REDUCE_ROWS and 1 <= d.ndst <= L.WL_REDUCE_DST:
+        r = L.WlReduce()
+        r.kind, r.R, r.C, r.ld, r.in_, r.ndst = d.kind, d.R, d.C, d.ld, d.in_, d.ndst
+        for q in range(d.ndst):
+            r.dst[q], r.dst_off[q], r.dst_len[q] = d.dst[q], d.dst_off[q], d.dst_len[q]
+        return C.string_at(C.addressof(r), C.sizeof(r))
+    return None
+
+
+_PART = {"whole": L.WL_WHOLE, "main": L.WL_MAIN, "epi": L.WL_EPI}
+
+
+def _cost(node):
+    """rough size, to start the big items of a level first"""
+    d = node.desc
+    if isinstance(d, L.GemmDesc):
+        if node.part == "epi":
+            return 1
+        return sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A)
+    if d.kind in (L.OP_MHA_FWD, L.OP_MHA_BWD):
+        return d.B * d.N * 16 * 4000 * (2 if d.kind == L.OP_MHA_BWD else 1)
+    return 1000
+
+
+def expand_for_worklists(descs) -> List[Node]:
+    """as expand(), but a split-K GEMM is cut in two only when both halves can ride in worklist launches"""
+    nodes = []
+    for d in descs:
+        if isinstance(d, L.GemmDesc) and d.splitk > 1 and gemm_capable(d):
+            nodes.append(Node(d, "main"))
+            nodes.append(Node(d, "epi"))
+        else:
+            nodes.append(Node(d))
+    for i, n in enumerate(nodes):
+        n.index = i
+    return nodes
+
+
+def pack(descs):
+    """program -> scheduled program: per level, the operators the worklist kernel has bodies for share NASREC_OP_WORKLIST launches
+    (as many as their descriptors need blobs), the others stay launches of their own.  Returns (new descriptor list, number of
+    levels).  Every WorklistDesc carries `.nodes` (its items' Nodes) for reports."""
+    nodes = expand_for_worklists(descs)
+    nl = assign_levels(nodes)
+    out = []
+    for lv in range(nl):
+        members = sorted((n for n in nodes if n.level == lv), key=lambda n: -_cost(n))
+        solo, items = [], []
+        for n in members:
+            b = item_bytes(n)
+            (items if b is not None else solo).append((n, b))
+        for n, _ in solo:
+            assert n.part == "whole"
+            out.append(n.desc)
+        if len(items) == 1 and items[0][0].part == "whole":
+            out.append(items[0][0].desc)  # nothing to share a launch with: the stand-alone kernel
+            continue
+        cur, off = None, 0
+        for n, b in items:
+            size = (len(b) + 15) & ~15
+            if cur is None or cur.n == L.WL_MAX_ITEMS or off + size > L.WL_BLOB_BYTES:
+                cur = L.WorklistDesc()
+                cur.kind, cur.n = L.OP_WORKLIST, 0
+                cur.nodes = []
+                off = 0
+                out.append(cur)
+            it = cur.item[cur.n]
+            it.kind, it.part, it.off = n.desc.kind, _PART[n.part], off
+            C.memmove(C.addressof(cur) + L.WorklistDesc.blob.offset + off, b, len(b))
+            cur.n += 1
+            cur.nodes.append(n)
+            off += size
+    return out, nl

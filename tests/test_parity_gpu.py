@@ -221,24 +221,69 @@ def test_data_parallel_code_path_single_rank():
             dist.destroy_process_group()
 
 
-def test_sample_chains_are_bit_identical_to_the_separate_launches():
-    """NASREC_OP_SAMPLE_CHAIN (plan.fuse_sample_chains): the forward of a fixed sub-network with its sample-local runs fused into
-    chain launches must reproduce the unfused program bit for bit — same bodies, same per-sample work split."""
+@pytest.mark.parametrize("case", ["fixed_criteo_xlarge", "fixed_kdd_autoctr", "fixed_criteo_xlarge_ln", "fixed_avazu_xlarge"])
+def test_level_scheduled_step_is_bit_identical_to_one_launch_per_operator(case):
+    """nasrec_amd/schedule.py + NASREC_OP_WORKLIST: a fixed sub-network's step with its independent operators packed into
+    heterogeneous launches (dense node || sparse node, weight gradients and split-K second passes beside the backward chain) must
+    reproduce the one-launch-per-operator program BIT FOR BIT — logits, loss, every gradient, parameters after two steps, eager
+    and graph — because the same bodies run on the same operands in the same summation order; only kernel boundaries move."""
+    z, meta = load_golden(os.path.join(os.path.dirname(NPZ[0]), case + ".npz"))
+    int_x, cat_x = torch.tensor(z["int_x"]).cuda(), torch.tensor(z["cat_x"]).cuda()
+    y = torch.tensor(z["y"]).cuda().view(-1)
+    res = []
+    for scheduled in (False, True):
+        for graph in (False, True):
+            eng = build_engine(z, meta)
+            eng.level_schedule = scheduled
+            eng.park_weight_grads = False  # the baseline runs the SAME operator list one launch each (no parked zmode batches)
+            logits = eng.forward(int_x, cat_x, meta["choice"]).clone()
+            cp = eng.forward_backward(int_x, cat_x, y, meta["choice"])
+            torch.cuda.synchronize()
+            grads, sg, loss = eng.flat_g.clone(), cp.sparse0.grad_tensor().clone(), float(cp.loss.item())
+            nwl = sum(isinstance(d, L.WorklistDesc) for d in (cp.fb.descs if cp.fb is not None else cp.fwd.descs + cp.bwd.descs))
+            for _ in range(2):
+                eng.train_step(int_x, cat_x, y, 0.05, meta["choice"], graph=graph)
+            torch.cuda.synchronize()
+            res.append((scheduled, nwl, logits, grads, sg, loss, eng.flat_p.clone(), [t.clone() for t in eng.tables]))
+    base = res[0]
+    assert base[1] == 0 and res[2][1] >= 8, "the scheduled plan should consist of worklist launches"
+    for r in res[1:]:
+        assert torch.equal(r[2], base[2]), "logits"
+        assert torch.equal(r[3], base[3]) and torch.equal(r[4], base[4]) and r[5] == base[5], "gradients / loss"
+        assert torch.equal(r[6], base[6]), "dense parameters after two steps"
+        for a, b in zip(r[7], base[7]):
+            assert torch.equal(a, b)
+
+
+def test_level_schedule_respects_every_dependency():
+    """the scheduler's footprint model against a brute-force check: running the levels of the Criteo best-1shot step in REVERSED
+    order inside each level (any order inside a level must be legal) gives the same bits as program order"""
+    from nasrec_amd import schedule as S
     z, meta = load_golden(os.path.join(os.path.dirname(NPZ[0]), "fixed_criteo_xlarge.npz"))
     int_x, cat_x = torch.tensor(z["int_x"]).cuda(), torch.tensor(z["cat_x"]).cuda()
-    outs, nchain = [], []
-    for fuse in (False, True):
-        eng = build_engine(z, meta)
-        eng.fuse_chains = fuse
-        outs.append(eng.forward(int_x, cat_x, meta["choice"]).clone())
-        cp = eng.compile(meta["choice"], int_x.shape[0], train=False)
-        nchain.append(sum(isinstance(d, L.ChainDesc) for d in cp.fwd.descs))
-        y = torch.tensor(z["y"]).cuda().view(-1)
-        loss = eng.train_step(int_x, cat_x, y, 0.05, meta["choice"])
-        torch.cuda.synchronize()
-        outs.append(eng.flat_p.clone())
-    assert nchain[0] == 0 and nchain[1] >= 3
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+    y = torch.tensor(z["y"]).cuda().view(-1)
+    eng = build_engine(z, meta)
+    eng.level_schedule = False
+    cp = eng.forward_backward(int_x, cat_x, y, meta["choice"])
+    torch.cuda.synchronize()
+    want = (cp.logits.clone(), eng.flat_g.clone(), cp.sparse0.grad_tensor().clone())
+    from nasrec_amd.engine import Program
+    descs = cp.fwd.descs + cp.bwd.descs
+    nodes = S.expand(descs)  # (split-K launches stay whole here: every node is a launchable descriptor)
+    nodes = [S.Node(d) for d in descs]
+    for i, n in enumerate(nodes):
+        n.index = i
+    nl = S.assign_levels(nodes)
+    assert nl < len(nodes) // 2, "the step is far from a chain"
+    order = []
+    for lv in range(nl):
+        order += [n.desc for n in reversed([n for n in nodes if n.level == lv])]
+    eng.flat_g.zero_()
+    sp = eng._sp()
+    eng._stage_inputs(sp, cp, int_x, cat_x, y)
+    Program(order).run(sp)
+    torch.cuda.synchronize()
+    assert torch.equal(cp.logits, want[0]) and torch.equal(eng.flat_g, want[1]) and torch.equal(cp.sparse0.grad_tensor(), want[2])
 
 
 def test_finetune_last_layer_mode_runs_only_the_final_backward():

@@ -42,8 +42,8 @@ with torch.cuda.stream(eng.stream):
                 info = "am=%d bm=%d cm=%d z=%d M=%d N=%d K=%s splitk=%d act=%d  %.1f TF/s" % (
                     d.amode, d.bmode, d.cmode, d.zmode, M, N, "+".join(str(s[2]) for s in segs) if not d.zmode else "%dx%d" % (len(segs), segs[0][2]),
                     d.splitk, d.act, fl / us / 1e6)
-            if isinstance(d, L.ChainDesc):
-                info = "chain of " + " + ".join(names.get(d.stage[i], "?") for i in range(d.n))
+            if isinstance(d, L.WorklistDesc):
+                info = "worklist of " + " || ".join(names.get(n.desc.kind, "?") + ("[%s]" % n.part if n.part != "whole" else "") for n in d.nodes)
             rows.append((phase, names.get(d.kind, str(d.kind)), us, info))
 for r in rows:
     print("%s %-14s %7.2f us  %s" % r)
