@@ -325,6 +325,32 @@ def main():
             torch.cuda.synchronize(device)
             result["forward_only_samples_per_s"] = B * 200 / (time.perf_counter() - t1)
 
+        if fixed and world == 1 and not args.force_dp_path:
+            # ---- secondary figure: the same step with the forward operators nobody reads dropped (opt-in, never `value`): the
+            # reference computes block 5 of this architecture and throws it away (last_n_blocks_out = 1, no later block selects it)
+            eng.dead_code_elimination = True
+            eng._plans.clear()
+            eng._last_plan = None
+            dp2 = DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=not args.no_graph)
+            for i in range(20):
+                dp2.step(*batches[i], sched.get_lr())
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for i in range(200):
+                dp2.step(*batches[20 + i], sched.get_lr())
+            torch.cuda.synchronize(device)
+            dt2 = (time.perf_counter() - t1) / 200
+            cp2 = dp2.last_plan()
+            dead = [d for d in P.iter_ops(cp2.dead_forward)]
+            result["with_dead_forward_ops_dropped"] = {
+                "samples_per_s": B / dt2, "ms_per_step": dt2 * 1e3, "dropped_launches": len(dead),
+                "dropped_gemm_gflop": sum(gemm_flops(d) for d in dead if isinstance(d, L.GemmDesc)) / 1e9,
+                "note": "opt-in (NASREC_DCE=1): identical logits / loss / gradients / parameters; the headline `value` executes every operator the reference executes"}
+            eng.dead_code_elimination = False
+            eng._plans.clear()
+            eng._last_plan = None
+            cp = dp.cp = eng.compile(choice, B, True, 5.0, 1e-2, graph=dp.graph)
+
         if world == 1:
             # ---- embedding stem on COLD rows: the staging launch (batch copy + gather of B x Fs 64-byte rows, a1 of SURVEY 8a) over
             # distinct id batches of the pool — random 64-B rows out of HBM, HBM-latency bound -----------------------------------

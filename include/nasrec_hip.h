@@ -228,7 +228,10 @@ typedef struct nasrec_mha_desc {
                            forward launch and read by the backward launch instead of recomputing the forward */
   int32_t partial_ld;   /* bwd: row stride of dparams_partial in floats (0 = NASREC_MHA_PARAMS); lets several Transformer nodes
                            share one partial buffer [B, n * NASREC_MHA_PARAMS] that ONE NASREC_OP_REDUCE_ROWS launch sums */
-  int32_t _pad;
+  int32_t bwd_form;     /* bwd: 0 = the launcher picks (8 waves per sample below batch 1024, 4 waves above); 4 = the 4-wave form
+                           whatever the batch — the form a worklist launch runs, so that a level-scheduled plan gives the same
+                           bits whether its Transformer backward rides in a worklist or stands alone (the two forms differ in
+                           the summation order of the weight gradients over the tokens) */
 } nasrec_mha_desc_t;
 
 /* out[c] = sum_r in[r*ld + c], r < R, c < C, fixed order.  Optionally scattered to up to NASREC_REDUCE_MAX_DST destination

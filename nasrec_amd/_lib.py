@@ -78,7 +78,7 @@ class FmDesc(C.Structure):
 
 class MhaDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("N", i32), ("ldx", i32), ("ldo", i32), ("dims_in_use", i32), ("x", vp), ("out", vp),
-                ("dout", vp), ("dx", vp), ("dparams_partial", vp), ("params", vp * 12), ("saved", vp), ("partial_ld", i32), ("_pad", i32)]
+                ("dout", vp), ("dx", vp), ("dparams_partial", vp), ("params", vp * 12), ("saved", vp), ("partial_ld", i32), ("bwd_form", i32)]
 
 
 class ReduceRowsDesc(C.Structure):

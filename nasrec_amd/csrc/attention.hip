@@ -38,7 +38,7 @@ int launch_mha(hipStream_t st, const nasrec_mha_desc_t* d) {
     if (d->saved == nullptr) return nasrec_set_error(-2, "mha backward needs the state saved by the forward launch (desc.saved)");
     // 8 waves per sample win where latency counts (batch 256: 23.5 against 26.7 us); at large batch the 4-wave form does the
     // same work with fewer wave-instructions per sample (B = 4096: 269 against 286 us)
-    if (d->B >= 1024)
+    if (d->B >= 1024 || d->bwd_form == 4)
       hipLaunchKernelGGL(mha_bwd_kernel<4>, dim3(d->B), dim3(256), 0, st, *d);
     else
       hipLaunchKernelGGL(mha_bwd_kernel<MHA_SLICE_BWD>, dim3(d->B), dim3(1024 / MHA_SLICE_BWD), 0, st, *d);

@@ -148,6 +148,8 @@ class SupernetEngine:
         # batch <= 256 (fixed sub-networks): operators that do not depend on each other share heterogeneous launches
         # (nasrec_amd/schedule.py); NASREC_WORKLIST=0 keeps one launch per operator (A/B runs, bit-identical results)
         self.level_schedule = os.environ.get("NASREC_WORKLIST", "1") != "0"
+        # opt-in: drop forward operators nobody reads (schedule.eliminate_dead_forward); off = every reference operator runs
+        self.dead_code_elimination = os.environ.get("NASREC_DCE", "0") == "1"
         if cfg.fixed:
             assert warm_choice is not None, "fixed mode needs the fixed choice"
             self.warm_choice = warm_choice
@@ -294,6 +296,8 @@ class SupernetEngine:
             # parked weight-gradient batches are for one-launch-per-operator plans; the level scheduler places the products itself
             ctx.defer_dw = defer_dw and getattr(self, "park_weight_grads", True) and not (self.level_schedule and cfg.fixed and B <= 256)
             ctx.arena = arena
+            if (self.level_schedule and cfg.fixed and B <= 256) or getattr(self, "mha_bwd_form", 0) == 4:
+                ctx.mha_bwd_form = 4
             cp.ctx = ctx
             new = (lambda n, dt=torch.float32: arena.alloc(n, dt)) if arena is not None else \
                 (lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device))
@@ -346,64 +350,21 @@ class SupernetEngine:
                 raise NotImplementedError("use_final_sigmoid is never enabled by the reference CLIs")
             scheduled = self.level_schedule and cfg.fixed and B <= 256
             cp.fwd_levels = cp.bwd_levels = None
+            cp.dead_forward = []
+            if train:  # (the backward program decides which forward results are read: built further down, before the packing)
+                self._ensure_table_state()
+                self._build_training_tail(cp, ctx, w, bptr, fsegs, B, K, grad_scale)
+            fwd_list = list(ctx.fwd)
+            if self.dead_code_elimination and cfg.fixed:
+                fwd_list, cp.dead_forward = S.eliminate_dead_forward(fwd_list, ctx.bwd if train else [])
             if scheduled:
-                fwd_descs, cp.fwd_levels = S.pack(ctx.fwd)
+                fwd_descs, cp.fwd_levels = S.pack(fwd_list)
             else:
-                fwd_descs = ctx.fwd
+                fwd_descs = fwd_list
             cp.fwd = Program(fwd_descs)
             cp.used_params = list(ctx.used_params)
             if train:
-                self._ensure_table_state()
-                bd = L.BceDesc()
-                bd.kind = L.OP_BCE
-                bd.B = B
-                bd.grad_scale = grad_scale if grad_scale is not None else 1.0 / B
-                bd.logits, bd.y, bd.loss, bd.dlogits = cp.logits.data_ptr(), cp.y.data_ptr(), cp.loss.data_ptr(), cp.dlogits.data_ptr()
-                pre = [bd]
-
-                def final_bwd():
-                    e = L.FinalDesc()
-                    e.kind = L.OP_FINAL_BWD
-                    e.B, e.nseg = B, 2
-                    e.w, e.bias, e.dlogits = w, bptr, cp.dlogits.data_ptr()
-                    e.dw, e.dbias = self.grads["_final.weight"].data_ptr(), self.grads["_final.bias"].data_ptr()
-                    for q, s in enumerate(fsegs):
-                        gp, acc = ctx.gtarget(s.view)
-                        e.seg[q], e.dseg[q], e.width[q], e.ld[q], e.off[q], e.dseg_accumulate[q] = s.view.ptr, gp, s.width, s.view.ld, s.koff, acc
-                    if B > 256:
-                        # d loss / d _final over a large batch: nsplit batch slices in parallel -> partial [nsplit, K + 1], summed in
-                        # fixed order by the launch behind it (one workgroup per 16 columns walked 4096 rows in 132 us)
-                        e.nsplit = max(2, min(32, B // 128))
-                        part = ctx.alloc(e.nsplit * (K + 1))
-                        e.dw = part.data_ptr()
-                        r = L.ReduceRowsDesc()
-                        r.kind = L.OP_REDUCE_ROWS
-                        r.R, r.C, r.ld, r.in_ = e.nsplit, K + 1, K + 1, part.data_ptr()
-                        r.ndst = 2
-                        r.dst[0], r.dst_off[0], r.dst_len[0] = self.grads["_final.weight"].data_ptr(), 0, K
-                        r.dst[1], r.dst_off[1], r.dst_len[1] = self.grads["_final.bias"].data_ptr(), K, 1
-                        ctx.emit(e)
-                        ctx.emit(r)
-                        return
-                    ctx.emit(e)
-
-                ctx.on_backward(final_bwd)
-                ctx.build_backward()
-                cp.chunk_tab, cp.nchunks = None, 0
-                if not cfg.fixed:
-                    # Paths differ from step to step.  torch skips parameters whose grad is None (everything outside the path),
-                    # so zero_grad, the norm and Adagrad touch ONLY the arena ranges this path trains — the same arithmetic on
-                    # the path's share of the arena (a quarter of it for a `default` xlarge path).  Gradients left over from
-                    # other paths outside these ranges are never read.
-                    names = [n for n in list(ctx.grad_params) + ["_final.weight", "_final.bias"] if not n.startswith("_embedding.")]
-                    flat = P.path_chunks([(self.offsets[n], self.params[n].numel()) for n in dict.fromkeys(names)])
-                    cp.nchunks = len(flat) // 2
-                    cp.chunk_tab = (arena.alloc(len(flat), torch.int64) if arena is not None
-                                    else torch.empty(len(flat), dtype=torch.int64, device=self.device))
-                    pre += P.const_i64_descs(cp.chunk_tab.data_ptr(), flat)
-                    ms = P.memset_desc(self.flat_g)
-                    ms.chunks, ms.nchunks = cp.chunk_tab.data_ptr(), cp.nchunks
-                    pre.append(ms)
+                bd, pre = cp.bce, cp._pre
                 # The training programs fold BCEWithLogits into the final-logit backward (the first closure to run); bwd_core
                 # keeps the plain one (d loss / d logits supplied by torch.autograd).
                 fi = next(i for i, dsc in enumerate(ctx.bwd) if isinstance(dsc, L.FinalDesc))
@@ -418,7 +379,7 @@ class SupernetEngine:
                 # block output no later block reads, second passes) runs beside the first backward levels
                 cp.fb = None
                 if scheduled:
-                    fb_descs, cp.fb_levels = S.pack(list(ctx.fwd) + bwd_descs)
+                    fb_descs, cp.fb_levels = S.pack(fwd_list + bwd_descs)
                     cp.fb = Program(fb_descs)
                     bwd_descs, cp.bwd_levels = S.pack(bwd_descs)
                 cp.bwd = Program(bwd_descs)
@@ -444,6 +405,62 @@ class SupernetEngine:
         self._plans[key] = cp
         self._last_plan = (fast, choice, cp)
         return cp
+
+    def _build_training_tail(self, cp, ctx, w, bptr, fsegs, B, K, grad_scale):
+        """BCE descriptor, the final-logit backward closure, the backward program (ctx.bwd) and, for a supernet, the path's chunk
+        table: everything the forward packing has to know about (which forward results the backward reads)"""
+        cfg, arena = self.cfg, cp.arena
+        bd = L.BceDesc()
+        bd.kind = L.OP_BCE
+        bd.B = B
+        bd.grad_scale = grad_scale if grad_scale is not None else 1.0 / B
+        bd.logits, bd.y, bd.loss, bd.dlogits = cp.logits.data_ptr(), cp.y.data_ptr(), cp.loss.data_ptr(), cp.dlogits.data_ptr()
+        pre = [bd]
+
+        def final_bwd():
+            e = L.FinalDesc()
+            e.kind = L.OP_FINAL_BWD
+            e.B, e.nseg = B, 2
+            e.w, e.bias, e.dlogits = w, bptr, cp.dlogits.data_ptr()
+            e.dw, e.dbias = self.grads["_final.weight"].data_ptr(), self.grads["_final.bias"].data_ptr()
+            for q, s in enumerate(fsegs):
+                gp, acc = ctx.gtarget(s.view)
+                e.seg[q], e.dseg[q], e.width[q], e.ld[q], e.off[q], e.dseg_accumulate[q] = s.view.ptr, gp, s.width, s.view.ld, s.koff, acc
+            if B > 256:
+                # d loss / d _final over a large batch: nsplit batch slices in parallel -> partial [nsplit, K + 1], summed in
+                # fixed order by the launch behind it (one workgroup per 16 columns walked 4096 rows in 132 us)
+                e.nsplit = max(2, min(32, B // 128))
+                part = ctx.alloc(e.nsplit * (K + 1))
+                e.dw = part.data_ptr()
+                r = L.ReduceRowsDesc()
+                r.kind = L.OP_REDUCE_ROWS
+                r.R, r.C, r.ld, r.in_ = e.nsplit, K + 1, K + 1, part.data_ptr()
+                r.ndst = 2
+                r.dst[0], r.dst_off[0], r.dst_len[0] = self.grads["_final.weight"].data_ptr(), 0, K
+                r.dst[1], r.dst_off[1], r.dst_len[1] = self.grads["_final.bias"].data_ptr(), K, 1
+                ctx.emit(e)
+                ctx.emit(r)
+                return
+            ctx.emit(e)
+
+        ctx.on_backward(final_bwd)
+        ctx.build_backward()
+        cp.chunk_tab, cp.nchunks = None, 0
+        if not cfg.fixed:
+            # Paths differ from step to step.  torch skips parameters whose grad is None (everything outside the path),
+            # so zero_grad, the norm and Adagrad touch ONLY the arena ranges this path trains — the same arithmetic on
+            # the path's share of the arena (a quarter of it for a `default` xlarge path).  Gradients left over from
+            # other paths outside these ranges are never read.
+            names = [n for n in list(ctx.grad_params) + ["_final.weight", "_final.bias"] if not n.startswith("_embedding.")]
+            flat = P.path_chunks([(self.offsets[n], self.params[n].numel()) for n in dict.fromkeys(names)])
+            cp.nchunks = len(flat) // 2
+            cp.chunk_tab = (arena.alloc(len(flat), torch.int64) if arena is not None
+                            else torch.empty(len(flat), dtype=torch.int64, device=self.device))
+            pre += P.const_i64_descs(cp.chunk_tab.data_ptr(), flat)
+            ms = P.memset_desc(self.flat_g)
+            ms.chunks, ms.nchunks = cp.chunk_tab.data_ptr(), cp.nchunks
+            pre.append(ms)
+        cp.bce, cp._pre = bd, pre
 
     def _optimizer_descs(self, cp, Bg, cat_x, sparse_grad, clip, eps):
         """clip_grad_norm_ + Adagrad (train_utils.py:285-286): row-sparse on the tables, flat on the dense arena."""

@@ -170,6 +170,7 @@ class Ctx:
         self.raw_sparse = None  # Buf of the embedding stem's output [B, Fs, 16] (set by the engine): see _flush_raw_dx
         self.deferred_raw: List = []
         self.sk_workspace = None  # optional callable -> tensor of L.SK_WORKSPACE_FLOATS floats shared by the plan's balanced GEMM launches
+        self.mha_bwd_form = 0  # nasrec_mha_desc_t.bwd_form of the Transformer backward launches (4: the form worklist launches run)
         self.block_marks: List = []  # (block index, length of the backward program once that block's gradients are complete)
 
     # -- memory -----------------------------------------------------------------------------------------------
@@ -1173,6 +1174,7 @@ def op_transformer(ctx, cfg, pre, ssegs, Ntot, max_dims, dims, out: SV):
         e.dx = xbuf.grad_tensor().data_ptr()
         xbuf.mark()
         e.saved = saved.data_ptr() if saved is not None else None
+        e.bwd_form = ctx.mha_bwd_form
         for q in range(12):
             e.params[q] = pp[q]
         ctx.emit(e)

@@ -445,3 +445,34 @@ def pack(descs):
             cur.nodes.append(n)
             off += size
     return out, nl
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# dead forward operators
+# ----------------------------------------------------------------------------------------------------------------
+def eliminate_dead_forward(fwd, later):
+    """Forward descriptors whose results nobody reads: not the final logit, not a later forward operator that is itself live, not
+    the backward program (`later`: it already holds live branches only — plan.py replays closures with liveness).  A fixed
+    sub-network can contain such operators: with last_n_blocks_out = 1 (supernet.py:592-598) the final layer reads the LAST block
+    only, and a block no later block selects in its macro choice is computed by the reference and thrown away (in
+    ea_criteo_kaggle_xlarge_best_1shot.json that is all of block 5: its 256 x 768 x 1565 Linear — a quarter of the step's flops —
+    its Transformer and its dense -> sparse projection).  Dropping them changes no logit, loss, gradient or parameter; the
+    reference leaves their parameters at grad None, and so does the engine either way.
+    -> (live forward descriptors, dropped descriptors).  Opt-in (SupernetEngine.dead_code_elimination / NASREC_DCE=1): the default
+    executes every operator the reference executes."""
+    nodes = [Node(d) for d in list(fwd) + list(later)]
+    nf = len(fwd)
+    live = [False] * nf + [True] * len(later)
+    for i in range(nf - 1, -1, -1):
+        n = nodes[i]
+        if n.writes is None or n.desc.kind == L.OP_FINAL_FWD:
+            live[i] = True
+            continue
+        for j in range(i + 1, len(nodes)):
+            if not live[j]:
+                continue
+            m = nodes[j]
+            if m.reads is None or any(overlap(w, r) for w in n.writes for r in m.reads):
+                live[i] = True
+                break
+    return [d for d, k in zip(fwd, live[:nf]) if k], [d for d, k in zip(fwd, live[:nf]) if not k]

@@ -236,6 +236,7 @@ def test_level_scheduled_step_is_bit_identical_to_one_launch_per_operator(case):
             eng = build_engine(z, meta)
             eng.level_schedule = scheduled
             eng.park_weight_grads = False  # the baseline runs the SAME operator list one launch each (no parked zmode batches)
+            eng.mha_bwd_form = 4           # ... and the Transformer-backward form the worklist launches run
             logits = eng.forward(int_x, cat_x, meta["choice"]).clone()
             cp = eng.forward_backward(int_x, cat_x, y, meta["choice"])
             torch.cuda.synchronize()
@@ -349,3 +350,33 @@ def test_place_embedding_on_cpu_mode_matches_the_reference_vectors():
         assert abs(n - nrm) <= 2e-5 * max(nrm, 1e-6) and abs(d - dot) <= 2e-5 * max(nrm, 1e-6), k
     with pytest.raises(L.EngineError):
         model.engine_train_step(int_x, cat_x, y.view(-1), lr=0.01)
+
+
+def test_dead_forward_elimination_changes_nothing_observable():
+    """opt-in NASREC_DCE / SupernetEngine.dead_code_elimination: forward operators nobody reads (a block no later block selects, with
+    last_n_blocks_out = 1) are dropped — logits, loss, every gradient and the parameters after two steps stay bit-identical, and the
+    Criteo best-1shot plan does drop launches (its block 5 is computed by the reference and thrown away)"""
+    import json as _json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ca = _json.load(open(os.path.join(root, "nasrec_amd", "configs", "criteo", "ea_criteo_kaggle_xlarge_best_1shot.json")))
+    choice = {"macro": ca["macro"], "micro": ca["micro"]}
+    tables = [1000] * 26
+    int_x, cat_x, y = O.synthetic_batch(64, 13, tables, seed=5)
+    int_x, cat_x, y = int_x.cuda(), cat_x.cuda(), y.view(-1).cuda()
+    res = []
+    for dce in (False, True):
+        cfg = P.NetConfig(ca["num_blocks"], ops_config_lib[ca["config"]], False, "relu", fixed=True)
+        eng = SupernetEngine(cfg, 13, 26, tables, warm_choice=choice)
+        eng.init_weights(seed=3)
+        eng.dead_code_elimination = dce
+        logits = eng.forward(int_x, cat_x, choice).clone()
+        cp = eng.forward_backward(int_x, cat_x, y, choice)
+        torch.cuda.synchronize()
+        g, sg, loss, ndead = eng.flat_g.clone(), cp.sparse0.grad_tensor().clone(), float(cp.loss.item()), len(cp.dead_forward)
+        for _ in range(2):
+            eng.train_step(int_x, cat_x, y, 0.05, choice, graph=True)
+        torch.cuda.synchronize()
+        res.append((logits, g, sg, loss, eng.flat_p.clone(), ndead))
+    a, b = res
+    assert a[5] == 0 and b[5] >= 5, "block 5 of the Criteo best-1shot sub-network is dead code"
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3] and torch.equal(a[4], b[4])
