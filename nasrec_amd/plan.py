@@ -160,7 +160,10 @@ class Ctx:
         self.closures: List = []
         self.keep: List = []  # tensors kept alive for the lifetime of the plan
         self.used_params: List[str] = []
+        self._used_set = set()
+        self._pcache: Dict[str, tuple] = {}  # name -> (shape, data_ptr): one lookup per parameter use
         self.grad_params: List[str] = []  # parameters whose gradient the backward program writes
+        self._grad_set = set()
         self.out = self.fwd  # current emission target
         self.deferred: List = []  # weight-gradient products parked until the end of the backward program
         self.bwd_tail_start = 0
@@ -195,6 +198,12 @@ class Ctx:
 
     # -- parameters -------------------------------------------------------------------------------------------
     def param(self, name, shape, used=True):
+        hit = self._pcache.get(name)
+        if hit is not None and hit[0] == shape:  # (the common case of a re-compiled path: same name, same shape object contents)
+            if used and name not in self._used_set:
+                self._used_set.add(name)
+                self.used_params.append(name)
+            return hit[1]
         shape = tuple(int(s) for s in shape)
         if name in self.shapes:
             assert self.shapes[name] == shape, (name, self.shapes[name], shape)
@@ -203,12 +212,16 @@ class Ctx:
             return 0
         p = self.params[name]
         assert tuple(p.shape) == shape, "parameter %s has shape %s, the path needs %s" % (name, tuple(p.shape), shape)
-        if used and name not in self.used_params:
+        if used and name not in self._used_set:
+            self._used_set.add(name)
             self.used_params.append(name)
-        return p.data_ptr()
+        ptr = p.data_ptr()
+        self._pcache[name] = (shape, ptr)
+        return ptr
 
     def gparam(self, name):
-        if name not in self.grad_params:
+        if name not in self._grad_set:
+            self._grad_set.add(name)
             self.grad_params.append(name)
         return self.grads[name].data_ptr()
 
@@ -332,28 +345,44 @@ def _fast_gemm_splitk(amode, bmode, cmode, segs, zmode):
     """Mirror of csrc/gemm_fast.hip `gemm_fast_eligible`: does this launch take the throughput-regime kernel (128x128x32
     tiles), and with which split-K?  -> S (>= 1) or None.  A product with few output tiles but a deep K (the weight gradients
     of a large batch: K = B) is split so that tiles x S fills the chip, >= 8 k-tiles of 32 per split."""
-    if cmode != L.CM_PLAIN or (amode, bmode) not in ((L.AM_KC, L.AM_KC), (L.AM_KC, L.AM_RC), (L.AM_RC, L.AM_RC)):
+    if cmode != L.CM_PLAIN or (amode, bmode) not in _FAST_BINDINGS:
         return None
-    live = [sd for sd in segs if sd.get("A")]
-    if not live or any(sd.get("Aaux") or sd.get("Baux") for sd in segs):
-        return None
-    if max(sd["K"] for sd in live) < 64:
-        return None
-    for sd in live:  # 31-bit byte offsets of the staging loads: operand extents stay below 2^29 floats (gemm_fast.hip:623-625)
-        r, ld = max(sd["M"], sd["N"]), max(sd.get("lda", 0), sd.get("ldb", 0))
-        if r * ld + sd["K"] >= (1 << 29) or sd["K"] * ld + r >= (1 << 29):
+    kmax = 0
+    kt_max = kt_sum = 0
+    any_live = False
+    for sd in segs:
+        if sd.get("Aaux") or sd.get("Baux"):
             return None
-    probs = segs if zmode else segs[:1]
-    tiles = sum(((sd["M"] + 127) // 128) * ((sd["N"] + 127) // 128) for sd in probs)
-    if 2 * sum(sd["M"] * sd["N"] for sd in probs) < tiles * 128 * 128:
+        if not sd.get("A"):
+            continue
+        any_live = True
+        K = sd["K"]
+        if K > kmax:
+            kmax = K
+        # 31-bit byte offsets of the staging loads: operand extents stay below 2^29 floats (gemm_fast.hip:623-625)
+        r, ld = max(sd["M"], sd["N"]), max(sd.get("lda", 0), sd.get("ldb", 0))
+        if r * ld + K >= (1 << 29) or K * ld + r >= (1 << 29):
+            return None
+        kt = (K + 31) // 32
+        kt_sum += kt
+        if kt > kt_max:
+            kt_max = kt
+    if not any_live or kmax < 64:
+        return None
+    tiles = area = 0
+    for sd in (segs if zmode else segs[:1]):
+        tiles += ((sd["M"] + 127) // 128) * ((sd["N"] + 127) // 128)
+        area += sd["M"] * sd["N"]
+    if 2 * area < tiles * 128 * 128:
         return None  # skinny problems: the small-tile kernel
-    kt = (max((sd["K"] + 31) // 32 for sd in live) if zmode else sum((sd["K"] + 31) // 32 for sd in live))
+    kt = kt_max if zmode else kt_sum
     S = 1
     if tiles < 256:
         S = max(1, min(-(-256 // tiles), kt // 8, 32))
     return S if tiles * S >= GEMM_FAST_MIN_TILES else None
 
 
+_FAST_BINDINGS = ((L.AM_KC, L.AM_KC), (L.AM_KC, L.AM_RC), (L.AM_RC, L.AM_RC))
 BALANCED_MIN_SAVING_US = 80.0
 
 
@@ -402,67 +431,91 @@ def gemm_kernel_name(d) -> str:
     return "gemm_fast_kernel" if tiles * max(1, d.splitk) >= GEMM_FAST_MIN_TILES else "gemm_kernel"
 
 
-def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, **kw):
-    """One GEMM launch descriptor for <= MAX_SEGS segments (list of dicts with nasrec_gemm_seg_t fields)."""
+def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, act=0, bias_on_rows=0, mask_on_rows=0, dims=-1, beta=0, bias=None, save_z=None,
+               save_act=None, pre_add=None, mul=None, splitk=None, rowsum_out=None):
+    """One GEMM launch descriptor for <= MAX_SEGS segments (list of dicts with nasrec_gemm_seg_t fields).
+    (This function runs ~60 times per compiled supernet path, i.e. per training step: plain loops, no generator expressions.)"""
     if not segs:
         return []
-    assert len(segs) <= L.MAX_SEGS
+    nseg = len(segs)
+    assert nseg <= L.MAX_SEGS
     d = L.GemmDesc()
     d.kind = L.OP_GEMM
     d.amode, d.bmode, d.cmode = amode, bmode, cmode
-    d.nseg = len(segs)
+    d.nseg = nseg
     d.zmode = zmode
-    d.act = kw.get("act", 0)
-    d.bias_on_rows = kw.get("bias_on_rows", 0)
-    d.mask_on_rows = kw.get("mask_on_rows", 0)
-    d.dims_in_use = kw.get("dims", -1)
-    d.beta = kw.get("beta", 0)
-    d.bias = kw.get("bias", None)
-    d.save_z = kw.get("save_z", None)
-    d.save_act = kw.get("save_act", None)
-    d.pre_add = kw.get("pre_add", None)
-    mul = kw.get("mul", None)
+    if act:
+        d.act = act
+    if bias_on_rows:
+        d.bias_on_rows = bias_on_rows
+    if mask_on_rows:
+        d.mask_on_rows = mask_on_rows
+    d.dims_in_use = dims
+    if beta:
+        d.beta = beta
+    if bias:
+        d.bias = bias
+    if save_z:
+        d.save_z = save_z
+    if save_act:
+        d.save_act = save_act
+    if pre_add:
+        d.pre_add = pre_add
     if mul:
         assert len(mul) <= L.MAX_SEGS
         d.mul_nseg = len(mul)
         for q, (ptr, off, width, ld) in enumerate(mul):
             d.mul_ptr[q], d.mul_off[q], d.mul_width[q], d.mul_ld[q] = ptr, off, width, ld
-    for q, sdict in enumerate(segs):
-        s = d.seg[q]
+    M = N = 0
+    kt_max = kt_sum = live_tiles = 0
+    dseg = d.seg
+    for q in range(nseg):
+        sdict = segs[q]
+        s = dseg[q]
         for k, v in sdict.items():
             setattr(s, k, v)
+        m, n = sdict["M"], sdict["N"]
         if "Mvalid" not in sdict:
-            s.Mvalid = sdict["M"]
-    M = max(sd["M"] for sd in segs)
-    N = max(sd["N"] for sd in segs)
-    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+            s.Mvalid = m
+        if m > M:
+            M = m
+        if n > N:
+            N = n
+        kt = (sdict["K"] + 31) // 32
+        kt_sum += kt
+        if kt > kt_max:
+            kt_max = kt
+        live_tiles += ((m + 63) // 64) * ((n + 63) // 64)  # (a zmode grid is padded to Mmax x Nmax)
+    B = ctx.B
     if zmode:
-        kt = max((sd["K"] + 31) // 32 for sd in segs)
-        live_tiles = sum(((sd["M"] + 63) // 64) * ((sd["N"] + 63) // 64) for sd in segs)  # the grid is padded to Mmax x Nmax
-        S = _splitk_for(live_tiles, kt)
+        S = _splitk_for(live_tiles, kt_max)
     else:
-        kt = sum((sd["K"] + 31) // 32 for sd in segs)
-        S = _splitk_for(tiles, kt)
-    fast = _fast_gemm_splitk(amode, bmode, cmode, segs, zmode)
+        S = _splitk_for(((M + 63) // 64) * ((N + 63) // 64), kt_sum)
+    fast = _fast_gemm_splitk(amode, bmode, cmode, segs, zmode) if B > 128 else None  # (a throughput-regime launch needs >= 120 128x128 tiles)
     if fast is not None:
         S = fast
-    if (amode == L.AM_TOKK and zmode and ctx.B >= 1024 and all(sd["M"] <= 80 and sd["N"] <= 80 and not sd.get("Aaux") and not sd.get("Baux")
-                                                              for sd in segs)):
-        # token-axis weight gradients at large batch (csrc/token_linear.hip `token_dw_kernel`): S workgroups of 16 wavefronts per
-        # problem, a wavefront per sample — one workgroup per CU, few slabs for the second pass
-        S = max(4, min(32, 256 // len(segs), ctx.B // 64))
-    S = kw.get("splitk", S)
+    if amode == L.AM_TOKK and zmode and B >= 1024:
+        ok = True
+        for sd in segs:
+            if sd["M"] > 80 or sd["N"] > 80 or sd.get("Aaux") or sd.get("Baux"):
+                ok = False
+                break
+        if ok:
+            # token-axis weight gradients at large batch (csrc/token_linear.hip `token_dw_kernel`): S workgroups of 16 wavefronts per
+            # problem, a wavefront per sample — one workgroup per CU, few slabs for the second pass
+            S = max(4, min(32, 256 // nseg, B // 64))
+    if splitk is not None:
+        S = splitk
     d.splitk = 1
-    if fast == 1 and S == 1 and ctx.B > 256 and ctx.sk_workspace is not None and _balanced_schedule_pays(segs, zmode):
+    if fast == 1 and S == 1 and B > 256 and ctx.sk_workspace is not None and _balanced_schedule_pays(segs, zmode):
         d.splitk = L.SPLITK_BALANCED
         d.workspace = ctx.sk_workspace().data_ptr()
     if S > 1:
         d.splitk = S
-        nprob = len(segs) if zmode else 1
-        ws = ctx.alloc(S * M * N * nprob)
+        ws = ctx.alloc(S * M * N * (nseg if zmode else 1))
         d.workspace = ws.data_ptr()
-    if kw.get("rowsum_out") is not None:
-        d.rowsum_out = kw["rowsum_out"]
+    if rowsum_out is not None:
+        d.rowsum_out = rowsum_out
     return [d]
 
 

@@ -28,16 +28,27 @@ for i in range(8):
     model.engine_train_step(*batches[i % 2], lr=1e-3)
 torch.cuda.synchronize()
 N = 40
-host, ev = [], [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
+eng = model._engine
+host, comp, ev = [], [], [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
 t0 = time.perf_counter()
 ev[0].record()
 for i in range(N):
     h0 = time.perf_counter()
+    # the plan compile of this step's path, timed on its own (it is pure host work; the enqueue behind it can block on a full
+    # hardware queue when the host runs several steps ahead, which is back-pressure, not cost)
+    st = np.random.get_state()
+    ch = model._resolve_choice(None)
+    eng.compile(ch, B, True, 5.0, 1e-2, graph=False)
+    h1 = time.perf_counter()
+    np.random.set_state(st)  # engine_train_step draws the same path again and hits the plan just compiled
     model.engine_train_step(*batches[i % 2], lr=1e-3)
     host.append(time.perf_counter() - h0)
+    comp.append(h1 - h0)
     ev[i + 1].record()
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 gpu = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(N)])
-print("cfg %d: wall %.2f ms/step; host (compile + enqueue) %.2f ms/step median %.2f max %.2f; GPU span per step median %.2f ms; sum of GPU spans / wall = %.3f" % (
-    cfgid, wall / N * 1e3, np.mean(host) * 1e3, np.median(host) * 1e3, np.max(host) * 1e3, np.median(gpu), gpu.sum() / (wall * 1e3)))
+print("cfg %d: wall %.2f ms/step; path sampling + plan compile %.2f ms/step mean, %.2f median, %.2f max; whole host call (incl. enqueue, which blocks when the "
+      "host is several steps ahead) %.2f mean %.2f median %.2f max; GPU span per step median %.2f ms; sum of GPU spans / wall = %.3f" % (
+    cfgid, wall / N * 1e3, np.mean(comp) * 1e3, np.median(comp) * 1e3, np.max(comp) * 1e3, np.mean(host) * 1e3, np.median(host) * 1e3, np.max(host) * 1e3,
+    np.median(gpu), gpu.sum() / (wall * 1e3)))
