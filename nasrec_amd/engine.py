@@ -332,7 +332,7 @@ class SupernetEngine:
             if (self.level_schedule and cfg.fixed and B <= 256) or getattr(self, "mha_bwd_form", 0) == 4:
                 ctx.mha_bwd_form = 4
             cp.ctx = ctx
-            new = (lambda n, dt=torch.float32: arena.alloc(n, dt)) if arena is not None else \
+            new = (lambda n, dt=torch.float32: arena.alloc(n, dt).tensor()) if arena is not None else \
                 (lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device))
             cp.int_x = new(B * self.Fd).view(B, self.Fd)
             cp.cat_x = new(B * self.Fs, torch.int64).view(B, self.Fs)
@@ -487,7 +487,7 @@ class SupernetEngine:
             names = [n for n in list(ctx.grad_params) + ["_final.weight", "_final.bias"] if not n.startswith("_embedding.")]
             flat = P.path_chunks([(self.offsets[n], self.params[n].numel()) for n in dict.fromkeys(names)])
             cp.nchunks = len(flat) // 2
-            cp.chunk_tab = (arena.alloc(len(flat), torch.int64) if arena is not None
+            cp.chunk_tab = (arena.alloc(len(flat), torch.int64).tensor() if arena is not None
                             else torch.empty(len(flat), dtype=torch.int64, device=self.device))
             pre += P.const_i64_descs(cp.chunk_tab.data_ptr(), flat)
             ms = P.memset_desc(self.flat_g)
@@ -500,7 +500,7 @@ class SupernetEngine:
         descs = []
         nb = (Bg + 255) // 256
         new = getattr(cp, "arena", None)
-        new = (lambda n, dt=torch.float32: cp.arena.alloc(n, dt)) if new is not None else \
+        new = (lambda n, dt=torch.float32: cp.arena.alloc(n, dt).tensor()) if new is not None else \
             (lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device))
         nblk = max(1, min(256, (self.flat_numel + 256 * 8 - 1) // (256 * 8)))
         tab, ntab = getattr(cp, "chunk_tab", None), getattr(cp, "nchunks", 0)

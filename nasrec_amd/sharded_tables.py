@@ -1,0 +1,306 @@
+"""Row-sharded embedding tables: the rows of every table are split over the ranks, ids / rows / row gradients travel by
+all-to-all (RCCL over xGMI on the GPUs, gloo in the CPU tests) — for tables that outgrow one GPU's HBM.  Bag size 1, as the reference's
+stem (`supernet.py:404-410,418-428`: Fs independent nn.Embedding look-ups stacked on dim 1).
+
+Placement: table f (n_f rows) is cut into `world` contiguous row ranges of rp_f = ceil(n_f / world) rows; rank r owns rows
+[r rp_f, min(n_f, (r + 1) rp_f)).  Row-wise (not table-wise) sharding balances any mix of table sizes (Criteo: 10 M-row and 3-row
+tables side by side).
+
+One training step (the dense network stays data-parallel, `nasrec_amd/parallel.py`):
+  1. route      every (sample b, field f) item goes to the owner of its row; items are sent ordered by (owner, f, b), so that an owner
+                sees each field's items in GLOBAL batch order (source rank, then b) — the order in which duplicate rows are summed;
+  2. lookup     all-to-all of the ids (+ one small all-to-all of the per-field counts), owners gather their rows (bit-exact copy),
+                all-to-all of the rows back: [B, Fs, 16] for the local forward;
+  3. backward   the local row gradients [B, Fs, 16] take the same route to the owners (one all-to-all);
+  4. update     every owner runs the row-sparse dedup + clip + Adagrad on ITS rows; the clip coefficient needs the global gradient norm:
+                the owners' partial sums of squares are all-reduced (a few hundred bytes).
+Equivalence target (tests/test_sharded_tables_cpu.py, gloo world 2): the step of a single process at the global batch with whole tables.
+
+The routing is plain torch (sort / bincount / cumsum on whatever device the ids live on); what runs on the rows is pluggable: the HIP
+engine's gather / dedup / Adagrad kernels on the GPU (`ShardedTableOps` in this file binds them), index ops in the CPU tests."""
+import math
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+E = 16
+PAD_ID = -(1 << 30)  # pad of the owner-side id matrix: out of every table's range (the row update skips it), unlike any sentinel of the dedup kernels
+
+
+class Route:
+    """how the items of one local batch travel: built by RowShardedTables.route(), used for the forward and the backward exchange"""
+    __slots__ = ("B", "order", "send_counts", "recv_counts", "recv_field_counts", "own_idx", "own_pos", "Bp", "nrecv")
+
+
+class RowShardedTables:
+    def __init__(self, num_embeddings: List[int], device, group=None, dtype=torch.float32, init_fn=None):
+        """num_embeddings: rows of every (whole) table.  init_fn(f, row_lo, row_hi) -> [row_hi - row_lo, 16] tensor initialises a
+        shard (default: zeros)."""
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.num_embeddings = [int(n) for n in num_embeddings]
+        self.Fs = len(self.num_embeddings)
+        self.device = torch.device(device)
+        self.rp = [max(1, math.ceil(n / self.world)) for n in self.num_embeddings]  # rows per rank of table f
+        self.lo = [min(n, self.rank * rp) for n, rp in zip(self.num_embeddings, self.rp)]
+        self.hi = [min(n, (self.rank + 1) * rp) for n, rp in zip(self.num_embeddings, self.rp)]
+        self.tables, self.state = [], []
+        for f in range(self.Fs):
+            rows = max(self.hi[f] - self.lo[f], 1)  # (an empty shard keeps one unused row so that every pointer is valid)
+            t = init_fn(f, self.lo[f], self.hi[f]).to(self.device, dtype) if (init_fn is not None and self.hi[f] > self.lo[f]) else \
+                torch.zeros(rows, E, dtype=dtype, device=self.device)
+            assert tuple(t.shape) == (rows, E)
+            self.tables.append(t.contiguous())
+            self.state.append(torch.zeros_like(self.tables[-1]))
+        self._rp_t = torch.tensor(self.rp, dtype=torch.int64, device=self.device)
+
+    # ---------------------------------------------------------------------------------------------------------------------
+    def route(self, cat_x: torch.Tensor) -> Route:
+        """cat_x [B, Fs] int64 (global row ids) -> Route.  One host synchronisation (the split sizes of the all-to-alls)."""
+        B, Fs, W = int(cat_x.shape[0]), self.Fs, self.world
+        ids = cat_x.t().contiguous()                       # [Fs, B]: flattened order = (f, b)
+        owner = ids // self._rp_t.view(Fs, 1)
+        local = ids - owner * self._rp_t.view(Fs, 1)
+        flat_owner = owner.reshape(-1)
+        order = torch.sort(flat_owner, stable=True).indices  # items by (owner, f, b)
+        field = torch.arange(Fs, device=ids.device).view(Fs, 1).expand(Fs, B).reshape(-1)
+        counts = torch.bincount(flat_owner * Fs + field, minlength=W * Fs).view(W, Fs)  # [dest, f]
+        r = Route()
+        r.B, r.order = B, order
+        if W > 1:
+            recv_fc = torch.empty_like(counts)
+            dist.all_to_all_single(recv_fc, counts, group=self.group)  # recv_fc[src, f]
+        else:
+            recv_fc = counts
+        both = torch.stack([counts.sum(1), recv_fc.sum(1)]).cpu()
+        r.send_counts, r.recv_counts = both[0].tolist(), both[1].tolist()
+        r.recv_field_counts = recv_fc
+        r.nrecv = int(sum(r.recv_counts))
+        send_ids = local.reshape(-1)[order]
+        recv_ids = self._a2a(send_ids, r.send_counts, r.recv_counts)
+        # owner side: column f of a padded [Bp, Fs] matrix = field f's items in (source, b) order; pads are PAD_ID (skipped by the update)
+        per_field = recv_fc.sum(0)                          # items of field f over all sources
+        Bp = max(int(per_field.max().item()) if r.nrecv else 0, 1)
+        r.Bp = Bp
+        src_off = torch.cumsum(recv_fc.sum(1), 0) - recv_fc.sum(1)               # start of source s in the received stream
+        in_src = torch.cumsum(recv_fc, 1) - recv_fc                              # start of field f inside source s
+        start = src_off.view(W, 1) + in_src                                      # [src, f] -> position in the received stream
+        col_off = torch.cumsum(recv_fc, 0) - recv_fc                             # [src, f] -> row inside column f
+        # position p of the received stream -> (row, column) of the padded matrix
+        seg_len = recv_fc.reshape(-1)                                            # segments in stream order are (src, f) row-major
+        seg_id = torch.repeat_interleave(torch.arange(W * Fs, device=ids.device), seg_len)
+        within = torch.arange(r.nrecv, device=ids.device) - start.reshape(-1)[seg_id]
+        rows = col_off.reshape(-1)[seg_id] + within
+        cols = seg_id % Fs
+        r.own_pos = rows * Fs + cols                                             # flat index into [Bp, Fs]
+        own_idx = torch.full((Bp * Fs,), PAD_ID, dtype=torch.int64, device=ids.device)
+        own_idx[r.own_pos] = recv_ids
+        r.own_idx = own_idx.view(Bp, Fs)
+        return r
+
+    def _a2a(self, send: torch.Tensor, send_counts, recv_counts) -> torch.Tensor:
+        """all_to_all_single along dim 0 with per-rank row counts"""
+        out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        if self.world > 1:
+            dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=self.group)
+        else:
+            out.copy_(send)
+        return out
+
+    # ---------------------------------------------------------------------------------------------------------------------
+    def lookup(self, cat_x: torch.Tensor, gather_fn=None):
+        """-> (rows [B, Fs, 16] of the LOCAL batch, Route).  gather_fn(own_idx [Bp, Fs] with pads as 0) -> [Bp, Fs, 16] runs the
+        owner-side gather on this rank's shards (default: torch indexing)."""
+        r = self.route(cat_x)
+        safe = r.own_idx.clamp_min(0)
+        if gather_fn is not None:
+            own_rows = gather_fn(safe)
+        else:
+            own_rows = torch.stack([self.tables[f][safe[:, f]] for f in range(self.Fs)], 1)
+        back = own_rows.reshape(-1, E)[r.own_pos]            # received-stream order
+        got = self._a2a(back, r.recv_counts, r.send_counts)  # rows of my items, in my send order
+        rows = torch.empty(self.Fs * r.B, E, dtype=got.dtype, device=got.device)
+        rows[r.order] = got
+        return rows.view(self.Fs, r.B, E).transpose(0, 1).contiguous(), r
+
+    def send_grads(self, r: Route, sg: torch.Tensor):
+        """local row gradients [B, Fs, 16] -> owner-side (own_idx [Bp, Fs] with pads -1, grads [Bp, Fs, 16] with zero pads)"""
+        flat = sg.view(r.B, self.Fs, E).transpose(0, 1).reshape(-1, E)[r.order]
+        got = self._a2a(flat, r.send_counts, r.recv_counts)
+        own = torch.zeros(r.Bp * self.Fs, E, dtype=got.dtype, device=got.device)
+        own[r.own_pos] = got
+        return r.own_idx, own.view(r.Bp, self.Fs, E)
+
+    # ---------------------------------------------------------------------------------------------------------------------
+    def reference_update(self, own_idx, own_g, coef: float, lr: float, eps: float):
+        """the owner-side row-sparse Adagrad in plain torch (CPU tests; the GPU path runs the HIP dedup + Adagrad kernels): duplicates
+        of a row are summed in arrival (= global batch) order, then g' = g coef; state += g'^2; p -= lr g' / (sqrt(state) + eps)"""
+        for f in range(self.Fs):
+            ids = own_idx[:, f]
+            keep = ids >= 0
+            if not bool(keep.any()):
+                continue
+            uniq, inv = torch.unique(ids[keep], return_inverse=True)
+            g = torch.zeros(uniq.numel(), E, dtype=own_g.dtype, device=own_g.device).index_add_(0, inv, own_g[keep, f]) * coef
+            self.state[f][uniq] += g * g
+            self.tables[f][uniq] -= lr * g / (self.state[f][uniq].sqrt() + eps)
+
+    def grad_sumsq(self, own_idx, own_g) -> torch.Tensor:
+        """this rank's share of the squared gradient norm of the tables (duplicates summed first)"""
+        tot = torch.zeros((), dtype=torch.float64, device=own_g.device)
+        for f in range(self.Fs):
+            ids = own_idx[:, f]
+            keep = ids >= 0
+            if not bool(keep.any()):
+                continue
+            uniq, inv = torch.unique(ids[keep], return_inverse=True)
+            g = torch.zeros(uniq.numel(), E, dtype=torch.float64, device=own_g.device).index_add_(0, inv, own_g[keep, f].double())
+            tot += (g * g).sum()
+        return tot
+
+    def whole_table(self, f: int) -> torch.Tensor:
+        """all-gather of table f (tests / checkpoints)"""
+        n, rp = self.num_embeddings[f], self.rp[f]
+        mine = torch.zeros(rp, E, dtype=self.tables[f].dtype, device=self.device)
+        k = self.hi[f] - self.lo[f]
+        if k > 0:
+            mine[:k] = self.tables[f][:k]
+        if self.world > 1:
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine, group=self.group)
+        else:
+            parts = [mine]
+        return torch.cat(parts, 0)[:n]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the training step over row-sharded tables
+# ----------------------------------------------------------------------------------------------------------------
+class ShardedTableStep:
+    """One training step with row-sharded tables and a data-parallel dense network, over a small protocol (so that the gloo tests run
+    THIS code with the oracle behind it, and the GPUs run it with the HIP engine behind it — EngineShardedOps below):
+        ops.forward_backward(int_x, rows [B,Fs,16], y, choice, grad_scale) -> (loss, row gradients [B,Fs,16]); dense gradients in ops.flat_g
+        ops.dense_sumsq() -> 0-d float64 tensor;  ops.dense_update(coef 0-d tensor, lr)
+        ops.gather(tables, own_idx_safe) -> [Bp,Fs,16] or None (default torch indexing)
+        ops.rows_sumsq(tables, own_idx, own_g) -> 0-d float64;  ops.rows_update(tables, own_idx, own_g, coef, lr, eps)"""
+
+    def __init__(self, ops, tables: RowShardedTables, B_local: int, clip: Optional[float] = 5.0, eps: float = 1e-2):
+        self.ops, self.tables, self.B, self.clip, self.eps = ops, tables, B_local, clip, eps
+        self.world = tables.world
+        self.last_norm = None
+
+    def step(self, int_x, cat_x, y, lr: float, choice=None):
+        t, ops = self.tables, self.ops
+        gather = getattr(ops, "gather", None)
+        rows, route = t.lookup(cat_x, (lambda idx: gather(t, idx)) if gather is not None else None)
+        loss, sg = ops.forward_backward(int_x, rows, y, choice, 1.0 / (self.B * self.world))
+        if self.world > 1:
+            dist.all_reduce(ops.flat_g, group=t.group)     # dense gradients: sum over the ranks (1 / (B world) is folded into dlogits)
+        own_idx, own_g = t.send_grads(route, sg)
+        ss = ops.rows_sumsq(t, own_idx, own_g) if hasattr(ops, "rows_sumsq") else t.grad_sumsq(own_idx, own_g)
+        if self.world > 1:
+            dist.all_reduce(ss, group=t.group)             # every owner's share of the tables' squared gradient norm
+        total = torch.sqrt(ops.dense_sumsq() + ss)
+        coef = torch.clamp(self.clip / (total + 1e-6), max=1.0) if self.clip is not None else torch.ones_like(total)
+        self.last_norm = total
+        ops.dense_update(coef, lr)
+        if hasattr(ops, "rows_update"):
+            ops.rows_update(t, own_idx, own_g, coef, lr, self.eps)
+        else:
+            t.reference_update(own_idx, own_g, float(coef), lr, self.eps)
+        return loss
+
+
+class EngineShardedOps:
+    """The protocol of ShardedTableStep on the HIP engine: a SupernetEngine in `host_embedding` mode (it holds no table; the looked-up
+    rows come with the batch) for the network, and the engine's gather / dedup / row-Adagrad kernels on this rank's table shards."""
+
+    def __init__(self, engine, clip=5.0, eps=1e-2):
+        import ctypes as C
+        from . import _lib as L
+        assert engine.host_embedding, "build the engine with host_embedding=True: the tables live in RowShardedTables"
+        self.eng, self.eps, self.L, self.C = engine, eps, L, C
+        self.flat_g = engine.flat_g
+        self.coef_dev = torch.ones(2, dtype=torch.float32, device=engine.device)
+        self._bufs = {}
+
+    def _launch(self, desc):
+        self.L.check(self.L.load().nasrec_launch(self.eng._sp(), self.C.addressof(desc)))
+
+    def forward_backward(self, int_x, rows, y, choice, grad_scale):
+        eng = self.eng
+        choice = choice if choice is not None else eng.warm_choice
+        cp = eng.compile(choice, int(int_x.shape[0]), train=True, grad_scale=grad_scale)
+        sp = eng._sp()
+        eng._stage_inputs(sp, cp, int_x, torch.zeros(int_x.shape[0], eng.Fs, dtype=torch.int64, device=eng.device), y, rows=rows)
+        (cp.fb if getattr(cp, "fb", None) is not None else cp.fwd).run(sp)
+        if getattr(cp, "fb", None) is None:
+            cp.bwd.run(sp)
+        self.cp = cp
+        return cp.loss, cp.sparse0.grad_tensor().view(int_x.shape[0], eng.Fs, E)
+
+    def dense_sumsq(self):
+        return self.flat_g.double().pow(2).sum()
+
+    def dense_update(self, coef, lr):
+        L, eng = self.L, self.eng
+        self.coef_dev[0] = coef.to(torch.float32)
+        eng.lr_dev.fill_(float(lr))
+        ad = L.AdagradDenseDesc()
+        ad.kind, ad.eps, ad.n = L.OP_ADAGRAD_DENSE, self.eps, eng.flat_numel
+        ad.p, ad.g, ad.state = eng.flat_p.data_ptr(), eng.flat_g.data_ptr(), eng.flat_s.data_ptr()
+        ad.lr, ad.coef = eng.lr_dev.data_ptr(), self.coef_dev.data_ptr()
+        tab, ntab = getattr(self.cp, "chunk_tab", None), getattr(self.cp, "nchunks", 0)
+        if tab is not None:
+            ad.chunks, ad.nchunks = tab.data_ptr(), ntab
+        self._launch(ad)
+
+    def gather(self, t: RowShardedTables, idx_safe):
+        L = self.L
+        Bp = int(idx_safe.shape[0])
+        out = torch.empty(Bp, t.Fs, E, dtype=torch.float32, device=idx_safe.device)
+        g = L.EmbedDesc()
+        g.kind, g.B, g.Fs = L.OP_EMBED_GATHER, Bp, t.Fs
+        g.idx, g.out, g.oob = idx_safe.data_ptr(), out.data_ptr(), self.eng.oob.data_ptr()
+        for f in range(t.Fs):
+            g.table[f], g.rows[f] = t.tables[f].data_ptr(), t.tables[f].shape[0]
+        self._launch(g)
+        self._keep = (idx_safe, out)
+        return out
+
+    def _dedup(self, t, own_idx, own_g):
+        L = self.L
+        Bp = int(own_idx.shape[0])
+        key = (Bp, t.Fs)
+        if self._bufs.get("key") != key:
+            dev = own_g.device
+            nb = (Bp + 255) // 256
+            self._bufs = dict(key=key, leader=torch.zeros(Bp * t.Fs, dtype=torch.int32, device=dev), gsum=torch.zeros(Bp * t.Fs * E, device=dev),
+                              partial=torch.zeros(t.Fs * nb, device=dev))
+        b = self._bufs
+        dd = L.EmbDedupDesc()
+        dd.kind, dd.B, dd.Fs = L.OP_EMB_DEDUP, Bp, t.Fs
+        dd.idx, dd.dout = own_idx.data_ptr(), own_g.data_ptr()
+        dd.leader, dd.gsum, dd.sumsq_partial = b["leader"].data_ptr(), b["gsum"].data_ptr(), b["partial"].data_ptr()
+        dd.overflow = self.eng.oob.data_ptr() + 4
+        self._launch(dd)
+        return b
+
+    def rows_sumsq(self, t, own_idx, own_g):
+        self._own = (own_idx.contiguous(), own_g.contiguous())
+        b = self._dedup(t, *self._own)
+        return b["partial"].double().sum()
+
+    def rows_update(self, t, own_idx, own_g, coef, lr, eps):
+        L = self.L
+        b = self._bufs
+        own_idx, own_g = self._own
+        ar = L.AdagradRowsDesc()
+        ar.kind, ar.B, ar.Fs, ar.eps = L.OP_ADAGRAD_ROWS, int(own_idx.shape[0]), t.Fs, eps
+        ar.idx, ar.leader, ar.gsum = own_idx.data_ptr(), b["leader"].data_ptr(), b["gsum"].data_ptr()
+        for f in range(t.Fs):
+            ar.table[f], ar.state[f], ar.rows[f] = t.tables[f].data_ptr(), t.state[f].data_ptr(), t.tables[f].shape[0]
+        ar.lr, ar.coef = self.eng.lr_dev.data_ptr(), self.coef_dev.data_ptr()
+        self._launch(ar)

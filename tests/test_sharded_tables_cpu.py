@@ -1,0 +1,169 @@
+"""world_size-2 gloo tests (CPU) of the row-sharded embedding tables (nasrec_amd/sharded_tables.py): ids, rows and row
+gradients travel by all-to-all, every rank owns a row range of every table, and the training step (ShardedTableStep — the code the
+GPUs run, here with the oracle behind its protocol) equals a single process at the global batch with whole tables
+(reference semantics: supernet.py:404-430 look-ups, train_utils.py:262-286 step)."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+WORLD = 2
+TABLES = [5, 64, 1, 301, 2]  # sizes that do not divide by the world size, a one-row table, a table smaller than the world... all in one
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _whole_tables(seed=3):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(n, 16, generator=g, dtype=torch.float64) * 0.1 for n in TABLES]
+
+
+def _case():
+    from oracle import nasrec_oracle as O
+    Bg, Fd, steps = 12, 3, 3
+    cfg = O.NetCfg(2, O.ops_config_lib["autoctr"], True, "relu", fixed=False)
+    P = O.Params(torch.float64)
+    batches = []
+    for s in range(steps):
+        int_x, cat_x, y = O.synthetic_batch(Bg, Fd, TABLES, seed=70 + s)
+        if s == 1:
+            cat_x[:, 1] = 17  # every sample hits the same row of table 1: duplicates across ranks, one owner sums them all
+        batches.append((int_x.double(), cat_x, y.double().view(-1, 1)))
+    whole = _whole_tables()
+    for f, t in enumerate(whole):
+        P["_embedding.%d.weight" % f] = t.clone()
+    with torch.no_grad():
+        O.supernet_forward(P, cfg, batches[0][0][:4], batches[0][1][:4], O.full_path_choice(cfg), num_embeddings=TABLES)
+    P.frozen = True
+    np.random.seed(77)
+    sampler = O.PathSampler(cfg, "default", "binomial-0.5")
+    choices = [json.loads(json.dumps(sampler.sample(), default=lambda o: o.tolist() if hasattr(o, "tolist") else o.item())) for _ in range(steps)]
+    return cfg, P, batches, choices, 0.05
+
+
+class OracleOps:
+    """the ShardedTableStep protocol with the CPU oracle as the network"""
+
+    def __init__(self, cfg, P, Fs, eps=1e-2):
+        self.cfg, self.P, self.Fs, self.eps = cfg, P, Fs, eps
+        self.names = [k for k in P if not k.startswith("_embedding.")]
+        self.sizes = [P[k].numel() for k in self.names]
+        self.flat_g = torch.zeros(sum(self.sizes), dtype=torch.float64)
+        self.state = {k: torch.zeros_like(P[k]) for k in self.names}
+        self.has_grad = []
+
+    def forward_backward(self, int_x, rows, y, choice, grad_scale):
+        from oracle import nasrec_oracle as O
+        B = int_x.shape[0]
+        leaves = {k: self.P[k].detach().requires_grad_(True) for k in self.names}
+        for f in range(self.Fs):
+            leaves["_embedding.%d.weight" % f] = rows[:, f].detach().clone().requires_grad_(True)  # row b = sample b's row
+        Pl = O.Params(torch.float64, frozen=True)
+        Pl.update(leaves)
+        logits = O.supernet_forward(Pl, self.cfg, int_x, torch.arange(B).view(B, 1).repeat(1, self.Fs), choice)
+        mean_loss = O.bce_with_logits_mean(logits.view(-1), y.view(-1))
+        keys = list(leaves)
+        grads = torch.autograd.grad(mean_loss * B * grad_scale, [leaves[k] for k in keys], allow_unused=True)
+        g = dict(zip(keys, grads))
+        self.has_grad = [g[k] is not None for k in self.names]
+        self.flat_g.copy_(torch.cat([(g[k] if g[k] is not None else torch.zeros_like(self.P[k])).reshape(-1) for k in self.names]))
+        return mean_loss.detach(), torch.stack([g["_embedding.%d.weight" % f] for f in range(self.Fs)], 1)
+
+    def dense_sumsq(self):
+        return self.flat_g.pow(2).sum()
+
+    def dense_update(self, coef, lr):
+        off = 0
+        for k, n, used in zip(self.names, self.sizes, self.has_grad):
+            if used:  # torch skips parameters whose grad is None
+                g = self.flat_g[off:off + n].view_as(self.P[k]) * coef
+                self.state[k] += g * g
+                self.P[k] -= lr * g / (self.state[k].sqrt() + self.eps)
+            off += n
+
+
+def _worker(rank, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.set_num_threads(2)
+    from nasrec_amd.sharded_tables import RowShardedTables, ShardedTableStep
+    cfg, P, batches, choices, lr = _case()
+    whole = _whole_tables()
+    t = RowShardedTables(TABLES, "cpu", dtype=torch.float64, init_fn=lambda f, lo, hi: whole[f][lo:hi].clone())
+    Bl = batches[0][0].shape[0] // WORLD
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    # look-up alone: the rows that come back are exactly the whole tables' rows of the local ids
+    rows, route = t.lookup(batches[0][1][sl].contiguous())
+    for f in range(len(TABLES)):
+        assert torch.equal(rows[:, f], whole[f][batches[0][1][sl, f]])
+    dense = {k: v for k, v in P.items() if not k.startswith("_embedding.")}
+    ops = OracleOps(cfg, O_params(dense), len(TABLES))
+    step = ShardedTableStep(ops, t, Bl, clip=5.0, eps=1e-2)
+    losses, norms = [], []
+    for (int_x, cat_x, y), ch in zip(batches, choices):
+        loss = step.step(int_x[sl], cat_x[sl].contiguous(), y[sl], lr, choice=ch)
+        losses.append(float(loss))
+        norms.append(float(step.last_norm))
+    out[rank] = dict(dense={k: v.detach().clone() for k, v in ops.P.items()}, tables=[t.whole_table(f).clone() for f in range(len(TABLES))],
+                     losses=losses, norms=norms, shard_rows=[tt.shape[0] for tt in t.tables])
+    dist.destroy_process_group()
+
+
+def O_params(d):
+    from oracle import nasrec_oracle as O
+    P = O.Params(torch.float64)
+    for k, v in d.items():
+        P[k] = v.clone()
+    P.frozen = True
+    return P
+
+
+def test_sharded_table_step_equals_single_process_with_whole_tables():
+    from oracle import nasrec_oracle as O
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(port, out), nprocs=WORLD, join=True)
+    cfg, P, batches, choices, lr = _case()
+    state, ref_norms = {}, []
+    for (int_x, cat_x, y), ch in zip(batches, choices):
+        res = O.train_step(P, state, cfg, ch, int_x, cat_x, y, lr=lr)
+        ref_norms.append(float(res[1]) if isinstance(res, tuple) and len(res) > 1 and torch.is_tensor(res[1]) else None)
+    r0, r1 = out[0], out[1]
+    for r in (r0, r1):
+        for k, v in r["dense"].items():
+            assert torch.allclose(v, P[k], rtol=0, atol=1e-10), k
+        for f in range(len(TABLES)):
+            assert torch.allclose(r["tables"][f], P["_embedding.%d.weight" % f], rtol=0, atol=1e-10), f
+    for k in r0["dense"]:
+        assert torch.equal(r0["dense"][k], r1["dense"][k])  # the dense replicas stay bit-identical
+    assert r0["norms"] == r1["norms"]
+    # every row has exactly one owner: shard sizes add up (empty shards keep one unused row)
+    for f, n in enumerate(TABLES):
+        rp = -(-n // WORLD)
+        assert [max(min(n, (r + 1) * rp) - min(n, r * rp), 1) for r in range(WORLD)] == [r0["shard_rows"][f], r1["shard_rows"][f]]
+
+
+def test_single_process_route_is_the_identity():
+    from nasrec_amd.sharded_tables import RowShardedTables
+    whole = _whole_tables()
+    t = RowShardedTables(TABLES, "cpu", dtype=torch.float64, init_fn=lambda f, lo, hi: whole[f][lo:hi].clone())
+    g = torch.Generator().manual_seed(1)
+    cat = torch.stack([torch.randint(0, n, (9,), generator=g) for n in TABLES], 1)
+    rows, route = t.lookup(cat)
+    for f in range(len(TABLES)):
+        assert torch.equal(rows[:, f], whole[f][cat[:, f]])
+    sg = torch.randn(9, len(TABLES), 16, generator=g, dtype=torch.float64)
+    own_idx, own_g = t.send_grads(route, sg)
+    assert torch.equal(own_idx, cat) and torch.equal(own_g, sg)  # world 1: the owner-side batch is the batch
