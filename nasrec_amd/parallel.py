@@ -138,8 +138,9 @@ class DataParallelStep:
             plan.forward()
             for run, _ in plan.segments:
                 run()
-            all_gather_rows(self.cat_all, plan.cat_local)
-            all_gather_rows(self.sg_all, plan.sparse_grad)
+            # TWO collectives, not three: the ids and the row gradients of the local batch travel as one packed all-gather
+            # (each collective costs a launch + a ring latency at this step size), then the dense gradient arena
+            self._gather_packed(plan.cat_local, plan.sparse_grad)
             dist.all_reduce(eng.flat_g, op=dist.ReduceOp.SUM)
             self.opt(plan)
             self._last = ("dp", plan)
@@ -158,6 +159,22 @@ class DataParallelStep:
         self.opt(plan)
         self._last = ("dp", plan)
         return plan.loss
+
+    def _gather_packed(self, cat_local, sg_local):
+        """ids [B, Fs] int64 + row gradients [B, Fs, 16] of every rank -> self.cat_all / self.sg_all (rank order) with ONE all-gather
+        of a packed byte buffer [ids | gradients] per rank"""
+        nb_i, nb_g = cat_local.numel() * 8, sg_local.numel() * sg_local.element_size()
+        if getattr(self, "_pack_local", None) is None or self._pack_local.numel() != nb_i + nb_g:
+            dev = cat_local.device
+            self._pack_local = torch.empty(nb_i + nb_g, dtype=torch.uint8, device=dev)
+            self._pack_all = torch.empty(self.world * (nb_i + nb_g), dtype=torch.uint8, device=dev)
+        pl, pa = self._pack_local, self._pack_all
+        pl[:nb_i].view(torch.int64).copy_(cat_local.reshape(-1))
+        pl[nb_i:].view(sg_local.dtype).copy_(sg_local.reshape(-1))
+        all_gather_rows(pa, pl)
+        pa = pa.view(self.world, nb_i + nb_g)
+        self.cat_all.view(self.world, -1).copy_(pa[:, :nb_i].contiguous().view(torch.int64).view(self.world, -1))
+        self.sg_all.view(self.world, -1).copy_(pa[:, nb_i:].contiguous().view(sg_local.dtype).view(self.world, -1))
 
     def last_loss(self):
         if self._last[0] == "dp":

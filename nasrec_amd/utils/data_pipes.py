@@ -91,20 +91,44 @@ class TsvShard:
 
 
 class NativeTsvShard(TsvShard):
-    """the same batches as TsvShard, parsed by nasrec_tsv_parse (C-ABI) in chunks of `chunk_bytes`"""
+    """the same batches as TsvShard, parsed by nasrec_tsv_parse (C-ABI) in chunks of `chunk_bytes`.
+
+    The rows of one parser call (~16 k) become ONE set of tensors — label, the log transform, the ids: three tensor operations per
+    16 k rows — and the batches are views of them: assembling every 256-row batch with its own tensor calls held the interpreter lock
+    for ~80 us per batch and capped eight reader threads at 0.4 M rows/s, below what the engine consumes at batch 256.
+    `iter_super(pin=True)` yields those row blocks in pinned host memory for the device staging of RoundRobinLoader."""
 
     chunk_bytes = 4 << 20
 
-    def _assemble(self, label, dense, cat):
+    def _assemble(self, label, dense, cat, pin=False):
         spec = self.spec
-        y = torch.from_numpy(label).float().view(-1, 1)
+        m = len(label)
+        if not pin:
+            y = torch.from_numpy(label).float().view(-1, 1)
+            if spec.dense_is_zero:
+                int_x = torch.zeros(m, spec.Fd, dtype=torch.float32)
+            else:
+                int_x = torch.log(torch.clamp_min(torch.from_numpy(dense), 0) + 1)
+            return int_x, torch.from_numpy(cat), y
+        y = torch.empty(m, 1, dtype=torch.float32, pin_memory=True)
+        y.copy_(torch.from_numpy(label).view(-1, 1))
+        int_x = torch.empty(m, spec.Fd, dtype=torch.float32, pin_memory=True)
         if spec.dense_is_zero:
-            int_x = torch.zeros(len(label), spec.Fd, dtype=torch.float32)
+            int_x.zero_()
         else:
-            int_x = torch.log(torch.clamp_min(torch.from_numpy(dense), 0) + 1)
-        return int_x, torch.from_numpy(cat), y
+            torch.log(torch.clamp_min(torch.from_numpy(dense), 0) + 1, out=int_x)
+        c = torch.empty(m, spec.Fs, dtype=torch.int64, pin_memory=True)
+        c.copy_(torch.from_numpy(cat))
+        return int_x, c, y
 
     def __iter__(self) -> Iterator[Batch]:
+        bs = self.batch_size
+        for int_x, cat_x, y in self.iter_super():
+            for i in range(0, len(y), bs):
+                yield int_x[i:i + bs], cat_x[i:i + bs], y[i:i + bs]
+
+    def iter_super(self, pin=False) -> Iterator[Batch]:
+        """row blocks (int_x, cat_x, y) whose length is a multiple of the batch size (the shard's last block may end in a short batch)"""
         from .. import _lib as L
         lib = L.load()
         spec, bs = self.spec, self.batch_size
@@ -113,8 +137,7 @@ class NativeTsvShard(TsvShard):
         consumed, status = C.c_int64(), C.c_int32()
 
         def fresh(carry=None):
-            # rows are parsed straight into these arrays and handed out as views (no per-batch copies); the < bs rows left
-            # over after a call move to the front of the next set
+            # rows are parsed straight into these arrays; the < bs rows left over after a block move to the front of the next set
             arrs = [np.empty(cap + 2 * bs, np.int64), np.empty((cap + 2 * bs, spec.Fd), np.int64), np.empty((cap + 2 * bs, spec.Fs), np.int64)]
             k = 0
             if carry is not None:
@@ -128,14 +151,12 @@ class NativeTsvShard(TsvShard):
         def emit(final=False):
             nonlocal arrs, fill
             nb = fill // bs
-            for i in range(nb):
-                yield self._assemble(arrs[0][i * bs:(i + 1) * bs], arrs[1][i * bs:(i + 1) * bs], arrs[2][i * bs:(i + 1) * bs])
-            rest = fill - nb * bs
-            if final and rest:
-                yield self._assemble(arrs[0][nb * bs:fill], arrs[1][nb * bs:fill], arrs[2][nb * bs:fill])
-                rest = 0
-            if nb or final:
-                arrs, fill = fresh([a[nb * bs:nb * bs + rest] for a in arrs] if rest else None)
+            m = fill if final else nb * bs
+            if m:
+                yield self._assemble(arrs[0][:m], arrs[1][:m], arrs[2][:m], pin)
+            rest = fill - m
+            if m or final:
+                arrs, fill = fresh([a[m:m + rest] for a in arrs] if rest else None)
 
         with open(self.path, "rb") as f:
             tail = b""
@@ -209,15 +230,52 @@ class _Prefetch:
         return item
 
 
+class _DeviceBlocks:
+    """a shard's row blocks staged to the GPU: parsed into pinned host memory by the shard's thread, copied with non-blocking H2D
+    copies on a side stream (the reference does three blocking `.to(gpu)` per batch on the compute stream, train_utils.py:257-259),
+    handed out as device batches once the copy's event has been waited for on the consumer's stream"""
+
+    def __init__(self, shard, device, stream):
+        self.shard, self.device, self.stream = shard, device, stream
+
+    def __iter__(self):
+        for host in self.shard.iter_super(pin=True):
+            with torch.cuda.stream(self.stream):
+                dev = tuple(t.to(self.device, non_blocking=True) for t in host)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            yield dev, ev, host  # (the pinned block stays referenced until the consumer drops the item)
+
+
 class RoundRobinLoader:
     """interleaves the batches of several shards in the order a one-worker-per-shard DataLoader delivers them; with
-    `prefetch` every shard is read by its own background thread"""
+    `prefetch` every shard is read by its own background thread; with `device` (native shards) the batches arrive ON the GPU,
+    staged block-wise through pinned memory on a second stream"""
 
-    def __init__(self, pipes, prefetch=False):
+    def __init__(self, pipes, prefetch=False, device=None):
         self.pipes, self.prefetch = list(pipes), prefetch
+        self.device = torch.device("cuda", device) if isinstance(device, int) else (torch.device(device) if device is not None else None)
+        if self.device is not None and (self.device.type != "cuda" or not all(isinstance(p, NativeTsvShard) for p in self.pipes)):
+            self.device = None
+        self._stream = None
+
+    def _device_batches(self, blocks, bs):
+        cur = torch.cuda.current_stream(self.device)
+        for dev, ev, host in blocks:
+            cur.wait_event(ev)
+            for t in dev:
+                t.record_stream(cur)
+            int_x, cat_x, y = dev
+            for i in range(0, len(y), bs):
+                yield int_x[i:i + bs], cat_x[i:i + bs], y[i:i + bs]
 
     def __iter__(self) -> Iterator[Batch]:
-        live = [_Prefetch(p) if self.prefetch else iter(p) for p in self.pipes]
+        if self.device is not None:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(self.device)
+            live = [iter(self._device_batches(_Prefetch(_DeviceBlocks(p, self.device, self._stream), depth=3), p.batch_size)) for p in self.pipes]
+        else:
+            live = [_Prefetch(p) if self.prefetch else iter(p) for p in self.pipes]
         while live:
             nxt = []
             for it in live:
@@ -300,4 +358,6 @@ def make_loaders(args):
     """train / test loaders of one run (what main_train.py:86-104 builds from the pipes)"""
     train, test, _, _ = GET_PIPES[args.dataset](args)
     threaded = any(isinstance(p, NativeTsvShard) for p in train)
-    return RoundRobinLoader(train, prefetch=threaded), RoundRobinLoader(test, prefetch=threaded)
+    # batches arrive on the GPU (pinned blocks, second stream) when the run has one: NASREC_STAGE_ON_DEVICE=0 keeps host batches
+    dev = getattr(args, "gpu", None) if (torch.cuda.is_available() and os.environ.get("NASREC_STAGE_ON_DEVICE", "1") != "0") else None
+    return RoundRobinLoader(train, prefetch=threaded, device=dev), RoundRobinLoader(test, prefetch=threaded, device=dev)

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Cost of the GLOBAL-batch row-gradient dedup + row Adagrad that every rank of a data-parallel step runs (replicated tables: each rank
+applies the gathered row gradients of all ranks, nasrec_amd/parallel.py): cfg 5 at 8 GPUs = 65 536 samples x 10 fields, cfg 3 / 4 at
+8 GPUs = 32 768 x 26 / 23.  One GPU is enough to time it: the kernels do not care where the rows came from."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from nasrec_amd import _lib as L, plan as P
+from nasrec_amd.engine import SupernetEngine
+from nasrec_amd.search_space import ops_config_lib
+from nasrec_amd.utils.config import DATASETS
+
+lib = L.load()
+for cfgid, world in ((5, 8), (3, 8), (4, 8), (5, 1)):
+    w = bench.WORKLOADS[cfgid]
+    ds = DATASETS[w["dataset"]]
+    tables = [min(n, w["cap"]) if w.get("cap") else n for n in ds["tables"]]
+    Bg, Fs = w["B"] * world, ds["Fs"]
+    cfg = P.NetConfig(1, ops_config_lib["autoctr"], True, "relu", fixed=False)
+    eng = SupernetEngine(cfg, ds["Fd"], Fs, tables)
+    eng._ensure_table_state()
+    g = torch.Generator().manual_seed(1)
+    cat = bench.synthetic_ids(Bg, tables, g).cuda()
+    sg = torch.randn(Bg * Fs * 16, device="cuda") * 1e-3
+
+    class H:
+        pass
+    h = H()
+    descs = eng._optimizer_descs(h, Bg, cat, sg, 5.0, 1e-2)
+    sp = torch.cuda.current_stream().cuda_stream
+    names = {getattr(L, n): n[3:] for n in dir(L) if n.startswith("OP_")}
+    parts = []
+    for d in descs:
+        us = bench.time_desc(lib, L, sp, d, iters=20) * 1e3
+        parts.append("%s %.0f us" % (names[d.kind], us))
+    torch.cuda.synchronize()
+    eng.check_indices()
+    print("cfg %d x %d GPUs: global batch %d x %d fields (%.1f MB of row gradients): %s" % (cfgid, world, Bg, Fs, Bg * Fs * 64 / 1e6, ", ".join(parts)))
+    del eng, cat, sg
+    torch.cuda.empty_cache()
