@@ -117,7 +117,9 @@ static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
   long wgs = 0;
   for (int q = 0; q < nprob; ++q) wgs += (long)((d->seg[q].M + 63) / 64) * ((d->seg[q].N + 63) / 64) * S;
   const bool deep = Kmax > 32;
-  if (AM == NASREC_AM_TOKK && token_dw_eligible(d)) {
+  if (AM == NASREC_AM_KC && BMODE == NASREC_AM_KC && CM == NASREC_CM_PLAIN && gemm_kslice_eligible(d)) {
+    return launch_gemm_kslice(st, d);  // batch-256 regime, one large forward product: K split inside the workgroup, single pass
+  } else if (AM == NASREC_AM_TOKK && token_dw_eligible(d)) {
     launch_token_dw(st, d, Mmax, Nmax);  // large batch: a wavefront per sample, operands straight to MFMA registers (token_linear.hip)
   } else if (CM == NASREC_CM_PLAIN && gemm_fast_eligible(d, Mmax, Nmax)) {
     // throughput regime: 128x128x32 tiles, 16-byte staging, LDS double buffer (gemm_fast.hip)

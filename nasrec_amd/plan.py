@@ -383,6 +383,26 @@ def _fast_gemm_splitk(amode, bmode, cmode, segs, zmode):
 
 
 _FAST_BINDINGS = ((L.AM_KC, L.AM_KC), (L.AM_KC, L.AM_RC), (L.AM_RC, L.AM_RC))
+def kslice_eligible(amode, bmode, cmode, segs, zmode):
+    """mirror of csrc/gemm_kslice.hip `gemm_kslice_eligible`: one large forward product of the batch-256 regime runs as a single pass
+    with K split inside the workgroup (no split-K workspace, no second launch)"""
+    if (amode, bmode, cmode) != (L.AM_KC, L.AM_KC, L.CM_PLAIN) or zmode:
+        return False
+    M, N = segs[0]["M"], segs[0]["N"]
+    K = 0
+    for sd in segs:
+        if sd.get("Aaux") or sd.get("Baux") or sd.get("ones_col") or (0 < sd.get("Mvalid", M) < M):
+            return False
+        if sd.get("A") and sd["K"] > 0:
+            K += sd["K"]
+            if M * sd["lda"] >= (1 << 29) or N * sd["ldb"] >= (1 << 29):
+                return False
+    if len(segs) > 4:  # KS_SEGS
+        return False
+    tiles = ((M + 31) // 32) * ((N + 31) // 32)
+    return M <= 512 and 128 <= tiles <= 512 and K >= 512
+
+
 BALANCED_MIN_SAVING_US = 80.0
 
 
@@ -417,6 +437,9 @@ def gemm_kernel_name(d) -> str:
     """which kernel family launch_gemm picks for this descriptor (mirror of csrc/gemm.hip / gemm_fast.hip)"""
     segs = [dict(A=d.seg[q].A, Aaux=d.seg[q].Aaux, Baux=d.seg[q].Baux, M=d.seg[q].M, N=d.seg[q].N, K=d.seg[q].K) for q in range(d.nseg)]
     live = [sd for sd in segs if sd["A"]]
+    if d.splitk <= 1 and kslice_eligible(d.amode, d.bmode, d.cmode, [dict(sd, ones_col=d.seg[q].ones_col, Mvalid=d.seg[q].Mvalid, lda=d.seg[q].lda,
+                                                                          ldb=d.seg[q].ldb) for q, sd in enumerate(segs)], d.zmode):
+        return "gemm_kslice_kernel"
     if (d.cmode == L.CM_TOKJ and d.bmode == L.AM_TOKR and d.amode in (L.AM_KC, L.AM_RC) and d.splitk <= 1 and not d.pre_add
             and not d.save_act and d.mul_nseg == 0 and all(sd["M"] <= 80 and sd["N"] >= 16 * 1024 and not sd["Aaux"] and not sd["Baux"] for sd in segs)):
         return "token_linear_kernel"  # (csrc/token_linear.hip `token_linear_eligible` has the complete rule)
@@ -506,6 +529,8 @@ def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, act=0, bias_on_rows=0, mas
             S = max(4, min(32, 256 // nseg, B // 64))
     if splitk is not None:
         S = splitk
+    elif B <= 512 and S > 1 and kslice_eligible(amode, bmode, cmode, segs, zmode):
+        S = 1  # csrc/gemm_kslice.hip: K is split inside the workgroup
     d.splitk = 1
     if fast == 1 and S == 1 and B > 256 and ctx.sk_workspace is not None and _balanced_schedule_pays(segs, zmode):
         d.splitk = L.SPLITK_BALANCED

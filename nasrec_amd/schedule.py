@@ -345,6 +345,11 @@ def gemm_capable(d) -> bool:
     S = d.splitk if d.splitk > 1 else 1
     if nprob == 1 and ((d.seg[0].M + 63) // 64) * ((d.seg[0].N + 63) // 64) * S >= 128:
         return False
+    from . import plan as P
+    if P.kslice_eligible(d.amode, d.bmode, d.cmode, [dict(A=d.seg[q].A, Aaux=d.seg[q].Aaux, Baux=d.seg[q].Baux, ones_col=d.seg[q].ones_col,
+                                                           Mvalid=d.seg[q].Mvalid, M=d.seg[q].M, N=d.seg[q].N, K=d.seg[q].K, lda=d.seg[q].lda,
+                                                           ldb=d.seg[q].ldb) for q in range(d.nseg)], d.zmode):
+        return False  # csrc/gemm_kslice.hip: a kernel of its own (1024-thread workgroups, 133 KB of LDS)
     s0 = d.seg[0]
     if not d.zmode:
         for q in range(d.nseg):

@@ -34,9 +34,26 @@ args = MT.build_parser().parse_args([
     "--learning_rate", "0.16", "--train_batch_size", "256", "--test_batch_size", "4096", "--wd", "0", "--logging_dir", os.path.join(tmp, "log"),
     "--gpu", "0", "--train_limit", str(a.rows), "--display_interval", "1000", "--test_interval", "1000000"])
 t1 = time.time()
+# time the epoch call on its own (model build and table initialisation are not pipeline time)
+_orig = MT.train_and_test_one_epoch
+epoch_s = []
+
+
+def timed(*a_, **k_):
+    import torch as _t
+    _t.cuda.synchronize()
+    t = time.time()
+    r = _orig(*a_, **k_)
+    _t.cuda.synchronize()
+    epoch_s.append(time.time() - t)
+    return r
+
+
+MT.train_and_test_one_epoch = timed
 logs = MT.main(args)
 import torch
 torch.cuda.synchronize()
 dt = time.time() - t1
-print("END-TO-END: %d rows, %.1f s wall (incl. model build, 2 test passes) -> %.0f rows/s; final train loss %.4f" % (
-    a.rows, dt, a.rows / dt, logs[0]["train_loss"][-1]))
+print("END-TO-END: %d rows, %.1f s wall (incl. model build, 2 test passes) -> %.0f rows/s; the epoch call alone (reader threads -> H2D -> fused step, "
+      "incl. its test passes over 4096 rows x %d shards): %.2f s -> %.0f rows/s; final train loss %.4f" % (
+    a.rows, dt, a.rows / dt, a.shards, epoch_s[0], a.rows / epoch_s[0], logs[0]["train_loss"][-1]))
