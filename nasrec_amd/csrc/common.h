@@ -32,6 +32,43 @@ __device__ __forceinline__ float act_apply(float z, int act) {
   }
 }
 
+// Pull the first BYTES of the kernel-argument segment through the scalar cache in ONE memory round trip.  The descriptors of this
+// engine are by-value kernel arguments of 0.4 - 4 KB, cold in every cache when a kernel starts; the compiler loads their fields lazily,
+// next to the first use, so a prologue that branches on one field before it reads the next pays a round trip to memory (1.5 - 2 us on
+// a cold L2) per level.  Called first in a kernel, this touches every 64-byte line at once; the compiler's own loads then hit the
+// scalar cache.  (One asm block with its own wait: the destination register is dead afterwards, never live across other code.)
+template <int BYTES>
+__device__ __forceinline__ void warm_kernarg() {
+  const unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  int sink;
+  static_assert(BYTES % 64 == 0 && BYTES >= 64 && BYTES <= 4096, "whole 64-byte lines");
+  if (BYTES <= 1024) {
+    asm volatile(
+        ".set nasrec_wk_off, 0\n"
+        ".rept %c2\n"
+        "s_load_dword %0, %1, nasrec_wk_off\n"
+        ".set nasrec_wk_off, nasrec_wk_off + 64\n"
+        ".endr\n"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(sink)
+        : "s"(p), "n"(BYTES / 64)
+        : "memory");
+  } else {  // more than 16 loads: the counter has 4 bits, drain in groups of 16
+    asm volatile(
+        ".set nasrec_wk_off, 0\n"
+        ".rept %c2\n"
+        ".rept 16\n"
+        "s_load_dword %0, %1, nasrec_wk_off\n"
+        ".set nasrec_wk_off, nasrec_wk_off + 64\n"
+        ".endr\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        ".endr"
+        : "=&s"(sink)
+        : "s"(p), "n"(BYTES / 1024)
+        : "memory");
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -397,7 +397,7 @@ def kslice_eligible(amode, bmode, cmode, segs, zmode):
             K += sd["K"]
             if M * sd["lda"] >= (1 << 29) or N * sd["ldb"] >= (1 << 29):
                 return False
-    if len(segs) > 4:  # KS_SEGS
+    if len(segs) > 4:  # KS_SEGS (csrc/gemm_kslice.hip)
         return False
     tiles = ((M + 31) // 32) * ((N + 31) // 32)
     return M <= 512 and 128 <= tiles <= 512 and K >= 512
