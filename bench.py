@@ -97,6 +97,19 @@ class BatchPool:
         return d[0], self.ids[i % self.n], d[1]
 
 
+def gemm_algorithmic_bytes(d):
+    """bytes a GEMM launch has to move if every operand element is read once and every output element written once"""
+    s0 = d.seg[0]
+    if d.zmode:
+        return sum(4 * (d.seg[q].M * d.seg[q].K + d.seg[q].N * d.seg[q].K + d.seg[q].M * d.seg[q].N) for q in range(d.nseg) if d.seg[q].A)
+    b = sum(4 * (s0.M + s0.N) * d.seg[q].K for q in range(d.nseg) if d.seg[q].A)
+    outs = 1 + (1 if d.save_z else 0) + (1 if d.save_act else 0) + (1 if d.beta else 0) + (1 if d.pre_add else 0)
+    b += 4 * s0.M * s0.N * outs + (4 * s0.N if d.bias else 0)
+    if 1 < d.splitk < 64:
+        b += 2 * 4 * d.splitk * s0.M * s0.N
+    return b
+
+
 def gemm_flops(d):
     f = 0
     for q in range(d.nseg):
@@ -378,7 +391,9 @@ def main():
                               "kernel": "%s<%d,%d,%d> M=%d N=%d K=%d nseg=%d splitk=%d" % (
                                   P.gemm_kernel_name(dom), dom.amode, dom.bmode, dom.cmode, s0.M, s0.N, sum(dom.seg[q].K for q in range(dom.nseg)),
                                   dom.nseg, dom.splitk),
-                              "flops_per_launch": fl, "avg_launch_us": ms * 1e3}
+                              "flops_per_launch": fl, "avg_launch_us": ms * 1e3,
+                              # operands + outputs of this launch, each once (split-K slabs written and read back included)
+                              "algorithmic_bytes": gemm_algorithmic_bytes(dom)}
         # HBM/fabric traffic of that launch: PMC counters cannot be collected from inside this process; a measured value is
         # quoted only when profiles/ holds one taken from THIS build (csrc hash) for exactly this launch, else null
         try:

@@ -32,16 +32,19 @@ __device__ __forceinline__ float act_apply(float z, int act) {
   }
 }
 
-// Pull the first BYTES of the kernel-argument segment through the scalar cache in ONE memory round trip.  The descriptors of this
-// engine are by-value kernel arguments of 0.4 - 4 KB, cold in every cache when a kernel starts; the compiler loads their fields lazily,
-// next to the first use, so a prologue that branches on one field before it reads the next pays a round trip to memory (1.5 - 2 us on
-// a cold L2) per level.  Called first in a kernel, this touches every 64-byte line at once; the compiler's own loads then hit the
-// scalar cache.  (One asm block with its own wait: the destination register is dead afterwards, never live across other code.)
+// Pull the first BYTES of the kernel-argument segment through the scalar cache in ONE memory round trip, from the workgroup's first
+// wave.  The descriptors of this engine are by-value kernel arguments of 0.4 - 4 KB, cold in every cache when a kernel starts; the
+// compiler loads their fields lazily, next to the first use, so a prologue that branches on one field before it reads the next pays
+// a round trip to memory (0.6 - 2 us on a cold L2) per level.  Called first in a kernel, this touches every 64-byte line at once;
+// the lazily placed loads of all waves then find the lines in (or on their way into) the scalar cache.  One wave only: scalar loads
+// are slow to issue (64 of them from every wave of every workgroup cost more than they saved: cfg 2 step 0.422 -> 0.447 ms).
+// (One asm block with its own wait: the destination register is dead afterwards, never live across other code.)
 template <int BYTES>
 __device__ __forceinline__ void warm_kernarg() {
+  static_assert(BYTES % 64 == 0 && BYTES >= 64 && BYTES <= 4096, "whole 64-byte lines");
+  if (threadIdx.x >= 64) return;
   const unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
   int sink;
-  static_assert(BYTES % 64 == 0 && BYTES >= 64 && BYTES <= 4096, "whole 64-byte lines");
   if (BYTES <= 1024) {
     asm volatile(
         ".set nasrec_wk_off, 0\n"

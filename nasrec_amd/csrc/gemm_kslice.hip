@@ -25,10 +25,11 @@
 // No workspace, no second launch; the summation order is a fixed function of the segment list, so results are reproducible run to run.
 // Measured (256 x 768, cold L2 every launch, tools/kslice_probe.py): K = 13 + 768 + 768 + 16 with bias + ReLU 13.4 us (46 TFLOP/s,
 // 0.29 of peak; general template + second pass 20.0 us, a register-staged 256-deep form 17.7 us, fragment loads straight to
-// registers 18.6 us, this form before the waves were specialised 16.0 us), K = 780 9.6 us.  What bounds it now (in-kernel stamps,
-// tools/kslice_stamps.py): the feeders deliver a chunk per ~1800 cycles against 1024 cycles of MFMA per chunk — every chunk is a
-// first touch for the XCD (the L2 is cold at launch and its 24 workgroups walk k in step), a piece takes the 2.3 us trip to the
-// Infinity Cache, and 96 KB is what fits in flight in LDS.
+// registers 18.6 us, this form before the waves were specialised 16.0 us), K = 780 9.6 us.  Where the rest goes (in-kernel stamps,
+// tools/kslice_stamps.py, K = 1565): ~1800 cycles per chunk against 1024 cycles of MFMA per SIMD and chunk.  The feeders never wait
+// for their pieces (a fifth LDS buffer, 128 KB in flight, changed nothing); they spend 500 (x) to 900 (W) cycles per chunk issuing
+// four pieces each, and the multipliers' 16 MFMAs per chunk take 1150 - 1600 cycles while feeders issue on the same SIMD (raising
+// the multipliers' s_setprio changed nothing either).  Launch + drain outside the workgroups' lifetime: ~3 us of the 13.4.
 #include <cstdlib>
 #include <cstring>
 #include "gemm_tile.h"
@@ -36,12 +37,13 @@
 #define KS_TM 32
 #define KS_TN 32
 #define KS_DC 128                       // k depth of a staged chunk = 2 halves x 64
-#define KS_NB 4                         // LDS buffers (KS_NB - 1 chunks in flight)
+#define KS_NB 4                         // LDS buffers (KS_NB - 1 chunks in flight; a fifth buffer, 128 KB in flight, changed nothing: the
+                                        // feeders never wait for their pieces, tools/kslice_stamps.py)
 #define KS_CH ((KS_TM + KS_TN) * KS_DC)  // floats per buffer: rows 0..31 = x tile, 32..63 = W tile
 #define KS_SEGS 4
 #ifdef KS_STAMPS  // tools/kslice_stamps.py: wave 0 of every workgroup writes the 100 MHz clock at six points into desc.workspace
 #define KS_STAMP(i) \
-  if (tid == 0 && d.workspace) d.workspace[blockIdx.x * 8 + (i)] = __builtin_bit_cast(float, (unsigned)__builtin_readcyclecounter())
+  if (tid == 0 && d.workspace) d.workspace[blockIdx.x * 64 + (i)] = __builtin_bit_cast(float, (unsigned)__builtin_readcyclecounter())
 // per-chunk attribution for wave 0 (a multiplier): cycles from reaching a barrier to leaving it (workspace[.. + 7]); everything else
 // of the k-loop is issue + MFMA time
 #define KS_LOOP_STAMP_A const unsigned ks_ta = (unsigned)__builtin_readcyclecounter()
@@ -61,7 +63,6 @@ __global__ __launch_bounds__(1024) void gemm_kslice_kernel(const nasrec_gemm_des
   const int tid = threadIdx.x, lane = tid & 63;
   KS_STAMP(0);
   warm_kernarg<1024>();  // (the epilogue's fields are read lazily, one by one)
-  KS_STAMP(1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = wave & 3;
   const int tm = tile >> 1, tn = tile & 1;
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(1024) void gemm_kslice_kernel(const nasrec_gemm_des
         float* dst = ks_lds + ibuf * KS_CH + (4 * f + i) * 256;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)dst, 16, vo, 0, 0, 0);
       }
-      ibuf = (ibuf + 1) & (KS_NB - 1);
+      ibuf = ibuf + 1 == KS_NB ? 0 : ibuf + 1;
       ik0 += KS_DC;
       if (ik0 >= iK && iseg < KS_SEGS) {
         iseg = next_live(iseg);
@@ -206,17 +207,38 @@ __global__ __launch_bounds__(1024) void gemm_kslice_kernel(const nasrec_gemm_des
         issue_segment();
       }
     };
-    KS_STAMP(2);
 #pragma unroll
     for (int c = 0; c < KS_NB - 1; ++c) issue();
-    KS_STAMP(3);
     // barrier c: this feeder's pieces of chunk c have landed (counted vmcnt: chunks c + 1, c + 2 may still be in flight) and the
     // multipliers are done reading chunk c - 1, whose buffer chunk c + 3 overwrites
+#ifdef KS_STAMPS
+    unsigned fw_data = 0, fw_bar = 0, fw_issue = 0;
+#endif
     for (int c = 0; c < nchunks; ++c) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#ifdef KS_STAMPS
+      const unsigned ta = (unsigned)__builtin_readcyclecounter();
+#endif
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // 4 pieces per chunk, KS_NB - 2 later chunks may stay in flight
+#ifdef KS_STAMPS
+      const unsigned tb = (unsigned)__builtin_readcyclecounter();
+#endif
       __builtin_amdgcn_s_barrier();
+#ifdef KS_STAMPS
+      const unsigned tc = (unsigned)__builtin_readcyclecounter();
+#endif
       issue();
+#ifdef KS_STAMPS
+      const unsigned td = (unsigned)__builtin_readcyclecounter();
+      fw_data += tb - ta, fw_bar += tc - tb, fw_issue += td - tc;
+#endif
     }
+#ifdef KS_STAMPS  // feeder 0 (wave 8): cycles waiting for its pieces / at barriers / issuing, over the k-loop
+    if (lane == 0 && d.workspace) {
+      d.workspace[blockIdx.x * 64 + 16 + wave * 3 + 0] = __builtin_bit_cast(float, fw_data);
+      d.workspace[blockIdx.x * 64 + 16 + wave * 3 + 1] = __builtin_bit_cast(float, fw_bar);
+      d.workspace[blockIdx.x * 64 + 16 + wave * 3 + 2] = __builtin_bit_cast(float, fw_issue);
+    }
+#endif
     KS_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -224,6 +246,7 @@ __global__ __launch_bounds__(1024) void gemm_kslice_kernel(const nasrec_gemm_des
     const int half = wave >> 2;
 #ifdef KS_STAMPS
     unsigned ks_wait = 0;
+    const unsigned ks_t0 = (unsigned)__builtin_readcyclecounter();
 #endif
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     f32x4 fa[2][4], fb[2][4];
@@ -276,7 +299,7 @@ __global__ __launch_bounds__(1024) void gemm_kslice_kernel(const nasrec_gemm_des
         fa[set][kb] = *reinterpret_cast<const f32x4*>(buf + (tm * 16 + fr) * KS_DC + 4 * (g ^ fr));
         fb[set][kb] = *reinterpret_cast<const f32x4*>(buf + (32 + tn * 16 + fr) * KS_DC + 4 * (g ^ fr));
       }
-      cbuf = (cbuf + 1) & (KS_NB - 1);
+      cbuf = cbuf + 1 == KS_NB ? 0 : cbuf + 1;
       ck += KS_DC;
       if (ck >= cK) {
         do {
@@ -339,7 +362,10 @@ __global__ __launch_bounds__(1024) void gemm_kslice_kernel(const nasrec_gemm_des
     }
     const f32x4 acc = acc0 + acc1;
 #ifdef KS_STAMPS
-    if (tid == 0 && d.workspace) d.workspace[blockIdx.x * 8 + 7] = __builtin_bit_cast(float, ks_wait);
+    if (lane == 0 && d.workspace) {
+      d.workspace[blockIdx.x * 64 + 16 + wave * 3 + 1] = __builtin_bit_cast(float, ks_wait);
+      d.workspace[blockIdx.x * 64 + 16 + wave * 3 + 2] = __builtin_bit_cast(float, (unsigned)__builtin_readcyclecounter() - ks_t0);
+    }
 #endif
     *reinterpret_cast<f32x4*>(&red[((half * 4 + tile) * 64 + lane) * 4]) = acc;
   }
