@@ -16,6 +16,7 @@ lands one level later beside unrelated work instead of costing a launch of its o
 
 Results are bit-identical to the unscheduled program: the same bodies run on the same operands, only launch boundaries move."""
 import ctypes as C
+import os
 from typing import List, Tuple
 
 from . import _lib as L
@@ -330,6 +331,12 @@ _PLAIN_KINDS = (L.OP_MHA_FWD, L.OP_MHA_BWD, L.OP_FM_FWD, L.OP_FM_BWD, L.OP_DOT_T
 WL_LDS_FLOATS = 1696 + 5 * 1024 + 1024  # csrc/worklist_body.h WL_LDS_FLOATS
 
 
+# measured on cfg 2 (ms per step): 128 -> 0.420, 160 -> 0.415, 260 -> 0.408, never solo -> 0.409: the two large backward products of
+# the dominant Linear (dx: 208 workgroups with its split-K, dW: 156) are worth more side by side in their level's worklist than each
+# alone on its better kernel
+SOLO_TILES = int(os.environ.get("NASREC_WL_SOLO_TILES", "256"))
+
+
 def gemm_capable(d) -> bool:
     """mirror of csrc/worklist.hip wl_gemm_geometry: can this GEMM launch run as a worklist item?"""
     if d.splitk == L.SPLITK_BALANCED or d.defer_second_pass:
@@ -339,11 +346,11 @@ def gemm_capable(d) -> bool:
         return False
     if d.splitk > 1 and not d.workspace:
         return False
-    # one large product (>= 128 workgroups of 64x64, the class launch_gemm_t gives 1024-thread workgroups) fills the chip on its
-    # own and is faster in its own kernel than on the worklist kernel's small tiles
+    # one large product (>= SOLO_TILES workgroups of 64x64) fills the chip on its own and is faster in its own kernel than on the
+    # worklist kernel's small tiles
     nprob = d.nseg if d.zmode else 1
     S = d.splitk if d.splitk > 1 else 1
-    if nprob == 1 and ((d.seg[0].M + 63) // 64) * ((d.seg[0].N + 63) // 64) * S >= 128:
+    if nprob == 1 and ((d.seg[0].M + 63) // 64) * ((d.seg[0].N + 63) // 64) * S >= SOLO_TILES:
         return False
     from . import plan as P
     if P.kslice_eligible(d.amode, d.bmode, d.cmode, [dict(A=d.seg[q].A, Aaux=d.seg[q].Aaux, Baux=d.seg[q].Baux, ones_col=d.seg[q].ones_col,
