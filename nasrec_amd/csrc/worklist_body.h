@@ -27,8 +27,10 @@ __device__ __forceinline__ const T& wl_ref(unsigned long long addr) {
 template <bool KCA, bool KCB, int TBM, int TBN, bool AUX>
 __device__ __forceinline__ void wl_gemm_cfg(unsigned long long blob, int vb_, int gx_, int gy_) {
   // ring depth 2: the kernel must fit 128 registers so that FOUR workgroups of different items share a CU (a level's items only run
-  // side by side if they are resident together); a staged k-tile is <= 20 floats per thread on these tiles
-  constexpr int RING = 2;
+  // side by side if they are resident together); a staged k-tile is <= 20 floats per thread on these tiles.  With mask operands a
+  // staged element is two registers: those instantiations spilled 37 - 90 registers at depth 2 (a 128 x 768 x 256 weight gradient
+  // behind a ReLU took 20 us as an item against 10 us with registers to spare) and stage one k-tile at a time instead.
+  constexpr int RING = AUX ? 1 : 2;
   const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
   const int vb = __builtin_amdgcn_readfirstlane(vb_), gx = __builtin_amdgcn_readfirstlane(gx_), gy = __builtin_amdgcn_readfirstlane(gy_);
   const int nprob = g.zmode ? g.nseg : 1;

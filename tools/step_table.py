@@ -7,12 +7,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
-from nasrec_amd import _lib as L, plan as P
+from nasrec_amd import _lib as L, plan as P, schedule as S
 from nasrec_amd.engine import SupernetEngine
 from nasrec_amd.search_space import ops_config_lib
 from nasrec_amd.utils.config import NUM_EMBEDDINGS_CRITEO
 
 B = int(os.environ.get("B", "256"))
+ITEMS = float(os.environ.get("ITEMS", "0"))  # ITEMS=12: break worklists of >= 12 us down into their items
 lib = L.load()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
@@ -45,9 +46,27 @@ with torch.cuda.stream(eng.stream):
             if isinstance(d, L.WorklistDesc):
                 info = "worklist of " + " || ".join(names.get(n.desc.kind, "?") + ("[%s]" % n.part if n.part != "whole" else "") for n in d.nodes)
             rows.append((phase, names.get(d.kind, str(d.kind)), us, info))
+            if isinstance(d, L.WorklistDesc) and ITEMS and us >= ITEMS:
+                # every item as a one-item worklist of its own (same body, same descriptor): what it costs without the others
+                for n in d.nodes:
+                    b = S.item_bytes(n)
+                    one = L.WorklistDesc()
+                    one.kind, one.n = L.OP_WORKLIST, 1
+                    it = one.item[0]
+                    it.kind, it.part, it.off = n.desc.kind, S._PART[n.part], 0
+                    C.memmove(C.addressof(one) + L.WorklistDesc.blob.offset, b, len(b))
+                    ius = bench.time_desc(lib, L, sp, one, iters=50) * 1e3
+                    dd = n.desc
+                    what = names.get(dd.kind, "?") + ("[%s]" % n.part if n.part != "whole" else "")
+                    if isinstance(dd, L.GemmDesc):
+                        segs = [(dd.seg[q].M, dd.seg[q].N, dd.seg[q].K) for q in range(dd.nseg) if dd.seg[q].A]
+                        what += " am=%d bm=%d cm=%d z=%d S=%d %s" % (dd.amode, dd.bmode, dd.cmode, dd.zmode, dd.splitk, segs[:4])
+                        if n.part != "epi":
+                            what += "   [stand-alone kernel%s: %.2f us]" % (" + second pass" if dd.splitk > 1 else "", bench.time_desc(lib, L, sp, dd, iters=50) * 1e3)
+                    rows.append(("   ", "  item", ius, what))
 for r in rows:
     print("%s %-14s %7.2f us  %s" % r)
-print("sum of isolated launches: %.1f us over %d launches" % (tot, len(rows)))
+print("sum of isolated launches: %.1f us over %d launches" % (tot, sum(1 for r in rows if r[1] != "  item")))
 
 # host enqueue time vs GPU time of the graph-replayed step
 import time
