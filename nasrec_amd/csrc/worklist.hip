@@ -51,14 +51,42 @@ static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, i
     it.nblk = per * nprob;
     return 0;
   }
+  // token-axis Linear forward (W x, binding KC / TOKR / TOKJ), unsplit, no mask operands / row predicates: a wavefront per (sample,
+  // 16 rows of W), operands straight from memory into MFMA registers (wl_token_fwd)
+  static const bool tok_body = getenv("NASREC_WL_TOKEN_BODY") == nullptr || atoi(getenv("NASREC_WL_TOKEN_BODY")) != 0;  // A/B knob
+  if (tok_body && it.part == 0 && !g->zmode && !aux && g->amode == NASREC_AM_KC && g->bmode == NASREC_AM_TOKR && g->cmode == NASREC_CM_TOKJ &&
+      Mmax <= 64 && (Nmax & 15) == 0) {
+    bool plain = true;
+    for (int q = 0; q < g->nseg; ++q) plain = plain && !g->seg[q].ones_col && !(g->seg[q].Mvalid > 0 && g->seg[q].Mvalid < Mmax);
+    if (plain) {
+      const int MT = (Mmax + 15) / 16;
+      it.geom[0] = MT;
+      it.geom[1] = 0;
+      it.geom[2] = WL_TOKS | (1 << 2);
+      it.nblk = ((Nmax >> 4) * MT + 3) / 4;
+      return 0;
+    }
+  }
   // the tile choice of launch_gemm_t (gemm.hip) on 256-thread workgroups
   int tile, tbm, tbn;
   if (wgs >= GEMM_SKINNY_BELOW) {
     tile = WL_T32x32, tbm = 32, tbn = 32;
-  } else if (Nmax >= Mmax) {
-    tile = WL_T64x16, tbm = 64, tbn = 16;
   } else {
-    tile = WL_T16x64, tbm = 16, tbn = 64;
+    // skinny launches: the strip shape that pads the problems least (token-axis products have M = 8 .. 64 rows of weights against
+    // N = 4096 token columns: 64 x 16 strips compute up to 4x the rows that exist); ties go to launch_gemm_t's rule.  The order in
+    // which an output element accumulates over k does not depend on the tile shape, so results stay bit-identical.
+    long pad64x16 = 0, pad16x64 = 0;
+    for (int q = 0; q < nprob; ++q) {
+      pad64x16 += (long)((g->seg[q].M + 63) / 64) * 64 * ((g->seg[q].N + 15) / 16) * 16;
+      pad16x64 += (long)((g->seg[q].M + 15) / 16) * 16 * ((g->seg[q].N + 63) / 64) * 64;
+    }
+    static const bool by_padding = getenv("NASREC_WL_TILE_BY_PADDING") == nullptr || atoi(getenv("NASREC_WL_TILE_BY_PADDING")) != 0;  // A/B knob
+    const bool wide = by_padding && pad64x16 != pad16x64 ? pad64x16 < pad16x64 : Nmax >= Mmax;
+    if (wide) {
+      tile = WL_T64x16, tbm = 64, tbn = 16;
+    } else {
+      tile = WL_T16x64, tbm = 16, tbn = 64;
+    }
   }
   it.geom[0] = (Nmax + tbn - 1) / tbn;
   it.geom[1] = (Mmax + tbm - 1) / tbm;

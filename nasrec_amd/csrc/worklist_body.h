@@ -9,7 +9,7 @@
 
 #define WL_TK 64  // staged k depth of every GEMM item (a product with K <= 32 pads its one tile with zeros: same sums, bit for bit)
 // tile configurations of GEMM items: geom[2] = tile | binding pair << 2 | mask operand << 4
-enum { WL_T32x32 = 1, WL_T64x16 = 2, WL_T16x64 = 3 };
+enum { WL_TOKS = 0, WL_T32x32 = 1, WL_T64x16 = 2, WL_T16x64 = 3 };  // WL_TOKS: wl_token_fwd (a wavefront per sample)
 
 // All bodies share the launch's DYNAMIC LDS buffer (sized by the launcher: 35 KB, or 52 KB when a Transformer backward is in the level).
 extern __shared__ __attribute__((aligned(16))) float wl_lds[];
@@ -60,6 +60,84 @@ __device__ __forceinline__ void wl_gemm_bind(int bind, int tile, unsigned long l
   else wl_gemm_tile<false, false, AUX>(tile, off, vb, gx, gy);                  // dy^T x, token-axis W^T dy
 }
 
+// Token-axis Linear forward, a wavefront per (sample, 16 rows of W): out[b][i][e] = sum_k W[i][k] x[b][k][e] (binding KC / TOKR / TOKJ,
+// modules.py:222-234, 358-361, 648-650).  On the general tile these products (M = 8 .. 64 rows of W against N = 16 B token columns,
+// K = 26 .. 234 tokens in up to four segments) are the slowest items of four forward levels (10 - 13 us each): a 64 x 16 or 16 x 64
+// strip stages both operands through LDS with one-dword loads that touch four samples per wave-instruction.  But for one sample the
+// B operand of v_mfma_f32_16x16x4_f32 IS the sample's memory: lane (e, g) of MFMA j of a 16-token step needs x[b][16 s + 4 g + j][e],
+// a dword per lane with 16 consecutive e per token, and lane (i, g) needs W[i][16 s + 4 g + j], one 16-byte load for the four j.
+// No LDS, no barrier; loads run KT steps ahead of the MFMAs.  The k-grouping (MFMA j of step s sums k = 16 s + 4 g + j, g = 0..3;
+// steps and segments in order) is exactly the general tile's, so the result is bit-identical to it.
+#define WL_TOK_DEPTH 3
+__device__ __forceinline__ void wl_token_fwd(unsigned long long blob, int vb_, int MT_) {
+  const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
+  const int vb = __builtin_amdgcn_readfirstlane(vb_), MT = __builtin_amdgcn_readfirstlane(MT_);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int e = lane & 15, fg = lane >> 4;
+  const nasrec_gemm_seg_t& s0 = g.seg[0];
+  const int M = s0.M, B = s0.N >> 4;
+  const int unit = vb * 4 + wave;  // (sample, row block)
+  const int b = unit / MT, mt = unit - b * MT;
+  if (b >= B) return;
+  const int row = min(mt * 16 + e, M - 1);  // (lane & 15 doubles as the row of the A fragment; rows beyond M are never stored)
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 fa[WL_TOK_DEPTH];
+  float fb[WL_TOK_DEPTH][4];
+  int lim[WL_TOK_DEPTH];  // valid k of the step in the slot (<= 0: nothing)
+  // cursor of the fetches: (segment, step inside it)
+  int fq = 0, fk = 0;
+  auto fetch = [&](int slot) {
+    while (fq < g.nseg && !(g.seg[fq].A && g.seg[fq].K > fk)) ++fq, fk = 0;
+    if (fq >= g.nseg) {
+      lim[slot] = 0;
+      return;
+    }
+    const nasrec_gemm_seg_t& sg = g.seg[fq];
+    const int K = sg.K, kk = fk + 4 * fg;
+    lim[slot] = K - fk;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.A), 0, (int)(4 * ((long)(M - 1) * sg.lda + K)), 0x00020000);
+    fa[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, 4 * (row * sg.lda + kk), 0, 0));
+    const float* xb = sg.B + (long)b * sg.ldb + e;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[slot][j] = xb[min(kk + j, K - 1) * 16];  // (unconditional: a select around a load makes the compiler wait per element)
+    fk += 16;
+  };
+  auto multiply = [&](int slot) {
+    const int l = lim[slot];
+    if (l <= 0) return;
+    f32x4 a = fa[slot];
+    float x[4] = {fb[slot][0], fb[slot][1], fb[slot][2], fb[slot][3]};
+    if (l < 16) {  // last step of a segment: the 16-byte load of W may run into the next segment's columns, the token index was clamped
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = 4 * fg + j < l;
+        a[j] = in ? a[j] : 0.f;
+        x[j] = in ? x[j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], x[j], acc, 0, 0, 0);
+  };
+  int steps = 0;
+  for (int q = 0; q < g.nseg; ++q)
+    if (g.seg[q].A && g.seg[q].K > 0) steps += (g.seg[q].K + 15) >> 4;
+#pragma unroll
+  for (int r = 0; r < WL_TOK_DEPTH; ++r) fetch(r);
+  for (int t = 0; t < steps; t += WL_TOK_DEPTH) {
+#pragma unroll
+    for (int r = 0; r < WL_TOK_DEPTH; ++r) {
+      multiply(r);
+      fetch(r);
+    }
+  }
+  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15 (e), row = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = mt * 16 + 4 * fg + r;
+    if (i < M) epilogue_store<NASREC_CM_TOKJ>(g, s0, i, b * 16 + e, acc[r]);
+  }
+}
+
 __device__ __forceinline__ void wl_gemm_second_pass(unsigned long long blob, int vb_, int per_) {
   const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
   const int vb = __builtin_amdgcn_readfirstlane(vb_), per = __builtin_amdgcn_readfirstlane(per_);
@@ -100,7 +178,8 @@ __global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(const nasrec
         break;
       }
       const int cfg = it.geom[2];  // tile | binding pair << 2 | mask operand << 4
-      if ((cfg >> 4) & 1) wl_gemm_bind<true>((cfg >> 2) & 3, cfg & 3, blob, vb, it.geom[0], it.geom[1]);
+      if ((cfg & 3) == WL_TOKS) wl_token_fwd(blob, vb, it.geom[0]);
+      else if ((cfg >> 4) & 1) wl_gemm_bind<true>((cfg >> 2) & 3, cfg & 3, blob, vb, it.geom[0], it.geom[1]);
       else wl_gemm_bind<false>((cfg >> 2) & 3, cfg & 3, blob, vb, it.geom[0], it.geom[1]);
       break;
     }
