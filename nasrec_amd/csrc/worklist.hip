@@ -67,6 +67,24 @@ static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, i
       return 0;
     }
   }
+  // token-axis Linear input gradients (W^T dy per input segment, binding RC / TOKR / TOKJ, zmode), unsplit, no mask operands, at most
+  // 64 output rows of the Linear: a wavefront per (sample, segment, 16 token rows) (wl_token_dx)
+  if (tok_body && it.part == 0 && g->zmode && !aux && g->amode == NASREC_AM_RC && g->bmode == NASREC_AM_TOKR && g->cmode == NASREC_CM_TOKJ && (Nmax & 15) == 0) {
+    bool plain = true;
+    int TU = 0;
+    for (int q = 0; q < g->nseg; ++q) {
+      const nasrec_gemm_seg_t& s = g->seg[q];
+      plain = plain && !s.ones_col && !(s.Mvalid > 0 && s.Mvalid < s.M) && s.N == Nmax && s.K <= 16 * WL_TOKDX_STEPS && s.M > 0;
+      TU += (s.M + 15) / 16;
+    }
+    if (plain) {
+      it.geom[0] = TU;
+      it.geom[1] = 0;
+      it.geom[2] = WL_TOKS | (2 << 2);
+      it.nblk = ((Nmax >> 4) * TU + 3) / 4;
+      return 0;
+    }
+  }
   // the tile choice of launch_gemm_t (gemm.hip) on 256-thread workgroups
   int tile, tbm, tbn;
   if (wgs >= GEMM_SKINNY_BELOW) {

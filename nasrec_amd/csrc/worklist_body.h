@@ -138,6 +138,63 @@ __device__ __forceinline__ void wl_token_fwd(unsigned long long blob, int vb_, i
   }
 }
 
+// Token-axis Linear input gradient, the same scheme: dx_q[b][r][e] = sum_i W[i][koff_q + r] dy[b][i][e] for every input segment q of
+// the Linear (binding RC / TOKR / TOKJ, one independent problem per segment: zmode).  A wavefront per (sample, segment, 16 token
+// rows); lane (r, g) of MFMA j of step s needs W[16 s + 4 g + j][r] (four dwords, a row of W apart), lane (e, g) needs
+// dy[b][16 s + 4 g + j][e].  K = the Linear's output rows (16 .. 64): one to four steps, all loads issued up front.
+#define WL_TOKDX_STEPS 4
+__device__ __forceinline__ void wl_token_dx(unsigned long long blob, int vb_, int TU_) {
+  const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
+  const int vb = __builtin_amdgcn_readfirstlane(vb_), TU = __builtin_amdgcn_readfirstlane(TU_);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int e = lane & 15, fg = lane >> 4;
+  const int unit = vb * 4 + wave;
+  const int b = unit / TU;
+  int t = unit - b * TU, q = 0;
+  if (b >= (g.seg[0].N >> 4)) return;
+  while (q < g.nseg && t >= ((g.seg[q].M + 15) >> 4)) t -= (g.seg[q].M + 15) >> 4, ++q;  // (segment, row block) of this unit
+  const nasrec_gemm_seg_t& sg = g.seg[q];
+  const int M = sg.M, K = sg.K;
+  if (!sg.A || K <= 0) {  // a dead problem still owns its output: zero unless it accumulates (what the general tile does)
+    if (!sg.accumulate) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = t * 16 + 4 * fg + r;
+        if (i < M) epilogue_store<NASREC_CM_TOKJ>(g, sg, i, b * 16 + e, 0.f);
+      }
+    }
+    return;
+  }
+  const int row = min(t * 16 + e, M - 1);
+  const float* wp = sg.A + row;                      // A(r, k) = A[k lda + r]
+  const float* yb = sg.B + (long)b * sg.ldb + e;     // B(j, k) = B[b ldb + e + 16 k]
+  float fa[WL_TOKDX_STEPS][4], fb[WL_TOKDX_STEPS][4];
+#pragma unroll
+  for (int s = 0; s < WL_TOKDX_STEPS; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = min(16 * s + 4 * fg + j, K - 1);  // (clamped, masked below)
+      fa[s][j] = wp[(long)k * sg.lda];
+      fb[s][j] = yb[k * 16];
+    }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < WL_TOKDX_STEPS; ++s) {
+    if (16 * s < K) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = 16 * s + 4 * fg + j < K;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(in ? fa[s][j] : 0.f, in ? fb[s][j] : 0.f, acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = t * 16 + 4 * fg + r;
+    if (i < M) epilogue_store<NASREC_CM_TOKJ>(g, sg, i, b * 16 + e, acc[r]);
+  }
+}
+
 __device__ __forceinline__ void wl_gemm_second_pass(unsigned long long blob, int vb_, int per_) {
   const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
   const int vb = __builtin_amdgcn_readfirstlane(vb_), per = __builtin_amdgcn_readfirstlane(per_);
@@ -178,7 +235,8 @@ __global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(const nasrec
         break;
       }
       const int cfg = it.geom[2];  // tile | binding pair << 2 | mask operand << 4
-      if ((cfg & 3) == WL_TOKS) wl_token_fwd(blob, vb, it.geom[0]);
+      if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 1) wl_token_fwd(blob, vb, it.geom[0]);
+      else if ((cfg & 3) == WL_TOKS) wl_token_dx(blob, vb, it.geom[0]);
       else if ((cfg >> 4) & 1) wl_gemm_bind<true>((cfg >> 2) & 3, cfg & 3, blob, vb, it.geom[0], it.geom[1]);
       else wl_gemm_bind<false>((cfg >> 2) & 3, cfg & 3, blob, vb, it.geom[0], it.geom[1]);
       break;
