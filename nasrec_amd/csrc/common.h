@@ -72,10 +72,21 @@ __device__ __forceinline__ void warm_kernarg() {
   }
 }
 
+// Sum over the 64 lanes, returned to every lane.  Data-parallel-primitive moves inside the vector ALU (two quad permutes, two row
+// rotations, two row broadcasts; the total lands in lane 63) instead of six ds_bpermute round trips through the LDS crossbar: the
+// Transformer backward does 40 of these per wave and sample (its bias-like gradients), each a dependent chain.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0xb1>(v);   // quad_perm:[1,0,3,2]
+  v += dpp_mov<0x4e>(v);   // quad_perm:[2,3,0,1]
+  v += dpp_mov<0x124>(v);  // row_ror:4
+  v += dpp_mov<0x128>(v);  // row_ror:8   (every lane of a row of 16 now holds the row's sum)
+  v += dpp_mov<0x142>(v);  // row_bcast:15
+  v += dpp_mov<0x143>(v);  // row_bcast:31 (lane 63: rows 0 + 1 + 2 + 3)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // host-side launch-error helper (defined in api.hip)
