@@ -60,6 +60,24 @@ __device__ __forceinline__ void wl_gemm_bind(int bind, int tile, unsigned long l
   else wl_gemm_tile<false, false, AUX>(tile, off, vb, gx, gy);                  // dy^T x, token-axis W^T dy
 }
 
+// Pull `bytes` of the launch's argument blob, starting at `addr`, through the scalar cache behind ONE wait (one asm block: its
+// registers are dead afterwards).  A body that walks a descriptor's k-segments one after the other reads each segment's fields when
+// it gets there — and every new segment is a cold line of kernel-argument memory, 1.6 us per segment measured in wl_token_fwd.
+__device__ __forceinline__ void wl_warm_blob(unsigned long long addr, int bytes) {
+  int sink, off;
+  asm volatile(
+      "s_mov_b32 %1, 0\n"
+      "1:\n"
+      "s_load_dword %0, %2, %1\n"
+      "s_add_u32 %1, %1, 64\n"
+      "s_cmp_lt_u32 %1, %3\n"
+      "s_cbranch_scc1 1b\n"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(sink), "=&s"(off)
+      : "s"(addr), "s"(bytes)
+      : "scc", "memory");
+}
+
 // Token-axis Linear forward, a wavefront per (sample, 16 rows of W): out[b][i][e] = sum_k W[i][k] x[b][k][e] (binding KC / TOKR / TOKJ,
 // modules.py:222-234, 358-361, 648-650).  On the general tile these products (M = 8 .. 64 rows of W against N = 16 B token columns,
 // K = 26 .. 234 tokens in up to four segments) are the slowest items of four forward levels (10 - 13 us each): a 64 x 16 or 16 x 64
@@ -68,12 +86,13 @@ __device__ __forceinline__ void wl_gemm_bind(int bind, int tile, unsigned long l
 // a dword per lane with 16 consecutive e per token, and lane (i, g) needs W[i][16 s + 4 g + j], one 16-byte load for the four j.
 // No LDS, no barrier; loads run KT steps ahead of the MFMAs.  The k-grouping (MFMA j of step s sums k = 16 s + 4 g + j, g = 0..3;
 // steps and segments in order) is exactly the general tile's, so the result is bit-identical to it.
-#define WL_TOK_DEPTH 3
+#define WL_TOK_DEPTH 4
 __device__ __forceinline__ void wl_token_fwd(unsigned long long blob, int vb_, int MT_) {
   const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
   const int vb = __builtin_amdgcn_readfirstlane(vb_), MT = __builtin_amdgcn_readfirstlane(MT_);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int e = lane & 15, fg = lane >> 4;
+  wl_warm_blob(blob, (int)offsetof(nasrec_gemm_desc_t, seg) + g.nseg * (int)sizeof(nasrec_gemm_seg_t));
   const nasrec_gemm_seg_t& s0 = g.seg[0];
   const int M = s0.M, B = s0.N >> 4;
   const int unit = vb * 4 + wave;  // (sample, row block)
@@ -84,43 +103,41 @@ __device__ __forceinline__ void wl_token_fwd(unsigned long long blob, int vb_, i
   f32x4 fa[WL_TOK_DEPTH];
   float fb[WL_TOK_DEPTH][4];
   int lim[WL_TOK_DEPTH];  // valid k of the step in the slot (<= 0: nothing)
-  // cursor of the fetches: (segment, step inside it)
+  // Cursor of the fetches: (segment, first k of the step).  A fetch is five UNCONDITIONAL buffer loads — past the last segment (or in
+  // a dead one) against a null resource, which returns zeros and moves nothing: with a branch around the loads the compiler cannot
+  // count what is in flight and waits for everything before every MFMA group (measured: one full memory latency per step).
   int fq = 0, fk = 0;
   auto fetch = [&](int slot) {
-    while (fq < g.nseg && !(g.seg[fq].A && g.seg[fq].K > fk)) ++fq, fk = 0;
-    if (fq >= g.nseg) {
-      lim[slot] = 0;
-      return;
-    }
-    const nasrec_gemm_seg_t& sg = g.seg[fq];
-    const int K = sg.K, kk = fk + 4 * fg;
+    const bool in = fq < g.nseg;
+    const nasrec_gemm_seg_t& sg = g.seg[in ? fq : 0];
+    const bool live = in && sg.A != nullptr && sg.K > 0;
+    const int K = live ? sg.K : 0, kk = fk + 4 * fg;
     lim[slot] = K - fk;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.A), 0, (int)(4 * ((long)(M - 1) * sg.lda + K)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.A), 0, live ? (int)(4 * ((long)(M - 1) * sg.lda + K)) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.B + (long)b * sg.ldb), 0, live ? 64 * K : 0, 0x00020000);
     fa[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, 4 * (row * sg.lda + kk), 0, 0));
-    const float* xb = sg.B + (long)b * sg.ldb + e;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fb[slot][j] = xb[min(kk + j, K - 1) * 16];  // (unconditional: a select around a load makes the compiler wait per element)
+    for (int j = 0; j < 4; ++j) fb[slot][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, 64 * (kk + j) + 4 * e, 0, 0));  // (tokens >= K: zeros)
     fk += 16;
+    const bool next = fk >= K;
+    fq = next ? fq + 1 : fq;
+    fk = next ? 0 : fk;
   };
   auto multiply = [&](int slot) {
     const int l = lim[slot];
     if (l <= 0) return;
     f32x4 a = fa[slot];
-    float x[4] = {fb[slot][0], fb[slot][1], fb[slot][2], fb[slot][3]};
-    if (l < 16) {  // last step of a segment: the 16-byte load of W may run into the next segment's columns, the token index was clamped
+    if (l < 16) {  // last step of a segment: the 16-byte load of W may run into the next segment's columns
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool in = 4 * fg + j < l;
-        a[j] = in ? a[j] : 0.f;
-        x[j] = in ? x[j] : 0.f;
-      }
+      for (int j = 0; j < 4; ++j) a[j] = 4 * fg + j < l ? a[j] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], x[j], acc, 0, 0, 0);
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], fb[slot][j], acc, 0, 0, 0);
   };
-  int steps = 0;
-  for (int q = 0; q < g.nseg; ++q)
-    if (g.seg[q].A && g.seg[q].K > 0) steps += (g.seg[q].K + 15) >> 4;
+  int steps = 0;  // (a dead segment costs one empty step)
+  for (int q = 0; q < g.nseg; ++q) steps += (g.seg[q].A && g.seg[q].K > 0) ? (g.seg[q].K + 15) >> 4 : 1;
 #pragma unroll
   for (int r = 0; r < WL_TOK_DEPTH; ++r) fetch(r);
   for (int t = 0; t < steps; t += WL_TOK_DEPTH) {
