@@ -58,13 +58,44 @@ static __device__ const int kParamLen[12] = {768, 48, 256, 16, 16, 16, 256, 16, 
 #define MHA_SLICE_BWD 2
 #endif
 
+// All loads first, all LDS stores after: a loop per parameter array compiles to load -> wait -> store per array, i.e. twelve
+// dependent memory round trips before the kernel does anything (0.5 - 2 us each on the cold L2 of a batch-256 step).  Every array is
+// a multiple of 16 floats and 16-byte aligned (the parameter arena aligns each parameter), so the 1696 floats are 424 16-byte
+// pieces, at most two per thread: the piece's array is found by compares on its offset.
 template <int NT>
-__device__ __forceinline__ void stage_params(const nasrec_mha_desc_t& d, float* Wsh, int tid) {
+struct ParamPieces {
+  static constexpr int PIECES = NASREC_MHA_PARAMS / 4, PER = (PIECES + NT - 1) / NT;
+  f32x4 v[PER];
+};
+// (two halves, so that a caller can put its own loads between them: everything the kernel needs first is then ONE round trip)
+template <int NT>
+__device__ __forceinline__ void stage_params_load(const nasrec_mha_desc_t& d, int tid, ParamPieces<NT>& pp) {
+  static_assert(NASREC_MHA_PARAMS % 4 == 0, "16-byte pieces");
 #pragma unroll
-  for (int q = 0; q < 12; ++q) {
-    const float* src = d.params[q];
-    for (int i = tid; i < kParamLen[q]; i += NT) Wsh[kParamOff[q] + i] = src[i];
+  for (int k = 0; k < ParamPieces<NT>::PER; ++k) {
+    const int off = 4 * min(tid + k * NT, ParamPieces<NT>::PIECES - 1);  // float offset of the piece inside the 1696-float record (clamped: the store is skipped)
+    // (the pointers go through readfirstlane: left as a select over d.params[q] the compiler turns the chain into a per-lane LOAD of
+    // the pointer from the argument array — one more dependent round trip)
+    unsigned lo = 0, hi = 0;
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      const unsigned long long pq = (unsigned long long)d.params[q];
+      const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pq), phi = __builtin_amdgcn_readfirstlane((unsigned)(pq >> 32));
+      const bool in = off >= kParamOff[q];
+      lo = in ? plo : lo;
+      hi = in ? phi : hi;
+      base = in ? kParamOff[q] : base;
+    }
+    typedef __attribute__((address_space(1))) const f32x4 gf32x4;  // (global, not flat: the integer round trip loses the address space)
+    pp.v[k] = *reinterpret_cast<gf32x4*>((((unsigned long long)hi << 32) | lo) + 4ull * (unsigned)(off - base));
   }
+}
+template <int NT>
+__device__ __forceinline__ void stage_params_store(float* Wsh, int tid, const ParamPieces<NT>& pp) {
+#pragma unroll
+  for (int k = 0; k < ParamPieces<NT>::PER; ++k)
+    if (tid + k * NT < ParamPieces<NT>::PIECES) *reinterpret_cast<f32x4*>(Wsh + 4 * (tid + k * NT)) = pp.v[k];
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -201,11 +232,12 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
   const int N = d.N;
   const bool active = lane < N;
   const bool saving = d.saved != nullptr;  // training: keep what the backward needs instead of recomputing it there
-  stage_params<NT>(d, Wsh, tid);
-  float x[16];
-  if (active) {
-    ld_row(d.x + (long)b * d.ldx + lane * 16, x);
-  } else {
+  float x[16];  // (issued before the parameters are parked: one round trip for both)
+  ParamPieces<NT> pp;
+  stage_params_load<NT>(d, tid, pp);
+  ld_row(d.x + (long)b * d.ldx + min(lane, N - 1) * 16, x);
+  stage_params_store<NT>(Wsh, tid, pp);
+  if (!active) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = 0.f;
   }
@@ -452,27 +484,32 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   const int N = d.N;
   const bool active = lane < N;
   float* gp = d.dparams_partial + (long)b * (d.partial_ld > 0 ? d.partial_ld : NASREC_MHA_PARAMS);
-  stage_params<NT>(d, Wsh, tid);
-  // ---- the sample's planes: global -> LDS with contiguous 16-byte accesses (x and the forward state are [token][16] planes) -----
+  // the lane's own global operands (token = lane): issued with the planes, used after the first barrier
+  const int tl = min(lane, N - 1);
+  const f32x2 rs2 = *reinterpret_cast<const f32x2*>(sv_plane(d.saved, b, N, SV_RSTD) + tl * 4);
+  Vec<S> dout_in = ldv<S>(d.dout + (long)b * d.ldo + tl * 16 + c0);
+  ParamPieces<NT> pp;
+  stage_params_load<NT>(d, tid, pp);
+  // ---- the sample's planes: global -> LDS with contiguous 16-byte accesses (x and the forward state are [token][16] planes).  All ten
+  // loads are issued before the first store: plane after plane (load, wait, store) was ten dependent round trips, about half of this
+  // kernel's time at batch 256 (one workgroup per CU, nothing else to hide them) ----------------------------------------------------
   {
-    const int n4 = N * 4;
-    auto plane_in = [&](float* lds, const float* src) {
-      for (int t = tid; t < n4; t += NT) *reinterpret_cast<f32x4*>(lds + 4 * t) = *reinterpret_cast<const f32x4*>(src + 4 * t);
-    };
-    plane_in(Xb, d.x + (long)b * d.ldx);
-    plane_in(Qb, sv_plane(d.saved, b, N, SV_Q));
-    plane_in(Kb, sv_plane(d.saved, b, N, SV_K));
-    plane_in(Vb, sv_plane(d.saved, b, N, SV_V));
-    plane_in(Ob, sv_plane(d.saved, b, N, SV_O));
-    plane_in(H1b, sv_plane(d.saved, b, N, SV_H1));
-    plane_in(F1b, sv_plane(d.saved, b, N, SV_F1));
-    plane_in(Bf[7], sv_plane(d.saved, b, N, SV_XH1));  // x-hats: only on their way to registers
-    plane_in(Bf[8], sv_plane(d.saved, b, N, SV_XH2));
-    const float* ml = sv_plane(d.saved, b, N, SV_M);
-    for (int t = tid; t < n4; t += NT) {  // [token][8 max | 8 1/sum] -> Mb, Lb
-      const f32x4 v = *reinterpret_cast<const f32x4*>(ml + 4 * t);
-      float* dst = ((t & 2) ? Lb : Mb) + (t >> 2) * 8 + (t & 1) * 4;
-      *reinterpret_cast<f32x4*>(dst) = v;
+    const int n4 = N * 4;  // 16-byte pieces per plane; N <= MHA_N = 64 tokens: at most one per thread
+    static_assert(4 * MHA_N <= NT || NT >= 256, "one piece per thread and plane");
+    const int t = min(tid, n4 - 1);
+    const float* src[10] = {d.x + (long)b * d.ldx,          sv_plane(d.saved, b, N, SV_Q),   sv_plane(d.saved, b, N, SV_K),   sv_plane(d.saved, b, N, SV_V),
+                            sv_plane(d.saved, b, N, SV_O),  sv_plane(d.saved, b, N, SV_H1),  sv_plane(d.saved, b, N, SV_F1),  sv_plane(d.saved, b, N, SV_XH1),
+                            sv_plane(d.saved, b, N, SV_XH2), sv_plane(d.saved, b, N, SV_M)};
+    float* dst[9] = {Xb, Qb, Kb, Vb, Ob, H1b, F1b, Bf[7], Bf[8]};  // (x-hats: only on their way to registers)
+    f32x4 v[10];
+#pragma unroll
+    for (int p = 0; p < 10; ++p) v[p] = *reinterpret_cast<const f32x4*>(src[p] + 4 * t);
+    stage_params_store<NT>(Wsh, tid, pp);
+    if (tid < n4) {
+#pragma unroll
+      for (int p = 0; p < 9; ++p) *reinterpret_cast<f32x4*>(dst[p] + 4 * tid) = v[p];
+      // [token][8 max | 8 1/sum] -> Mb, Lb
+      *reinterpret_cast<f32x4*>(((tid & 2) ? Lb : Mb) + (tid >> 2) * 8 + (tid & 1) * 4) = v[9];
     }
   }
   __syncthreads();  // parameters and the token rows are in LDS
@@ -501,10 +538,9 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
       mx[h] = Mb[lane * 8 + HP * w + h];
       li[h] = Lb[lane * 8 + HP * w + h];
     }
-    const float* rs = sv_plane(d.saved, b, N, SV_RSTD) + lane * 4;
-    rstd1 = rs[0];
-    rstd2 = rs[1];
-    if (!(d.dims_in_use >= 0 && lane >= d.dims_in_use)) dout = ldv<S>(d.dout + (long)b * d.ldo + lane * 16 + c0);
+    rstd1 = rs2[0];
+    rstd2 = rs2[1];
+    if (!(d.dims_in_use >= 0 && lane >= d.dims_in_use)) dout = dout_in;
   }
   // ---- LayerNorm 2 ----
   bgrad_slice<S>(vmul<S>(dout, xh2), c0, lane, gp + OFF_L2W);
