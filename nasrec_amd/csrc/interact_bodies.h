@@ -13,11 +13,29 @@ __device__ __forceinline__ void tri_decode(int p, int& i, int& j) {
   j = p - i * (i - 1) / 2;
 }
 
+
+// One wavefront copies n floats global -> LDS (dst index by a functor), eight loads in flight per lane: a plain loop compiles to
+// load -> wait -> store per trip, i.e. n / 64 dependent memory round trips (12 - 16 of them for a 46-feature DotProduct sample:
+// most of that kernel's time on the cold L2 of a batch-256 step).  Indices past n are clamped for the load and skipped for the store.
+template <typename Dst>
+__device__ __forceinline__ void wave_copy_in(const float* src, int n, int lane, Dst dst) {
+  for (int q0 = 0; q0 < n; q0 += 64 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[min(q0 + 64 * u + lane, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + 64 * u + lane;
+      if (q < n) dst(q, v[u]);
+    }
+  }
+}
+
 // one wavefront = one sample b; ts = TRI_MAXK1 * TRI_LD floats of LDS owned by that wavefront
 __device__ __forceinline__ void dot_tri_fwd_sample(const nasrec_dot_tri_desc_t& d, int b, int lane, float* ts) {
   const int k1 = d.k1;
   const float* Tb = d.T + (long)b * k1 * 16;
-  for (int q = lane; q < k1 * 16; q += 64) ts[(q >> 4) * TRI_LD + (q & 15)] = Tb[q];
+  wave_copy_in(Tb, k1 * 16, lane, [&](int q, float v) { ts[(q >> 4) * TRI_LD + (q & 15)] = v; });
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
   const int P = k1 * (k1 - 1) / 2;
@@ -44,10 +62,16 @@ __device__ __forceinline__ void fm_fwd_sample(const nasrec_fm_desc_t& d, int b, 
   const int g = lane >> 4, e = lane & 15;
   const float* x = d.x + (long)b * d.ldx + e;
   float s = 0.f, q = 0.f;
-  for (int n = g; n < d.N; n += 4) {
-    float v = x[n * 16];
-    s += v;
-    q = fmaf(v, v, q);
+  for (int n0 = g; n0 < d.N; n0 += 4 * 8) {  // eight loads in flight (same summation order as the plain loop)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x[min(n0 + 4 * u, d.N - 1) * 16];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (n0 + 4 * u < d.N) {
+        s += v[u];
+        q = fmaf(v[u], v[u], q);
+      }
   }
   s += __shfl_xor(s, 16, 64);
   q += __shfl_xor(q, 16, 64);
@@ -87,8 +111,8 @@ __device__ __forceinline__ void dot_tri_bwd_sample(const nasrec_dot_tri_desc_t& 
   const int P = k1 * (k1 - 1) / 2;
   const float* Tb = d.T + (long)b * k1 * 16;
   const float* dob = d.dout + (long)b * d.ld_out;
-  for (int q = lane; q < k1 * 16; q += 64) ts[(q >> 4) * TRI_LD + (q & 15)] = Tb[q];
-  for (int q = lane; q < P; q += 64) ds[q] = dob[q];
+  wave_copy_in(Tb, k1 * 16, lane, [&](int q, float v) { ts[(q >> 4) * TRI_LD + (q & 15)] = v; });
+  wave_copy_in(dob, P, lane, [&](int q, float v) { ds[q] = v; });
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
   float* dTb = d.dT + (long)b * k1 * 16;
@@ -115,13 +139,28 @@ __device__ __forceinline__ void fm_bwd_sample(const nasrec_fm_desc_t& d, int b, 
   const float* x = d.x + (long)b * d.ldx + e;
   float* dx = d.dx + (long)b * d.ldx + e;
   float s = 0.f;
-  for (int n = g; n < d.N; n += 4) s += x[n * 16];
+  const float g2 = 2.f * d.dix[(long)b * d.ld_ix + e];  // (issued with the first batch)
+  for (int n0 = g; n0 < d.N; n0 += 4 * 8) {  // eight loads in flight (same summation order as the plain loop)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x[min(n0 + 4 * u, d.N - 1) * 16];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (n0 + 4 * u < d.N) s += v[u];
+  }
   s += __shfl_xor(s, 16, 64);
   s += __shfl_xor(s, 32, 64);
-  const float g2 = 2.f * d.dix[(long)b * d.ld_ix + e];
-  for (int n = g; n < d.N; n += 4) {
-    float r = g2 * (s - x[n * 16]);
-    dx[n * 16] = d.accumulate ? dx[n * 16] + r : r;
+  for (int n0 = g; n0 < d.N; n0 += 4 * 8) {
+    float v[8], o[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int n = min(n0 + 4 * u, d.N - 1);
+      v[u] = x[n * 16];
+      o[u] = d.accumulate ? dx[n * 16] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (n0 + 4 * u < d.N) dx[(n0 + 4 * u) * 16] = o[u] + g2 * (s - v[u]);
   }
 }
 
