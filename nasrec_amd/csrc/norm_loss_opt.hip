@@ -15,7 +15,20 @@ __global__ __launch_bounds__(256) void final_fwd_kernel(const nasrec_final_desc_
     if (!d.seg[q]) continue;
     const float* x = d.seg[q] + (long)b * d.ld[q];
     const float* w = d.w + d.off[q];
-    for (int j = lane; j < d.width[q]; j += 64) s = fmaf(x[j], w[j], s);
+    // four trips' loads in flight (same summation order as the plain loop, which compiles to load -> wait -> fma per trip)
+    const int W = d.width[q];
+    for (int j0 = lane; j0 < W; j0 += 64 * 4) {
+      float xv[4], wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(j0 + 64 * u, W - 1);
+        xv[u] = x[j];
+        wv[u] = w[j];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + 64 * u < W) s = fmaf(xv[u], wv[u], s);
+    }
   }
   s = wave_sum(s);
   if (lane == 0) d.logits[b] = s + d.bias[0];
@@ -117,9 +130,22 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const nasrec_final_desc_
         }
       }
     }
-    for (int b = bq; b < d.B; b += 16) {
-      float f = (k == K) ? 1.f : (src ? src[(long)b * ld + jj] : 0.f);
-      s = fmaf(dl(b), f, s);
+    // eight samples' loads in flight (same summation order as the plain loop: sixteen dependent round trips at batch 256)
+    const bool has = k < K && src != nullptr;
+    const float* sp = has ? src + jj : d.w;  // (an address that is always valid: the loads below are unconditional)
+    const int sld = has ? ld : 0;
+    for (int b0 = bq; b0 < d.B; b0 += 16 * 8) {
+      float f[8], g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = min(b0 + 16 * u, d.B - 1);
+        const float v = sp[(long)b * sld];
+        f[u] = (k == K) ? 1.f : (has ? v : 0.f);
+        g[u] = dl(b);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (b0 + 16 * u < d.B) s = fmaf(g[u], f[u], s);
     }
   }
   red[bq][kl] = s;
