@@ -74,17 +74,22 @@ __device__ __forceinline__ void dedup_small_body(const nasrec_emb_dedup_desc_t& 
   const int b = threadIdx.x;
   const long gb = (long)chunk * 256 + b;  // sample index in the batch
   const bool live = gb < d.B;
-  const int my = live ? (int)d.idx[gb * d.Fs + f] : -1 - b;  // dead lanes get unique negative ids
-  sidx[b] = my;
+  // the id and the gradient row are loaded together (the id's LDS store waits for it: with the row loads behind that store they
+  // were a second dependent round trip)
+  const long gl = live ? gb : 0;
   f32x4 g[4];
-  if (live) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(d.dout + (gb * d.Fs + f) * 16);
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(d.dout + (gl * d.Fs + f) * 16);
 #pragma unroll
     for (int v = 0; v < 4; ++v) g[v] = src[v];
-  } else {
+  }
+  const int my_in = (int)d.idx[gl * d.Fs + f];
+  if (!live) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) g[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  const int my = live ? my_in : -1 - b;  // dead lanes get unique negative ids
+  sidx[b] = my;
 #pragma unroll
   for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(&rows[b * 20 + 4 * v]) = g[v];
   __syncthreads();
