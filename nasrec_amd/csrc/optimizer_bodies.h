@@ -27,19 +27,27 @@ __device__ __forceinline__ void sumsq_body(const nasrec_sumsq_desc_t& d, int blk
       for (long j = 4 * n4 + tid; j < n; j += 256) s1 = fmaf(x[j], x[j], s1);
     }
   } else {
-    const long stride = (long)nblk * 256;
+    // 16-byte loads, four in flight per thread and trip (the arena is 16-byte aligned): with one float per load a thread of the
+    // batch-256 step (2.2 M gradients over 256 workgroups) made nine dependent trips to memory, now two
+    const long stride = (long)nblk * 256, n4 = d.n >> 2;
     long i = (long)blk * 256 + tid;
-    for (; i + 3 * stride < d.n; i += 4 * stride) {
-      const float a = d.x[i], b = d.x[i + stride], c = d.x[i + 2 * stride], e = d.x[i + 3 * stride];
-      s0 = fmaf(a, a, s0);
-      s1 = fmaf(b, b, s1);
-      s2 = fmaf(c, c, s2);
-      s3 = fmaf(e, e, s3);
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(d.x + 4 * i), b = *reinterpret_cast<const f32x4*>(d.x + 4 * (i + stride));
+      const f32x4 c = *reinterpret_cast<const f32x4*>(d.x + 4 * (i + 2 * stride)), e = *reinterpret_cast<const f32x4*>(d.x + 4 * (i + 3 * stride));
+      s0 += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+      s1 += (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]);
+      s2 += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+      s3 += (e[0] * e[0] + e[1] * e[1]) + (e[2] * e[2] + e[3] * e[3]);
     }
-    for (; i < d.n; i += stride) {
-      const float a = d.x[i];
-      s0 = fmaf(a, a, s0);
+    {  // up to three more pieces per thread, loaded together
+      f32x4 r[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) r[u] = *reinterpret_cast<const f32x4*>(d.x + 4 * (i + u * stride < n4 ? i + u * stride : 0));
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (i + u * stride < n4) s0 += (r[u][0] * r[u][0] + r[u][1] * r[u][1]) + (r[u][2] * r[u][2] + r[u][3] * r[u][3]);
     }
+    for (long j = 4 * n4 + (long)blk * 256 + tid; j < d.n; j += stride) s1 = fmaf(d.x[j], d.x[j], s1);
   }
   red[tid] = (s0 + s1) + (s2 + s3);
   __syncthreads();
