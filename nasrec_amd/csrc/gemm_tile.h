@@ -117,6 +117,18 @@ __device__ __forceinline__ void splitk_second_pass(const nasrec_gemm_desc_t& d, 
   // association order is still a fixed function of S, so results stay reproducible
   float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
   int q = 0;
+  for (; q + 16 <= S; q += 16) {  // sixteen slabs in flight (same chains: 32 slabs were eight dependent trips of four loads)
+    float a[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a[u] = slab[(long)(q + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      v0 += a[u];
+      v1 += a[u + 1];
+      v2 += a[u + 2];
+      v3 += a[u + 3];
+    }
+  }
   for (; q + 4 <= S; q += 4) {
     const float a0 = slab[(long)q * stride], a1 = slab[(long)(q + 1) * stride];
     const float a2 = slab[(long)(q + 2) * stride], a3 = slab[(long)(q + 3) * stride];
