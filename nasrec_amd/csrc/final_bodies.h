@@ -1,0 +1,176 @@
+// Device bodies of the final-logit kernels (supernet.py:592-598 / 657-664 and the fused BCEWithLogits, main_train.py:122), shared by
+// the stand-alone kernels (norm_loss_opt.hip) and by the worklist launches (worklist_body.h: the final-logit backward sits in the
+// same level as other operators of the step; as an item it runs beside them instead of before them).
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// final logit: one wavefront per sample, lanes stride the (segmented) feature axis
+// ---------------------------------------------------------------------------------------------------
+// workgroup vb of (B + 3) / 4: one wavefront per sample
+__device__ __forceinline__ void final_fwd_block(const nasrec_final_desc_t& d, int vb) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = vb * 4 + wave;
+  if (b >= d.B) return;
+  float s = 0.f;
+  for (int q = 0; q < d.nseg; ++q) {
+    if (!d.seg[q]) continue;
+    const float* x = d.seg[q] + (long)b * d.ld[q];
+    const float* w = d.w + d.off[q];
+    // four trips' loads in flight (same summation order as the plain loop, which compiles to load -> wait -> fma per trip)
+    const int W = d.width[q];
+    for (int j0 = lane; j0 < W; j0 += 64 * 4) {
+      float xv[4], wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(j0 + 64 * u, W - 1);
+        xv[u] = x[j];
+        wv[u] = w[j];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + 64 * u < W) s = fmaf(xv[u], wv[u], s);
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) d.logits[b] = s + d.bias[0];
+}
+
+__device__ __forceinline__ float bce_grad(float z, float y, float scale) { return (1.f / (1.f + expf(-z)) - y) * scale; }
+__device__ __forceinline__ float bce_term(float z, float y) { return fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z))); }
+
+// backward: part A (blocks [0, nA)): dseg[b,j] (+)= dlogits[b] * w[off+j]
+//           part B (blocks [nA, nA+nB)): dw[k] = sum_b dlogits[b] * feat[b,k]; dbias = sum_b dlogits[b]
+//           part C (block nA+nB, only with the fused BCE): loss and the per-sample gradient
+// With d.y != NULL, dlogits[b] is derived on the fly from logits[b] and y[b] (BCEWithLogits fused into this launch).
+// workgroup vb of nA + nB (+ 1 with the fused loss); lds: 272 floats
+#define FINAL_BWD_LDS_FLOATS 272
+__device__ __forceinline__ void final_bwd_block(const nasrec_final_desc_t& d, int K, int nA, int nB, int vb, float* lds) {
+  const bool fused = d.y != nullptr;
+  auto dl = [&](int b) { return fused ? bce_grad(d.logits[b], d.y[b], d.grad_scale) : d.dlogits[b]; };
+  if (vb < nA) {
+    const long t = (long)vb * 256 + threadIdx.x;
+    if (t >= (long)d.B * K) return;
+    const int b = (int)(t / K), k = (int)(t % K);
+    for (int q = 0; q < d.nseg; ++q) {
+      const int jj = k - d.off[q];
+      if (jj >= 0 && jj < d.width[q]) {
+        if (d.dseg[q]) {
+          float* p = d.dseg[q] + (long)b * d.ld[q] + jj;
+          const float v = dl(b) * d.w[k];
+          *p = d.dseg_accumulate[q] ? *p + v : v;
+        }
+        break;
+      }
+    }
+    return;
+  }
+  if (vb >= nA + nB) {  // part C
+    float* redl = lds;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < d.B; b += 256) {
+      const float z = d.logits[b], y = d.y[b];
+      s += bce_term(z, y);
+      if (d.dlogits_out) d.dlogits_out[b] = bce_grad(z, y, d.grad_scale);
+    }
+    redl[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) redl[threadIdx.x] += redl[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0 && d.loss) d.loss[0] = redl[0] / (float)d.B;
+    return;
+  }
+  if (d.nsplit > 1) {
+    // large batch: workgroup = 64 columns (256-byte coalesced rows) x one of nsplit batch slices; 4 waves take every 4th row
+    float(*reds)[64] = reinterpret_cast<float(*)[64]>(lds);
+    const int nBk = nB / d.nsplit;
+    const int blk = vb - nA, slice = blk / nBk, kl = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k = (blk - slice * nBk) * 64 + kl;
+    const int b0 = (int)((long)d.B * slice / d.nsplit), b1 = (int)((long)d.B * (slice + 1) / d.nsplit);
+    float s0 = 0.f, s1 = 0.f;
+    if (k <= K) {
+      const float* src = nullptr;
+      int ld = 0, jj = 0;
+      if (k < K) {
+        for (int q = 0; q < d.nseg; ++q) {
+          jj = k - d.off[q];
+          if (jj >= 0 && jj < d.width[q]) {
+            src = d.seg[q];
+            ld = d.ld[q];
+            break;
+          }
+        }
+      }
+      int b = b0 + w;
+      for (; b + 4 < b1; b += 8) {
+        const float f0 = (k == K) ? 1.f : (src ? src[(long)b * ld + jj] : 0.f);
+        const float f1 = (k == K) ? 1.f : (src ? src[(long)(b + 4) * ld + jj] : 0.f);
+        s0 = fmaf(dl(b), f0, s0);
+        s1 = fmaf(dl(b + 4), f1, s1);
+      }
+      for (; b < b1; b += 4) s0 = fmaf(dl(b), (k == K) ? 1.f : (src ? src[(long)b * ld + jj] : 0.f), s0);
+    }
+    reds[w][kl] = s0 + s1;
+    __syncthreads();
+    if (w == 0 && k <= K) d.dw[(long)slice * (K + 1) + k] = (reds[0][kl] + reds[1][kl]) + (reds[2][kl] + reds[3][kl]);
+    return;
+  }
+  float(*red)[17] = reinterpret_cast<float(*)[17]>(lds);
+  const int kl = threadIdx.x & 15, bq = threadIdx.x >> 4;
+  const int k = (vb - nA) * 16 + kl;  // k == K is the bias column
+  float s = 0.f;
+  if (k <= K) {
+    const float* src = nullptr;
+    int ld = 0, jj = 0;
+    if (k < K) {
+      for (int q = 0; q < d.nseg; ++q) {
+        jj = k - d.off[q];
+        if (jj >= 0 && jj < d.width[q]) {
+          src = d.seg[q];
+          ld = d.ld[q];
+          break;
+        }
+      }
+    }
+    // eight samples' loads in flight (same summation order as the plain loop: sixteen dependent round trips at batch 256)
+    const bool has = k < K && src != nullptr;
+    const float* sp = has ? src + jj : d.w;  // (an address that is always valid: the loads below are unconditional)
+    const int sld = has ? ld : 0;
+    for (int b0 = bq; b0 < d.B; b0 += 16 * 8) {
+      float f[8], g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = min(b0 + 16 * u, d.B - 1);
+        const float v = sp[(long)b * sld];
+        f[u] = (k == K) ? 1.f : (has ? v : 0.f);
+        g[u] = dl(b);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (b0 + 16 * u < d.B) s = fmaf(g[u], f[u], s);
+    }
+  }
+  red[bq][kl] = s;
+  __syncthreads();
+  if (bq == 0 && k <= K) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q][kl];
+    if (k < K)
+      d.dw[k] = tot;
+    else
+      d.dbias[0] = tot;
+  }
+}
+
+// grid of the backward: nA element-wise workgroups (dseg), nB column blocks (dw, dbias), + 1 for the fused loss
+__host__ __device__ inline void final_bwd_geometry(const nasrec_final_desc_t& d, int& K, int& nA, int& nB) {
+  K = 0;
+  for (int q = 0; q < d.nseg; ++q) K = K > d.off[q] + d.width[q] ? K : d.off[q] + d.width[q];
+  const long tA = (long)d.B * K;
+  nA = (int)((tA + 255) / 256);
+  nB = (K + 1 + 15) / 16;
+  if (d.nsplit > 1) nB = ((K + 1 + 63) / 64) * d.nsplit;
+}

@@ -171,6 +171,20 @@ int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
         it.nblk = (int)(((long)d->B * W + 255) / 256);
         break;
       }
+      case NASREC_OP_FINAL_FWD:
+        WL_NEED(nasrec_final_desc_t);
+        it.nblk = (reinterpret_cast<const nasrec_final_desc_t*>(blob)->B + 3) / 4;
+        break;
+      case NASREC_OP_FINAL_BWD: {
+        WL_NEED(nasrec_final_desc_t);
+        const nasrec_final_desc_t* d = reinterpret_cast<const nasrec_final_desc_t*>(blob);
+        if (d->y != nullptr && d->logits == nullptr) return nasrec_set_error(-2, "worklist: final_bwd with the fused loss needs desc.logits");
+        int K, nA, nB;
+        final_bwd_geometry(*d, K, nA, nB);
+        it.geom[0] = K, it.geom[1] = nA, it.geom[2] = nB;
+        it.nblk = nA + nB + (d->y != nullptr ? 1 : 0);
+        break;
+      }
       case NASREC_OP_GATE_BWD: {
         WL_NEED(nasrec_gate_bwd_desc_t);
         const nasrec_gate_bwd_desc_t* d = reinterpret_cast<const nasrec_gate_bwd_desc_t*>(blob);

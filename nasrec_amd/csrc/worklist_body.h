@@ -2,6 +2,7 @@
 #pragma once
 #include "attention_body.h"
 #include "gemm_rt.h"
+#include "final_bodies.h"
 #include "interact_bodies.h"
 
 #define WL_LDS_BIG_FLOATS MHA_BWD_LDS_FLOATS(4)  // 12960 floats = 52 KB
@@ -301,6 +302,12 @@ __global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(const nasrec
       break;
     case NASREC_OP_REDUCE_ROWS:
       reduce_rows_block(wl_ref<nasrec_wl_reduce_t>(blob), vb, tid, lds);
+      break;
+    case NASREC_OP_FINAL_FWD:
+      final_fwd_block(wl_ref<nasrec_final_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb));
+      break;
+    case NASREC_OP_FINAL_BWD:
+      final_bwd_block(wl_ref<nasrec_final_desc_t>(blob), it.geom[0], it.geom[1], it.geom[2], __builtin_amdgcn_readfirstlane(vb), lds);
       break;
     default:
       break;

@@ -327,7 +327,8 @@ def levels_of(descs):
 # ----------------------------------------------------------------------------------------------------------------
 _GEMM_HEAD = L.GemmDesc.seg.offset
 _SEG_BYTES = C.sizeof(L.GemmSeg)
-_PLAIN_KINDS = (L.OP_MHA_FWD, L.OP_MHA_BWD, L.OP_FM_FWD, L.OP_FM_BWD, L.OP_DOT_TRI_FWD, L.OP_DOT_TRI_BWD, L.OP_COPY_SEGS, L.OP_GATE_BWD)
+_PLAIN_KINDS = (L.OP_MHA_FWD, L.OP_MHA_BWD, L.OP_FM_FWD, L.OP_FM_BWD, L.OP_DOT_TRI_FWD, L.OP_DOT_TRI_BWD, L.OP_COPY_SEGS, L.OP_GATE_BWD,
+                L.OP_FINAL_FWD, L.OP_FINAL_BWD)
 WL_LDS_FLOATS = 1696 + 5 * 1024 + 1024  # csrc/worklist_body.h WL_LDS_FLOATS
 
 

@@ -66,6 +66,12 @@ with torch.cuda.stream(eng.stream):
                     rows.append(("   ", "  item", ius, what))
 for r in rows:
     print("%s %-14s %7.2f us  %s" % r)
+if getattr(cp, "fb", None) is not None:  # the program the step actually runs: forward and backward scheduled together
+    def short(d):
+        if isinstance(d, L.WorklistDesc):
+            return "WL[" + ",".join(names.get(n.desc.kind, "?")[:8] + (":" + n.part[0] if n.part != "whole" else "") for n in d.nodes) + "]"
+        return names.get(d.kind, str(d.kind))
+    print("joint forward+backward program (%d launches): %s" % (len(cp.fb.descs), "  ".join(short(d) for d in cp.fb.descs)))
 print("sum of isolated launches: %.1f us over %d launches" % (tot, sum(1 for r in rows if r[1] != "  item")))
 
 # host enqueue time vs GPU time of the graph-replayed step
