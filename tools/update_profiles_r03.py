@@ -144,6 +144,10 @@ def install(O):
                      "write_size_kb": w, "traffic_bytes_per_launch": int(round((2 * f + w) * 1024)),
                      "algorithmic_bytes_per_launch": r["roofline"].get("algorithmic_bytes"),
                      "per_dispatch_duration_us": {"median": d["median_us"], "mean": d["mean_us"], "dispatches": d["dispatches"], "source": "rocprofv3 --kernel-trace of `python3 bench.py --no-cpu-baseline`"}}
+                if c == 2:
+                    j["note"] = ("FETCH_SIZE counts what the 8 private L2s request from the fabric (Infinity Cache included), not HBM reads: every launch starts on cold "
+                                 "L2s, and each XCD needs the 128 rows of x and 192 rows of W of its 4 x 6 block of output tiles = 2.0 MB for K = 1565, "
+                                 "the minimum for 8 equal blocks -> 8 x 2.0 = 15.8 MB of fabric reads against 6.4 MB of operands; HBM sees each operand byte at most once")
                 json.dump(j, open(os.path.join(P, "dominant_gemm_traffic_cfg%d.json" % c), "w"), indent=1)
     if os.path.exists(os.path.join(S, "bench_cfg2_pmc_mfma.csv")):
         shutil.copy(os.path.join(S, "bench_cfg2_pmc_mfma.csv"), os.path.join(P, "r03_bench_cfg2_pmc_mfma.csv"))
