@@ -12,6 +12,7 @@
 // 3 contiguity pairs x 4 tiles x mask operand = 24 instantiations instead of 6 bindings x 16.  The LDS tiles live in a buffer handed in by the
 // caller (the worklist kernel shares one buffer among all its bodies).
 #pragma once
+#include <type_traits>
 #include "gemm_tile.h"
 
 struct RtStride {
@@ -31,11 +32,14 @@ __device__ __forceinline__ long rt_offset(const RtStride& s, int r, int k) {
 }
 
 // thread -> (row, k) of the staging loads of an R x TK operand tile: lanes run along the contiguous axis
+// k-contiguous operands are staged four k per lane (one 16-byte load, one ds_write_b128: a wave-instruction covers 4 rows x 256 B
+// instead of one row — the one-dword form spent the texture-address path on 64 instructions per 16 KB tile); the others one element
+// per lane along r.  `it` counts LOADS: NIT / RT_V of them per thread and k-tile.
 template <bool KCONTIG, int NT, int TK, int R>
 __device__ __forceinline__ void rt_stage_coords(int tid, int it, int& rr, int& kk) {
   if (KCONTIG) {
-    kk = tid & (TK - 1);
-    rr = tid / TK + (NT / TK) * it;
+    kk = 4 * (tid & (TK / 4 - 1));
+    rr = tid / (TK / 4) + (NT / (TK / 4)) * it;
   } else {
     rr = tid & (R - 1);
     kk = tid / R + (NT / R) * it;
@@ -55,7 +59,9 @@ template <bool KCA, bool KCB, int NT, int TK, int TBM, int TBN, bool AUX, int RI
 __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mmax, int Nmax, const int bx, const int by, const int bz, float* lds) {
   const int AM = d.amode, BMODE = d.bmode, CM = d.cmode;
   constexpr int LDS_LD = TK + 4;
-  constexpr int NITA = TBM * TK / NT, NITB = TBN * TK / NT;
+  constexpr int VA = KCA ? 4 : 1, VB = KCB ? 4 : 1;                   // floats per staging load
+  constexpr int NITA = TBM * TK / NT / VA, NITB = TBN * TK / NT / VB;  // staging loads per thread and k-tile
+  static_assert((TBM * TK / NT) % VA == 0 && (TBN * TK / NT) % VB == 0 && TK % 16 == 0, "whole 16-byte pieces");
   constexpr int PER_WAVE = (TBM / 16) * (TBN / 16) / (NT / 64);
   constexpr int WTM = (PER_WAVE >= 2 && TBM >= 32) ? 32 : 16;
   constexpr int WTN = 16 * PER_WAVE / (WTM / 16);
@@ -197,8 +203,18 @@ __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mm
     }
   };
 
-  float ra[RING][NITA], rb[RING][NITB];
-  float xa[AUX ? RING : 1][AUX ? NITA : 1], xb[AUX ? RING : 1][AUX ? NITB : 1];
+  float ra[RING][NITA][VA], rb[RING][NITB][VB];
+  float xa[AUX ? RING : 1][AUX ? NITA : 1][VA], xb[AUX ? RING : 1][AUX ? NITB : 1][VB];
+  auto stage_load = [](auto vtag, const __amdgpu_buffer_rsrc_t& rs, int voff, int soff, float* dst) {
+    if (decltype(vtag)::value == 4) {
+      const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+      dst[0] = t[0], dst[1 % decltype(vtag)::value] = t[1], dst[2 % decltype(vtag)::value] = t[2], dst[3 % decltype(vtag)::value] = t[3];
+    } else {
+      dst[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    }
+  };
+  using TagA = std::integral_constant<int, VA>;
+  using TagB = std::integral_constant<int, VB>;
   int lim[RING];  // valid k of the tile held in the slot (>= TK: a full tile; 0: no tile)
   int fetched = t0;  // index of the next tile to fetch
   // one fetch path for full and partial tiles: a slot whose k lies beyond the segment reads the tile's first k instead (zeroed
@@ -209,17 +225,19 @@ __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mm
     lim[slot] = l;
     const __amdgpu_buffer_rsrc_t ua = live ? rsA : rs_null, ub = live ? rsB : rs_null;
     const int sa = fkt * stepA, sb = fkt * stepB;
+    // (a 16-byte piece whose first k lies in the segment may run past its last k: those elements are zeroed when parked; what they
+    // read is the operand's own row or the bytes right behind it — operands live in the engine's arenas)
 #pragma unroll
     for (int it = 0; it < NITA; ++it) {
       const int o = (int)((kkA[it] < l) ? voffA[it] : voffA[it] - koffA[it]);
-      ra[slot][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ua, o, sa, 0));
-      if (AUX) xa[slot][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(live ? rsAx : rs_null, o, sa, 0));
+      stage_load(TagA{}, ua, o, sa, ra[slot][it]);
+      if (AUX) stage_load(TagA{}, live ? rsAx : rs_null, o, sa, xa[slot][it]);
     }
 #pragma unroll
     for (int it = 0; it < NITB; ++it) {
       const int o = (int)((kkB[it] < l) ? voffB[it] : voffB[it] - koffB[it]);
-      rb[slot][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ub, o, sb, 0));
-      if (AUX) xb[slot][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(live ? rsBx : rs_null, o, sb, 0));
+      stage_load(TagB{}, ub, o, sb, rb[slot][it]);
+      if (AUX) stage_load(TagB{}, live ? rsBx : rs_null, o, sb, xb[slot][it]);
     }
   };
   // advance the fetch cursor by one tile (the segment switch is a branch without loads)
@@ -243,22 +261,36 @@ __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mm
     for (int it = 0; it < NITA; ++it) {
       int rr, kk;
       rt_stage_coords<KCA, NT, TK, TBM>(tid, it, rr, kk);
-      float a = ra[slot][it];
-      if (AUX) a = (!hasAaux || xa[slot][it] > 0.f) ? a : 0.f;
-      if (edgeA) a = rvA[it] ? a : 0.f;
-      a = (kk < l) ? a : 0.f;
-      As[rr * LDS_LD + kk] = a;
+      float a[VA];
+#pragma unroll
+      for (int e = 0; e < VA; ++e) {
+        a[e] = ra[slot][it][e];
+        if (AUX) a[e] = (!hasAaux || xa[slot][it][e] > 0.f) ? a[e] : 0.f;
+        if (edgeA) a[e] = rvA[it] ? a[e] : 0.f;
+        a[e] = (kk + e < l) ? a[e] : 0.f;
+      }
+      if (VA == 4)
+        *reinterpret_cast<f32x4*>(&As[rr * LDS_LD + kk]) = (f32x4){a[0], a[1 % VA], a[2 % VA], a[3 % VA]};
+      else
+        As[rr * LDS_LD + kk] = a[0];
     }
 #pragma unroll
     for (int it = 0; it < NITB; ++it) {
       int rr, kk;
       rt_stage_coords<KCB, NT, TK, TBN>(tid, it, rr, kk);
-      float b = rb[slot][it];
-      if (AUX) b = (!hasBaux || xb[slot][it] > 0.f) ? b : 0.f;
-      if (edgeB) b = rvB[it] ? b : 0.f;
-      b = (kk < l) ? b : 0.f;
-      if (cOnes && oneB[it]) b = (kk < l) ? 1.f : 0.f;
-      Bs[rr * LDS_LD + kk] = b;
+      float b[VB];
+#pragma unroll
+      for (int e = 0; e < VB; ++e) {
+        b[e] = rb[slot][it][e];
+        if (AUX) b[e] = (!hasBaux || xb[slot][it][e] > 0.f) ? b[e] : 0.f;
+        if (edgeB) b[e] = rvB[it] ? b[e] : 0.f;
+        b[e] = (kk + e < l) ? b[e] : 0.f;
+        if (cOnes && oneB[it]) b[e] = (kk + e < l) ? 1.f : 0.f;
+      }
+      if (VB == 4)
+        *reinterpret_cast<f32x4*>(&Bs[rr * LDS_LD + kk]) = (f32x4){b[0], b[1 % VB], b[2 % VB], b[3 % VB]};
+      else
+        Bs[rr * LDS_LD + kk] = b[0];
     }
   };
   auto mfma_tile = [&]() {
