@@ -32,17 +32,18 @@ __device__ __forceinline__ long rt_offset(const RtStride& s, int r, int k) {
 }
 
 // thread -> (row, k) of the staging loads of an R x TK operand tile: lanes run along the contiguous axis
-// k-contiguous operands are staged four k per lane (one 16-byte load, one ds_write_b128: a wave-instruction covers 4 rows x 256 B
-// instead of one row — the one-dword form spent the texture-address path on 64 instructions per 16 KB tile); the others one element
-// per lane along r.  `it` counts LOADS: NIT / RT_V of them per thread and k-tile.
+// Operands are staged four floats per lane (one 16-byte load): along k for k-contiguous operands (parked with one ds_write_b128: a
+// wave-instruction covers 4 rows x 256 B), along r for the others (RC is contiguous in r, TOKR in groups of 16; parked as four
+// dwords in four LDS rows).  The one-dword form spent the texture-address path on 64 instructions per 16 KB tile.
+// `it` counts LOADS: (rows x TK / NT) / 4 of them per thread and k-tile; (rr, kk) is the piece's first element.
 template <bool KCONTIG, int NT, int TK, int R>
 __device__ __forceinline__ void rt_stage_coords(int tid, int it, int& rr, int& kk) {
   if (KCONTIG) {
     kk = 4 * (tid & (TK / 4 - 1));
     rr = tid / (TK / 4) + (NT / (TK / 4)) * it;
   } else {
-    rr = tid & (R - 1);
-    kk = tid / R + (NT / R) * it;
+    rr = 4 * (tid & (R / 4 - 1));
+    kk = tid / (R / 4) + (NT / (R / 4)) * it;
   }
 }
 
@@ -59,9 +60,9 @@ template <bool KCA, bool KCB, int NT, int TK, int TBM, int TBN, bool AUX, int RI
 __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mmax, int Nmax, const int bx, const int by, const int bz, float* lds) {
   const int AM = d.amode, BMODE = d.bmode, CM = d.cmode;
   constexpr int LDS_LD = TK + 4;
-  constexpr int VA = KCA ? 4 : 1, VB = KCB ? 4 : 1;                   // floats per staging load
+  constexpr int VA = 4, VB = 4;                                        // floats per staging load
   constexpr int NITA = TBM * TK / NT / VA, NITB = TBN * TK / NT / VB;  // staging loads per thread and k-tile
-  static_assert((TBM * TK / NT) % VA == 0 && (TBN * TK / NT) % VB == 0 && TK % 16 == 0, "whole 16-byte pieces");
+  static_assert((TBM * TK / NT) % VA == 0 && (TBN * TK / NT) % VB == 0 && TK % 16 == 0 && TBM % 4 == 0 && TBN % 4 == 0, "whole 16-byte pieces");
   constexpr int PER_WAVE = (TBM / 16) * (TBN / 16) / (NT / 64);
   constexpr int WTM = (PER_WAVE >= 2 && TBM >= 32) ? 32 : 16;
   constexpr int WTN = 16 * PER_WAVE / (WTM / 16);
@@ -118,7 +119,7 @@ __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mm
   const int Ra = (s0.Mvalid > 0 && s0.Mvalid < M) ? s0.Mvalid : M;
   const int Rb = cOnes ? N - 1 : N;
   const bool edgeA = (m0 + TBM > Ra), edgeB = (n0 + TBN > Rb);
-  bool rvA[NITA], rvB[NITB], oneB[NITB];
+  bool rvA[NITA], rvB[NITB];  // the piece's FIRST row exists (pieces that start outside the operand are redirected to row 0)
   int kkA[NITA], kkB[NITB];
 #pragma unroll
   for (int it = 0; it < NITA; ++it) {
@@ -131,7 +132,6 @@ __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mm
     int rr;
     rt_stage_coords<KCB, NT, TK, TBN>(tid, it, rr, kkB[it]);
     rvB[it] = (n0 + rr) < Rb;
-    oneB[it] = cOnes && (n0 + rr == N - 1);
   }
 
   // ---- fetch cursor (segment state) ------------------------------------------------------------------------------------
@@ -263,16 +263,18 @@ __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mm
       rt_stage_coords<KCA, NT, TK, TBM>(tid, it, rr, kk);
       float a[VA];
 #pragma unroll
-      for (int e = 0; e < VA; ++e) {
+      for (int e = 0; e < VA; ++e) {  // element e: (rr, kk + e) along k, (rr + e, kk) along r
         a[e] = ra[slot][it][e];
         if (AUX) a[e] = (!hasAaux || xa[slot][it][e] > 0.f) ? a[e] : 0.f;
-        if (edgeA) a[e] = rvA[it] ? a[e] : 0.f;
-        a[e] = (kk + e < l) ? a[e] : 0.f;
+        if (edgeA) a[e] = (m0 + rr + (KCA ? 0 : e) < Ra) ? a[e] : 0.f;
+        a[e] = (kk + (KCA ? e : 0) < l) ? a[e] : 0.f;
       }
-      if (VA == 4)
-        *reinterpret_cast<f32x4*>(&As[rr * LDS_LD + kk]) = (f32x4){a[0], a[1 % VA], a[2 % VA], a[3 % VA]};
-      else
-        As[rr * LDS_LD + kk] = a[0];
+      if (KCA) {
+        *reinterpret_cast<f32x4*>(&As[rr * LDS_LD + kk]) = (f32x4){a[0], a[1], a[2], a[3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < VA; ++e) As[(rr + e) * LDS_LD + kk] = a[e];
+      }
     }
 #pragma unroll
     for (int it = 0; it < NITB; ++it) {
@@ -283,14 +285,17 @@ __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mm
       for (int e = 0; e < VB; ++e) {
         b[e] = rb[slot][it][e];
         if (AUX) b[e] = (!hasBaux || xb[slot][it][e] > 0.f) ? b[e] : 0.f;
-        if (edgeB) b[e] = rvB[it] ? b[e] : 0.f;
-        b[e] = (kk + e < l) ? b[e] : 0.f;
-        if (cOnes && oneB[it]) b[e] = (kk + e < l) ? 1.f : 0.f;
+        if (edgeB) b[e] = (n0 + rr + (KCB ? 0 : e) < Rb) ? b[e] : 0.f;
+        const bool kin = kk + (KCB ? e : 0) < l;
+        b[e] = kin ? b[e] : 0.f;
+        if (cOnes && (n0 + rr + (KCB ? 0 : e) == N - 1)) b[e] = kin ? 1.f : 0.f;
       }
-      if (VB == 4)
-        *reinterpret_cast<f32x4*>(&Bs[rr * LDS_LD + kk]) = (f32x4){b[0], b[1 % VB], b[2 % VB], b[3 % VB]};
-      else
-        Bs[rr * LDS_LD + kk] = b[0];
+      if (KCB) {
+        *reinterpret_cast<f32x4*>(&Bs[rr * LDS_LD + kk]) = (f32x4){b[0], b[1], b[2], b[3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < VB; ++e) Bs[(rr + e) * LDS_LD + kk] = b[e];
+      }
     }
   };
   auto mfma_tile = [&]() {
