@@ -10,6 +10,9 @@
 
 #define WL_TK 64  // staged k depth of every GEMM item (a product with K <= 32 pads its one tile with zeros: same sums, bit for bit)
 // tile configurations of GEMM items: geom[2] = tile | binding pair << 2 | mask operand << 4
+#ifndef WL_AUX_RING2
+#define WL_AUX_RING2 0  // (A/B knob: ring depth 2 for the mask-operand instantiations too)
+#endif
 enum { WL_TOKS = 0, WL_T32x32 = 1, WL_T64x16 = 2, WL_T16x64 = 3 };  // WL_TOKS: wl_token_fwd (a wavefront per sample)
 
 // All bodies share the launch's DYNAMIC LDS buffer (sized by the launcher: 35 KB, or 52 KB when a Transformer backward is in the level).
@@ -31,7 +34,7 @@ __device__ __forceinline__ void wl_gemm_cfg(unsigned long long blob, int vb_, in
   // side by side if they are resident together); a staged k-tile is <= 20 floats per thread on these tiles.  With mask operands a
   // staged element is two registers: those instantiations spilled 37 - 90 registers at depth 2 (a 128 x 768 x 256 weight gradient
   // behind a ReLU took 20 us as an item against 10 us with registers to spare) and stage one k-tile at a time instead.
-  constexpr int RING = AUX ? 1 : 2;
+  constexpr int RING = (AUX && !WL_AUX_RING2) ? 1 : 2;
   const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
   const int vb = __builtin_amdgcn_readfirstlane(vb_), gx = __builtin_amdgcn_readfirstlane(gx_), gy = __builtin_amdgcn_readfirstlane(gy_);
   const int nprob = g.zmode ? g.nseg : 1;
