@@ -15,12 +15,34 @@
 // Row predicates (Mvalid, the virtual ones-column) are per workgroup: launch_gemm_t routes a launch whose k-segments disagree on
 // them to gemm_tile.
 #pragma once
+#include <type_traits>
 #include "gemm_tile.h"
+
+// thread -> first element (rr, kk) of staging load `it`: V = 4 floats per lane (one 16-byte load) along the operand's contiguous axis
+// — k for KC / TOKK (parked with one ds_write_b128), r for RC / TOKR (four dword parks) — or V = 1, the one-dword map of
+// gemm_tile.h, when a thread's share of the tile is not a multiple of four floats (the shallow TK = 32 strips).  The LDS image is
+// the same either way; the one-dword form needs 4x the staging instructions (gemm_rt.h, the worklist's copy of this loop).
+template <int MODE, int V, int NT, int TK, int R>
+__device__ __forceinline__ void ring_stage_coords(int tid, int it, int& rr, int& kk) {
+  constexpr bool KC = MODE == NASREC_AM_KC || MODE == NASREC_AM_TOKK;
+  if (V == 1) {
+    stage_coords<MODE, NT, TK, R>(tid, it, rr, kk);
+  } else if (KC) {
+    kk = 4 * (tid & (TK / 4 - 1));
+    rr = tid / (TK / 4) + (NT / (TK / 4)) * it;
+  } else {
+    rr = 4 * (tid & (R / 4 - 1));
+    kk = tid / (R / 4) + (NT / (R / 4)) * it;
+  }
+}
 
 template <int AM, int BMODE, int CM, int NT, int TK, int TBM, int TBN, bool AUX, int RING>
 __device__ __forceinline__ void gemm_tile_ring(const nasrec_gemm_desc_t& d, int Mmax, int Nmax, const int bx, const int by, const int bz) {
   constexpr int LDS_LD = TK + 4;
-  constexpr int NITA = TBM * TK / NT, NITB = TBN * TK / NT;
+  constexpr bool KCA = AM == NASREC_AM_KC || AM == NASREC_AM_TOKK, KCB = BMODE == NASREC_AM_KC || BMODE == NASREC_AM_TOKK;
+  constexpr int VA = (TBM * TK / NT) % 4 == 0 && TK % 16 == 0 && TBM % 4 == 0 ? 4 : 1;  // floats per staging load
+  constexpr int VB = (TBN * TK / NT) % 4 == 0 && TK % 16 == 0 && TBN % 4 == 0 ? 4 : 1;
+  constexpr int NITA = TBM * TK / NT / VA, NITB = TBN * TK / NT / VB;                    // staging loads per thread and k-tile
   constexpr int PER_WAVE = (TBM / 16) * (TBN / 16) / (NT / 64);
   constexpr int WTM = (PER_WAVE >= 2 && TBM >= 32) ? 32 : 16;
   constexpr int WTN = 16 * PER_WAVE / (WTM / 16);
@@ -76,20 +98,19 @@ __device__ __forceinline__ void gemm_tile_ring(const nasrec_gemm_desc_t& d, int 
   const int Ra = (s0.Mvalid > 0 && s0.Mvalid < M) ? s0.Mvalid : M;
   const int Rb = cOnes ? N - 1 : N;
   const bool edgeA = (m0 + TBM > Ra), edgeB = (n0 + TBN > Rb);
-  bool rvA[NITA], rvB[NITB], oneB[NITB];
+  bool rvA[NITA], rvB[NITB];  // the piece's FIRST row exists (pieces that start outside the operand are redirected to row 0)
   int kkA[NITA], kkB[NITB];
 #pragma unroll
   for (int it = 0; it < NITA; ++it) {
     int rr;
-    stage_coords<AM, NT, TK, TBM>(tid, it, rr, kkA[it]);
+    ring_stage_coords<AM, VA, NT, TK, TBM>(tid, it, rr, kkA[it]);
     rvA[it] = (m0 + rr) < Ra;
   }
 #pragma unroll
   for (int it = 0; it < NITB; ++it) {
     int rr;
-    stage_coords<BMODE, NT, TK, TBN>(tid, it, rr, kkB[it]);
+    ring_stage_coords<BMODE, VB, NT, TK, TBN>(tid, it, rr, kkB[it]);
     rvB[it] = (n0 + rr) < Rb;
-    oneB[it] = cOnes && (n0 + rr == N - 1);
   }
 
   // ---- fetch cursor (segment state) ------------------------------------------------------------------------------------
@@ -133,12 +154,18 @@ __device__ __forceinline__ void gemm_tile_ring(const nasrec_gemm_desc_t& d, int 
       const nasrec_gemm_seg_t& g = d.seg[sq];
       sg = {g.A, g.B, g.Aaux, g.Baux, g.K, g.lda, g.ldb};
     }
-    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.A), 0, 0x7fffffff, 0x00020000);
-    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.B), 0, 0x7fffffff, 0x00020000);
+    // resources end with the operand's last element (offset of (rows - 1, K - 1) + 1): a 16-byte piece that starts inside the operand
+    // and runs past its end gets zeros for the dwords beyond it (the range check of a raw buffer is per dword: tools/micro/
+    // buffer_oob_probe.hip) instead of touching memory behind the tensor — operands may be plain torch tensors (opexec plans)
+    const int Rb_mem = cOnes ? N - 1 : N;
+    const int extA = (M > 0 && sg.K > 0) ? (int)(4 * (operand_offset<AM>(M - 1, sg.K - 1, sg.lda) + 1)) : 0;
+    const int extB = (Rb_mem > 0 && sg.K > 0) ? (int)(4 * (operand_offset<BMODE>(Rb_mem - 1, sg.K - 1, sg.ldb) + 1)) : 0;
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.A), 0, extA, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.B), 0, extB, 0x00020000);
     hasAaux = AUX && sg.Aaux != nullptr;
     hasBaux = AUX && sg.Baux != nullptr;
-    rsAx = hasAaux ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.Aaux), 0, 0x7fffffff, 0x00020000) : rs_null;
-    rsBx = hasBaux ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.Baux), 0, 0x7fffffff, 0x00020000) : rs_null;
+    rsAx = hasAaux ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.Aaux), 0, extA, 0x00020000) : rs_null;
+    rsBx = hasBaux ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.Baux), 0, extB, 0x00020000) : rs_null;
     cK = sg.K;
     seg_tiles = (cK + TK - 1) / TK;
     const int lda = sg.lda, ldb = sg.ldb;
@@ -147,21 +174,32 @@ __device__ __forceinline__ void gemm_tile_ring(const nasrec_gemm_desc_t& d, int 
 #pragma unroll
     for (int it = 0; it < NITA; ++it) {
       int rr, kk;
-      stage_coords<AM, NT, TK, TBM>(tid, it, rr, kk);
+      ring_stage_coords<AM, VA, NT, TK, TBM>(tid, it, rr, kk);
       koffA[it] = 4u * (unsigned)operand_offset<AM>(0, kk, lda);
       voffA[it] = 4u * (unsigned)operand_offset<AM>(rvA[it] ? m0 + rr : 0, kk, lda);
     }
 #pragma unroll
     for (int it = 0; it < NITB; ++it) {
       int rr, kk;
-      stage_coords<BMODE, NT, TK, TBN>(tid, it, rr, kk);
+      ring_stage_coords<BMODE, VB, NT, TK, TBN>(tid, it, rr, kk);
       koffB[it] = 4u * (unsigned)operand_offset<BMODE>(0, kk, ldb);
       voffB[it] = 4u * (unsigned)operand_offset<BMODE>(rvB[it] ? n0 + rr : 0, kk, ldb);
     }
   };
 
-  float ra[RING][NITA], rb[RING][NITB];
-  float xa[AUX ? RING : 1][AUX ? NITA : 1], xb[AUX ? RING : 1][AUX ? NITB : 1];
+  float ra[RING][NITA][VA], rb[RING][NITB][VB];
+  float xa[AUX ? RING : 1][AUX ? NITA : 1][VA], xb[AUX ? RING : 1][AUX ? NITB : 1][VB];
+  auto stage_load = [](auto vtag, const __amdgpu_buffer_rsrc_t& rs, int voff, int soff, float* dst) {
+    constexpr int V = decltype(vtag)::value;
+    if (V == 4) {
+      const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+      dst[0] = t[0], dst[1 % V] = t[1], dst[2 % V] = t[2], dst[3 % V] = t[3];
+    } else {
+      dst[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    }
+  };
+  using TagA = std::integral_constant<int, VA>;
+  using TagB = std::integral_constant<int, VB>;
   int lim[RING];  // valid k of the tile held in the slot (>= TK: a full tile; 0: no tile)
   int fetched = t0;  // index of the next tile to fetch
   // one fetch path for full and partial tiles: a slot whose k lies beyond the segment reads the tile's first k instead (zeroed
@@ -172,17 +210,18 @@ __device__ __forceinline__ void gemm_tile_ring(const nasrec_gemm_desc_t& d, int 
     lim[slot] = l;
     const __amdgpu_buffer_rsrc_t ua = live ? rsA : rs_null, ub = live ? rsB : rs_null;
     const int sa = fkt * stepA, sb = fkt * stepB;
+    // (a 16-byte piece whose first element lies in the operand may run past its last k / row: those elements are zeroed when parked)
 #pragma unroll
     for (int it = 0; it < NITA; ++it) {
       const int o = (int)((kkA[it] < l) ? voffA[it] : voffA[it] - koffA[it]);
-      ra[slot][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ua, o, sa, 0));
-      if (AUX) xa[slot][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(live ? rsAx : rs_null, o, sa, 0));
+      stage_load(TagA{}, ua, o, sa, ra[slot][it]);
+      if (AUX) stage_load(TagA{}, live ? rsAx : rs_null, o, sa, xa[slot][it]);
     }
 #pragma unroll
     for (int it = 0; it < NITB; ++it) {
       const int o = (int)((kkB[it] < l) ? voffB[it] : voffB[it] - koffB[it]);
-      rb[slot][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ub, o, sb, 0));
-      if (AUX) xb[slot][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(live ? rsBx : rs_null, o, sb, 0));
+      stage_load(TagB{}, ub, o, sb, rb[slot][it]);
+      if (AUX) stage_load(TagB{}, live ? rsBx : rs_null, o, sb, xb[slot][it]);
     }
   };
   // advance the fetch cursor by one tile (the segment switch is a branch without loads)
@@ -205,23 +244,42 @@ __device__ __forceinline__ void gemm_tile_ring(const nasrec_gemm_desc_t& d, int 
 #pragma unroll
     for (int it = 0; it < NITA; ++it) {
       int rr, kk;
-      stage_coords<AM, NT, TK, TBM>(tid, it, rr, kk);
-      float a = ra[slot][it];
-      if (AUX) a = (!hasAaux || xa[slot][it] > 0.f) ? a : 0.f;
-      if (edgeA) a = rvA[it] ? a : 0.f;
-      a = (kk < l) ? a : 0.f;
-      As[rr * LDS_LD + kk] = a;
+      ring_stage_coords<AM, VA, NT, TK, TBM>(tid, it, rr, kk);
+      float a[VA];
+#pragma unroll
+      for (int e = 0; e < VA; ++e) {  // element e: (rr, kk + e) along k, (rr + e, kk) along r
+        a[e] = ra[slot][it][e];
+        if (AUX) a[e] = (!hasAaux || xa[slot][it][e] > 0.f) ? a[e] : 0.f;
+        if (edgeA) a[e] = (m0 + rr + (KCA ? 0 : e) < Ra) ? a[e] : 0.f;
+        a[e] = (kk + (KCA ? e : 0) < l) ? a[e] : 0.f;
+      }
+      if (VA == 4 && KCA) {
+        *reinterpret_cast<f32x4*>(&As[rr * LDS_LD + kk]) = (f32x4){a[0], a[1 % VA], a[2 % VA], a[3 % VA]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < VA; ++e) As[(rr + (KCA ? 0 : e)) * LDS_LD + kk + (KCA ? e : 0)] = a[e];
+      }
     }
 #pragma unroll
     for (int it = 0; it < NITB; ++it) {
       int rr, kk;
-      stage_coords<BMODE, NT, TK, TBN>(tid, it, rr, kk);
-      float b = rb[slot][it];
-      if (AUX) b = (!hasBaux || xb[slot][it] > 0.f) ? b : 0.f;
-      if (edgeB) b = rvB[it] ? b : 0.f;
-      b = (kk < l) ? b : 0.f;
-      if (cOnes && oneB[it]) b = (kk < l) ? 1.f : 0.f;
-      Bs[rr * LDS_LD + kk] = b;
+      ring_stage_coords<BMODE, VB, NT, TK, TBN>(tid, it, rr, kk);
+      float b[VB];
+#pragma unroll
+      for (int e = 0; e < VB; ++e) {
+        b[e] = rb[slot][it][e];
+        if (AUX) b[e] = (!hasBaux || xb[slot][it][e] > 0.f) ? b[e] : 0.f;
+        if (edgeB) b[e] = (n0 + rr + (KCB ? 0 : e) < Rb) ? b[e] : 0.f;
+        const bool kin = kk + (KCB ? e : 0) < l;
+        b[e] = kin ? b[e] : 0.f;
+        if (cOnes && (n0 + rr + (KCB ? 0 : e) == N - 1)) b[e] = kin ? 1.f : 0.f;
+      }
+      if (VB == 4 && KCB) {
+        *reinterpret_cast<f32x4*>(&Bs[rr * LDS_LD + kk]) = (f32x4){b[0], b[1 % VB], b[2 % VB], b[3 % VB]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < VB; ++e) Bs[(rr + (KCB ? 0 : e)) * LDS_LD + kk + (KCB ? e : 0)] = b[e];
+      }
     }
   };
   auto mfma_tile = [&]() {

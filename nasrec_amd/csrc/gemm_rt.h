@@ -175,16 +175,22 @@ __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mm
       const nasrec_gemm_seg_t& g = d.seg[sq];
       sg = {g.A, g.B, g.Aaux, g.Baux, g.K, g.lda, g.ldb};
     }
-    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.A), 0, 0x7fffffff, 0x00020000);
-    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.B), 0, 0x7fffffff, 0x00020000);
-    hasAaux = AUX && sg.Aaux != nullptr;
-    hasBaux = AUX && sg.Baux != nullptr;
-    rsAx = hasAaux ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.Aaux), 0, 0x7fffffff, 0x00020000) : rs_null;
-    rsBx = hasBaux ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.Baux), 0, 0x7fffffff, 0x00020000) : rs_null;
-    cK = sg.K;
-    seg_tiles = (cK + TK - 1) / TK;
     const int lda = sg.lda, ldb = sg.ldb;
     const RtStride sa_ = rt_stride(AM, lda), sb_ = rt_stride(BMODE, ldb);
+    // resources end with the operand's last element (offset of (rows - 1, K - 1) + 1): a 16-byte piece that starts inside the operand
+    // and runs past its end gets zeros for the dwords beyond it (the range check of a raw buffer is per dword: tools/micro/
+    // buffer_oob_probe.hip) instead of touching memory behind the tensor
+    const int Rb_mem = cOnes ? N - 1 : N;
+    const int extA = (M > 0 && sg.K > 0) ? (int)(4 * (rt_offset(sa_, M - 1, sg.K - 1) + 1)) : 0;
+    const int extB = (Rb_mem > 0 && sg.K > 0) ? (int)(4 * (rt_offset(sb_, Rb_mem - 1, sg.K - 1) + 1)) : 0;
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.A), 0, extA, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.B), 0, extB, 0x00020000);
+    hasAaux = AUX && sg.Aaux != nullptr;
+    hasBaux = AUX && sg.Baux != nullptr;
+    rsAx = hasAaux ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.Aaux), 0, extA, 0x00020000) : rs_null;
+    rsBx = hasBaux ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.Baux), 0, extB, 0x00020000) : rs_null;
+    cK = sg.K;
+    seg_tiles = (cK + TK - 1) / TK;
     stepA = (int)(4 * rt_offset(sa_, 0, TK));
     stepB = (int)(4 * rt_offset(sb_, 0, TK));
 #pragma unroll
@@ -225,8 +231,7 @@ __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mm
     lim[slot] = l;
     const __amdgpu_buffer_rsrc_t ua = live ? rsA : rs_null, ub = live ? rsB : rs_null;
     const int sa = fkt * stepA, sb = fkt * stepB;
-    // (a 16-byte piece whose first k lies in the segment may run past its last k: those elements are zeroed when parked; what they
-    // read is the operand's own row or the bytes right behind it — operands live in the engine's arenas)
+    // (a 16-byte piece whose first element lies in the segment may run past its last k / row: those elements are zeroed when parked)
 #pragma unroll
     for (int it = 0; it < NITA; ++it) {
       const int o = (int)((kkA[it] < l) ? voffA[it] : voffA[it] - koffA[it]);
