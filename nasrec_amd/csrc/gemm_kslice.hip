@@ -64,7 +64,13 @@ __global__ __launch_bounds__(1024) void gemm_kslice_kernel(const nasrec_gemm_des
   KS_STAMP(0);
   warm_kernarg<1024>();  // (the epilogue's fields are read lazily, one by one)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = wave & 3;
+#ifndef KS_FEED_FIRST
+#define KS_FEED_FIRST 1
+#endif
+  // role index: roles 8..15 feed, 0..7 multiply.  The feeders take the OLDER waves 0..7 (the issue arbiter favours the older wave of a
+  // SIMD, and the feeders' piece issue is what sets the chunk period): the launch 13.9 -> 13.55 us on both boxes of the A/B
+  const int rw = KS_FEED_FIRST ? (wave ^ 8) : wave;
+  const int tile = rw & 3;
   const int tm = tile >> 1, tn = tile & 1;
   const int fr = lane & 15, fg = lane >> 4;
   // the (at most KS_SEGS) K-segments, in scalar registers: a chunk's segment is found by compare / select, no descriptor reads in the loop
@@ -145,16 +151,16 @@ __global__ __launch_bounds__(1024) void gemm_kslice_kernel(const nasrec_gemm_des
     sN[q] = (sK[q] + KS_DC - 1) / KS_DC;
     nchunks += sN[q];
   }
-  // ---- roles: waves 0..7 multiply (tile = wave & 3, k-half = wave >> 2: two per SIMD), waves 8..15 only feed the LDS-DMA ------------
+  // ---- roles: rw 0..7 multiply (tile = rw & 3, k-half = rw >> 2: two per SIMD), rw 8..15 only feed the LDS-DMA ------------
   // A wave that issues a DMA piece stalls 100 - 200 cycles per piece, and with every wave doing both jobs in barrier lock-step the
   // MFMA pipes idled through every issue phase (measured: DMA and MFMA time added up, 1900 cycles per chunk for 1024 of MFMA).
   // With the jobs split the issue stalls of the feeders sit under the MFMAs of the multipliers.
-  const bool feeder = wave >= 8;
+  const bool feeder = rw >= 8;
   float* red = ks_lds;  // (after the loop) [half][tile][reg][lane]
   if (feeder) {
-    // feeder f = wave - 8 owns pieces 4f .. 4f + 3 of every chunk: piece q fills LDS rows 2q, 2q + 1 (512 B each; rows 0..31 = x tile,
+    // feeder f = rw - 8 owns pieces 4f .. 4f + 3 of every chunk: piece q fills LDS rows 2q, 2q + 1 (512 B each; rows 0..31 = x tile,
     // 32..63 = W tile: feeders 0..3 read x, 4..7 read W); lane -> (row, 16-byte slot p), which holds k-group p ^ (row & 15)
-    const int f = wave - 8;
+    const int f = rw - 8;
     const bool isB = f >= 4;
     const int pslot = lane & 31;
     int grow[4], gkg[4], growld[4];
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(1024) void gemm_kslice_kernel(const nasrec_gemm_des
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   } else {
-    const int half = wave >> 2;
+    const int half = rw >> 2;
 #ifdef KS_STAMPS
     unsigned ks_wait = 0;
     const unsigned ks_t0 = (unsigned)__builtin_readcyclecounter();
