@@ -217,6 +217,11 @@ __device__ __forceinline__ void ln_stats(const Vec<S>& v, float* redA, float* re
 #define MHA_FWD_LDS_FLOATS(S) (NASREC_MHA_PARAMS + 5 * MHA_N * 16 + 4 * 64 * (16 / (S)))
 #define MHA_BWD_LDS_FLOATS(S) (NASREC_MHA_PARAMS + 9 * MHA_N * 16 + 3 * MHA_N * 8 + 2 * 64 * (16 / (S)))
 
+#ifdef MHA_STAMPS  // timing-only build (tools/mha_stamps.py): wave 0 keeps the clock at the stage boundaries and overwrites the first words of its parameter-gradient partial (backward) / output row (forward) with it
+#define MHA_STAMP(i) mha_st[i] = (unsigned)__builtin_readcyclecounter()
+#else
+#define MHA_STAMP(i)
+#endif
 template <int S>
 __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const int b, float* lds) {
   constexpr int NW = 16 / S, NT = 64 * NW, HP = S / 2;
@@ -232,6 +237,10 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
   const int N = d.N;
   const bool active = lane < N;
   const bool saving = d.saved != nullptr;  // training: keep what the backward needs instead of recomputing it there
+#ifdef MHA_STAMPS
+  unsigned mha_st[16];
+#endif
+  MHA_STAMP(0);
   float x[16];  // (issued before the parameters are parked: one round trip for both)
   ParamPieces<NT> pp;
   stage_params_load<NT>(d, tid, pp);
@@ -242,6 +251,7 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
     for (int e = 0; e < 16; ++e) x[e] = 0.f;
   }
   __syncthreads();
+  MHA_STAMP(1);
   // in-projection, the wave's S columns of q, k, v
   Vec<S> q4 = mv_slice<S>(Wsh + OFF_WIN, Wsh + OFF_BIN, c0, x);
 #pragma unroll
@@ -269,6 +279,7 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
       sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_V), Ob, N, tid);
       __syncthreads();  // Ob is rewritten right after the attention loop (another wave may get there first)
     }
+    MHA_STAMP(2);
     const f32x2 qa = {q4[0] * LOG2E, q4[2 % S] * LOG2E}, qb = {q4[1] * LOG2E, q4[3 % S] * LOG2E};
     f32x2 m2 = {-INFINITY, -INFINITY};
 #pragma unroll 8
@@ -278,6 +289,7 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
       m2[0] = fmaxf(m2[0], s2[0]);
       m2[1] = fmaxf(m2[1], s2[1]);
     }
+    MHA_STAMP(3);
     f32x2 l2 = {0.f, 0.f}, oa = {0.f, 0.f}, ob = {0.f, 0.f};
 #pragma unroll 8
     for (int j = 0; j < N; ++j) {
@@ -340,9 +352,11 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
     o4[2 * h + 1] *= li[h];
   }
   }
+  MHA_STAMP(4);
   stv<S>(Ob + lane * 16 + c0, o4);
   __syncthreads();
   if (saving) sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_O), Ob, N, tid);
+  MHA_STAMP(5);
   // out-projection + residual + LayerNorm 1
   float row[16];
   ld_row(Ob + lane * 16, row);
@@ -364,6 +378,7 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
     sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_H1), Hb, N, tid);
     sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_XH1), Ks, N, tid);
   }
+  MHA_STAMP(6);
   // FFN
   ld_row(Hb + lane * 16, row);
   Vec<S> f1 = mv_slice<S>(Wsh + OFF_W1, Wsh + OFF_C1, c0, row);
@@ -376,8 +391,10 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
   Vec<S> r2 = mv_slice<S>(Wsh + OFF_W2, Wsh + OFF_C2, c0, row);
 #pragma unroll
   for (int r = 0; r < S; ++r) r2[r] += h1[r];
+  MHA_STAMP(7);
   float mu2, rstd2;
   ln_stats<S>(r2, red[2], red[3], w, lane, mu2, rstd2);
+  MHA_STAMP(8);
   Vec<S> xh2, out;
   const bool masked = d.dims_in_use >= 0 && lane >= d.dims_in_use;
 #pragma unroll
@@ -400,6 +417,12 @@ __device__ __forceinline__ void mha_fwd_sample(const nasrec_mha_desc_t& d, const
     sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_XH2), Vs, N, tid);
     sv_copy_out<NT>(sv_plane(d.saved, b, N, SV_M), Ob, N, tid);
   }
+#ifdef MHA_STAMPS
+  MHA_STAMP(9);
+  __syncthreads();
+  if (tid == 0)
+    for (int i = 0; i < 10; ++i) d.out[(long)b * d.ldo + i] = __builtin_bit_cast(float, mha_st[i]);
+#endif
 }
 
 
@@ -425,12 +448,25 @@ __device__ __forceinline__ void wgrad_slice(const float* G, const float* V, int 
 // batch) backward: 222 -> 213 us at B = 4096; at batch 256 the serial MFMA chain of one wave costs 0.6 us more than the slices.
 __device__ __forceinline__ void wgrad_mfma(const float* G, const float* V, int lane, int N, float* out) {
   const int r = lane & 15, g = lane >> 4;
+  // every LDS read of the product is issued before the first MFMA (a loop of read, wait, multiply was 16 dependent LDS round trips
+  // on one wave while the others wait at the stage's barrier: tools/mha_stamps.py); one accumulator, tokens in order as before.
+  // (Running it on EVERY wave of the one-matrix stages — each on its own SIMD's idle matrix pipe, one storing — so that the vector
+  // work of the stage could sit between the MFMAs moved time between the stages and left the body where it was: 445 -> 435.)
+  float a[MHA_N / 4], b[MHA_N / 4];
+#pragma unroll
+  for (int s = 0; s < MHA_N / 4; ++s) {
+    const int t = 4 * s + g;
+    const int tt = t < N ? t : 0;
+    a[s] = G[tt * 16 + r];
+    b[s] = V[tt * 16 + r];
+  }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int t0 = 0; t0 < N; t0 += 4) {
-    const int t = t0 + g;
-    const float a = t < N ? G[t * 16 + r] : 0.f;
-    const float b = t < N ? V[t * 16 + r] : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < MHA_N / 4; ++s) {
+    if (4 * s < N) {  // (uniform)
+      const bool ok = 4 * s + g < N;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? a[s] : 0.f, ok ? b[s] : 0.f, acc, 0, 0, 0);
+    }
   }
   // D: row o = 4 * (lane >> 4) + reg, column i = lane & 15
 #pragma unroll
@@ -485,6 +521,10 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   const bool active = lane < N;
   float* gp = d.dparams_partial + (long)b * (d.partial_ld > 0 ? d.partial_ld : NASREC_MHA_PARAMS);
   // the lane's own global operands (token = lane): issued with the planes, used after the first barrier
+#ifdef MHA_STAMPS
+  unsigned mha_st[16];
+#endif
+  MHA_STAMP(0);
   const int tl = min(lane, N - 1);
   const f32x2 rs2 = *reinterpret_cast<const f32x2*>(sv_plane(d.saved, b, N, SV_RSTD) + tl * 4);
   Vec<S> dout_in = ldv<S>(d.dout + (long)b * d.ldo + tl * 16 + c0);
@@ -506,6 +546,10 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
     for (int p = 0; p < 10; ++p) v[p] = *reinterpret_cast<const f32x4*>(src[p] + 4 * t);
     stage_params_store<NT>(Wsh, tid, pp);
     if (tid < n4) {
+      if (S == 4) {  // q, k, v rows as (h0c0, h1c0, h0c1, h1c1): the operand pairs of the packed attention loops below
+#pragma unroll
+        for (int p = 1; p < 4; ++p) v[p] = (f32x4){v[p][0], v[p][2], v[p][1], v[p][3]};
+      }
 #pragma unroll
       for (int p = 0; p < 9; ++p) *reinterpret_cast<f32x4*>(dst[p] + 4 * tid) = v[p];
       // [token][8 max | 8 1/sum] -> Mb, Lb
@@ -513,6 +557,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
     }
   }
   __syncthreads();  // parameters and the token rows are in LDS
+  MHA_STAMP(1);
   Vec<S> x4 = vzero<S>(), q4 = vzero<S>(), k4 = vzero<S>(), v4 = vzero<S>(), o4 = vzero<S>(), h1 = vzero<S>(), xh1 = vzero<S>(),
          f1 = vzero<S>(), xh2 = vzero<S>(), dout = vzero<S>();
   float mx[HP], li[HP];
@@ -542,6 +587,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
     rstd2 = rs2[1];
     if (!(d.dims_in_use >= 0 && lane >= d.dims_in_use)) dout = dout_in;
   }
+  MHA_STAMP(2);
   // ---- LayerNorm 2 ----
   bgrad_slice<S>(vmul<S>(dout, xh2), c0, lane, gp + OFF_L2W);
   bgrad_slice<S>(dout, c0, lane, gp + OFF_L2B);
@@ -563,6 +609,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   for (int r = 0; r < S; ++r) dr2[r] = (gw[r] - c1 - xh2[r] * c2) * rstd2;
   stv<S>(DR2b + lane * 16 + c0, dr2);
   __syncthreads();
+  MHA_STAMP(3);
   // ---- FFN 2: f2 = W2 f1 + c2 ----
   if (S == 4) {
     if (w == 0) wgrad_mfma(DR2b, F1b, lane, N, gp + OFF_W2);
@@ -578,6 +625,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   for (int r = 0; r < S; ++r) df1[r] = f1[r] > 0.f ? df1[r] : 0.f;
   stv<S>(DF1b + lane * 16 + c0, df1);
   __syncthreads();
+  MHA_STAMP(4);
   // ---- FFN 1: f1 = relu(W1 h1 + c1) ----
   if (S == 4) {
     if (w == 1) wgrad_mfma(DF1b, H1b, lane, N, gp + OFF_W1);
@@ -588,6 +636,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   ld_row(DF1b + lane * 16, row);
   Vec<S> dh1 = dr2;
   mvt_slice_acc<S>(Wsh + OFF_W1, c0, row, dh1);
+  MHA_STAMP(5);
   // ---- LayerNorm 1 ----
   bgrad_slice<S>(vmul<S>(dh1, xh1), c0, lane, gp + OFF_L1W);
   bgrad_slice<S>(dh1, c0, lane, gp + OFF_L1B);
@@ -609,6 +658,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   for (int r = 0; r < S; ++r) dr1[r] = (gw[r] - c1 - xh1[r] * c2) * rstd1;
   stv<S>(DR1b + lane * 16 + c0, dr1);
   __syncthreads();
+  MHA_STAMP(6);
   // ---- out-projection: a = Wout o + bout ----
   if (S == 4) {
     if (w == 2) wgrad_mfma(DR1b, Ob, lane, N, gp + OFF_WOUT);
@@ -625,12 +675,58 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
     dd[h] = fmaf(dO[2 * h], o4[2 * h], dO[2 * h + 1] * o4[2 * h + 1]);
     Db[lane * 8 + HP * w + h] = dd[h];
   }
-  stv<S>(DOb + lane * 16 + c0, dO);
+  if (S == 4) {
+    *reinterpret_cast<f32x4*>(DOb + lane * 16 + c0) = (f32x4){dO[0], dO[2 % S], dO[1], dO[3 % S]};  // (pairs, like q / k / v)
+  } else {
+    stv<S>(DOb + lane * 16 + c0, dO);
+  }
   __syncthreads();  // also: every wave is done reading DR1b
+  MHA_STAMP(7);
   // ---- attention backward, the wave's HP heads ----
-  Vec<S> dq = vzero<S>();  // phase A: lane = query
+  Vec<S> dq = vzero<S>(), dk = vzero<S>(), dv = vzero<S>();
+  if (S == 4) {
+    // Two heads per wave = one packed-fp32 lane pair (v_pk_mul / v_pk_fma: 2 heads per instruction), on rows parked as (h0c0, h1c0,
+    // h0c1, h1c1); every element sees the operations of the scalar form below in the same order (same bits).  q4 / k4 / v4 hold
+    // their rows in that pair order here.
+    const f32x2 qa = {q4[0], q4[1]}, qb = {q4[2 % S], q4[3 % S]}, doa = {dO[0], dO[2 % S]}, dob = {dO[1], dO[3 % S]};
+    const f32x2 m2 = {mx[0], mx[1 % HP]}, l2 = {li[0], li[1 % HP]}, dd2 = {dd[0], dd[1 % HP]};
+    f32x2 dqa = {0.f, 0.f}, dqb = {0.f, 0.f};  // phase A: lane = query
 #pragma unroll 4
-  for (int j = 0; j < N; ++j) {
+    for (int j = 0; j < N; ++j) {
+      const f32x4 kj = ld4(Kb + j * 16 + c0), vj = ld4(Vb + j * 16 + c0);
+      const f32x2 ka = {kj[0], kj[1]}, kb = {kj[2], kj[3]}, va = {vj[0], vj[1]}, vb = {vj[2], vj[3]};
+      const f32x2 t = __builtin_elementwise_fma(qa, ka, qb * kb) - m2;
+      const f32x2 p = (f32x2){__expf(t[0]), __expf(t[1])} * l2;
+      const f32x2 ds = p * (__builtin_elementwise_fma(doa, va, dob * vb) - dd2);
+      dqa = __builtin_elementwise_fma(ds, ka, dqa);
+      dqb = __builtin_elementwise_fma(ds, kb, dqb);
+    }
+    dq[0] = dqa[0] * MHA_SCALE;
+    dq[1] = dqb[0] * MHA_SCALE;
+    dq[2 % S] = dqa[1] * MHA_SCALE;
+    dq[3 % S] = dqb[1] * MHA_SCALE;
+    MHA_STAMP(8);
+    const f32x2 ka = {k4[0], k4[1]}, kb = {k4[2 % S], k4[3 % S]}, va = {v4[0], v4[1]}, vb = {v4[2 % S], v4[3 % S]};
+    f32x2 dka = {0.f, 0.f}, dkb = {0.f, 0.f}, dva = {0.f, 0.f}, dvb = {0.f, 0.f};  // phase B: lane = key
+#pragma unroll 4
+    for (int i = 0; i < N; ++i) {
+      const f32x4 qi = ld4(Qb + i * 16 + c0), doi = ld4(DOb + i * 16 + c0);
+      const f32x2 qia = {qi[0], qi[1]}, qib = {qi[2], qi[3]}, da = {doi[0], doi[1]}, db = {doi[2], doi[3]};
+      const f32x2 mi = *reinterpret_cast<const f32x2*>(Mb + i * 8 + HP * w), l_ = *reinterpret_cast<const f32x2*>(Lb + i * 8 + HP * w),
+                  di = *reinterpret_cast<const f32x2*>(Db + i * 8 + HP * w);
+      const f32x2 t = __builtin_elementwise_fma(qia, ka, qib * kb) - mi;
+      const f32x2 p = (f32x2){__expf(t[0]), __expf(t[1])} * l_;
+      dva = __builtin_elementwise_fma(p, da, dva);
+      dvb = __builtin_elementwise_fma(p, db, dvb);
+      const f32x2 ds = p * (__builtin_elementwise_fma(da, va, db * vb) - di);
+      dka = __builtin_elementwise_fma(ds, qia, dka);
+      dkb = __builtin_elementwise_fma(ds, qib, dkb);
+    }
+    dk[0] = dka[0]; dk[1] = dkb[0]; dk[2 % S] = dka[1]; dk[3 % S] = dkb[1];
+    dv[0] = dva[0]; dv[1] = dvb[0]; dv[2 % S] = dva[1]; dv[3 % S] = dvb[1];
+  } else {
+#pragma unroll 4
+  for (int j = 0; j < N; ++j) {  // phase A: lane = query
     const Vec<S> kj = ldv<S>(Kb + j * 16 + c0);
     const Vec<S> vj = ldv<S>(Vb + j * 16 + c0);
 #pragma unroll
@@ -643,9 +739,9 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   }
 #pragma unroll
   for (int r = 0; r < S; ++r) dq[r] *= MHA_SCALE;
-  Vec<S> dk = vzero<S>(), dv = vzero<S>();  // phase B: lane = key
+  MHA_STAMP(8);
 #pragma unroll 4
-  for (int i = 0; i < N; ++i) {
+  for (int i = 0; i < N; ++i) {  // phase B: lane = key
     const Vec<S> qi = ldv<S>(Qb + i * 16 + c0);
     const Vec<S> doi = ldv<S>(DOb + i * 16 + c0);
 #pragma unroll
@@ -659,6 +755,8 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
       dk[2 * h + 1] = fmaf(ds, qi[2 * h + 1], dk[2 * h + 1]);
     }
   }
+  }
+  MHA_STAMP(9);
   if (!active) {
     dq = vzero<S>();
     dk = vzero<S>();
@@ -669,6 +767,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   stv<S>(DKb + lane * 16 + c0, dk);
   stv<S>(DVb + lane * 16 + c0, dv);
   __syncthreads();
+  MHA_STAMP(10);
   // ---- in-projection: [q;k;v] = Win x + bin ----
   if (S == 4) {  // one matrix per wave on the matrix cores (large batch); the 8-wave form keeps the row slices (latency)
     if (w == 0) wgrad_mfma(DQb, Xb, lane, N, gp + OFF_WIN);
@@ -682,6 +781,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   bgrad_slice<S>(dq, c0, lane, gp + OFF_BIN);
   bgrad_slice<S>(dk, c0, lane, gp + OFF_BIN + 16);
   bgrad_slice<S>(dv, c0, lane, gp + OFF_BIN + 32);
+  MHA_STAMP(11);
   Vec<S> dx = dr1;
   ld_row(DQb + lane * 16, row);
   mvt_slice_acc<S>(Wsh + OFF_WIN, c0, row, dx);
@@ -690,5 +790,11 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   ld_row(DVb + lane * 16, row);
   mvt_slice_acc<S>(Wsh + OFF_WIN + 512, c0, row, dx);
   if (active) stv<S>(d.dx + (long)b * d.ldx + lane * 16 + c0, dx);
+#ifdef MHA_STAMPS
+  MHA_STAMP(12);
+  __syncthreads();
+  if (tid == 0)
+    for (int i = 0; i < 13; ++i) gp[i] = __builtin_bit_cast(float, mha_st[i]);
+#endif
 }
 
