@@ -348,6 +348,49 @@ def test_rowsparse_adagrad_equals_dense_reference(lib, B):
         assert torch.equal(lead[:, f], want)
 
 
+@pytest.mark.parametrize("B", [256, 255, 37, 1])
+def test_rowsparse_dedup_sums_duplicates_in_ascending_sample_order(lib, B):
+    """one-workgroup dedup (B <= 256) on heavy duplication — every id equal, a 1-row, a 4-row and a 7-row table, one field without
+    duplicates: the leader's row is the fp32 sum of its duplicates' rows in ascending sample order, BIT for bit (sixteen lanes per
+    leader add one float each; the sequential fp32 loop below is the same chain), leaders = first occurrences, the sum-of-squares
+    partial matches, and a second launch gives the same bytes"""
+    torch.manual_seed(11)
+    Fs = 5
+    idx = torch.stack([torch.full((B,), 3), torch.zeros(B, dtype=torch.int64), torch.randint(0, 4, (B,)), torch.randint(0, 7, (B,)),
+                       torch.randperm(1000)[:B]], 1)
+    dout = torch.randn(B, Fs, 16)
+    gi, gd = dev(idx), dev(dout)
+    leader, gsum, part = dev(torch.zeros(B * Fs, dtype=torch.int32)), dev(torch.zeros(B * Fs * 16)), dev(torch.full((Fs,), 7.0))
+    dd = L.EmbDedupDesc()
+    dd.kind, dd.B, dd.Fs = L.OP_EMB_DEDUP, B, Fs
+    dd.idx, dd.dout, dd.leader, dd.gsum, dd.sumsq_partial = gi.data_ptr(), gd.data_ptr(), leader.data_ptr(), gsum.data_ptr(), part.data_ptr()
+    launch(lib, dd)
+    torch.cuda.synchronize()
+    lead = leader.cpu().view(B, Fs)
+    gs = gsum.cpu().view(B, Fs, 16)
+    total = 0.0
+    for f in range(Fs):
+        first, acc = {}, {}
+        for b in range(B):
+            i = int(idx[b, f])
+            if i in first:
+                acc[i] = acc[i] + dout[b, f]  # fp32, ascending b
+            else:
+                first[i], acc[i] = b, dout[b, f].clone()
+        want = torch.zeros(B, dtype=torch.int32)
+        want[list(first.values())] = 1
+        assert torch.equal(lead[:, f], want), "field %d: leaders are not the first occurrences" % f
+        for i, b in first.items():
+            assert torch.equal(gs[b, f], acc[i]), "field %d row %d: not the ascending-order fp32 sum" % (f, i)
+            total += float(acc[i].double().pow(2).sum())
+    assert abs(float(part.double().sum()) - total) <= 1e-5 * total
+    g1, p1 = gsum.clone(), part.clone()
+    launch(lib, dd)
+    torch.cuda.synchronize()
+    sel = lead.bool().view(-1)
+    assert torch.equal(part, p1) and torch.equal(gsum.view(-1, 16)[sel], g1.view(-1, 16)[sel])
+
+
 @pytest.mark.parametrize("B", [8192, 20000, 65536])
 def test_rowsparse_dedup_at_global_batches_of_a_data_parallel_step(lib, B):
     """the partitioned merge (grid Fs x ceil(B/4096)) at the global batches of BASELINE configs 4 / 5 on 8 GPUs (32 768 and
