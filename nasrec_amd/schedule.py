@@ -397,16 +397,27 @@ def item_bytes(node):
 _PART = {"whole": L.WL_WHOLE, "main": L.WL_MAIN, "epi": L.WL_EPI}
 
 
+# stand-alone times of the non-GEMM items of the batch-256 step, ns (tools/step_table.py ITEMS=11)
+_ITEM_NS = {L.OP_MHA_BWD: 18000, L.OP_MHA_FWD: 11000, L.OP_DOT_TRI_BWD: 10000, L.OP_DOT_TRI_FWD: 6000, L.OP_REDUCE_ROWS: 4500,
+            L.OP_FM_BWD: 3900, L.OP_FM_FWD: 3500}
+_COST_MODEL = os.environ.get("NASREC_WL_COST", "time")
+
+
 def _cost(node):
-    """rough size, to start the big items of a level first"""
+    """rough duration of an item on its own, ns: the long items of a level go first in its launch (workgroups are dispatched in
+    blockIdx order; a long item queued behind the short ones starts late and the level ends late)"""
     d = node.desc
+    if _COST_MODEL == "size":  # (the round-2 order: products by size, everything else behind them)
+        if isinstance(d, L.GemmDesc):
+            return 1 if node.part == "epi" else sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A)
+        if d.kind in (L.OP_MHA_FWD, L.OP_MHA_BWD):
+            return d.B * d.N * 16 * 4000 * (2 if d.kind == L.OP_MHA_BWD else 1)
+        return 1000
     if isinstance(d, L.GemmDesc):
         if node.part == "epi":
-            return 1
-        return sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A)
-    if d.kind in (L.OP_MHA_FWD, L.OP_MHA_BWD):
-        return d.B * d.N * 16 * 4000 * (2 if d.kind == L.OP_MHA_BWD else 1)
-    return 1000
+            return 3600
+        return 5000 + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A) // 20000
+    return _ITEM_NS.get(d.kind, 3000)
 
 
 def expand_for_worklists(descs) -> List[Node]:
