@@ -287,6 +287,39 @@ def test_level_schedule_respects_every_dependency():
     assert torch.equal(cp.logits, want[0]) and torch.equal(eng.flat_g, want[1]) and torch.equal(cp.sparse0.grad_tensor(), want[2])
 
 
+def test_level_launch_items_are_ordered_by_duration_and_the_order_changes_no_bits(monkeypatch):
+    """schedule.pack: within a worklist launch the items go by decreasing estimated duration (schedule._cost: the DotProduct
+    backward before the small products, a Transformer body first), and that order is only a dispatch order — the step under
+    NASREC_WL_COST=size (the previous order) gives the same logits and gradients bit for bit"""
+    from nasrec_amd import schedule as S, _lib as L
+    z, meta = load_golden(os.path.join(os.path.dirname(NPZ[0]), "fixed_criteo_xlarge.npz"))
+    int_x, cat_x = torch.tensor(z["int_x"]).cuda(), torch.tensor(z["cat_x"]).cuda()
+    y = torch.tensor(z["y"]).cuda().view(-1)
+    out = {}
+    for model in ("time", "size"):
+        monkeypatch.setattr(S, "_COST_MODEL", model)
+        eng = build_engine(z, meta)
+        cp = eng.forward_backward(int_x, cat_x, y, meta["choice"])
+        torch.cuda.synchronize()
+        out[model] = (cp.logits.clone(), eng.flat_g.clone(), cp.sparse0.grad_tensor().clone())
+        prog = cp.fb if getattr(cp, "fb", None) is not None else None
+        descs = prog.descs if prog is not None else cp.fwd.descs + cp.bwd.descs
+        lists = [d for d in descs if isinstance(d, L.WorklistDesc)]
+        assert lists, "the level-scheduled step has worklist launches"
+        seen_dot_first = False
+        for d in lists:
+            costs = [S._cost(n) for n in d.nodes]
+            assert costs == sorted(costs, reverse=True), (model, costs)
+            kinds = [n.desc.kind for n in d.nodes]
+            if model == "time" and L.OP_DOT_TRI_BWD in kinds and any(k == L.OP_GEMM for k in kinds):
+                small = [i for i, n in enumerate(d.nodes) if n.desc.kind == L.OP_GEMM and S._cost(n) < 10000]
+                seen_dot_first = seen_dot_first or (small and kinds.index(L.OP_DOT_TRI_BWD) < min(small))
+        if model == "time":
+            assert seen_dot_first, "a DotProduct backward is dispatched before the small products of its level"
+    for a, b in zip(out["time"], out["size"]):
+        assert torch.equal(a, b)
+
+
 def test_finetune_last_layer_mode_runs_only_the_final_backward():
     """SuperNet.set_mode_to_finelune_last_only (the searcher's candidate evaluation, eval_subnet_from_supernet.py): the gradient
     of _final equals the full backward's, every other parameter keeps grad None, and only the final-logit backward is launched."""
