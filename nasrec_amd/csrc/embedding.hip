@@ -69,9 +69,9 @@ int launch_embed_gather(hipStream_t st, const nasrec_embed_desc_t* d) {
 // reads in one lane instead of 64 dependent global loads; the summation order is ascending b.
 // `chunk`: the body works on samples [256*chunk, 256*chunk + 256) (batches > 256 run it once per chunk and merge the
 // chunk leaders afterwards, emb_dedup_merge_kernel); `final`: write the sum-of-squares partial of the leaders.
-// LDS of dedup_small_body beyond sidx / rows / red: the leaders that have duplicates ([0] = their number, then their sample indices)
-// and those leaders' match masks
-#define DEDUP_WORK_INTS (1 + 256 + 256 * 8)
+// LDS of dedup_small_body beyond sidx / rows / red (16-byte aligned): per 16-lane group the duplicate list of the leader it serves,
+// the leaders' match masks, the leaders that have duplicates and their number
+#define DEDUP_WORK_INTS (16 * 256 + 256 * 8 + 256 + 4)
 __device__ __forceinline__ void dedup_small_body(const nasrec_emb_dedup_desc_t& d, int f, int chunk, bool final, int* sidx, float* rows,
                                                  float* red, int* work) {
   const int b = threadIdx.x;
@@ -93,7 +93,7 @@ __device__ __forceinline__ void dedup_small_body(const nasrec_emb_dedup_desc_t& 
   }
   const int my = live ? my_in : -1 - b;  // dead lanes get unique negative ids
   sidx[b] = my;
-  if (b == 0) work[0] = 0;  // (number of leaders with duplicates, below)
+  if (b == 0) work[16 * 256 + 256 * 8 + 256] = 0;  // (number of leaders with duplicates, below)
 #pragma unroll
   for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(&rows[b * 20 + 4 * v]) = g[v];
   __syncthreads();
@@ -119,9 +119,10 @@ __device__ __forceinline__ void dedup_small_body(const nasrec_emb_dedup_desc_t& 
   // row): a leader adding whole rows in its own lane spent ~200 clocks per duplicate on one wave — 6 of the launch's 12 us on the
   // bench's 4-row table, 21 us when all 256 ids are equal (the launch on distinct ids: 6.1 us).  Same additions in the
   // same order per element: same bits.
-  int* ndup = work;
-  int* dlist = work + 1;
-  unsigned* dmask = reinterpret_cast<unsigned*>(work + 257);
+  int* glist = work;  // [16 groups][256]
+  unsigned* dmask = reinterpret_cast<unsigned*>(work + 16 * 256);
+  int* dlist = work + 16 * 256 + 256 * 8;
+  int* ndup = dlist + 256;
   bool dup = false;
   if (lead) {
 #pragma unroll
@@ -140,19 +141,42 @@ __device__ __forceinline__ void dedup_small_body(const nasrec_emb_dedup_desc_t& 
   __syncthreads();
   const int nd = *ndup;
   if (nd > 0) {  // (uniform)
-    const int e = b & 15;
-    for (int k = b >> 4; k < nd; k += 16) {
+    const int e = b & 15, grp = b >> 4;
+    int* gl = glist + grp * 256;
+    for (int k = grp; k < nd; k += 16) {
       const int l = dlist[k];
-      float acc = rows[l * 20 + e];
-      for (int w = 0; w < 8; ++w) {
-        unsigned mm = dmask[l * 8 + w];
-        while (mm) {  // (four duplicates per trip with their LDS reads in flight together: 255 equal ids 17.3 -> 14.1 us, the bench's ids 9.4 -> 10.2)
-          const int p = 32 * w + __ffs((int)mm) - 1;
-          mm &= mm - 1;
-          acc += rows[p * 20 + e];
-        }
+      // the leader's duplicates as a list, ascending: lane e turns bits [16 e, 16 e + 16) of the mask into indices behind those of
+      // the lanes below it (prefix sum over the group's 16 lanes = one DPP row); walking the mask bit by bit cost a dependent
+      // ffs / LDS round trip per duplicate (125 clocks), the list is read four entries at a time (eight: no faster)
+      unsigned bits = (dmask[l * 8 + (e >> 1)] >> (16 * (e & 1))) & 0xffffu;
+      const int cnt = __popc(bits);
+      int pre = cnt;
+      pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xf, 0xf, true);  // row_shr:1 (lanes without a source add 0)
+      pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xf, 0xf, true);  // row_shr:2
+      pre += __builtin_amdgcn_update_dpp(0, pre, 0x114, 0xf, 0xf, true);  // row_shr:4
+      pre += __builtin_amdgcn_update_dpp(0, pre, 0x118, 0xf, 0xf, true);  // row_shr:8
+      const int total = __shfl(pre, (threadIdx.x & 48) | 15, 64);
+      int off = pre - cnt;
+      while (bits) {
+        gl[off++] = 16 * e + __ffs((int)bits) - 1;
+        bits &= bits - 1;
       }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the group's lanes are lanes of one wave: its LDS writes are in order
+      float acc = rows[l * 20 + e];
+      int i = 0;
+      for (; i + 4 <= total; i += 4) {
+        const int4 p = *reinterpret_cast<const int4*>(gl + i);
+        const float r0 = rows[p.x * 20 + e], r1 = rows[p.y * 20 + e], r2 = rows[p.z * 20 + e], r3 = rows[p.w * 20 + e];
+        acc += r0;
+        acc += r1;
+        acc += r2;
+        acc += r3;
+      }
+      for (; i < total; ++i) acc += rows[gl[i] * 20 + e];
       rows[l * 20 + e] = acc;  // (a leader's row is nobody's duplicate: no other group reads it)
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the list is rewritten for the group's next leader)
     }
     __syncthreads();
     if (dup) {
@@ -184,7 +208,7 @@ __global__ __launch_bounds__(256) void emb_dedup_small_kernel(const nasrec_emb_d
   __shared__ __attribute__((aligned(16))) int sidx[256];
   __shared__ __attribute__((aligned(16))) float rows[256 * 20];  // 20-float rows: 16-byte aligned, bank-spread
   __shared__ float red[256];
-  __shared__ int work[DEDUP_WORK_INTS];
+  __shared__ __attribute__((aligned(16))) int work[DEDUP_WORK_INTS];
   dedup_small_body(d, blockIdx.x, 0, true, sidx, rows, red, work);
 }
 
@@ -193,7 +217,7 @@ __global__ __launch_bounds__(256) void opt_reduce_kernel(const nasrec_opt_reduce
   __shared__ __attribute__((aligned(16))) int sidx[256];
   __shared__ __attribute__((aligned(16))) float rows[256 * 20];
   __shared__ float red[256];
-  __shared__ int work[DEDUP_WORK_INTS];
+  __shared__ __attribute__((aligned(16))) int work[DEDUP_WORK_INTS];
   const int nd = d.dedup.Fs;
   if ((int)blockIdx.x < nd)
     dedup_small_body(d.dedup, blockIdx.x, 0, true, sidx, rows, red, work);
@@ -254,7 +278,7 @@ __global__ __launch_bounds__(256) void emb_dedup_chunk_kernel(const nasrec_emb_d
   __shared__ __attribute__((aligned(16))) int sidx[256];
   __shared__ __attribute__((aligned(16))) float rows[256 * 20];
   __shared__ float red[256];
-  __shared__ int work[DEDUP_WORK_INTS];
+  __shared__ __attribute__((aligned(16))) int work[DEDUP_WORK_INTS];
   dedup_small_body(d, blockIdx.x, blockIdx.y, false, sidx, rows, red, work);
 }
 
