@@ -64,9 +64,10 @@ int launch_embed_gather(hipStream_t st, const nasrec_embed_desc_t* d) {
 
 // Batch <= 256 (one workgroup per field, thread = sample): every sample parks its id and its 64-byte gradient row in
 // LDS with ONE parallel round of global loads; then each thread scans the ids in ascending order, four per
-// ds_read_b128 (all lanes read the same address: broadcast): a match below b means "not the leader", and a leader adds
-// the LDS rows of the later matches to its own row in registers.  A 64-fold duplicate on a 4-row table costs 64 LDS row
-// reads in one lane instead of 64 dependent global loads; the summation order is ascending b.
+// ds_read_b128 (all lanes read the same address: broadcast): a match below b means "not the leader".  The LDS rows of a
+// leader's later matches are added to its row in ascending b by sixteen lanes, one float of the row each, from an index list
+// the group builds out of the leader's match mask (below): a 64-fold duplicate on a 4-row table costs 64 LDS reads per lane
+// instead of 64 dependent global loads, and leaders without duplicates keep their row in registers.
 // `chunk`: the body works on samples [256*chunk, 256*chunk + 256) (batches > 256 run it once per chunk and merge the
 // chunk leaders afterwards, emb_dedup_merge_kernel); `final`: write the sum-of-squares partial of the leaders.
 // LDS of dedup_small_body beyond sidx / rows / red (16-byte aligned): per 16-lane group the duplicate list of the leader it serves,
