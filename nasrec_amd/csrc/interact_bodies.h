@@ -31,11 +31,31 @@ __device__ __forceinline__ void wave_copy_in(const float* src, int n, int lane, 
   }
 }
 
+// The T rows of one sample (k1 x 16 floats, 64-byte aligned) global -> registers by 16-byte loads, every load of the wavefront in
+// flight at once (k1 <= 64: at most four per lane), and registers -> LDS rows of TRI_LD floats.
+struct TriRows {
+  f32x4 v[TRI_MAXK1 * 4 / 64];
+};
+__device__ __forceinline__ void tri_rows_load(const float* Tb, int k1, int lane, TriRows& r) {
+#pragma unroll
+  for (int u = 0; u < TRI_MAXK1 * 4 / 64; ++u)
+    if (64 * u < k1 * 4) r.v[u] = *reinterpret_cast<const f32x4*>(Tb + 4 * min(64 * u + lane, k1 * 4 - 1));  // (uniform guard)
+}
+__device__ __forceinline__ void tri_rows_store(float* ts, int k1, int lane, const TriRows& r) {
+#pragma unroll
+  for (int u = 0; u < TRI_MAXK1 * 4 / 64; ++u) {
+    const int q = 64 * u + lane;  // 16-byte piece q = (row q >> 2, columns 4 (q & 3) ..)
+    if (q < k1 * 4) *reinterpret_cast<f32x4*>(ts + (q >> 2) * TRI_LD + 4 * (q & 3)) = r.v[u];
+  }
+}
+
 // one wavefront = one sample b; ts = TRI_MAXK1 * TRI_LD floats of LDS owned by that wavefront
 __device__ __forceinline__ void dot_tri_fwd_sample(const nasrec_dot_tri_desc_t& d, int b, int lane, float* ts) {
   const int k1 = d.k1;
   const float* Tb = d.T + (long)b * k1 * 16;
-  wave_copy_in(Tb, k1 * 16, lane, [&](int q, float v) { ts[(q >> 4) * TRI_LD + (q & 15)] = v; });
+  TriRows tr;
+  tri_rows_load(Tb, k1, lane, tr);
+  tri_rows_store(ts, k1, lane, tr);
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
   const int P = k1 * (k1 - 1) / 2;
@@ -111,26 +131,50 @@ __device__ __forceinline__ void dot_tri_bwd_sample(const nasrec_dot_tri_desc_t& 
   const int P = k1 * (k1 - 1) / 2;
   const float* Tb = d.T + (long)b * k1 * 16;
   const float* dob = d.dout + (long)b * d.ld_out;
-  wave_copy_in(Tb, k1 * 16, lane, [&](int q, float v) { ts[(q >> 4) * TRI_LD + (q & 15)] = v; });
-  wave_copy_in(dob, P, lane, [&](int q, float v) { ds[q] = v; });
+  // every global load of the sample before the first LDS store: the T rows (<= 4 16-byte loads per lane) and the P <= 2016 output
+  // gradients (<= 32 dwords per lane; their row start is not 16-byte aligned).  In batches of 8 per lane these were five dependent
+  // round trips on the cold L2 of a batch-256 step — half of the item's 10 us.
+  TriRows tr;
+  tri_rows_load(Tb, k1, lane, tr);
+  constexpr int DMAX = (TRI_MAXK1 * (TRI_MAXK1 - 1) / 2 + 63) / 64;
+  float dv[DMAX];
+#pragma unroll
+  for (int u = 0; u < DMAX; ++u)
+    if (64 * u < P) dv[u] = dob[min(64 * u + lane, P - 1)];  // (uniform guard)
+  tri_rows_store(ts, k1, lane, tr);
+#pragma unroll
+  for (int u = 0; u < DMAX; ++u)
+    if (64 * u + lane < P) ds[64 * u + lane] = dv[u];
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0);
   float* dTb = d.dT + (long)b * k1 * 16;
-  for (int item = lane; item < k1 * 4; item += 64) {
-    const int i = item >> 2, q = item & 3;
+  // item = (row i, 4 columns q); a round of 64 items covers rows imin .. imax.  Both loops run over a UNIFORM range of j with every
+  // LDS read unconditional and the lane's own bound (j < i, j > i) applied to the weight: with the lane's bound as the loop bound
+  // the trip count diverged over the wavefront, nothing was unrolled and every trip exposed its LDS round trip (~110 clocks per j,
+  // 7 of the item's 10 us at k1 = 46).  A lane adds the same terms in the same order as before (the others are + 0 * T[j]).
+  for (int item0 = 0; item0 < k1 * 4; item0 += 64) {
+    const int item = item0 + lane;
+    const int i = min(item >> 2, k1 - 1), q = item & 3;
+    const int imin = item0 >> 2, imax = min((item0 + 63) >> 2, k1 - 1);
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int rowbase = i * (i - 1) / 2;
-    for (int j = 0; j < i; ++j) {
-      const float w = ds[rowbase + j];
-      f32x4 t = *reinterpret_cast<const f32x4*>(ts + j * TRI_LD + 4 * q);
-      acc += w * t;
+    const float* wrow = ds + i * (i - 1) / 2;
+    const float* tq = ts + 4 * q;
+#pragma unroll 8
+    for (int j = 0; j < imax; ++j) {  // rows below the lane's: dO[p(i, j)], j < i
+      const float w = wrow[j];
+      const f32x4 t = *reinterpret_cast<const f32x4*>(tq + j * TRI_LD);
+      acc += (j < i ? w : 0.f) * t;
     }
-    for (int j = i + 1; j < k1; ++j) {
-      const float w = ds[j * (j - 1) / 2 + i];
-      f32x4 t = *reinterpret_cast<const f32x4*>(ts + j * TRI_LD + 4 * q);
-      acc += w * t;
+    const float* wcol = ds + i;
+    int tj = (imin + 1) * imin / 2;  // p(j, 0) of the first j
+#pragma unroll 8
+    for (int j = imin + 1; j < k1; ++j) {  // rows above: dO[p(j, i)], j > i
+      const float w = wcol[tj];
+      tj += j;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(tq + j * TRI_LD);
+      acc += (j > i ? w : 0.f) * t;
     }
-    *reinterpret_cast<f32x4*>(dTb + i * 16 + 4 * q) = acc;
+    if (item < k1 * 4) *reinterpret_cast<f32x4*>(dTb + i * 16 + 4 * q) = acc;
   }
 }
 
