@@ -206,10 +206,33 @@ int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
   }
   wl.total_blocks = first;
   if (first < 1) return 0;
+  // the item table packed into the twelve leading scalar arguments (worklist_body.h: they are preloaded into SGPRs)
+  static_assert(NASREC_WL_MAX_ITEMS == 12 && NASREC_WL_BLOB_BYTES <= 256 * 16 && offsetof(nasrec_worklist_desc_t, blob) % 16 == 0, "packed item table");
+  unsigned pf[6], pm[6];
+  bool packed = first < 0xffff;
+  for (int q = 0; q < 6; ++q) {
+    unsigned f2[2], m2[2];
+    for (int h = 0; h < 2; ++h) {
+      const int k = 2 * q + h;
+      if (k < wl.n) {
+        f2[h] = (unsigned)wl.item[k].first;
+        m2[h] = (unsigned)wl.item[k].kind | ((unsigned)wl.item[k].part << 6) | ((unsigned)(wl.item[k].off >> 4) << 8);
+        packed = packed && wl.item[k].kind < 64 && wl.item[k].part < 4;
+      } else {
+        f2[h] = 0xffffu;
+        m2[h] = 0;
+      }
+    }
+    pf[q] = f2[0] | (f2[1] << 16);
+    pm[q] = m2[0] | (m2[1] << 16);
+  }
+  if (!packed) pf[0] = WL_PACKED_NONE;
   if (big) {
-    hipLaunchKernelGGL(worklist_kernel<true>, dim3((unsigned)first), dim3(256), sizeof(float) * WL_LDS_BIG_FLOATS, st, wl);
+    hipLaunchKernelGGL(worklist_kernel<true>, dim3((unsigned)first), dim3(256), sizeof(float) * WL_LDS_BIG_FLOATS, st, pf[0], pf[1], pf[2], pf[3], pf[4],
+                       pf[5], pm[0], pm[1], pm[2], pm[3], pm[4], pm[5], wl);
   } else {
-    hipLaunchKernelGGL(worklist_kernel<false>, dim3((unsigned)first), dim3(256), sizeof(float) * WL_LDS_FLOATS, st, wl);
+    hipLaunchKernelGGL(worklist_kernel<false>, dim3((unsigned)first), dim3(256), sizeof(float) * WL_LDS_FLOATS, st, pf[0], pf[1], pf[2], pf[3], pf[4],
+                       pf[5], pm[0], pm[1], pm[2], pm[3], pm[4], pm[5], wl);
   }
   return nasrec_check_launch("worklist");
 }

@@ -239,19 +239,50 @@ __device__ __forceinline__ void wl_mha_fwd(unsigned long long blob, int vb) {
 
 // BIG: the variant that also carries the Transformer backward (164 registers, 52 KB of LDS: three workgroups per CU instead of four /
 // five) — used for the levels that contain one, so that the level's other items run beside it instead of before it
+// The item table once more as twelve leading scalar kernel arguments: the build passes -amdgpu-kernarg-preload-count=12, so on gfx950
+// they arrive in SGPRs with the wavefront (no memory access): f = first workgroup of item k (16 bits each, 0xffff behind the last
+// item), m = kind | part << 6 | (blob offset / 16) << 8.  The search for the workgroup's item, its kind and the address of its
+// descriptor then cost scalar ALU only; read from the argument segment — cold at every launch — the search was one dependent
+// ~1 us miss per 64-byte line of the table before the descriptor's own (a one-item launch 5.45 us against 4.65 us for the
+// stand-alone kernel).  WL_PACKED_NONE in f01: the table did not fit 16 bits per entry, use the copy in memory.
+#define WL_PACKED_NONE 0xffffffffu
+#define WL_HEAD_BYTES 48  // the twelve scalars in front of the descriptor in the argument segment
 template <bool BIG>
-__global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(const nasrec_worklist_desc_t wl) {
+__global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(unsigned f01, unsigned f23, unsigned f45, unsigned f67, unsigned f89, unsigned fab,
+                                                                    unsigned m01, unsigned m23, unsigned m45, unsigned m67, unsigned m89, unsigned mab,
+                                                                    const nasrec_worklist_desc_t wl) {
   float* lds = wl_lds;
   const int bid = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  int k = 0;
+  int k = 0, it_first = 0, it_kind, it_part, it_off;
+  if (f01 != WL_PACKED_NONE) {
+    const unsigned f[6] = {f01, f23, f45, f67, f89, fab}, m[6] = {m01, m23, m45, m67, m89, mab};
+    unsigned meta = m01 & 0xffffu;
+#pragma unroll
+    for (int q = 1; q < NASREC_WL_MAX_ITEMS; ++q) {
+      const unsigned fq = (f[q >> 1] >> (16 * (q & 1))) & 0xffffu, mq = (m[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+      if ((unsigned)bid >= fq) {  // (ascending; 0xffff behind the last item)
+        k = q;
+        it_first = (int)fq;
+        meta = mq;
+      }
+    }
+    it_kind = meta & 63;
+    it_part = (meta >> 6) & 3;
+    it_off = (int)(meta >> 8) * 16;
+  } else {
 #pragma unroll 1
-  while (k + 1 < wl.n && bid >= wl.item[k + 1].first) ++k;
-  const nasrec_wl_item_t& it = wl.item[k];
-  const int vb = bid - it.first;
-  const unsigned long long blob = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(nasrec_worklist_desc_t, blob) + it.off;
-  switch (it.kind) {
+    while (k + 1 < wl.n && bid >= wl.item[k + 1].first) ++k;
+    it_first = wl.item[k].first;
+    it_kind = wl.item[k].kind;
+    it_part = wl.item[k].part;
+    it_off = wl.item[k].off;
+  }
+  const nasrec_wl_item_t& it = wl.item[k];  // (geometry only below)
+  const int vb = bid - it_first;
+  const unsigned long long blob = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + WL_HEAD_BYTES + offsetof(nasrec_worklist_desc_t, blob) + it_off;
+  switch (it_kind) {
     case NASREC_OP_GEMM: {
-      if (it.part == 2) {
+      if (it_part == 2) {
         wl_gemm_second_pass(blob, vb, it.geom[0]);
         break;
       }
