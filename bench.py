@@ -137,6 +137,55 @@ def time_desc(lib, L, stream_ptr, desc, iters=200):
     return ms.value / iters
 
 
+def launch_kernel_name(L, P, d):
+    """the device kernel a descriptor launches (as rocprofv3 names it, template arguments shortened)"""
+    if isinstance(d, L.WorklistDesc):
+        return "worklist_kernel<%s>" % ("true" if any(n.desc.kind == L.OP_MHA_BWD for n in d.nodes) else "false")  # csrc/worklist.hip:143-146
+    if isinstance(d, L.GemmDesc):
+        return P.gemm_kernel_name(d)
+    names = {getattr(L, n): n[3:].lower() for n in dir(L) if n.startswith("OP_")}
+    return names.get(d.kind, "kind%d" % d.kind) + "_kernel"
+
+
+def launch_work(L, S, d, n_dense=0):
+    """(MFMA flops, algorithmic bytes, item summary) of one launch: flops = the products' 2·M·N·K (split-K second passes and the
+    vector-ALU bodies — Transformer, FM, DotProduct cores — count 0: the MFMA roof is about the matrix pipe); bytes = every operand
+    / result window of every item once (schedule.desc_io, the footprints the level scheduler itself trusts; split-K slabs written by the
+    main pass and read back by the second pass included)"""
+    nodes = d.nodes if isinstance(d, L.WorklistDesc) else [S.Node(d)]
+    names = {getattr(L, n): n[3:] for n in dir(L) if n.startswith("OP_")}
+    fl, by, items = 0.0, 0, []
+    # kinds outside the scheduler's model (they are never reordered): staging + gather, the optimizer's launches
+    k = d.kind
+    if k == L.OP_STAGE_INPUTS:   # batch copy (read + write) + B x Fs table rows of 64 B read and written
+        by = d.B * (d.Fd * 8 + d.Fs * 16 + 8) + d.B * d.Fs * 128
+    elif k in (L.OP_OPT_REDUCE, L.OP_EMB_DEDUP):  # ids + row gradients read, summed rows + leaders written (+ the gradient arena read once)
+        dd = d.dedup if k == L.OP_OPT_REDUCE else d
+        by = dd.B * dd.Fs * (8 + 64 + 64 + 4) + (n_dense * 4 if k == L.OP_OPT_REDUCE else 0)
+    elif k == L.OP_SUMSQ:
+        by = n_dense * 4
+    elif k == L.OP_OPT_APPLY:    # dense: g read, state and parameter read + written; rows: summed gradient read, table row + state row r/w
+        by = n_dense * 20 + d.rows.B * d.rows.Fs * (64 + 4 * 64)
+    for n in nodes:
+        if isinstance(n.desc, L.GemmDesc) and n.part != "epi":
+            fl += gemm_flops(n.desc)
+        if n.reads is not None:
+            by += sum(a.rows * a.width for a in n.reads) + sum(a.rows * a.width for a in n.writes)
+        items.append(names.get(n.desc.kind, "?") + ("" if n.part == "whole" else ":" + n.part))
+    return fl, by, items
+
+
+def launch_table(lib, L, P, S, sp, descs, iters, n_dense=0):
+    """one row per launch of the step: kernel, items, flops, algorithmic bytes, isolated duration (HIP events on the launch stream,
+    back-to-back launches of the same descriptor: cold L2 at every kernel boundary, warm Infinity Cache — what it sees inside the step)"""
+    rows = []
+    for d in descs:
+        fl, by, items = launch_work(L, S, d, n_dense)
+        us = time_desc(lib, L, sp, d, iters=iters) * 1e3
+        rows.append({"kernel": launch_kernel_name(L, P, d), "items": items, "mflop": fl / 1e6, "alg_KB": by / 1e3, "us": us})
+    return rows
+
+
 def csrc_build_id():
     """hash of the kernel sources: a measured artefact under profiles/ is only quoted for the build it was taken from"""
     h = hashlib.sha1()
@@ -186,6 +235,47 @@ def cpu_baseline(w, choice_or_sampler, tables, threads, Fd):
                     n, B, sum(tables), "" if fixed else ", one sampled path per step", dt))
 
 
+def spawn_ranks(n, argv, script=None, timeout=None):
+    """`python bench.py --gpus N` typed on its own (no torchrun around it): this process — which has not touched a GPU and never will
+    — starts N rank processes through `python -m torch.distributed.run` (the launch line the driver itself uses), lets rank 0's JSON
+    line through on stdout and returns a non-zero code when any rank failed.  Child processes, never an exec: a process that
+    initialised the GPU must not be replaced, and the parent stays clean of HIP.  The reference's own multi-GPU entry starts its
+    workers itself, too (nasrec/searcher/searcher.py:134-152)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL / cross-process device memory on this host driver
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()  # (the exact child this call started)
+        out, _ = proc.communicate()
+        sys.stderr.write("bench.py: the %d-rank run did not finish within %s s\n" % (n, timeout))
+        return 124, None
+    for ln in out.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if proc.returncode != 0:
+        sys.stderr.write("bench.py: a rank of the %d-rank run failed (exit code %d)\n" % (n, proc.returncode))
+        return proc.returncode, line
+    if line is None:
+        sys.stderr.write("bench.py: the %d-rank run printed no result line\n" % n)
+        return 1, None
+    return 0, line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS))
@@ -206,6 +296,11 @@ def main():
     steps = args.steps if args.steps is not None else (300 if fixed else 60)
     warmup = args.warmup if args.warmup is not None else (30 if fixed else 10)
     B = w["B"]
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        rc, line = spawn_ranks(args.gpus, sys.argv[1:])
+        if line is not None and rc == 0:
+            print(line)
+        raise SystemExit(rc)
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.scaling == "strong":
         if B % world_env:
@@ -216,8 +311,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d, but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -320,6 +414,13 @@ def main():
                    "embedding_update": "row-sparse clip+Adagrad (== dense reference update for weight_decay 0)"},
         "final_loss": loss,
     }
+    if dp.exchange:
+        pl = dp._last[1]
+        result["config"]["dp_exchange"] = {
+            "captured_in_one_graph": bool(getattr(pl, "step_graph", None)),
+            "launches_up_to_cut": getattr(pl, "cuts", None),
+            "pieces": [{"allreduce_ranges": len(list(rg)), "allreduce_MB": sum(n for _, n in rg) * 4 / 1e6} for _, rg in pl.segments],
+            "allgather_MB": {"ids": B * world * Fs * 8 / 1e6, "row_gradients": B * world * Fs * 64 / 1e6}}
 
     if rank == 0:  # (N > 1: the roofline of the dominant launch and the step accounting are rank 0's; forward-only and the CPU baseline are N = 1 legs)
         sp = torch.cuda.current_stream(device).cuda_stream
@@ -381,29 +482,79 @@ def main():
                                                "achieved_GBps": B * Fs * 128 / us / 1e3, "bound": "hbm latency (random 64-B rows: read + write)",
                                                "frac_of_hbm_peak": B * Fs * 128 / us / 1e3 / HBM_PEAK_GBS}
 
-        # ---- roofline of the dominant kernel: the largest GEMM launch of the (last) step's plan, fp32 MFMA bound ---------
+        # ---- the largest GEMM launch of the (last) step's plan, fp32 MFMA bound ---------------------------------------------
         dom = max(allg, key=gemm_flops)
         ms = time_desc(lib, L, sp, dom, iters=200 if fixed else 30)
         fl = gemm_flops(dom)
         s0 = dom.seg[0]
-        result["roofline"] = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                              "kernel": "%s<%d,%d,%d> M=%d N=%d K=%d nseg=%d splitk=%d" % (
-                                  P.gemm_kernel_name(dom), dom.amode, dom.bmode, dom.cmode, s0.M, s0.N, sum(dom.seg[q].K for q in range(dom.nseg)),
-                                  dom.nseg, dom.splitk),
-                              "flops_per_launch": fl, "avg_launch_us": ms * 1e3,
-                              # operands + outputs of this launch, each once (split-K slabs written and read back included)
-                              "algorithmic_bytes": gemm_algorithmic_bytes(dom)}
+        big = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+               "kernel": "%s<%d,%d,%d> M=%d N=%d K=%d nseg=%d splitk=%d" % (
+                   P.gemm_kernel_name(dom), dom.amode, dom.bmode, dom.cmode, s0.M, s0.N, sum(dom.seg[q].K for q in range(dom.nseg)),
+                   dom.nseg, dom.splitk),
+               "flops_per_launch": fl, "avg_launch_us": ms * 1e3,
+               # operands + outputs of this launch, each once (split-K slabs written and read back included)
+               "algorithmic_bytes": gemm_algorithmic_bytes(dom)}
         # HBM/fabric traffic of that launch: PMC counters cannot be collected from inside this process; a measured value is
         # quoted only when profiles/ holds one taken from THIS build (csrc hash) for exactly this launch, else null
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "dominant_gemm_traffic_cfg%d.json" % args.config)))
-            if tj.get("build_id") == csrc_build_id() and tj.get("kernel") == result["roofline"]["kernel"]:
-                result["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
-                result["roofline"]["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % tj.get("source", "profiles/")
-                result["roofline"]["algorithmic_bytes"] = tj["algorithmic_bytes_per_launch"]
+            if tj.get("build_id") == csrc_build_id() and tj.get("kernel") == big["kernel"]:
+                big["traffic"] = tj["traffic_bytes_per_launch"]
+                big["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % tj.get("source", "profiles/")
+                big["algorithmic_bytes"] = tj["algorithmic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
+        result["roofline_largest_gemm"] = big
+        # ---- `roofline`: the kernel that DOMINATES THE STEP BY TIME.  Every launch of the step is timed on its own; launches are
+        # grouped by device kernel; the kernel with the largest share of the step's time is the line's `roofline`, with the aggregate
+        # rate of its launches (sum of algorithmic flops / sum of launch durations) against the fp32 MFMA roof, and the same for
+        # its algorithmic bytes against the HBM roof.  `roofline_levels` is the table it is computed from. -------------------------
+        from nasrec_amd import schedule as S
+        step_descs = [cp.stage] + (list(cp.fb.descs) if getattr(cp, "fb", None) is not None else list(cp.fwd.descs) + list(cp.bwd.descs)) + list(cp.opt.descs)
+        if not dp.exchange or fixed:
+            n_dense = sum(int(np.prod(eng.shapes[n])) for n in cp.used_params if not n.startswith("_embedding."))
+            rows = launch_table(lib, L, P, S, sp, step_descs, 100 if fixed else 10, n_dense)
+            if fixed:  # (a sampled supernet path has ~150 launches: its table stays in roofline_kernels, aggregated by kernel)
+                result["roofline_levels"] = rows
+            agg = {}
+            for r in rows:
+                a = agg.setdefault(r["kernel"], {"us": 0.0, "mflop": 0.0, "alg_KB": 0.0, "launches": 0})
+                a["us"] += r["us"]
+                a["mflop"] += r["mflop"]
+                a["alg_KB"] += r["alg_KB"]
+                a["launches"] += 1
+            tot_us = sum(a["us"] for a in agg.values())
+            # (the two instantiations of the worklist kernel are one kernel for this purpose: same bodies, the <true> variant adds the
+            # Transformer backward and its LDS)
+            fam = {}
+            for k, a in agg.items():
+                f = fam.setdefault(k.split("<")[0], {"us": 0.0, "mflop": 0.0, "alg_KB": 0.0, "launches": 0, "variants": []})
+                for key in ("us", "mflop", "alg_KB", "launches"):
+                    f[key] += a[key]
+                f["variants"].append(k)
+            name, a = max(fam.items(), key=lambda kv: kv[1]["us"])
+            tf = a["mflop"] / a["us"] / 1e6 if a["us"] else 0.0
+            gbs = a["alg_KB"] / a["us"] / 1e3 if a["us"] else 0.0
+            result["roofline"] = {
+                "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                "traffic": None, "kernel": name, "variants": sorted(a["variants"]), "launches_per_step": a["launches"],
+                "share_of_step_time": a["us"] / tot_us if tot_us else None,
+                "flops_per_launch": a["mflop"] * 1e6 / a["launches"], "avg_launch_us": a["us"] / a["launches"],
+                "algorithmic_bytes": a["alg_KB"] * 1e3 / a["launches"],
+                "hbm_achieved_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                "note": "aggregate over this kernel's launches in one step (sum of flops / sum of isolated launch durations); a launch of this "
+                        "kernel is one dependency level of the step, latency-bound at batch 256 (DESIGN.md 3); per-launch rows in roofline_levels"}
+            result["roofline_kernels"] = {k: dict(v, share=v["us"] / tot_us) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"])}
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic_cfg%d.json" % args.config)))
+                if tj.get("build_id") == csrc_build_id() and tj.get("kernel") == name:
+                    result["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
+                    result["roofline"]["traffic_unit"] = "bytes per launch, mean over the kernel's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % tj.get("source", "profiles/")
+            except (OSError, KeyError, ValueError):
+                pass
+        else:
+            result["roofline"] = big
         # ---- whole-step accounting -----------------------------------------------------------------------------
         step_s = float(np.median(per_step)) * 1e-3
         step_flops = sum(gemm_flops(d) for d in allg)

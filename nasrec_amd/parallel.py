@@ -3,8 +3,10 @@
 The path shards over the batch (samples are independent; LayerNorm is per row — SURVEY §8e).  Per step, after the
 local forward/backward:
   * dense gradients: all-reduce (sum) of the flat gradient arena; the 1/(B·world) factor is already folded into dlogits, so the
-    sum equals the gradient of the mean loss over the global batch.  Fixed sub-network (8.9 MB): ONE all-reduce behind the last
-    product.  Supernet (up to 686 MB of parameters, of which a sampled path touches a fraction): the backward program is cut at
+    sum equals the gradient of the mean loss over the global batch.  Fixed sub-network (8.9 MB, of which the backward's live set
+    writes about half): the joint forward + backward launch list is cut into NASREC_DP_SEGMENTS pieces where finished gradient
+    has piled up (`gradient_ready_index`: last writer of every parameter from the launches' own footprints), and each piece is
+    followed by the all-reduce of the ranges final after it.  Supernet (up to 686 MB of parameters, of which a sampled path touches a fraction): the backward program is cut at
     the block boundaries, and as soon as block i's gradients are complete the arena ranges of the parameters THIS PATH trained
     in block i go out as one asynchronous all-reduce each — buckets in reverse block order, overlapped with the rest of the
     backward; parameters the path did not touch are zero on every rank and are not sent at all;
@@ -12,8 +14,9 @@ local forward/backward:
     instead of all-reducing 2.16 GB of dense table gradient — then every rank runs the same row-sparse
     dedup + clip + Adagrad over the global batch, so the replicated tables stay bit-identical across ranks;
   * the global-norm clip coefficient comes out identical on every rank because it is computed from identical data.
-Fixed sub-networks (batch 256, a 0.6 ms step) issue the three collectives back to back behind the backward with the plain
-(handle-free) API: at that step size the host cost of asynchronous work handles outweighs what their overlap could hide.
+Fixed sub-networks (batch 256, a 0.3 ms step): work handles cost ~40 us of host time per collective, more than the step can hide,
+so the WHOLE exchange step — launches, collectives on RCCL's stream and the event edges between the two streams — is captured
+once into a graph (`DataParallelStep._capture`); a step is the staging launch plus one graph launch.
 Path sampling under DP: the reference draws ONE path per step from the global `np.random` stream (supernet.py:525-529); all
 ranks share the seed, hence the same path, hence a step that equals a single process at the global batch (`choice=` of
 `DataParallelStep.step`).  The collectives are asynchronous: the ids go out right after staging, the row gradients when the
@@ -71,6 +74,63 @@ def coalesce_ranges(ranges: List[Tuple[int, int]], gap: int = BUCKET_GAP) -> Lis
     return out
 
 
+DP_SEGMENTS = int(__import__("os").environ.get("NASREC_DP_SEGMENTS", "4"))
+
+
+def gradient_ready_index(eng, descs):
+    """{dense parameter name: index of the LAST launch of `descs` that writes its gradient}; parameters no launch writes are
+    left out.  Read off the launches' own write footprints (schedule.desc_io — the model the level scheduler trusts); a launch of a
+    kind the model does not know counts as writing every gradient."""
+    import bisect
+    from . import _lib as L
+    from . import schedule as S
+    names = sorted(eng.offsets, key=lambda n: eng.offsets[n])
+    starts = [eng.offsets[n] for n in names]
+    base, total = eng.flat_g.data_ptr(), eng.flat_numel
+    ready = {}
+    for i, d in enumerate(descs):
+        if isinstance(d, L.WorklistDesc):
+            nodes = d.nodes
+        elif d.kind == L.OP_SPLITK_EPILOGUES:
+            nodes = [S.Node(d.g[q], "epi") for q in range(d.n)]
+        else:
+            nodes = [S.Node(d)]
+        for nd in nodes:
+            if nd.writes is None:
+                for n in names:
+                    ready[n] = i
+                continue
+            for w in nd.writes:
+                lo, hi = (w.ptr - base) // 4, (w.end - base + 3) // 4
+                if hi <= 0 or lo >= total:
+                    continue
+                j = max(bisect.bisect_right(starts, lo) - 1, 0)
+                while j < len(names) and starts[j] < hi:
+                    if starts[j] + eng.params[names[j]].numel() > lo:
+                        ready[names[j]] = i
+                    j += 1
+    return ready
+
+
+def cut_segments(ready, n_launches, numel, nseg):
+    """[(end index, [names final after descs[:end]])]: at most `nseg` pieces covering all launches; a cut is placed behind a launch
+    once a 1/nseg share of the gradient bytes has become final since the previous cut"""
+    by_idx = {}
+    for n, i in ready.items():
+        by_idx.setdefault(i, []).append(n)
+    total = sum(numel[n] for n in ready)
+    share = max(total // max(nseg, 1), 1)
+    pieces, names, acc = [], [], 0
+    for i in sorted(by_idx):
+        names += by_idx[i]
+        acc += sum(numel[n] for n in by_idx[i])
+        if acc >= share and i + 1 < n_launches and len(pieces) < nseg - 1:
+            pieces.append((i + 1, names))
+            names, acc = [], 0
+    pieces.append((n_launches, names))
+    return pieces
+
+
 class DPPlan:
     """What one (choice, local batch) looks like to the data-parallel step."""
     stage: Callable      # (int_x, cat_x, y, lr) -> None: batch into the plan's static buffers
@@ -105,7 +165,7 @@ class DataParallelStep:
         dev = engine.device
         self.cat_all = torch.zeros(Bg, engine.Fs, dtype=torch.int64, device=dev)
         self.sg_all = torch.zeros(Bg * engine.Fs * 16, dtype=getattr(engine, "grad_dtype", torch.float32), device=dev)
-        self.opt = self.dp.dp_optimizer(Bg, self.cat_all, self.sg_all, clip, eps, self.graph)
+        self.opt = self.dp.dp_optimizer(Bg, self.cat_all, self.sg_all, clip, eps, False)  # (graph: the whole exchange step is captured as one, _capture)
         if self.fixed:
             self.cp = self._plan(choice)
 
@@ -117,7 +177,7 @@ class DataParallelStep:
         if hit is None:
             if len(self._plans) >= 8:
                 self._plans.pop(next(iter(self._plans)))
-            hit = self.dp.dp_plan(choice, self.B, 1.0 / (self.B * self.world), self.clip, self.eps, self.graph)
+            hit = self.dp.dp_plan(choice, self.B, 1.0 / (self.B * self.world), self.clip, self.eps, False)
             self._plans[key] = hit
         return hit
 
@@ -130,51 +190,67 @@ class DataParallelStep:
             return loss
         plan = self._plan(choice)
         plan.stage(int_x, cat_x, y, lr)
-        if self.fixed:
-            # Batch-256 regime: the step is a few hundred microseconds and the HOST is what the exchange competes with.  Work
-            # handles (async_op=True) cost ~40 us of host time per collective and made the step host-bound (757 us against 609 us
-            # for the plain step on one GPU); the plain calls, issued back to back behind the backward, cost 46 us in all
-            # (tools/scratch/dp_overhead.py).  They still run on RCCL's stream: the compute stream just waits for them in order.
-            plan.forward()
-            for run, _ in plan.segments:
-                run()
-            # TWO collectives, not three: the ids and the row gradients of the local batch travel as one packed all-gather
-            # (each collective costs a launch + a ring latency at this step size), then the dense gradient arena
-            self._gather_packed(plan.cat_local, plan.sparse_grad)
-            dist.all_reduce(eng.flat_g, op=dist.ReduceOp.SUM)
-            self.opt(plan)
-            self._last = ("dp", plan)
-            return plan.loss
+        self._last = ("dp", plan)
+        if self.graph:
+            # Batch-256 regime: the step is a few hundred microseconds and the HOST is what the exchange competes with (a work handle
+            # costs ~40 us of host time per collective: 757 us against 609 us for the plain step in round 2).  So the whole exchange —
+            # collectives on RCCL's stream, the event edges between it and the compute stream, every launch of the step — is
+            # captured ONCE into a graph; a step is the staging launch + one graph launch, and the overlap costs the host nothing.
+            g = getattr(plan, "step_graph", None)
+            if g is None:
+                g = plan.step_graph = self._capture(plan)
+            if g is not False:
+                g.replay()
+                return plan.loss
+        self._exchange_step(plan)
+        return plan.loss
+
+    def _exchange_step(self, plan):
+        """forward, backward in segments, the exchange under it, the optimizer over the global batch — the same sequence for fixed
+        sub-networks and sampled paths, eager (work handles) or under graph capture.
+          ids          all-gather right after staging: hidden under the whole forward / backward;
+          dense grads  one all-reduce per (segment, arena range) as soon as the segment that completes the range has been
+                       enqueued — RCCL's stream waits for that point of the compute stream only, the rest of the backward runs
+                       beside the transfer; the last segment's ranges are the exposed part;
+          row grads    all-gather when the backward has reached the embedding stem (its last launch);
+        the compute stream waits for all of them in front of the optimizer launches, nowhere else."""
+        flat_g = self.engine.flat_g
         pending = [all_gather_rows_async(self.cat_all, plan.cat_local)]
         plan.forward()
-        flat_g = eng.flat_g
         for run, ranges in plan.segments:
             run()
-            for off, n in ranges:  # this segment completed these arena ranges: out they go, under the rest of the backward
+            for off, n in ranges:
                 pending.append(dist.all_reduce(flat_g[off:off + n], op=dist.ReduceOp.SUM, async_op=True))
         pending.append(all_gather_rows_async(self.sg_all, plan.sparse_grad))
         for w in pending:
             if w is not None:
                 w.wait()  # nccl: the compute stream waits for the collective (no host block)
         self.opt(plan)
-        self._last = ("dp", plan)
-        return plan.loss
 
-    def _gather_packed(self, cat_local, sg_local):
-        """ids [B, Fs] int64 + row gradients [B, Fs, 16] of every rank -> self.cat_all / self.sg_all (rank order) with ONE all-gather
-        of a packed byte buffer [ids | gradients] per rank"""
-        nb_i, nb_g = cat_local.numel() * 8, sg_local.numel() * sg_local.element_size()
-        if getattr(self, "_pack_local", None) is None or self._pack_local.numel() != nb_i + nb_g:
-            dev = cat_local.device
-            self._pack_local = torch.empty(nb_i + nb_g, dtype=torch.uint8, device=dev)
-            self._pack_all = torch.empty(self.world * (nb_i + nb_g), dtype=torch.uint8, device=dev)
-        pl, pa = self._pack_local, self._pack_all
-        pl[:nb_i].view(torch.int64).copy_(cat_local.reshape(-1))
-        pl[nb_i:].view(sg_local.dtype).copy_(sg_local.reshape(-1))
-        all_gather_rows(pa, pl)
-        pa = pa.view(self.world, nb_i + nb_g)
-        self.cat_all.view(self.world, -1).copy_(pa[:, :nb_i].contiguous().view(torch.int64).view(self.world, -1))
-        self.sg_all.view(self.world, -1).copy_(pa[:, nb_i:].contiguous().view(sg_local.dtype).view(self.world, -1))
+    def _capture(self, plan):
+        """the exchange step of a fixed sub-network as ONE graph (torch.cuda.CUDAGraph: ProcessGroupNCCL's collectives are capturable,
+        and the engine launches on whatever stream is current — inside the capture that is the capturing stream).  Returns False when
+        the platform refuses (the step then runs eagerly, same results)."""
+        dev = self.engine.device
+        if dev.type != "cuda":
+            return False
+        # communicators are created lazily by the first collective of each kind, which must not happen inside a capture
+        w0 = torch.zeros(8, device=dev)
+        w1 = torch.zeros(8 * self.world, device=dev)
+        dist.all_reduce(w0)
+        all_gather_rows(w1, w0)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._exchange_step(plan)
+        except Exception as e:  # noqa: BLE001
+            import warnings
+            warnings.warn("data-parallel step: graph capture of the exchange failed (%s); running it eagerly" % (e,))
+            torch.cuda.synchronize(dev)
+            return False
+        torch.cuda.synchronize(dev)
+        return g
 
     def last_loss(self):
         if self._last[0] == "dp":
@@ -226,9 +302,9 @@ class EngineDP:
         from .engine import Program
         eng = self.engine
         fixed = eng.cfg.fixed
-        # weight-sharing supernet at a large batch: weight-gradient products stay in backward order (nothing to gain from parking
-        # them at the end when no launch is latency-bound), so that a block's gradients are complete when its backward is
-        cp = eng.compile(choice, B, True, clip, eps, graph=False, grad_scale=grad_scale, defer_dw=fixed)
+        # weight-gradient products stay in backward order (never parked behind the backward): a block's gradients are complete when
+        # its backward is, and can travel under the blocks that follow
+        cp = eng.compile(choice, B, True, clip, eps, graph=False, grad_scale=grad_scale, defer_dw=False)
         plan = DPPlan()
         plan.cp = cp
         plan.cat_local, plan.loss = cp.cat_x, cp.loss
@@ -237,18 +313,23 @@ class EngineDP:
         descs = cp.bwd.descs
         with torch.cuda.stream(eng.stream):
             if fixed:
-                # forward + whole backward (the parked weight-gradient products included) as ONE graph: the collectives of the
-                # batch-256 step are issued behind it (DataParallelStep.step), so a second segment would only add a graph launch
-                fb = Program(cp.fb.descs if getattr(cp, "fb", None) is not None else cp.fwd.descs + descs)
-                tail = None
-                if graph:
-                    fb.capture(eng.stream.cuda_stream)
-                    if tail is not None:
-                        tail.capture(eng.stream.cuda_stream)
-                run = (lambda p: (lambda: p.replay(eng._sp()))) if graph else (lambda p: (lambda: p.run(eng._sp())))
-                plan.forward = run(fb)
-                whole = [(0, eng.flat_numel)]
-                plan.segments = [(run(tail), whole)] if tail is not None else [(lambda: None, whole)]
+                # forward + backward as ONE launch list (batch <= 256: the level-scheduled joint program, whose DAG places every
+                # weight-gradient product as early as its operands allow), cut where enough finished gradient has piled up: each
+                # piece is followed by the all-reduce of the arena ranges that are FINAL after it (no later launch writes them),
+                # which then travels under the rest of the backward.  Parameters nothing writes (operators off the backward's
+                # live set: grad None in the reference) stay zero on every rank and are not sent.
+                descs = list(cp.fb.descs) if getattr(cp, "fb", None) is not None else list(cp.fwd.descs) + list(cp.bwd.descs)
+                ready = gradient_ready_index(eng, descs)
+                pieces = cut_segments(ready, len(descs), {n: eng.params[n].numel() for n in ready}, DP_SEGMENTS)
+                plan.forward = lambda: None
+                plan.ready, plan.cuts = ready, [end for end, _ in pieces]
+                segs, start = [], 0
+                for end, names in pieces:
+                    prog = Program(descs[start:end])
+                    ranges = coalesce_ranges([(eng.offsets[n], eng.params[n].numel()) for n in names], gap=3)  # (3: alignment padding only — a 4-float slot could be another bucket's parameter)
+                    segs.append(((lambda p: (lambda: p.run(eng._sp())))(prog), ranges))
+                    start = end
+                plan.segments = segs
             else:
                 plan.forward = lambda: cp.fwd.run(eng._sp())
                 marks = sorted(cp.bwd_marks, key=lambda m: m[1])  # (block, end index in the backward program), ascending position

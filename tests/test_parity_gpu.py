@@ -1,7 +1,8 @@
 """End-to-end parity of the HIP engine (through the C-ABI) against the golden vectors produced by the real reference
 and against the fp64 oracle, for every committed sub-network / supernet case.  Run with `-m gpu` on an MI355X.
 
-Tolerances (BASELINE.json: "fp32 logits within 1e-5"): |logit_hip - logit_ref_fp64| <= 1e-5 * max(1, max|logit|);
+Tolerances (BASELINE.json: "fp32 logits within 1e-5"): |logit_hip - logit_ref_fp64| <= 1e-5 * max(1, max|logit|) AND
+<= max(1e-5, 1.25 x the reference's own |fp32 - fp64| on the same inputs), i.e. absolute 1e-5 wherever the reference's fp32 run meets it;
 gradient checksums within 2e-5 of the gradient norm; three Adagrad steps keep parameters within 2e-5."""
 import os
 
@@ -66,6 +67,13 @@ def test_logits_match_reference(path):
     err = float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max())
     _report_logit_err(os.path.basename(path)[:-4], err, scale, z)
     assert err <= 1e-5 * scale, "logit err %.3e (scale %.2f)" % (err, scale)
+    # ... and tied to MEASURED noise, not only to the logit scale: the fixture holds the reference's own fp32 and fp64 logits on
+    # these inputs; the engine may not be further from fp64 than 1.25 x the reference's fp32 run is (or 1e-5 absolute, whichever is
+    # larger) — an engine that drifted to several times the reference's own rounding noise on a large-logit network fails here
+    ref32 = float(np.abs(z["logits_f32"].astype(np.float64) - ref).max())
+    assert err <= max(1e-5, 1.25 * ref32), "logit err %.3e against the reference's own fp32-vs-fp64 distance %.3e" % (err, ref32)
+    if scale <= 2.0:
+        assert err <= 1e-5, "absolute 1e-5 wherever max|logit| <= 2 (err %.3e)" % err
     # hipGraph replay gives bit-identical logits
     out2 = eng.forward(int_x, cat_x, meta["choice"], graph=True).clone()
     out3 = eng.forward(int_x, cat_x, meta["choice"], graph=True)
@@ -214,6 +222,35 @@ def test_data_parallel_code_path_single_rank():
                 dp.step(int_x, cat_x, y, lr=0.05)
             torch.cuda.synchronize()
             outs.append(eng.state_dict())
+            if force:
+                plan = dp._last[1]
+                assert isinstance(plan.step_graph, torch.cuda.CUDAGraph), "the exchange step should be captured as one graph"
+                # the pieces' all-reduce ranges: disjoint, exactly the parameters some launch writes, each final at its cut
+                names = sorted(eng.offsets, key=lambda n: eng.offsets[n])
+                sent = torch.zeros(eng.flat_numel, dtype=torch.int32)
+                assert len(plan.segments) >= 3 and plan.cuts == sorted(plan.cuts)
+                for (_, ranges), end in zip(plan.segments, plan.cuts):
+                    for off, n in ranges:
+                        sent[off:off + n] += 1
+                        for nm in names:
+                            if eng.offsets[nm] < off + n and off < eng.offsets[nm] + eng.params[nm].numel():
+                                assert nm in plan.ready and plan.ready[nm] < end, (nm, end)
+                assert int(sent.max()) == 1
+                for nm, idx in plan.ready.items():
+                    o = eng.offsets[nm]
+                    assert int(sent[o:o + eng.params[nm].numel()].min()) == 1, nm
+                never = [nm for nm in names if nm not in plan.ready]
+                for nm in never:  # grad None in the reference: zero here, not sent
+                    assert float(eng.grads[nm].abs().max()) == 0.0, nm
+                # ... and the eager form of the same exchange step (work handles instead of a captured graph) lands on the same bits
+                eng2 = build_engine(z, meta)
+                dp2 = DataParallelStep(eng2, meta["choice"], int_x.shape[0], clip=5.0, eps=1e-2, graph=False, force_exchange=True)
+                for _ in range(3):
+                    dp2.step(int_x, cat_x, y, lr=0.05)
+                torch.cuda.synchronize()
+                sd2 = eng2.state_dict()
+                for k in sd2:
+                    assert torch.equal(sd2[k], outs[-1][k]), k
         for k in outs[0]:
             assert torch.allclose(outs[0][k], outs[1][k], rtol=0, atol=1e-6), k
     finally:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Cost of the GLOBAL-batch row-gradient dedup + row Adagrad that every rank of a data-parallel step runs (replicated tables: each rank
-applies the gathered row gradients of all ranks, nasrec_amd/parallel.py): cfg 5 at 8 GPUs = 65 536 samples x 10 fields, cfg 3 / 4 at
+applies the gathered row gradients of all ranks, nasrec_amd/parallel.py): cfg 2 at 8 / 4 / 2 GPUs = 2048 / 1024 / 512 samples x 26 fields, cfg 5 at 8 GPUs = 65 536 samples x 10 fields, cfg 3 / 4 at
 8 GPUs = 32 768 x 26 / 23.  One GPU is enough to time it: the kernels do not care where the rows came from."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ from nasrec_amd.search_space import ops_config_lib
 from nasrec_amd.utils.config import DATASETS
 
 lib = L.load()
-for cfgid, world in ((5, 8), (3, 8), (4, 8), (5, 1)):
+for cfgid, world in ((2, 8), (2, 4), (2, 2), (2, 1), (5, 8), (3, 8), (4, 8), (5, 1)):
     w = bench.WORKLOADS[cfgid]
     ds = DATASETS[w["dataset"]]
     tables = [min(n, w["cap"]) if w.get("cap") else n for n in ds["tables"]]
