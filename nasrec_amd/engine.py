@@ -478,14 +478,15 @@ class SupernetEngine:
 
         ctx.on_backward(final_bwd)
         ctx.build_backward()
-        cp.chunk_tab, cp.nchunks = None, 0
+        cp.chunk_tab, cp.nchunks, cp.path_spans = None, 0, None
         if not cfg.fixed:
             # Paths differ from step to step.  torch skips parameters whose grad is None (everything outside the path),
             # so zero_grad, the norm and Adagrad touch ONLY the arena ranges this path trains — the same arithmetic on
             # the path's share of the arena (a quarter of it for a `default` xlarge path).  Gradients left over from
             # other paths outside these ranges are never read.
             names = [n for n in list(ctx.grad_params) + ["_final.weight", "_final.bias"] if not n.startswith("_embedding.")]
-            flat = P.path_chunks([(self.offsets[n], self.params[n].numel()) for n in dict.fromkeys(names)])
+            cp.path_spans = [(self.offsets[n], self.params[n].numel()) for n in dict.fromkeys(names)]
+            flat = P.path_chunks(cp.path_spans)
             cp.nchunks = len(flat) // 2
             cp.chunk_tab = (arena.alloc(len(flat), torch.int64).tensor() if arena is not None
                             else torch.empty(len(flat), dtype=torch.int64, device=self.device))

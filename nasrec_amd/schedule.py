@@ -82,6 +82,8 @@ def _gemm_io(d, part):
     Mm = max(d.seg[q].M for q in range(nprob))
     Nm = max(d.seg[q].N for q in range(nprob))
     ws = _flat(d.workspace, S * Mm * Nm * nprob) if (S > 1 and d.workspace) else None
+    if d.splitk == L.SPLITK_BALANCED and d.workspace:
+        ws = _flat(d.workspace, L.SK_WORKSPACE_FLOATS)  # the engine-wide partial-tile workspace of the balanced schedule: shared by launches
     if part in ("whole", "main"):
         for q in range(d.nseg):
             s = d.seg[q]
@@ -96,6 +98,11 @@ def _gemm_io(d, part):
         if part == "main":
             W.append(ws)
             return R, W
+        if part == "whole" and ws is not None:  # a split-K product that stays one launch writes its slabs and reads them back
+            W.append(ws)
+            R.append(ws)
+            if d.counters:
+                W.append(_flat(d.counters, Mm * Nm))  # (upper bound of the arrival counters' extent)
     if part == "epi":
         R.append(ws)
     for q in range(nprob):

@@ -182,7 +182,8 @@ class ShardedTableStep:
     """One training step with row-sharded tables and a data-parallel dense network, over a small protocol (so that the gloo tests run
     THIS code with the oracle behind it, and the GPUs run it with the HIP engine behind it — EngineShardedOps below):
         ops.forward_backward(int_x, rows [B,Fs,16], y, choice, grad_scale) -> (loss, row gradients [B,Fs,16]); dense gradients in ops.flat_g
-        ops.dense_sumsq() -> 0-d float64 tensor;  ops.dense_update(coef 0-d tensor, lr)
+        ops.dense_sumsq() -> 0-d float64 tensor (over the step's path only);  ops.dense_update(coef 0-d tensor, lr)
+        ops.grad_ranges() -> [(offset, numel)] of ops.flat_g that this step's path wrote, or None for the whole arena (optional)
         ops.gather(tables, own_idx_safe) -> [Bp,Fs,16] or None (default torch indexing)
         ops.rows_sumsq(tables, own_idx, own_g) -> 0-d float64;  ops.rows_update(tables, own_idx, own_g, coef, lr, eps)"""
 
@@ -197,7 +198,16 @@ class ShardedTableStep:
         rows, route = t.lookup(cat_x, (lambda idx: gather(t, idx)) if gather is not None else None)
         loss, sg = ops.forward_backward(int_x, rows, y, choice, 1.0 / (self.B * self.world))
         if self.world > 1:
-            dist.all_reduce(ops.flat_g, group=t.group)     # dense gradients: sum over the ranks (1 / (B world) is folded into dlogits)
+            # dense gradients: sum over the ranks (1 / (B world) is folded into dlogits).  A sampled supernet path writes (and zeroes)
+            # only ITS ranges of the gradient arena; what lies outside are leftovers of earlier paths, which nothing reads — summing
+            # them in place over the ranks, step after step, would grow them by a factor `world` per step until they overflow, and
+            # the clip norm must not see them either: only the path's ranges travel and count (ops.grad_ranges; None = whole arena)
+            ranges = ops.grad_ranges() if hasattr(ops, "grad_ranges") else None
+            if ranges is None:
+                dist.all_reduce(ops.flat_g, group=t.group)
+            else:
+                for off, n in ranges:
+                    dist.all_reduce(ops.flat_g[off:off + n], group=t.group)
         own_idx, own_g = t.send_grads(route, sg)
         ss = ops.rows_sumsq(t, own_idx, own_g) if hasattr(ops, "rows_sumsq") else t.grad_sumsq(own_idx, own_g)
         if self.world > 1:
@@ -241,8 +251,30 @@ class EngineShardedOps:
         self.cp = cp
         return cp.loss, cp.sparse0.grad_tensor().view(int_x.shape[0], eng.Fs, E)
 
+    def grad_ranges(self):
+        """arena ranges of the parameters the last step's path trained (engine.compile: `cp.path_spans`, merged over alignment padding
+        only); None for a fixed sub-network, whose whole arena is written or zero"""
+        spans = getattr(self.cp, "path_spans", None)
+        if spans is None:
+            return None
+        from .parallel import coalesce_ranges
+        return coalesce_ranges(spans, gap=3)
+
     def dense_sumsq(self):
-        return self.flat_g.double().pow(2).sum()
+        """squared norm of the dense gradients of the step's path: the engine's own fixed-order square-sum launch over the path's
+        chunk table (what `_optimizer_descs` runs in the plain step), partial sums added in fp64"""
+        L, eng = self.L, self.eng
+        tab, ntab = getattr(self.cp, "chunk_tab", None), getattr(self.cp, "nchunks", 0)
+        if getattr(self, "_sq_partial", None) is None:
+            self._sq_partial = torch.zeros(256, dtype=torch.float32, device=eng.device)
+        sq = L.SumsqDesc()
+        sq.kind = L.OP_SUMSQ
+        sq.nblocks = max(1, min(256, ntab if tab is not None else (eng.flat_numel + 256 * 8 - 1) // (256 * 8)))
+        sq.n, sq.x, sq.partial = eng.flat_numel, eng.flat_g.data_ptr(), self._sq_partial.data_ptr()
+        if tab is not None:
+            sq.chunks, sq.nchunks = tab.data_ptr(), ntab
+        self._launch(sq)
+        return self._sq_partial[:sq.nblocks].double().sum()
 
     def dense_update(self, coef, lr):
         L, eng = self.L, self.eng

@@ -200,28 +200,74 @@ class NativeTsvShard(TsvShard):
 
 class _Prefetch:
     """runs an iterable in a background thread with a bounded queue (the C parser releases the GIL, so one thread per
-    shard parses in parallel)"""
+    shard parses in parallel).  `close()` (also on garbage collection, and from RoundRobinLoader when its iterator is abandoned —
+    `next(iter(loader))`, `break` on max_train_steps) stops the thread and drops what it had queued: with device staging a queue
+    item is a ~16 k-row block on the GPU plus its pinned host copy, and an abandoned producer blocked in `put` would hold
+    several of them, and an open file, for the life of the process."""
 
     _END = object()
 
     def __init__(self, source, depth=4):
         self.q = queue.Queue(maxsize=depth)
         self.err = None
+        self._stop = threading.Event()
         self.t = threading.Thread(target=self._run, args=(source,), daemon=True)
         self.t.start()
 
+    def _put(self, item) -> bool:
+        while not self._stop.is_set():
+            try:
+                self.q.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                pass
+        return False
+
     def _run(self, source):
+        it = iter(source)
         try:
-            for item in source:
-                self.q.put(item)
+            for item in it:
+                if not self._put(item):
+                    break
+                del item
         except BaseException as e:  # surfaced in the consumer
             self.err = e
-        self.q.put(self._END)
+        finally:
+            close = getattr(it, "close", None)
+            if close is not None:  # a generator: run its clean-up (file handles) now, in this thread
+                try:
+                    close()
+                except Exception:  # noqa: BLE001
+                    pass
+        self._put(self._END)
+
+    def close(self):
+        self._stop.set()
+        try:
+            while True:
+                self.q.get_nowait()
+        except queue.Empty:
+            pass
+        if self.t is not threading.current_thread():
+            self.t.join(timeout=2.0)
+        try:  # (an item the producer slipped in between the drain and its exit)
+            while True:
+                self.q.get_nowait()
+        except queue.Empty:
+            pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def __iter__(self):
         return self
 
     def __next__(self):
+        if self._stop.is_set():
+            raise StopIteration
         item = self.q.get()
         if item is self._END:
             if self.err is not None:
@@ -269,22 +315,42 @@ class RoundRobinLoader:
             for i in range(0, len(y), bs):
                 yield int_x[i:i + bs], cat_x[i:i + bs], y[i:i + bs]
 
+    def peek(self) -> Batch:
+        """the first batch (what `next(iter(loader))` returns — the reference peeks one batch per epoch and per warm-up,
+        train_utils.py:224-225,392-433) read on the host path: no reader threads, no device blocks, nothing left behind"""
+        it = iter(self.pipes[0])
+        try:
+            return next(it)
+        finally:
+            close = getattr(it, "close", None)
+            if close is not None:
+                close()
+
     def __iter__(self) -> Iterator[Batch]:
+        threads = []
         if self.device is not None:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(self.device)
-            live = [iter(self._device_batches(_Prefetch(_DeviceBlocks(p, self.device, self._stream), depth=3), p.batch_size)) for p in self.pipes]
+            threads = [_Prefetch(_DeviceBlocks(p, self.device, self._stream), depth=3) for p in self.pipes]
+            live = [iter(self._device_batches(t, p.batch_size)) for t, p in zip(threads, self.pipes)]
+        elif self.prefetch:
+            live = threads = [_Prefetch(p) for p in self.pipes]
         else:
-            live = [_Prefetch(p) if self.prefetch else iter(p) for p in self.pipes]
-        while live:
-            nxt = []
-            for it in live:
-                try:
-                    yield next(it)
-                    nxt.append(it)
-                except StopIteration:
-                    pass
-            live = nxt
+            live = [iter(p) for p in self.pipes]
+        try:
+            while live:
+                nxt = []
+                for it in live:
+                    try:
+                        yield next(it)
+                        nxt.append(it)
+                    except StopIteration:
+                        pass
+                live = nxt
+        finally:  # also reached through GeneratorExit when the consumer abandons the iterator
+            live = None
+            for t in threads:
+                t.close()
 
 
 class SyntheticPipe:

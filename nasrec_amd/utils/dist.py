@@ -134,8 +134,21 @@ def any_rank(flag: bool, device=None) -> bool:
     if world <= 1:
         return bool(flag)
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=_coll_device(device))
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_side_group())
     return bool(int(t.item()))
+
+
+_SIDE_GROUP = None
+
+
+def _side_group():
+    """one extra process group (its own communicator and stream) for the small control collectives — step agreement, the collective
+    NaN flag — so that they never queue behind the gradient exchange of the default group.  Created collectively on first use:
+    every rank reaches its first control collective at the same point of the program."""
+    global _SIDE_GROUP
+    if _SIDE_GROUP is None or _SIDE_GROUP[0] is not dist.group.WORLD:
+        _SIDE_GROUP = (dist.group.WORLD, dist.new_group())
+    return _SIDE_GROUP[1]
 
 
 def _coll_device(device=None):
@@ -146,16 +159,20 @@ def _coll_device(device=None):
 
 class StepAgreement:
     """`post(ok)` for step k + 1 while step k runs, `take()` at the top of step k + 1: True iff EVERY rank said ok.  The tiny
-    all-reduce(MIN) runs on a side stream, so reading its result never waits for the training kernels queued on the compute stream
-    (the host keeps its run-ahead).  Single process: the local flag."""
+    all-reduce(MIN) runs in a process group OF ITS OWN (ProcessGroupNCCL runs all collectives of one group on one internal stream in
+    issue order: on the default group the agreement for step k + 1 would queue behind step k - 1's gradient all-reduce, and `take()`
+    would wait for that step's backward) and is issued from a side stream, so reading its result does not wait for the training
+    kernels queued on the compute stream.  Single process: the local flag."""
 
     def __init__(self, device=None):
         self.world = world_info()[1]
         self.pending = None
         self.dev = None
         self.stream = None
+        self.group = None
         if self.world > 1:
             self.dev = _coll_device(device)
+            self.group = _side_group()
             if self.dev.type == "cuda":
                 self.stream = torch.cuda.Stream(self.dev)
 
@@ -166,10 +183,10 @@ class StepAgreement:
         if self.stream is not None:
             with torch.cuda.stream(self.stream):
                 t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         else:
             t = torch.tensor([1 if ok else 0], dtype=torch.int32)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         self.pending = t
 
     def take(self) -> bool:

@@ -149,7 +149,7 @@ def train_and_test_one_epoch(model, epoch: int, optimizer: Any, lr_scheduler, tr
                              grad_clip_value: float = None, tb_writer=None, use_amp: bool = False, use_engine_step: Optional[bool] = None):
     """One epoch of training with tests in between; returns the reference's log dict (train_utils.py:181-390).
     `use_engine_step`: None = fused engine step whenever it applies, False = always the torch route."""
-    next(iter(test_loader))  # the reference peeks one test batch here (train_utils.py:224-225)
+    _peek(test_loader)  # the reference peeks one test batch here (train_utils.py:224-225)
     model.train()
     logs = {k: [] for k in ("train_loss", "train_AUROC", "train_Accuracy", "test_loss", "test_AUROC", "test_Accuracy", "epoch", "iters")}
     fused = _fused_step_applies(model, optimizer, l2_loss_fn, use_amp) if use_engine_step is None else bool(use_engine_step)
@@ -183,9 +183,12 @@ def train_and_test_one_epoch(model, epoch: int, optimizer: Any, lr_scheduler, tr
             if full:
                 if use_amp:
                     scaler.scale(total_loss).backward()
-                    scaler.unscale_(optimizer)
                     if world > 1:
+                        # the DDP order: exchange the still-SCALED gradients, then unscale — every rank then sees the same inf / NaN
+                        # (found_inf) and skips or takes the step together; unscaling first would let the overflowing rank skip
+                        # alone while the others step on inf-averaged gradients
                         allreduce_grads(model)
+                    scaler.unscale_(optimizer)
                     if grad_clip_value is not None:
                         torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip_value)
                     scaler.step(optimizer)
@@ -264,10 +267,17 @@ def train_and_test_one_epoch(model, epoch: int, optimizer: Any, lr_scheduler, tr
     return logs
 
 
+def _peek(loader):
+    """first batch of a loader without leaving reader threads / device blocks behind (RoundRobinLoader.peek); any other iterable:
+    the reference's `next(iter(loader))`"""
+    peek = getattr(loader, "peek", None)
+    return peek() if peek is not None else next(iter(loader))
+
+
 def warmup_model(model: nn.Module, train_loader, gpu: Union[int, None]):
     """one forward pass: fixes every lazy shape (train_utils.py:392-410)"""
     model = model.to(gpu)
-    int_x, cat_x, _ = next(iter(train_loader))
+    int_x, cat_x, _ = _peek(train_loader)
     model(int_x.to(gpu), cat_x.to(gpu))
     return model
 
@@ -277,7 +287,7 @@ def warmup_supernet_model(model: nn.Module, train_loader, gpu, freeze_gc: bool =
     SupernetEngine.reserve — only for a process that keeps this one model for its whole life (the train_supernet CLI)"""
     assert isinstance(model, SuperNet), NotImplementedError("For 'warmup_supernet_model', the passed in model must be a 'SuperNet' object.")
     model = model.to(gpu)
-    int_x, cat_x, _ = next(iter(train_loader))
+    int_x, cat_x, _ = _peek(train_loader)
     model.configure_path_sampling_strategy("full-path")
     model(int_x.to(gpu), cat_x.to(gpu))
     eng = getattr(model, "_engine", None)
@@ -293,7 +303,7 @@ def get_model_flops_and_params(model, train_loader, gpu):
     from .. import _lib as L
     from .. import plan as P
     model = model.to(gpu)
-    int_x, cat_x, _ = next(iter(train_loader))
+    int_x, cat_x, _ = _peek(train_loader)
     int_x, cat_x = int_x.to(gpu), cat_x.to(gpu)
     with torch.no_grad():
         model(int_x, cat_x)

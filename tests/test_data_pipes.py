@@ -81,3 +81,43 @@ def test_native_reader_hands_python_only_constructs_back_and_agrees(tmp_path):
     bad.write_text("1\t2\t3\n")
     with pytest.raises(ValueError):
         list(DP.NativeTsvShard(str(bad), spec, 8))
+
+
+def test_abandoned_iterators_stop_their_reader_threads(tmp_path, monkeypatch):
+    """`next(iter(loader))`, `break` on max_train_steps: the harness abandons loader iterators all the time (train_utils.py:152,
+    the warm-ups, eval_subnet_from_supernet for every candidate).  A reader thread must not outlive its iterator blocked in
+    `put` (with device staging it would hold GPU blocks and pinned memory), and `peek()` returns the same first batch without
+    starting one."""
+    import gc
+    import threading
+    import time
+    monkeypatch.setenv("NASREC_TSV_READER", "native")
+    z = np.load(os.path.join(GOLDEN, "datapipes.npz"), allow_pickle=False)
+    for s in range(2):
+        d = tmp_path / ("shard-%d" % s)
+        d.mkdir()
+        body = str(z["criteo-kaggle/shard-%d/trainval.txt" % s]) + "\n"
+        (d / "trainval.txt").write_text(body * 40)  # long enough that a reader fills its queue and blocks
+        (d / "test.txt").write_text(body)
+    args = argparse.Namespace(dataset="criteo-kaggle", root_dir=str(tmp_path), train_split="trainval", validate_split="test",
+                              train_batch_size=2, test_batch_size=2)
+    train, _ = DP.make_loaders(args)
+    assert train.prefetch
+    base = threading.active_count()
+    first = next(iter(train))
+    for _ in range(5):
+        b = next(iter(train))
+        assert all(torch.equal(x, y) for x, y in zip(b, first))
+    it = iter(train)
+    for k, _ in enumerate(it):
+        if k == 3:
+            break
+    del it
+    gc.collect()
+    deadline = time.time() + 5.0
+    while threading.active_count() > base and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() == base, "reader threads of abandoned iterators are still alive"
+    p = train.peek()
+    assert threading.active_count() == base and all(torch.equal(x, y) for x, y in zip(p, first))
+    assert len(list(train)) == len(list(train))  # a complete pass still works, twice

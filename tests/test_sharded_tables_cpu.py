@@ -39,6 +39,12 @@ def _case():
         int_x, cat_x, y = O.synthetic_batch(Bg, Fd, TABLES, seed=70 + s)
         if s == 1:
             cat_x[:, 1] = 17  # every sample hits the same row of table 1: duplicates across ranks, one owner sums them all
+        if s == 2:
+            # table 3 (301 rows -> 151 + 150): every sample of rank 0's half of the batch asks for a row rank 1 owns and vice versa —
+            # no look-up of this field is served locally, and the two row ranges are uneven
+            half = Bg // WORLD
+            cat_x[:half, 3] = 151 + (cat_x[:half, 3] % 150)
+            cat_x[half:, 3] = cat_x[half:, 3] % 151
         batches.append((int_x.double(), cat_x, y.double().view(-1, 1)))
     whole = _whole_tables()
     for f, t in enumerate(whole):
@@ -59,7 +65,9 @@ class OracleOps:
         self.cfg, self.P, self.Fs, self.eps = cfg, P, Fs, eps
         self.names = [k for k in P if not k.startswith("_embedding.")]
         self.sizes = [P[k].numel() for k in self.names]
-        self.flat_g = torch.zeros(sum(self.sizes), dtype=torch.float64)
+        # like the engine's gradient arena in supernet mode: a step writes the slots of ITS path only; everything else keeps whatever
+        # an earlier path (here: the constructor) left there, and must neither travel nor count in the clip norm
+        self.flat_g = torch.full((sum(self.sizes),), 1e3, dtype=torch.float64)
         self.state = {k: torch.zeros_like(P[k]) for k in self.names}
         self.has_grad = []
 
@@ -77,11 +85,23 @@ class OracleOps:
         grads = torch.autograd.grad(mean_loss * B * grad_scale, [leaves[k] for k in keys], allow_unused=True)
         g = dict(zip(keys, grads))
         self.has_grad = [g[k] is not None for k in self.names]
-        self.flat_g.copy_(torch.cat([(g[k] if g[k] is not None else torch.zeros_like(self.P[k])).reshape(-1) for k in self.names]))
+        off = 0
+        for k, n in zip(self.names, self.sizes):
+            if g[k] is not None:
+                self.flat_g[off:off + n] = g[k].reshape(-1)
+            off += n
         return mean_loss.detach(), torch.stack([g["_embedding.%d.weight" % f] for f in range(self.Fs)], 1)
 
+    def grad_ranges(self):
+        out, off = [], 0
+        for n, used in zip(self.sizes, self.has_grad):
+            if used:
+                out.append((off, n))
+            off += n
+        return out
+
     def dense_sumsq(self):
-        return self.flat_g.pow(2).sum()
+        return sum(self.flat_g[off:off + n].pow(2).sum() for off, n in self.grad_ranges())
 
     def dense_update(self, coef, lr):
         off = 0
@@ -149,6 +169,10 @@ def test_sharded_table_step_equals_single_process_with_whole_tables():
     for k in r0["dense"]:
         assert torch.equal(r0["dense"][k], r1["dense"][k])  # the dense replicas stay bit-identical
     assert r0["norms"] == r1["norms"]
+    # the sampled paths differ from step to step, and each leaves part of the supernet untouched: those slots of the gradient arena
+    # held leftovers (1e3) throughout — had they been all-reduced or counted, the clip norm (and every update) would be off by orders
+    assert len({json.dumps(c, sort_keys=True) for c in choices}) > 1
+    assert all(n < 100.0 for n in r0["norms"]), r0["norms"]
     # every row has exactly one owner: shard sizes add up (empty shards keep one unused row)
     for f, n in enumerate(TABLES):
         rp = -(-n // WORLD)
