@@ -263,9 +263,11 @@ def spawn_ranks(n, argv, script=None, timeout=None):
         sys.stderr.write("bench.py: the %d-rank run did not finish within %s s\n" % (n, timeout))
         return 124, None
     for ln in out.splitlines():
-        if ln.startswith("{") and '"metric"' in ln:
-            line = ln
-        else:
+        at = ln.find('{"metric"')  # (other writers on the same pipe — gloo / RCCL banners from C++ — can land in front of it on one line)
+        if at >= 0 and ln.rstrip().endswith("}"):
+            line = ln[at:].rstrip()
+            ln = ln[:at]
+        if ln.strip():
             sys.stderr.write(ln + "\n")
     if proc.returncode != 0:
         sys.stderr.write("bench.py: a rank of the %d-rank run failed (exit code %d)\n" % (n, proc.returncode))
@@ -307,6 +309,12 @@ def main():
             raise SystemExit("--scaling strong: the config's batch %d does not divide over %d GPUs" % (B, world_env))
         B = B // world_env  # per-GPU share of the config's (global) batch
 
+    # stdout carries ONE line, the result: RCCL prints a version banner on stdout through C stdio (it came out BEHIND the JSON line
+    # when stdout was a file), so everything else that is written to file descriptor 1 from here on — C libraries and Python's own
+    # prints alike — goes to stderr, and the result line is written to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -534,15 +542,18 @@ def main():
                     f[key] += a[key]
                 f["variants"].append(k)
             name, a = max(fam.items(), key=lambda kv: kv[1]["us"])
-            tf = a["mflop"] / a["us"] / 1e6 if a["us"] else 0.0
-            gbs = a["alg_KB"] / a["us"] / 1e3 if a["us"] else 0.0
+            tf = a["mflop"] / a["us"] if a["us"] else 0.0      # MFLOP / us = TFLOP/s
+            gbs = a["alg_KB"] / a["us"] if a["us"] else 0.0    # KB / us = GB/s
+            mf, hf = tf / MFMA_F32_PEAK_TFLOPS, gbs / HBM_PEAK_GBS
+            hbm = hf > mf  # the roof the kernel is closer to
             result["roofline"] = {
-                "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                "bound": "hbm" if hbm else "mfma", "achieved": gbs if hbm else tf, "peak": HBM_PEAK_GBS if hbm else MFMA_F32_PEAK_TFLOPS,
+                "unit": "GB/s" if hbm else "TFLOP/s", "frac": hf if hbm else mf,
                 "traffic": None, "kernel": name, "variants": sorted(a["variants"]), "launches_per_step": a["launches"],
                 "share_of_step_time": a["us"] / tot_us if tot_us else None,
                 "flops_per_launch": a["mflop"] * 1e6 / a["launches"], "avg_launch_us": a["us"] / a["launches"],
                 "algorithmic_bytes": a["alg_KB"] * 1e3 / a["launches"],
-                "hbm_achieved_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                "mfma_achieved_TFLOPs": tf, "mfma_frac": mf, "hbm_achieved_GBps": gbs, "hbm_frac": hf,
                 "note": "aggregate over this kernel's launches in one step (sum of flops / sum of isolated launch durations); a launch of this "
                         "kernel is one dependency level of the step, latency-bound at batch 256 (DESIGN.md 3); per-launch rows in roofline_levels"}
             result["roofline_kernels"] = {k: dict(v, share=v["us"] / tot_us) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"])}
@@ -578,7 +589,7 @@ def main():
             result["cpu_baseline"]["host_logical_cpus"] = avail
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
     if rank == 0:
-        print(json.dumps(result))
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -319,6 +319,11 @@ typedef struct nasrec_final_desc {
      [nsplit, K + 1] (column K = the bias gradient, dbias is unused) that a NASREC_OP_REDUCE_ROWS launch sums in fixed order */
   int32_t nsplit;
   int32_t _pad;
+  /* last_n_blocks_out > 1 (supernet.py:592-596 / 657-661): the reference concatenates the last blocks' sparse outputs on the LAST
+     dim ([B, N, n*16]) before flattening, so block j's token t sits at weight columns off + t*(n*16) + [0, 16).  tok_stride[q] != 0
+     gives such a segment: feature j of the (contiguous [B, N*16]) segment meets weight w[off[q] + (j / 16) * tok_stride[q] + j % 16];
+     0 = the plain contiguous placement w[off[q] + j]. */
+  int32_t tok_stride[NASREC_MAX_SEGS];
 } nasrec_final_desc_t;
 
 /* BCEWithLogitsLoss(mean) forward + dlogits (main_train.py:122; train_utils.py:266):

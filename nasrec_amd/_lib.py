@@ -107,7 +107,7 @@ class FinalDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("nseg", i32), ("grad_scale", f32), ("w", vp), ("bias", vp), ("logits", vp), ("dlogits", vp),
                 ("dw", vp), ("dbias", vp), ("seg", vp * MAX_SEGS), ("dseg", vp * MAX_SEGS), ("width", i32 * MAX_SEGS),
                 ("ld", i32 * MAX_SEGS), ("off", i32 * MAX_SEGS), ("dseg_accumulate", i32 * MAX_SEGS), ("y", vp), ("loss", vp),
-                ("dlogits_out", vp), ("nsplit", i32), ("_pad", i32)]
+                ("dlogits_out", vp), ("nsplit", i32), ("_pad", i32), ("tok_stride", i32 * MAX_SEGS)]
 
 
 class BceDesc(C.Structure):
@@ -249,8 +249,8 @@ def load():
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
                  "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_worklist"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 11:
-        raise EngineError("ABI version mismatch: library %d, binding 11" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 12:
+        raise EngineError("ABI version mismatch: library %d, binding 12" % lib.nasrec_abi_version())
     sizes = (i32 * 40)()
     n = lib.nasrec_desc_sizes(sizes, 40)
     for kind, cls in DESC_BY_KIND.items():

@@ -93,6 +93,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 int nasrec_set_error(int code, const char* fmt, ...);
 int nasrec_check_launch(const char* what);
 
+// A dynamic-LDS limit above the default 64 KB is a property of (kernel, DEVICE): `mask` remembers which devices of this process have
+// been told for one kernel (a process may drive several GPUs: main_train.py --gpu N next to another engine on cuda:0).  True when
+// the caller has to set the attribute on the current device.  (Setting it twice is harmless, so no lock.)
+static inline bool nasrec_lds_attr_needed(unsigned long long& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 // per-kind launchers (each .hip file defines its own)
 int launch_gemm(hipStream_t s, const nasrec_gemm_desc_t* d);
 int launch_embed_gather(hipStream_t s, const nasrec_embed_desc_t* d);

@@ -4,6 +4,25 @@
 #pragma once
 #include "common.h"
 
+// weight column of feature j of segment q, and its inverse (feature of weight column k, or -1): contiguous, or token-strided for the
+// interleaved sparse outputs of last_n_blocks_out > 1 (nasrec_final_desc_t.tok_stride)
+__device__ __forceinline__ int final_wcol(const nasrec_final_desc_t& d, int q, int j) {
+  const int ts = d.tok_stride[q];
+  return d.off[q] + (ts ? (j >> 4) * ts + (j & 15) : j);
+}
+__device__ __forceinline__ int final_feat(const nasrec_final_desc_t& d, int q, int k) {
+  const int r = k - d.off[q], ts = d.tok_stride[q];
+  if (r < 0) return -1;
+  if (!ts) return r < d.width[q] ? r : -1;
+  const int t = r / ts, e = r - t * ts;
+  const int j = t * 16 + e;
+  return (e < 16 && j < d.width[q]) ? j : -1;
+}
+__host__ __device__ inline int final_seg_extent(const nasrec_final_desc_t& d, int q) {
+  const int ts = d.tok_stride[q], W = d.width[q];
+  return (ts && W > 0) ? ((W - 1) >> 4) * ts + ((W - 1) & 15) + 1 : W;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // final logit: one wavefront per sample, lanes stride the (segmented) feature axis
 // ---------------------------------------------------------------------------------------------------
@@ -18,14 +37,14 @@ __device__ __forceinline__ void final_fwd_block(const nasrec_final_desc_t& d, in
     const float* x = d.seg[q] + (long)b * d.ld[q];
     const float* w = d.w + d.off[q];
     // four trips' loads in flight (same summation order as the plain loop, which compiles to load -> wait -> fma per trip)
-    const int W = d.width[q];
+    const int W = d.width[q], ts = d.tok_stride[q];
     for (int j0 = lane; j0 < W; j0 += 64 * 4) {
       float xv[4], wv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = min(j0 + 64 * u, W - 1);
         xv[u] = x[j];
-        wv[u] = w[j];
+        wv[u] = w[ts ? (j >> 4) * ts + (j & 15) : j];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -53,8 +72,8 @@ __device__ __forceinline__ void final_bwd_block(const nasrec_final_desc_t& d, in
     if (t >= (long)d.B * K) return;
     const int b = (int)(t / K), k = (int)(t % K);
     for (int q = 0; q < d.nseg; ++q) {
-      const int jj = k - d.off[q];
-      if (jj >= 0 && jj < d.width[q]) {
+      const int jj = final_feat(d, q, k);
+      if (jj >= 0) {
         if (d.dseg[q]) {
           float* p = d.dseg[q] + (long)b * d.ld[q] + jj;
           const float v = dl(b) * d.w[k];
@@ -95,8 +114,8 @@ __device__ __forceinline__ void final_bwd_block(const nasrec_final_desc_t& d, in
       int ld = 0, jj = 0;
       if (k < K) {
         for (int q = 0; q < d.nseg; ++q) {
-          jj = k - d.off[q];
-          if (jj >= 0 && jj < d.width[q]) {
+          jj = final_feat(d, q, k);
+          if (jj >= 0) {
             src = d.seg[q];
             ld = d.ld[q];
             break;
@@ -126,8 +145,8 @@ __device__ __forceinline__ void final_bwd_block(const nasrec_final_desc_t& d, in
     int ld = 0, jj = 0;
     if (k < K) {
       for (int q = 0; q < d.nseg; ++q) {
-        jj = k - d.off[q];
-        if (jj >= 0 && jj < d.width[q]) {
+        jj = final_feat(d, q, k);
+        if (jj >= 0) {
           src = d.seg[q];
           ld = d.ld[q];
           break;
@@ -168,7 +187,7 @@ __device__ __forceinline__ void final_bwd_block(const nasrec_final_desc_t& d, in
 // grid of the backward: nA element-wise workgroups (dseg), nB column blocks (dw, dbias), + 1 for the fused loss
 __host__ __device__ inline void final_bwd_geometry(const nasrec_final_desc_t& d, int& K, int& nA, int& nB) {
   K = 0;
-  for (int q = 0; q < d.nseg; ++q) K = K > d.off[q] + d.width[q] ? K : d.off[q] + d.width[q];
+  for (int q = 0; q < d.nseg; ++q) K = K > d.off[q] + final_seg_extent(d, q) ? K : d.off[q] + final_seg_extent(d, q);
   const long tA = (long)d.B * K;
   nA = (int)((tA + 255) / 256);
   nB = (K + 1 + 15) / 16;

@@ -413,12 +413,10 @@ bool gemm_kslice_eligible(const nasrec_gemm_desc_t* d) {
 int launch_gemm_kslice(hipStream_t st, const nasrec_gemm_desc_t* d) {
   const nasrec_gemm_seg_t& s0 = d->seg[0];
   const int tiles_m = (s0.M + KS_TM - 1) / KS_TM, tiles_n = (s0.N + KS_TN - 1) / KS_TN;
-  static bool attr = false;
+  static unsigned long long attr_devices = 0;
   const size_t lds = sizeof(float) * KS_NB * KS_CH;
-  if (!attr) {
+  if (nasrec_lds_attr_needed(attr_devices))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kslice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
   hipLaunchKernelGGL(gemm_kslice_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(1024), lds, st, *d, tiles_m, tiles_n);
   return nasrec_check_launch("gemm_kslice");
 }

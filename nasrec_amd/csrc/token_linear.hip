@@ -138,11 +138,9 @@ bool token_linear_eligible(const nasrec_gemm_desc_t* d) {
 
 template <int AM, int RB>
 static void launch_token_linear_rb(hipStream_t st, const nasrec_gemm_desc_t* d, int grid, int wgs, size_t lds) {
-  static bool big_lds = false;  // more than the default 64 KB of dynamic LDS must be requested once per kernel
-  if (lds > 65536 && !big_lds) {
+  static unsigned long long big_lds_devices = 0;  // more than the default 64 KB of dynamic LDS must be requested once per kernel and device
+  if (lds > 65536 && nasrec_lds_attr_needed(big_lds_devices))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&token_linear_kernel<AM, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, TL_MAX_LDS);
-    big_lds = true;
-  }
   hipLaunchKernelGGL((token_linear_kernel<AM, RB>), dim3(grid), dim3(1024), lds, st, *d, wgs);
 }
 

@@ -368,16 +368,15 @@ class SupernetEngine:
             cp.stage = st
             d_last, s_last = P.network_walk(ctx, cfg, choice, dense0, sparse0)
             # final logit (supernet.py:592-598 / 657-664)
-            K = d_last.width + s_last.N * E
+            fsegs, K = P.final_segments(d_last, s_last)
             w = ctx.param("_final.weight", (1, K))
             bptr = ctx.param("_final.bias", (1,))
-            fsegs = [P.Seg(d_last, 0, d_last.width), P.Seg(s_last.dense(), d_last.width, s_last.N * E)]
             fd = L.FinalDesc()
             fd.kind = L.OP_FINAL_FWD
-            fd.B, fd.nseg = B, 2
+            fd.B, fd.nseg = B, len(fsegs)
             fd.w, fd.bias, fd.logits = w, bptr, cp.logits.data_ptr()
-            for q, s in enumerate(fsegs):
-                fd.seg[q], fd.width[q], fd.ld[q], fd.off[q] = s.view.ptr, s.width, s.view.ld, s.koff
+            for q, (s, ts) in enumerate(fsegs):
+                fd.seg[q], fd.width[q], fd.ld[q], fd.off[q], fd.tok_stride[q] = s.view.ptr, s.width, s.view.ld, s.koff, ts
             ctx.emit(fd)
             if cfg.use_final_sigmoid:
                 raise NotImplementedError("use_final_sigmoid is never enabled by the reference CLIs")
@@ -453,12 +452,13 @@ class SupernetEngine:
         def final_bwd():
             e = L.FinalDesc()
             e.kind = L.OP_FINAL_BWD
-            e.B, e.nseg = B, 2
+            e.B, e.nseg = B, len(fsegs)
             e.w, e.bias, e.dlogits = w, bptr, cp.dlogits.data_ptr()
             e.dw, e.dbias = self.grads["_final.weight"].data_ptr(), self.grads["_final.bias"].data_ptr()
-            for q, s in enumerate(fsegs):
+            for q, (s, ts) in enumerate(fsegs):
                 gp, acc = ctx.gtarget(s.view)
                 e.seg[q], e.dseg[q], e.width[q], e.ld[q], e.off[q], e.dseg_accumulate[q] = s.view.ptr, gp, s.width, s.view.ld, s.koff, acc
+                e.tok_stride[q] = ts
             if B > 256:
                 # d loss / d _final over a large batch: nsplit batch slices in parallel -> partial [nsplit, K + 1], summed in
                 # fixed order by the launch behind it (one workgroup per 16 columns walked 4096 rows in 132 us)

@@ -112,20 +112,43 @@ def gradient_ready_index(eng, descs):
     return ready
 
 
+def merge_over_unwritten(eng, order, mine, ready):
+    """arena ranges covering the parameters `mine` (one piece's finished gradients) with as few ranges as possible: two of them
+    become one range when everything between them is alignment padding or gradients NO launch of the step writes (zero on every
+    rank, now and for ever: summing zeros changes nothing) — never across a parameter another piece finishes.  Every collective
+    costs a launch and a ring latency; a fixed sub-network's piece is one or two ranges this way."""
+    out, cur = [], None
+    for n in order:
+        if n in mine:
+            lo, hi = eng.offsets[n], eng.offsets[n] + eng.params[n].numel()
+            cur = [cur[0], hi] if cur is not None else [lo, hi]
+            if out and out[-1][2]:
+                out[-1] = cur + [True]
+            else:
+                out.append(cur + [True])
+        elif n in ready:  # somebody else's gradient: the open range ends in front of it
+            cur = None
+            if out:
+                out[-1][2] = False
+    return [(lo, hi - lo) for lo, hi, _ in out]
+
+
 def cut_segments(ready, n_launches, numel, nseg):
     """[(end index, [names final after descs[:end]])]: at most `nseg` pieces covering all launches; a cut is placed behind a launch
     once a 1/nseg share of the gradient bytes has become final since the previous cut"""
     by_idx = {}
     for n, i in ready.items():
         by_idx.setdefault(i, []).append(n)
-    total = sum(numel[n] for n in ready)
-    share = max(total // max(nseg, 1), 1)
+    left = sum(numel[n] for n in ready)
     pieces, names, acc = [], [], 0
-    for i in sorted(by_idx):
+    idxs = sorted(by_idx)
+    for pos, i in enumerate(idxs):
         names += by_idx[i]
         acc += sum(numel[n] for n in by_idx[i])
-        if acc >= share and i + 1 < n_launches and len(pieces) < nseg - 1:
+        share = max(left // max(nseg - len(pieces), 1), 1)  # an equal share of what is still to come (one huge parameter does not use up the cuts)
+        if acc >= share and pos + 1 < len(idxs) and len(pieces) < nseg - 1:
             pieces.append((i + 1, names))
+            left -= acc
             names, acc = [], 0
     pieces.append((n_launches, names))
     return pieces
@@ -324,10 +347,10 @@ class EngineDP:
                 plan.forward = lambda: None
                 plan.ready, plan.cuts = ready, [end for end, _ in pieces]
                 segs, start = [], 0
+                order = sorted(eng.offsets, key=lambda n: eng.offsets[n])
                 for end, names in pieces:
                     prog = Program(descs[start:end])
-                    ranges = coalesce_ranges([(eng.offsets[n], eng.params[n].numel()) for n in names], gap=3)  # (3: alignment padding only — a 4-float slot could be another bucket's parameter)
-                    segs.append(((lambda p: (lambda: p.run(eng._sp())))(prog), ranges))
+                    segs.append(((lambda p: (lambda: p.run(eng._sp())))(prog), merge_over_unwritten(eng, order, set(names), ready)))
                     start = end
                 plan.segments = segs
             else:

@@ -42,7 +42,10 @@ class NetConfig:
     def __init__(self, num_blocks, ops_config, use_layernorm, activation="relu", embedding_dim=16, fixed=False,
                  last_n_blocks_out=1, use_final_sigmoid=False):
         assert embedding_dim == E, "the engine is specialised for embedding_dim == 16 (supernet.py:224)"
-        assert last_n_blocks_out == 1, "last_n_blocks_out != 1 is not used by any reference script"
+        if not 1 <= int(last_n_blocks_out) <= L.MAX_SEGS // 2:
+            raise NotImplementedError("last_n_blocks_out = %s: the final-logit descriptor holds %d segments (dense + sparse of at most %d blocks)"
+                                      % (last_n_blocks_out, L.MAX_SEGS, L.MAX_SEGS // 2))
+        self.last_n_blocks_out = int(last_n_blocks_out)
         self.num_blocks = num_blocks
         self.ops_config = ops_config
         self.use_layernorm = bool(use_layernorm)
@@ -1521,7 +1524,8 @@ class Plan:
 
 
 def network_walk(ctx, cfg: NetConfig, choice, int_x: DV, sparse0: SV):
-    """SuperNet.forward / fixed_forward wiring (supernet.py:513-668). Returns (dense_last, sparse_last)."""
+    """SuperNet.forward / fixed_forward wiring (supernet.py:513-668). Returns (dense outputs, sparse outputs) of the last
+    `cfg.last_n_blocks_out` entries of the running lists — what the final layer reads (:592-596 / :657-661)."""
     dlist, slist = [int_x], [sparse0]
     for i in range(cfg.num_blocks):
         def mark(i=i):
@@ -1541,7 +1545,27 @@ def network_walk(ctx, cfg: NetConfig, choice, int_x: DV, sparse0: SV):
         d_out, s_out = block_walk(ctx, cfg, "_blocks.%d" % i, cfg.block_ops(i), choice["micro"][i], d_in, Dtot, s_in, Ntot, l_in, Ltot, r_in, Rtot)
         dlist.append(d_out)
         slist.append(s_out)
-    return dlist[-1], slist[-1]
+    n = cfg.last_n_blocks_out
+    return dlist[-n:], slist[-n:]
+
+
+def final_segments(d_last: List[DV], s_last: List[SV]):
+    """feats = cat(dense outputs, -1) ++ flatten(cat(sparse outputs, dim=-1)) (supernet.py:592-597 / 657-662) as final-logit segments:
+    -> ([(Seg, tok_stride)], K).  One block: its sparse slab is one contiguous run of weight columns.  Several: the reference
+    concatenates [B, N, 16] tensors on the LAST dim, so block j's token t meets weight columns D + t * (n * 16) + j * 16 + [0, 16) —
+    a token-strided segment (nasrec_final_desc_t.tok_stride); torch.cat demands equal N there, and so does this."""
+    segs, k = [], 0
+    for v in d_last:
+        segs.append((Seg(v, k, v.width), 0))
+        k += v.width
+    n = len(s_last)
+    if len({v.N for v in s_last}) != 1:
+        raise RuntimeError("Sizes of tensors must match except in dimension 2 (last_n_blocks_out = %d concatenates the sparse outputs of "
+                           "the last blocks on their last dim, supernet.py:594-596): token counts %s" % (n, [v.N for v in s_last]))
+    N = s_last[0].N
+    for j, v in enumerate(s_last):
+        segs.append((Seg(v.dense(), k + (j * E if n > 1 else 0), N * E), n * E if n > 1 else 0))
+    return segs, k + n * N * E
 
 
 def infer_param_shapes(cfg: NetConfig, choice, Fd, Fs, num_embeddings) -> Dict[str, tuple]:
@@ -1551,7 +1575,7 @@ def infer_param_shapes(cfg: NetConfig, choice, Fd, Fs, num_embeddings) -> Dict[s
     for f in range(Fs):
         ctx.param("_embedding.%d.weight" % f, (int(num_embeddings[f]), E))
     d_last, s_last = network_walk(ctx, cfg, choice, DV(Buf(ctx, 2 * Fd, False), 0, Fd, Fd), SV(Buf(ctx, 2 * Fs * E, False), 0, Fs, Fs * E))
-    K = d_last.width + s_last.N * E
+    _, K = final_segments(d_last, s_last)
     ctx.param("_final.weight", (1, K))
     ctx.param("_final.bias", (1,))
     return ctx.shapes

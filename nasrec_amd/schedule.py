@@ -210,7 +210,10 @@ def desc_io(d, part="whole") -> Tuple[List[Acc], List[Acc]]:
             R.append(_operand(d.aux, d.mode, d.R, d.K, d.ld))
         W.append(_flat(d.out, d.R))
     elif k in (L.OP_FINAL_FWD, L.OP_FINAL_BWD):
-        K = max([d.off[q] + d.width[q] for q in range(d.nseg)] + [0])
+        def extent(q):  # weight columns a segment spans (token-strided for last_n_blocks_out > 1: nasrec_final_desc_t.tok_stride)
+            ts, Wq = d.tok_stride[q], d.width[q]
+            return ((Wq - 1) // 16) * ts + (Wq - 1) % 16 + 1 if (ts and Wq > 0) else Wq
+        K = max([d.off[q] + extent(q) for q in range(d.nseg)] + [0])
         for q in range(d.nseg):
             if d.seg[q]:
                 R.append(Acc(d.seg[q], d.B, d.width[q], d.ld[q]))

@@ -437,7 +437,10 @@ class SuperNet(nn.Module):
             ids = cat_feats.cpu()
             rows = torch.stack([emb(ids[:, f]) for f, emb in enumerate(self._embedding)], dim=1).to(int_feats.device)
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for _, p in self._param_names)
-        if needs_grad:
+        # torch.jit.trace (TensorBoard's writer.add_graph, main_train.py:137 / train_supernet.py:192; fvcore's FLOP counter,
+        # train_utils.py:444-452): the network traces as ONE opaque node (prim::PythonOp) that consumes the inputs and every
+        # parameter — the no-grad route would hand the tracer a result that depends on nothing it has seen
+        if needs_grad or torch.jit.is_tracing():
             out = _SupernetFunction.apply(self, choice, int_feats, cat_feats, rows, *[p for _, p in self._param_names])
         else:
             out = eng.forward(int_feats, cat_feats, choice, rows=rows).clone()

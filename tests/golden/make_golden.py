@@ -221,6 +221,40 @@ def supernet_cases():
                  extra_meta=dict(mode="supernet", use_layernorm=True, activation=act, choice=choice, num_blocks=nb, config=space))
 
 
+def last_n_cases():
+    """last_n_blocks_out = 2 (supernet.py:592-598 / 657-664: the final layer reads the last TWO blocks; their sparse outputs are
+    concatenated on the last dim, which interleaves them per token and needs equal token counts):
+      supernet_xlarge_any_last2   weight-sharing supernet (every block's sparse output has the space's maximum token count)
+      fixed_criteo_xlarge_last2   the Criteo xlarge best-1shot sub-network with the last-but-one block's sparse node set to the last
+                                  block's token count (the published choice has 16 vs 48 tokens there and fails in torch.cat)"""
+    ops = ops_config_lib["xlarge"]
+    cfg = O.NetCfg(3, O.ops_config_lib["xlarge"], True, "silu")
+    np.random.seed(31)
+    choice = clean_choice(O.PathSampler(cfg, "any-path", "uniform").sample())
+
+    def mk(tables, choice=choice):
+        m = SuperNet(num_blocks=3, ops_config=ops, use_layernorm=True, activation="silu", num_embeddings=tables,
+                     sparse_input_size=DATASETS["criteo"]["Fs"], path_sampling_strategy="full-path", fixed=False, last_n_blocks_out=2)
+        with torch.no_grad():
+            m(torch.zeros(2, 13), torch.zeros(2, 26, dtype=torch.long))
+        m.configure_path_sampling_strategy("fixed-path")
+        m.configure_choice(choice)
+        return m
+    run_case(mk, "criteo", 4, 301, "supernet_xlarge_any_last2.npz",
+             extra_meta=dict(mode="supernet", use_layernorm=True, activation="silu", choice=choice, num_blocks=3, config="xlarge", last_n_blocks_out=2))
+    ch = json.load(open("/root/reference/nasrec/configs/criteo/ea_criteo_kaggle_xlarge_best_1shot.json"))
+    ch["micro"][-2]["sparse_in_dims"] = ch["micro"][-1]["sparse_in_dims"]
+    ch["micro"][-2]["dense_sparse_interact"] = ch["micro"][-1]["dense_sparse_interact"]
+
+    def mkf(tables, ch=ch):
+        return SuperNet(num_blocks=ch["num_blocks"], ops_config=ops_config_lib[ch["config"]], use_layernorm=False, activation="relu",
+                        num_embeddings=tables, sparse_input_size=26, path_sampling_strategy="fixed-path", fixed=True, fixed_choice=ch,
+                        last_n_blocks_out=2)
+    run_case(mkf, "criteo", 8, 302, "fixed_criteo_xlarge_last2.npz",
+             extra_meta=dict(mode="fixed", use_layernorm=False, activation="relu", choice=clean_choice({"macro": ch["macro"], "micro": ch["micro"]}),
+                             num_blocks=ch["num_blocks"], config=ch["config"], last_n_blocks_out=2))
+
+
 def sampler_traces():
     """G4: the reference's own sampling sequence, read back from model.choice after each forward."""
     out = []
@@ -326,6 +360,8 @@ if __name__ == "__main__":
         fixed_cases()
     if "supernet" in which:
         supernet_cases()
+    if "last_n" in which or not sys.argv[1:]:
+        last_n_cases()
     if "samplers" in which:
         sampler_traces()
     if "lr" in which:

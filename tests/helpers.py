@@ -23,7 +23,8 @@ def load_golden(path):
 
 def oracle_cfg(meta):
     ops = O.ops_config_lib[meta["config"]]
-    return O.NetCfg(meta["num_blocks"], ops, meta["use_layernorm"], meta["activation"], fixed=(meta["mode"] == "fixed"))
+    return O.NetCfg(meta["num_blocks"], ops, meta["use_layernorm"], meta["activation"], fixed=(meta["mode"] == "fixed"),
+                    last_n_blocks_out=meta.get("last_n_blocks_out", 1))
 
 
 def oracle_params(meta, dtype=torch.float64):

@@ -46,7 +46,7 @@ def _report_logit_err(name, err, scale, z):
 
 def build_engine(z, meta):
     cfg = P.NetConfig(meta["num_blocks"], ops_config_lib[meta["config"]], meta["use_layernorm"], meta["activation"],
-                      fixed=(meta["mode"] == "fixed"))
+                      fixed=(meta["mode"] == "fixed"), last_n_blocks_out=meta.get("last_n_blocks_out", 1))
     Fd, Fs = z["int_x"].shape[1], z["cat_x"].shape[1]
     eng = SupernetEngine(cfg, Fd, Fs, meta["tables"], warm_choice=meta["choice"] if cfg.fixed else None)
     assert {k: list(v) for k, v in eng.shapes.items()} == meta["param_shapes"]
@@ -199,6 +199,45 @@ def test_module_dropin_with_unchanged_torch_harness(case):
     for k in sd:
         a, b = sd[k].double().cpu(), sd2[k].double().cpu()
         assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(a.abs().max())), k
+
+
+@pytest.mark.parametrize("case", ["fixed_criteo_xlarge", "supernet_autoctr_single"])
+def test_model_survives_jit_trace(case):
+    """the unchanged reference CLIs trace the model: `writer.add_graph(model, (int_x, cat_x))` (main_train.py:137,
+    train_supernet.py:192) is torch.jit.trace(model, args, strict=False) underneath, and fvcore's FlopCountAnalysis
+    (train_utils.py:444-452) is torch.jit._get_trace_graph.  Both must go through (the network shows up as one opaque node), return
+    the eager logits, and leave the model usable for training afterwards."""
+    from nasrec_amd.supernet.supernet import SuperNet
+    from helpers import GOLDEN
+    z, meta = load_golden(os.path.join(GOLDEN, case + ".npz"))
+    fixed = meta["mode"] == "fixed"
+    model = SuperNet(num_blocks=meta["num_blocks"], ops_config=ops_config_lib[meta["config"]], use_layernorm=meta["use_layernorm"],
+                     activation=meta["activation"], num_embeddings=meta["tables"], sparse_input_size=z["cat_x"].shape[1],
+                     path_sampling_strategy="fixed-path" if fixed else "full-path", fixed=fixed,
+                     fixed_choice=meta["choice"] if fixed else None).to("cuda")
+    int_x, cat_x, y = torch.tensor(z["int_x"]).cuda(), torch.tensor(z["cat_x"]).cuda(), torch.tensor(z["y"]).cuda()
+    with torch.no_grad():
+        model(int_x, cat_x)
+    if not fixed:
+        model.configure_path_sampling_strategy("fixed-path")
+        model.configure_choice(meta["choice"])
+    model.load_state_dict({k: torch.tensor(O.seeded_param(k, shp)) for k, shp in meta["param_shapes"].items()})
+    with torch.no_grad():
+        eager = model(int_x, cat_x).clone()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # TracerWarnings about Python values: expected, the reference's own forward raises them too
+        traced = torch.jit.trace(model, (int_x, cat_x), strict=False)
+        graph, out = torch.jit._get_trace_graph(model, (int_x, cat_x))
+    kinds = [n.kind() for n in traced.graph.nodes()]
+    assert any("PythonOp" in k for k in kinds), kinds
+    assert torch.equal(out, eager)
+    assert float(np.abs(eager.cpu().numpy().astype(np.float64) - z["logits_f64"]).max()) <= 1e-5 * max(1.0, float(np.abs(z["logits_f64"]).max()))
+    # training still works after the trace
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(model(int_x, cat_x), y)
+    loss.backward()
+    assert abs(float(loss) - float(z["loss_f64"])) <= 1e-5 * max(1.0, abs(float(z["loss_f64"])))
+    assert model._final.weight.grad is not None
 
 
 def test_data_parallel_code_path_single_rank():

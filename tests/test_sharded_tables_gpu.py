@@ -54,7 +54,8 @@ def test_sharded_step_matches_the_whole_table_step(case, B):
 def _sharded_engine(z, meta):
     """host_embedding engine + row-sharded tables holding the fixture's name-seeded parameters"""
     fixed = meta["mode"] == "fixed"
-    cfg = P.NetConfig(meta["num_blocks"], ops_config_lib[meta["config"]], meta["use_layernorm"], meta["activation"], fixed=fixed)
+    cfg = P.NetConfig(meta["num_blocks"], ops_config_lib[meta["config"]], meta["use_layernorm"], meta["activation"], fixed=fixed,
+                      last_n_blocks_out=meta.get("last_n_blocks_out", 1))
     Fd, Fs, tables = z["int_x"].shape[1], z["cat_x"].shape[1], meta["tables"]
     eng = SupernetEngine(cfg, Fd, Fs, tables, warm_choice=meta["choice"] if fixed else None, host_embedding=True)
     missing = eng.load_params({k: O.seeded_param(k, shp) for k, shp in meta["param_shapes"].items() if not k.startswith("_embedding.")})

@@ -42,7 +42,7 @@ def compile_once(choice):
     sbuf = ctx.buf(B * Fs * 16)
     ctx.raw_sparse = sbuf
     ctx._pcache = PCACHE
-    d_last, s_last = P.network_walk(ctx, cfg, choice, P.DV(int_buf, 0, Fd, Fd), P.SV(sbuf, 0, Fs, Fs * 16))
+    (d_last,), (s_last,) = P.network_walk(ctx, cfg, choice, P.DV(int_buf, 0, Fd, Fd), P.SV(sbuf, 0, Fs, Fs * 16))
     fsegs = [P.Seg(d_last, 0, d_last.width), P.Seg(s_last.dense(), d_last.width, s_last.N * 16)]
 
     def final_bwd():  # stands in for the engine's final-logit backward: makes the last block's outputs live

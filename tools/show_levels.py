@@ -20,7 +20,7 @@ def build_cpu_plan(cfg_json, B, Fd, Fs, defer_dw=False):
     int_buf = P.Buf(ctx, B * Fd, need_grad=False)
     sbuf = ctx.buf(B * Fs * 16)
     ctx.raw_sparse = sbuf
-    d_last, s_last = P.network_walk(ctx, cfg, choice, P.DV(int_buf, 0, Fd, Fd), P.SV(sbuf, 0, Fs, Fs * 16))
+    (d_last,), (s_last,) = P.network_walk(ctx, cfg, choice, P.DV(int_buf, 0, Fd, Fd), P.SV(sbuf, 0, Fs, Fs * 16))
     K = d_last.width + s_last.N * 16
     w = ctx.param("_final.weight", (1, K)); bptr = ctx.param("_final.bias", (1,))
     logits, dlog = ctx.alloc(B), ctx.alloc(B)
