@@ -21,7 +21,7 @@ def build(meta, Fs):
     return SuperNet(num_blocks=meta["num_blocks"], ops_config=ops_config_lib[meta["config"]], use_layernorm=meta["use_layernorm"],
                     activation=meta["activation"], num_embeddings=meta["tables"], sparse_input_size=Fs,
                     path_sampling_strategy="fixed-path" if fixed else "full-path", fixed=fixed,
-                    fixed_choice=meta["choice"] if fixed else None)
+                    fixed_choice=meta["choice"] if fixed else None, last_n_blocks_out=meta.get("last_n_blocks_out", 1))
 
 
 @pytest.mark.parametrize("path", NPZ, ids=[os.path.basename(p)[:-4] for p in NPZ])
@@ -71,7 +71,7 @@ def test_c_abi_exports_every_declared_symbol_and_struct_layouts():
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.nasrec_abi_version() == 11
+    assert lib.nasrec_abi_version() == 12
     assert lib.nasrec_launch(None, None) != 0  # null descriptor: error code + message, no crash
     assert b"null descriptor" in lib.nasrec_last_error()
 

@@ -135,7 +135,8 @@ def test_three_adagrad_steps(path, graph):
 # the drop-in nn.Module path: reference-style harness (torch BCE loss, clip_grad_norm_, torch.optim.Adagrad) on top of
 # nasrec_amd.supernet.SuperNet, compared with what the real reference produced with the same harness
 # ---------------------------------------------------------------------------------------------------------------
-MODULE_CASES = ["fixed_criteo_xlarge", "fixed_avazu_xlarge", "supernet_xlarge_any", "supernet_autoctr_single"]
+MODULE_CASES = ["fixed_criteo_xlarge", "fixed_avazu_xlarge", "supernet_xlarge_any", "supernet_autoctr_single", "supernet_xlarge_any_last2",
+                "fixed_criteo_xlarge_last2"]
 
 
 @pytest.mark.parametrize("case", MODULE_CASES)
@@ -148,7 +149,7 @@ def test_module_dropin_with_unchanged_torch_harness(case):
     model = SuperNet(num_blocks=meta["num_blocks"], ops_config=ops_config_lib[meta["config"]], use_layernorm=meta["use_layernorm"],
                      activation=meta["activation"], num_embeddings=meta["tables"], sparse_input_size=Fs,
                      path_sampling_strategy="fixed-path" if fixed else "full-path", fixed=fixed,
-                     fixed_choice=meta["choice"] if fixed else None).to("cuda")
+                     fixed_choice=meta["choice"] if fixed else None, last_n_blocks_out=meta.get("last_n_blocks_out", 1)).to("cuda")
     int_x, cat_x, y = torch.tensor(z["int_x"]).cuda(), torch.tensor(z["cat_x"]).cuda(), torch.tensor(z["y"]).cuda()
     with torch.no_grad():
         model(int_x, cat_x)  # warm-up (train_utils.py:392-433)
