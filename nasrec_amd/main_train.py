@@ -102,9 +102,12 @@ def train_and_eval_one_model(model, args):
         epoch_logs.append(logs)
     print("Dumping logs to {}!".format(args.logging_dir))
     from nasrec_amd.utils.dist import world_info
+    ckpt = os.path.join(args.logging_dir, "{}_checkpoint.pt".format(args.net))
     if world_info()[0] == 0:  # replicas are identical (broadcast at start, same global-batch update on every rank): rank 0 writes the artefacts
-        save_model_checkpoint(model, os.path.join(args.logging_dir, "{}_checkpoint.pt".format(args.net)), optimizer)
+        save_model_checkpoint(model, ckpt, optimizer)
         dump_pickle_data(os.path.join(args.logging_dir, "train_test_logs.pickle"), epoch_logs)
+    elif getattr(model, "_table_sharding", None):  # row-sharded tables: the whole-table state_dict is a collective
+        save_model_checkpoint(model, None, None)
     return epoch_logs
 
 
@@ -113,7 +116,7 @@ def get_model(args):
     if args.net == "supernet":
         return SuperNet(sparse_input_size=_num_sparse_inputs_dict[args.dataset], num_blocks=7, ops_config=ops_config_lib["xlarge"],
                         use_layernorm=True, activation=args.activation, num_embeddings=_num_embedding_dict[args.dataset],
-                        path_sampling_strategy="full-path")
+                        path_sampling_strategy="full-path", table_sharding=args.table_sharding)
     if args.net == "supernet-config":
         choice = load_json(args.supernet_config)
         print(choice)
@@ -121,7 +124,7 @@ def get_model(args):
         return SuperNet(sparse_input_size=_num_sparse_inputs_dict[args.dataset], num_blocks=choice["num_blocks"],
                         ops_config=ops_config_lib[choice["config"]], use_layernorm=False, activation=args.activation,
                         num_embeddings=_num_embedding_dict[args.dataset], path_sampling_strategy="fixed-path", fixed=True,
-                        fixed_choice=choice)
+                        fixed_choice=choice, table_sharding=args.table_sharding)
     raise NotImplementedError("Model {} is not implemented!".format(args.net))
 
 
@@ -164,6 +167,11 @@ def build_parser():
     p.add_argument("--test_only_at_last_step", type=int, default=0, help="Whether only test the last step.")
     p.add_argument("--ema", type=float, default=0.0, help="EMA strength ranging from 0 to 1 (not implemented, as in the reference).")
     p.add_argument("--gpu", type=int, default=None, help="GPU ID to use.")
+    # not a reference flag: placement of the embedding tables under torchrun (nasrec_amd/sharded_tables.py)
+    p.add_argument("--table-sharding", dest="table_sharding", type=str, default="none", choices=["none", "row"],
+                   help="none: every rank holds whole tables (replicated, row gradients all-gathered); row: every rank owns a row range "
+                        "of every table, ids / rows / row gradients travel by all-to-all (tables that outgrow one GPU).  Needs the fused "
+                        "step: --optimizer adagrad --wd 0")
     return p
 
 

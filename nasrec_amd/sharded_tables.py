@@ -34,9 +34,10 @@ class Route:
 
 
 class RowShardedTables:
-    def __init__(self, num_embeddings: List[int], device, group=None, dtype=torch.float32, init_fn=None):
+    def __init__(self, num_embeddings: List[int], device, group=None, dtype=torch.float32, init_fn=None, shards=None):
         """num_embeddings: rows of every (whole) table.  init_fn(f, row_lo, row_hi) -> [row_hi - row_lo, 16] tensor initialises a
-        shard (default: zeros)."""
+        shard (default: zeros); shards: this rank's row ranges as existing [max(rows, 1), 16] tensors, ADOPTED (no copy: the drop-in
+        module hands over its nn.Embedding weights)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -49,6 +50,12 @@ class RowShardedTables:
         self.tables, self.state = [], []
         for f in range(self.Fs):
             rows = max(self.hi[f] - self.lo[f], 1)  # (an empty shard keeps one unused row so that every pointer is valid)
+            if shards is not None:
+                t = shards[f]
+                assert tuple(t.shape) == (rows, E) and t.is_contiguous() and t.device.type == self.device.type, (f, tuple(t.shape), rows)
+                self.tables.append(t)
+                self.state.append(torch.zeros_like(t))
+                continue
             t = init_fn(f, self.lo[f], self.hi[f]).to(self.device, dtype) if (init_fn is not None and self.hi[f] > self.lo[f]) else \
                 torch.zeros(rows, E, dtype=dtype, device=self.device)
             assert tuple(t.shape) == (rows, E)

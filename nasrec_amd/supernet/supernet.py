@@ -116,7 +116,11 @@ class SuperNet(nn.Module):
                  num_embeddings: List[int] = NUM_EMBEDDINGS_CRITEO, sparse_input_size: int = 26, embedding_dim: int = 16,
                  last_n_blocks_out: int = 1, path_sampling_strategy: str = "default", fixed: bool = False, fixed_choice: Any = None,
                  place_embedding_on_cpu: bool = False, anypath_choice: str = "uniform", supernet_training_steps: int = 0,
-                 candidate_choices: Optional[List] = None, use_final_sigmoid: bool = False):
+                 candidate_choices: Optional[List] = None, use_final_sigmoid: bool = False, table_sharding: Optional[str] = None):
+        """table_sharding (not a reference argument): None = every process holds whole tables (the reference's layout); "row" = the
+        rows of every table are split over the ranks of the process group (nasrec_amd/sharded_tables.py) — for tables that outgrow
+        one GPU.  `_embedding[f]` then holds THIS rank's row range; `state_dict()` returns whole tables (a collective when world > 1);
+        training goes through the fused engine step (Adagrad, weight decay 0), evaluation through the ordinary no-grad forward."""
         super().__init__()
         assert num_blocks >= 1, ValueError("Supernet must contain a minimum of 1 block, but found {}!".format(num_blocks))
         self._num_blocks = num_blocks
@@ -131,6 +135,9 @@ class SuperNet(nn.Module):
         self._macro_path_sampling_strategy = path_sampling_strategy_lib[path_sampling_strategy]["macro"]
         self._candidate_choices = candidate_choices
         self._fixed = fixed
+        assert table_sharding in (None, "none", "row"), "table_sharding must be None or 'row'"
+        self._table_sharding = "row" if table_sharding == "row" else None
+        self._sharded = self._sharded_ops = None
         self._embedding = self._embedding_layers(sparse_input_size, num_embeddings, embedding_dim)
         self._final = nn.LazyLinear(1)
         self._final_sigmoid = nn.Sigmoid() if use_final_sigmoid else None
@@ -181,7 +188,43 @@ class SuperNet(nn.Module):
                     w.copy_(checkpoint["embedding_layers.{}.weight".format(idx)].to(w.device))
 
     def _embedding_layers(self, sparse_input_size, num_embeddings, embedding_dim):
+        if self._table_sharding == "row":
+            return nn.ModuleList([nn.Embedding(self._shard_rows(num_embeddings[i])[2], embedding_dim) for i in range(sparse_input_size)])
         return nn.ModuleList([nn.Embedding(num_embeddings[i], embedding_dim) for i in range(sparse_input_size)])
+
+    @staticmethod
+    def _shard_rows(n):
+        """(first row, end row, rows held) of this rank's range of an n-row table — RowShardedTables' placement: ceil(n / world)
+        rows per rank; an empty range keeps one unused row so that every pointer is valid"""
+        import math
+        import torch.distributed as dist
+        rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+        rp = max(1, math.ceil(int(n) / world))
+        lo, hi = min(int(n), rank * rp), min(int(n), (rank + 1) * rp)
+        return lo, hi, max(hi - lo, 1)
+
+    def state_dict(self, *args, **kwargs):
+        """row-sharded tables: `_embedding.f.weight` is returned WHOLE (all-gather of the shards — a collective when world > 1: every
+        rank must call it), so checkpoints keep the reference's keys and shapes whatever the placement"""
+        sd = super().state_dict(*args, **kwargs)
+        if self._table_sharding == "row" and self._sharded is not None and self._sharded.world > 1:
+            prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
+            for f in range(self._sparse_input_size):
+                sd["%s_embedding.%d.weight" % (prefix, f)] = self._sharded.whole_table(f)
+        return sd
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        if self._table_sharding == "row":  # whole tables in, this rank's rows kept
+            state_dict = dict(state_dict)
+            for f in range(self._sparse_input_size):
+                k = "_embedding.%d.weight" % f
+                if k in state_dict and int(state_dict[k].shape[0]) == int(self._num_embeddings[f]):
+                    lo, hi, rows = self._shard_rows(self._num_embeddings[f])
+                    t = state_dict[k][lo:hi]
+                    if hi - lo < rows:
+                        t = torch.cat([t, torch.zeros(rows - (hi - lo), t.shape[1], dtype=t.dtype, device=t.device)])
+                    state_dict[k] = t
+        return super().load_state_dict(state_dict, *args, **kwargs)
 
     # ------------------------------------------------------------------------------------------------ sampling
     def configure_path_sampling_strategy(self, strategy):
@@ -327,15 +370,19 @@ class SuperNet(nn.Module):
         self._shapes = shapes
         from ..opexec import materialize_lazies
         materialize_lazies(self, shapes, delete_unused=True, device=self._embedding[0].weight.device)
-        got = {k: tuple(v.shape) for k, v in self.state_dict().items()}
-        assert got == {k: tuple(v) for k, v in shapes.items()}, "materialised module tree does not match the inferred parameter set"
+        got = {k: tuple(v.shape) for k, v in nn.Module.state_dict(self).items()}
+        want = {k: tuple(v) for k, v in shapes.items()}
+        if self._table_sharding == "row":  # this rank's row ranges
+            for f in range(self._sparse_input_size):
+                want["_embedding.%d.weight" % f] = (self._shard_rows(self._num_embeddings[f])[2], self._embedding_dim)
+        assert got == want, "materialised module tree does not match the inferred parameter set"
         self._materialized = True
 
     def _bind_engine(self, device):
         from ..engine import SupernetEngine
         params = dict(self.named_parameters())
         Fd = self._Fd
-        host = bool(self._place_embedding_on_cpu)
+        host = bool(self._place_embedding_on_cpu) or self._table_sharding == "row"
         eng = SupernetEngine(self._net_config(), Fd, self._sparse_input_size, self._num_embeddings, device=device,
                              warm_choice=self._warm_choice(), host_embedding=host,
                              tables=None if host else [params["_embedding.%d.weight" % f].data for f in range(self._sparse_input_size)])
@@ -346,6 +393,16 @@ class SuperNet(nn.Module):
             if not name.startswith("_embedding."):
                 p.data = eng.params[name]
         self._engine = eng
+        self._sharded = self._sharded_ops = None
+        self.__dict__.pop("_sharded_step", None)
+        if self._table_sharding == "row":
+            # the engine holds no table (host_embedding mode: the looked-up rows come with the batch); this rank's row ranges are the
+            # nn.Embedding weights themselves, adopted by RowShardedTables; gather / dedup / row-Adagrad run on them with the
+            # engine's kernels (EngineShardedOps)
+            from ..sharded_tables import EngineShardedOps, RowShardedTables
+            self._sharded = RowShardedTables(self._num_embeddings, device,
+                                             shards=[params["_embedding.%d.weight" % f].data for f in range(self._sparse_input_size)])
+            self._sharded_ops = EngineShardedOps(eng)
         self._param_names = [(n, p) for n, p in self.named_parameters() if not (host and n.startswith("_embedding."))]
         st = self.__dict__.pop("_stashed_opt_state", None)
         if st is not None:  # accumulators of the engine this one replaces
@@ -370,8 +427,8 @@ class SuperNet(nn.Module):
             self._bind_engine(dev)
 
     def __deepcopy__(self, memo):
-        eng, names = self._engine, self._param_names
-        self._engine, self._param_names = None, []
+        eng, names, sh = self._engine, self._param_names, (self._sharded, self._sharded_ops, self.__dict__.pop("_sharded_step", None))
+        self._engine, self._param_names, self._sharded, self._sharded_ops = None, [], None, None
         try:
             cls = self.__class__
             new = cls.__new__(cls)
@@ -379,7 +436,9 @@ class SuperNet(nn.Module):
             for k, v in self.__dict__.items():
                 new.__dict__[k] = copy.deepcopy(v, memo)
         finally:
-            self._engine, self._param_names = eng, names
+            self._engine, self._param_names, self._sharded, self._sharded_ops = eng, names, sh[0], sh[1]
+            if sh[2] is not None:
+                self.__dict__["_sharded_step"] = sh[2]
         return new  # the copy re-binds its own engine at its next forward
 
     def to(self, *args, **kwargs):
@@ -431,6 +490,16 @@ class SuperNet(nn.Module):
         self._ensure_engine(int_feats)
         eng = self._engine
         rows = None
+        if self._table_sharding == "row":
+            if torch.is_grad_enabled() and any(p.requires_grad for _, p in self._param_names) and not torch.jit.is_tracing():
+                from .._lib import EngineError
+                raise EngineError("row-sharded tables: train through the fused engine step (engine_train_step: Adagrad, weight decay 0 — "
+                                  "the route train_and_test_one_epoch takes for the published recipes); a differentiable forward "
+                                  "would need the row gradients routed back to their owners by torch.autograd, which is not built. "
+                                  "Evaluate under torch.no_grad().")
+            rows, _ = self._sharded.lookup(cat_feats, lambda idx: self._sharded_ops.gather(self._sharded, idx))
+            out = eng.forward(int_feats, cat_feats, choice, rows=rows).clone()
+            return self._final_sigmoid(out) if self._final_sigmoid is not None else out
         if self._place_embedding_on_cpu:
             # supernet.py:418-428: ids to the host, lookup in host memory, rows to the device ("10~100x slow down", :253-254) — the
             # one place where the reference itself runs the stem on the CPU; everything downstream stays on the engine
@@ -464,6 +533,14 @@ class SuperNet(nn.Module):
         self._engine_steps = getattr(self, "_engine_steps", 0) + 1
         self._last_step_batch = int(int_feats.shape[0])
         self._last_step_key = (choice, clip, eps, graph)
+        if self._table_sharding == "row":
+            from ..sharded_tables import ShardedTableStep
+            st = self.__dict__.get("_sharded_step")
+            key = (id(self._engine), int(int_feats.shape[0]), clip, eps)
+            if st is None or st[0] != key:
+                st = (key, ShardedTableStep(self._sharded_ops, self._sharded, int(int_feats.shape[0]), clip=clip, eps=eps))
+                self.__dict__["_sharded_step"] = st
+            return st[1].step(int_feats, cat_feats, y, lr, choice=choice)
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             # one process per GPU (utils/dist.py): the batch is this rank's share of the global batch; same path on every rank
@@ -480,6 +557,8 @@ class SuperNet(nn.Module):
         """logits [B, 1] of the most recent engine_train_step (what `model(int_x, cat_x)` returned inside that step)"""
         choice, clip, eps, graph = self._last_step_key
         B = self._last_step_batch
+        if self._table_sharding == "row":
+            return self._sharded_ops.cp.logits.view(B, 1)
         dp = self.__dict__.get("_dp_step")
         if dp is not None and dp[1].exchange:
             return dp[1].last_plan().logits.view(B, 1)
@@ -494,7 +573,9 @@ class SuperNet(nn.Module):
         assert eng is not None, "run one forward first (lazy shapes)"
         eng._ensure_table_state()
         for name, p in self.named_parameters():
-            if name.startswith("_embedding."):
+            if name.startswith("_embedding.") and self._table_sharding == "row":
+                tgt = self._sharded.state[int(name.split(".")[1])]
+            elif name.startswith("_embedding."):
                 tgt = eng.table_state[int(name.split(".")[1])]
             elif name in eng.state:
                 tgt = eng.state[name]

@@ -69,6 +69,8 @@ def train_and_eval_one_model(model, args):
     if world_info()[0] == 0:  # replicas are identical (broadcast at start, same global-batch update on every rank): rank 0 writes the artefacts
         dump_pickle_data(os.path.join(logging_dir, "train_test_logs.pickle"), logs)  # the last epoch only, as the reference does
         save_model_checkpoint(model, os.path.join(logging_dir, "supernet_checkpoint.pt"), optimizer)
+    elif getattr(model, "_table_sharding", None):  # row-sharded tables: the whole-table state_dict is a collective
+        save_model_checkpoint(model, None, None)
     return epoch_logs
 
 
@@ -78,7 +80,8 @@ def main(args):
     model = SuperNet(sparse_input_size=_num_sparse_inputs_dict[args.dataset], num_blocks=args.num_blocks,
                      ops_config=ops_config_lib[args.config], use_layernorm=(args.use_layernorm == 1), activation="relu",
                      num_embeddings=_num_embedding_dict[args.dataset], path_sampling_strategy=args.strategy,
-                     anypath_choice=args.anypath_choice, supernet_training_steps=args.supernet_training_steps, candidate_choices=None)
+                     anypath_choice=args.anypath_choice, supernet_training_steps=args.supernet_training_steps, candidate_choices=None,
+                     table_sharding=args.table_sharding)
     return train_and_eval_one_model(model.to(args.gpu), args)
 
 
@@ -115,6 +118,9 @@ def build_parser():
     p.add_argument("--optimizer", type=str, default="adagrad", choices=["adagrad", "sgd", "adam", "rmsprop", "ds-optimizer"])
     p.add_argument("--pretrained_dlrm_emb_path", type=str, default=None, help="Pretrained embedding path from DLRM model.")
     p.add_argument("--gpu", type=int, default=0, help="GPU ID to use.")
+    # not a reference flag: placement of the embedding tables under torchrun (nasrec_amd/sharded_tables.py)
+    p.add_argument("--table-sharding", dest="table_sharding", type=str, default="none", choices=["none", "row"],
+                   help="none: whole tables on every rank; row: every rank owns a row range of every table (all-to-all of ids / rows / row gradients)")
     return p
 
 

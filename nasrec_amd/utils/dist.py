@@ -53,7 +53,8 @@ def world_info():
 
 def _replica_tensors(model):
     """every tensor that defines a replica: parameters, buffers, and the engine's Adagrad accumulators once they exist"""
-    out = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
+    sharded = getattr(model, "_table_sharding", None) == "row"  # row-sharded tables: every rank owns DIFFERENT rows — not replica state
+    out = [p.data for n, p in model.named_parameters() if not (sharded and n.startswith("_embedding."))] + [b.data for b in model.buffers()]
     eng = getattr(model, "_engine", None)
     if eng is not None:
         if getattr(eng, "flat_s", None) is not None:

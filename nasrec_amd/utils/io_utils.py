@@ -44,8 +44,12 @@ def load_model_checkpoint(load_path):
 
 
 def save_model_checkpoint(model, save_path, optimizer=None):
+    """save_path None: build the checkpoint but write nothing — row-sharded tables make `model.state_dict()` a collective (every rank
+    contributes its rows), so every rank calls this and only rank 0 passes a path"""
     blob = {"model_state_dict": model.state_dict()}
     if optimizer is not None:
         blob["optimizer_state_dict"] = optimizer.state_dict()
+    if save_path is None:
+        return
     torch.save(blob, save_path)
     print("Saved weights to {}!".format(save_path))

@@ -199,3 +199,61 @@ def test_search_candidates_are_scored_by_last_layer_finetuning(monkeypatch):
     for sd in models:
         moved = sorted(k for k in sd if not torch.equal(sd[k], ckpt["model_state_dict"][k]))
         assert moved == ["_final.bias", "_final.weight"], moved
+
+
+def test_table_sharding_row_flag_trains_like_whole_tables(tmp_path, capsys):
+    """`main_train.py --table-sharding row` (row-sharded tables as a usable mode) against the same command line with
+    whole tables: identical seeds, so identical initial weights and batches — train / test losses of every logged step and the saved
+    checkpoint (whole tables under the reference's keys, Adagrad sums included) must agree to fp32 rounding.  Single rank here: the
+    route degenerates to the identity, every kernel and the whole step composition of the sharded mode runs; the N > 1 routing is the
+    gloo world-2 test's (tests/test_sharded_tables_cpu.py)."""
+    root = _shards(tmp_path)
+    runs = []
+    for mode in ("none", "row"):
+        logdir = str(tmp_path / ("logs_" + mode))
+        args = MT.build_parser().parse_args([
+            "--root_dir", root, "--net", "supernet-config", "--supernet_config", CFG, "--num_epochs", "1", "--learning_rate", "0.1",
+            "--train_batch_size", "8", "--test_batch_size", "16", "--wd", "0", "--logging_dir", logdir, "--gpu", "0", "--test_interval", "4",
+            "--display_interval", "2", "--train_limit", "96", "--table-sharding", mode])
+        torch.manual_seed(0)
+        np.random.seed(0)
+        logs = MT.main(args)
+        ck = torch.load(os.path.join(logdir, "supernet-config_checkpoint.pt"), map_location="cpu")
+        runs.append((logs[0], ck))
+    capsys.readouterr()
+    (la, ca), (lb, cb) = runs
+    assert la["iters"] == lb["iters"]
+    assert np.allclose(la["train_loss"], lb["train_loss"], rtol=1e-5, atol=1e-6), (la["train_loss"], lb["train_loss"])
+    assert np.allclose(la["test_loss"], lb["test_loss"], rtol=1e-5, atol=1e-6)
+    assert list(ca["model_state_dict"]) == list(cb["model_state_dict"])
+    for k, v in ca["model_state_dict"].items():
+        assert v.shape == cb["model_state_dict"][k].shape and torch.allclose(v, cb["model_state_dict"][k], rtol=0, atol=2e-5), k
+    sa, sb = ca["optimizer_state_dict"]["state"], cb["optimizer_state_dict"]["state"]
+    assert len(sa) == len(sb)
+    for i in sa:
+        assert torch.allclose(sa[i]["sum"], sb[i]["sum"], rtol=1e-4, atol=1e-7), i
+
+
+def test_table_sharding_row_refuses_the_torch_route(tmp_path):
+    """row-sharded tables have no differentiable forward: a recipe that needs the torch route (weight decay != 0) must fail loudly, not
+    train on stale or partial tables"""
+    from nasrec_amd._lib import EngineError
+    root = _shards(tmp_path)
+    args = MT.build_parser().parse_args([
+        "--root_dir", root, "--net", "supernet-config", "--supernet_config", CFG, "--learning_rate", "0.1", "--train_batch_size", "8",
+        "--test_batch_size", "16", "--wd", "1e-4", "--logging_dir", str(tmp_path / "l"), "--gpu", "0", "--train_limit", "48", "--table-sharding", "row"])
+    with pytest.raises(EngineError):
+        MT.main(args)
+
+
+def test_train_supernet_cli_with_row_sharded_tables(tmp_path, capsys):
+    args = TS.build_parser().parse_args([
+        "--dataset", "kdd", "--root_dir", "synthetic:steps=6,test_steps=1,seed=3", "--logging_dir", str(tmp_path / "sn"), "--config", "autoctr",
+        "--num_blocks", "3", "--use_layernorm", "1", "--strategy", "default", "--anypath_choice", "binomial-0.5", "--supernet_training_steps", "2",
+        "--train_batch_size", "16", "--test_batch_size", "16", "--train_limit", "64", "--learning_rate", "0.05", "--display_interval", "2",
+        "--gpu", "0", "--table-sharding", "row"])
+    np.random.seed(0)
+    torch.manual_seed(0)
+    logs = TS.main(args)
+    capsys.readouterr()
+    assert len(logs[0]["test_loss"]) == 1 and np.isfinite(logs[0]["test_loss"][0]) and all(np.isfinite(v) for v in logs[0]["train_loss"])

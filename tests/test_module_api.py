@@ -132,3 +132,18 @@ def test_lr_schedulers_match_reference_traces():
         s2 = CosineAnnealingWarmupRestarts(c["first_cycle_steps"], c["cycle_mult"], c["max_lr"], c["min_lr"], c["warmup_steps"], c["gamma"])
         s2.load_state_dict(st)
         assert s2.step() == s.step()
+
+
+def test_row_sharded_module_keeps_the_reference_state_dict_in_a_single_process():
+    """SuperNet(table_sharding="row") with world size 1: this rank's row range is the whole table, so the module tree, the
+    state_dict keys / shapes and the parameter order are the reference's; load_state_dict takes whole tables"""
+    z, meta = load_golden(os.path.join(GOLDEN, "fixed_kdd_autoctr.npz"))
+    m = SuperNet(num_blocks=meta["num_blocks"], ops_config=ops_config_lib[meta["config"]], use_layernorm=meta["use_layernorm"],
+                 activation=meta["activation"], num_embeddings=meta["tables"], sparse_input_size=z["cat_x"].shape[1],
+                 path_sampling_strategy="fixed-path", fixed=True, fixed_choice=meta["choice"], table_sharding="row")
+    assert SuperNet._shard_rows(7) == (0, 7, 7)
+    m._materialize(z["int_x"].shape[1])
+    sd = m.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == meta["param_shapes"]
+    assert [n for n, _ in m.named_parameters()] == meta["param_order"]
+    m.load_state_dict({k: torch.zeros(v.shape) for k, v in sd.items()}, strict=True)
