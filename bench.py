@@ -291,6 +291,9 @@ def main():
                     help="id distribution (SURVEY 8d): uniform over each table = the cache-hostile primary case; zipf = Zipf(1.05) with 2 %% zeros")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: the config's batch PER GPU (global batch grows with N); strong: the config's batch is the GLOBAL batch")
+    ap.add_argument("--table-sharding", choices=["none", "row"], default="none",
+                    help="row: every rank owns a row range of every table (nasrec_amd/sharded_tables.py: ids / rows / row gradients by all-to-all, "
+                         "owner-side dedup + clip + Adagrad) instead of replicated tables with an all-gather of row gradients")
     ap.add_argument("--id-pool", type=int, default=None, help="number of pre-generated id batches (default: enough to overflow the Infinity Cache)")
     args = ap.parse_args()
     w = WORKLOADS[args.config]
@@ -345,18 +348,41 @@ def main():
     steps_per_epoch = w["train_limit"] // B
     sched = CosineAnnealingWarmupRestarts(steps_per_epoch, max_lr=LR_MAX if fixed else 0.12, min_lr=LR_MIN, warmup_steps=steps_per_epoch // 10)
 
+    sharded = args.table_sharding == "row"
+
+    class ShardedRun:
+        """bench-side adapter: ShardedTableStep (row-sharded tables, f-4) behind the handful of attributes the reporting below reads"""
+        exchange, graph = False, False
+
+        def __init__(self, eng):
+            from nasrec_amd.sharded_tables import EngineShardedOps, RowShardedTables, ShardedTableStep
+            g = torch.Generator(device="cpu").manual_seed(7)
+            self.t = RowShardedTables(tables, device, init_fn=lambda f, lo, hi: torch.randn(hi - lo, 16, generator=g) * (2.0 / (tables[f] + 16)) ** 0.5)
+            self.ops = EngineShardedOps(eng, clip=5.0, eps=1e-2)
+            self.stepper = ShardedTableStep(self.ops, self.t, B, clip=5.0, eps=1e-2)
+            self._loss = None
+
+        def step(self, int_x, cat_x, y, lr, choice=None):
+            self._loss = self.stepper.step(int_x, cat_x, y, lr, choice=choice)
+
+        def last_loss(self):
+            return self._loss
+
+        def last_plan(self):
+            return self.ops.cp
+
     if fixed:
         choice_all = json.load(open(os.path.join(ROOT, "nasrec_amd", "configs", "criteo", "ea_criteo_kaggle_xlarge_best_1shot.json")))
         choice = {"macro": choice_all["macro"], "micro": choice_all["micro"]}
         # main_train.py:258-269: best-1shot sub-networks are built WITHOUT LayerNorm (use_layernorm hard-coded False)
         cfg = P.NetConfig(choice_all["num_blocks"], ops_config_lib[choice_all["config"]], False, "relu", fixed=True)
-        eng = SupernetEngine(cfg, Fd, Fs, tables, device=device, warm_choice=choice, world_size=world)
+        eng = SupernetEngine(cfg, Fd, Fs, tables, device=device, warm_choice=choice, world_size=world, host_embedding=sharded)
         eng.init_weights(seed=0)
-        dp = DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=not args.no_graph, force_exchange=args.force_dp_path)
+        dp = ShardedRun(eng) if sharded else DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=not args.no_graph, force_exchange=args.force_dp_path)
 
         def one_step(i):
             bx = batches[i % len(batches)]
-            dp.step(bx[0], bx[1], bx[2], sched.get_lr())
+            dp.step(bx[0], bx[1], bx[2], sched.get_lr(), choice=choice)
             sched.step()
         parallelism = "dp%d (RCCL all-reduce of dense grads + all-gather of row-sparse embedding grads)" % world
     else:
@@ -366,7 +392,8 @@ def main():
         from nasrec_amd.supernet.supernet import SuperNet
         torch.manual_seed(0)
         model = SuperNet(num_blocks=7, ops_config=ops_config_lib[w["space"]], use_layernorm=True, num_embeddings=tables, sparse_input_size=Fs,
-                         path_sampling_strategy="full-path", fixed=False, anypath_choice="binomial-0.5").to(device)
+                         path_sampling_strategy="full-path", fixed=False, anypath_choice="binomial-0.5",
+                         table_sharding="row" if sharded else None).to(device)
         with torch.no_grad():
             model(batches[0][0][:64], batches[0][1][:64])
         eng = model._engine
@@ -375,6 +402,14 @@ def main():
         model.configure_path_sampling_strategy("default")
         np.random.seed(0)
         dp = DataParallelStep(eng, None, B, clip=5.0, eps=1e-2, graph=False, force_exchange=args.force_dp_path)
+        if sharded:  # the module built the engine in host_embedding mode and adopted its nn.Embedding weights as this rank's shards
+            class _ModuleRun(ShardedRun):
+                def __init__(self):
+                    from nasrec_amd.sharded_tables import ShardedTableStep
+                    self.t, self.ops = model._sharded, model._sharded_ops
+                    self.stepper = ShardedTableStep(self.ops, self.t, B, clip=5.0, eps=1e-2)
+                    self._loss = None
+            dp = _ModuleRun()
 
         def one_step(i):
             bx = batches[i % len(batches)]
@@ -383,6 +418,10 @@ def main():
             sched.step()
         parallelism = "dp%d (same sampled path on every rank; bucketed RCCL all-reduce of the path's dense grads overlapped with the " \
                       "backward + all-gather of row-sparse embedding grads)" % world
+
+    if sharded:
+        parallelism = "dp%d dense network (all-reduce of the path's dense grads) + row-sharded tables (all-to-all of ids / rows / row gradients, " \
+                      "owner-side dedup + clip + Adagrad)" % world
 
     def fence():
         torch.cuda.synchronize(device)
@@ -419,7 +458,7 @@ def main():
                    "parallelism": parallelism,
                    "ids": "%s over each table; %d pre-generated id batches = %.0f MB of distinct-ish table rows per lap of the pool (Infinity Cache: 256 MB)"
                           % (args.ids, len(batches), len(batches) * B * Fs * 64 / 1e6),
-                   "embedding_update": "row-sparse clip+Adagrad (== dense reference update for weight_decay 0)"},
+                   "embedding_update": "row-sparse clip+Adagrad (== dense reference update for weight_decay 0)", "table_sharding": args.table_sharding},
         "final_loss": loss,
     }
     if dp.exchange:
@@ -434,7 +473,7 @@ def main():
         sp = torch.cuda.current_stream(device).cuda_stream
         cp = dp.last_plan()
         allg = [d for d in P.iter_ops(cp.fwd.descs + cp.bwd.descs) if isinstance(d, L.GemmDesc)]
-        if fixed and world == 1:
+        if fixed and world == 1 and not sharded:
             # ---- forward-only throughput (eval path) ---------------------------------------------------------------
             fgraph = not args.no_graph  # (--no-graph: nothing is graph-replayed — counter collection hangs on replays now and then)
             eng.compile(choice, B, train=False, graph=fgraph)
@@ -447,7 +486,7 @@ def main():
             torch.cuda.synchronize(device)
             result["forward_only_samples_per_s"] = B * 200 / (time.perf_counter() - t1)
 
-        if fixed and world == 1 and not args.force_dp_path:
+        if fixed and world == 1 and not args.force_dp_path and not sharded:
             # ---- secondary figure: the same step with the forward operators nobody reads dropped (opt-in, never `value`): the
             # reference computes block 5 of this architecture and throws it away (last_n_blocks_out = 1, no later block selects it)
             eng.dead_code_elimination = True
@@ -473,7 +512,7 @@ def main():
             eng._last_plan = None
             cp = dp.cp = eng.compile(choice, B, True, 5.0, 1e-2, graph=dp.graph)
 
-        if world == 1:
+        if world == 1 and not sharded:
             # ---- embedding stem on COLD rows: the staging launch (batch copy + gather of B x Fs 64-byte rows, a1 of SURVEY 8a) over
             # distinct id batches of the pool — random 64-B rows out of HBM, HBM-latency bound -----------------------------------
             ng = min(200, len(batches))

@@ -75,6 +75,7 @@ def coalesce_ranges(ranges: List[Tuple[int, int]], gap: int = BUCKET_GAP) -> Lis
 
 
 DP_SEGMENTS = int(__import__("os").environ.get("NASREC_DP_SEGMENTS", "4"))
+_MEASURE_SKIP = __import__("os").environ.get("NASREC_DP_MEASURE_SKIP", "").split(",")
 
 
 def gradient_ready_index(eng, descs):
@@ -238,13 +239,16 @@ class DataParallelStep:
           row grads    all-gather when the backward has reached the embedding stem (its last launch);
         the compute stream waits for all of them in front of the optimizer launches, nowhere else."""
         flat_g = self.engine.flat_g
-        pending = [all_gather_rows_async(self.cat_all, plan.cat_local)]
+        skip = _MEASURE_SKIP  # measurement knob (tools/dp_overhead.sh): leave collectives out to see what each kind costs; never set in a run
+        pending = [all_gather_rows_async(self.cat_all, plan.cat_local)] if "gather" not in skip else []
         plan.forward()
         for run, ranges in plan.segments:
             run()
             for off, n in ranges:
-                pending.append(dist.all_reduce(flat_g[off:off + n], op=dist.ReduceOp.SUM, async_op=True))
-        pending.append(all_gather_rows_async(self.sg_all, plan.sparse_grad))
+                if "reduce" not in skip:
+                    pending.append(dist.all_reduce(flat_g[off:off + n], op=dist.ReduceOp.SUM, async_op=True))
+        if "gather" not in skip:
+            pending.append(all_gather_rows_async(self.sg_all, plan.sparse_grad))
         for w in pending:
             if w is not None:
                 w.wait()  # nccl: the compute stream waits for the collective (no host block)

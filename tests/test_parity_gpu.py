@@ -186,7 +186,7 @@ def test_module_dropin_with_unchanged_torch_harness(case):
     model2 = SuperNet(num_blocks=meta["num_blocks"], ops_config=ops_config_lib[meta["config"]], use_layernorm=meta["use_layernorm"],
                       activation=meta["activation"], num_embeddings=meta["tables"], sparse_input_size=Fs,
                       path_sampling_strategy="fixed-path" if fixed else "full-path", fixed=fixed,
-                      fixed_choice=meta["choice"] if fixed else None).to("cuda")
+                      fixed_choice=meta["choice"] if fixed else None, last_n_blocks_out=meta.get("last_n_blocks_out", 1)).to("cuda")
     with torch.no_grad():
         model2(int_x, cat_x)
     if not fixed:

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Where the single-rank cost of the data-parallel exchange step goes (bench.py --force-dp-path, cfg 2): the captured step with all
+# collectives, without the all-gathers, without the all-reduces, without any, with 1 / 2 / 8 pieces, next to the plain step.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/dp_overhead
+mkdir -p $O
+cd $R
+run() { name=$1; shift; env "$@" timeout 200 python bench.py --force-dp-path --no-cpu-baseline --steps 600 --warmup 50 2>/dev/null | grep '^{' | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('$name', round(r['ms_per_step'],4), round(r['median_ms_per_step'],4), r['config'].get('dp_exchange',{}).get('launches_up_to_cut'))" >> $O/result.txt; }
+rm -f $O/result.txt
+timeout 200 python bench.py --no-cpu-baseline --steps 600 --warmup 50 2>/dev/null | grep '^{' | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('plain', round(r['ms_per_step'],4), round(r['median_ms_per_step'],4))" >> $O/result.txt
+run all A=1
+run no_gather NASREC_DP_MEASURE_SKIP=gather
+run no_reduce NASREC_DP_MEASURE_SKIP=reduce
+run none NASREC_DP_MEASURE_SKIP=gather,reduce
+run pieces1 NASREC_DP_SEGMENTS=1
+run pieces2 NASREC_DP_SEGMENTS=2
+run pieces8 NASREC_DP_SEGMENTS=8
+cat $O/result.txt
