@@ -38,6 +38,11 @@ BUCKET_GAP = 16384  # floats: arena ranges closer than this are sent as one all-
 
 def all_gather_rows(out: torch.Tensor, local: torch.Tensor):
     """out[r*n:(r+1)*n] = local of rank r (n = local.numel()); works on nccl and gloo."""
+    if dist.get_world_size() == 1:
+        # a gather over one rank is a copy: as a kernel on the calling stream, not as the library's device-to-device memcpy (which a
+        # captured graph replays as a memcpy node: ~30 us each on this stack, the whole 62 us the single-rank exchange step cost)
+        out.view(-1).copy_(local.reshape(-1))
+        return
     try:
         dist.all_gather_into_tensor(out.view(-1), local.reshape(-1))
     except (RuntimeError, NotImplementedError):
@@ -48,6 +53,9 @@ def all_gather_rows(out: torch.Tensor, local: torch.Tensor):
 
 def all_gather_rows_async(out: torch.Tensor, local: torch.Tensor):
     """all_gather_rows without blocking the compute stream; returns the work handle (None if it completed inline)"""
+    if dist.get_world_size() == 1:
+        all_gather_rows(out, local)
+        return None
     try:
         return dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), async_op=True)
     except (RuntimeError, NotImplementedError):

@@ -323,6 +323,82 @@ def assign_levels(nodes: List[Node]) -> int:
     return (max(n.level for n in nodes) + 1) if nodes else 0
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# slack: ASAP levels put every operator as early as its operands allow, but a level lasts as long as its slowest member plus
+# whatever the chip cannot hold at once — and many operators are in no hurry: weight-gradient products and their second passes
+# (nobody reads a weight gradient before the optimizer), bias / parameter reductions, forward operators whose result no later block
+# selects.  `balance_levels` moves such nodes, inside the window their dependencies leave, to the level where they cost least:
+# typically beside a Transformer backward (one wavefront per SIMD for 17-20 us: the matrix pipes are idle) instead of beside the
+# two large products of the step's critical path.  Same bodies on the same operands: bit-identical results.
+# ----------------------------------------------------------------------------------------------------------------
+BALANCE = os.environ.get("NASREC_WL_BALANCE", "1") != "0"
+_LATENCY_NS = 5000  # what a level costs however little it does (launch, descriptor + operand first touch on cold caches, drain)
+
+
+def _work_ns(node):
+    """the part of an item's stand-alone duration that occupies the chip (adds up when items share a level), as opposed to latency
+    (which overlaps): a product's M*N*K term; a quarter of the sample-per-workgroup bodies (one wavefront per SIMD)"""
+    c = _cost(node)
+    if isinstance(node.desc, L.GemmDesc):
+        return max(c - _LATENCY_NS, 0) if node.part != "epi" else 400
+    return c // 4
+
+
+def _level_ns(members):
+    """estimated duration of a level's worklist launch"""
+    if not members:
+        return 0
+    return max(max(_cost(n) for n in members), _LATENCY_NS + sum(_work_ns(n) for n in members))
+
+
+def balance_levels(nodes: List[Node], nl: int) -> None:
+    """in place: nodes with slack move to the level of their window [last predecessor + 1, first successor - 1] that makes the
+    estimated sum of level durations smallest (local search from the ASAP schedule; the number of levels never grows)"""
+    n = len(nodes)
+    pred = [[] for _ in range(n)]
+    succ = [[] for _ in range(n)]
+    for i in range(n):
+        for j in range(i):
+            if _depends(nodes[i], nodes[j]):
+                pred[i].append(j)
+                succ[j].append(i)
+    movable = [i for i in range(n) if nodes[i].reads is not None and item_bytes(nodes[i]) is not None]
+    levels = [[] for _ in range(nl)]
+    for i in movable:
+        levels[nodes[i].level].append(nodes[i])
+    order = sorted(movable, key=lambda i: -_cost(nodes[i]))
+    size = {id(nodes[i]): (len(item_bytes(nodes[i])) + 15) & ~15 for i in movable}
+
+    def fits(lv, nd):  # one launch per level: at most WL_MAX_ITEMS items in WL_BLOB_BYTES of descriptors (a second launch would cost a boundary)
+        return len(levels[lv]) < L.WL_MAX_ITEMS and sum(size[id(m)] for m in levels[lv]) + size[id(nd)] <= L.WL_BLOB_BYTES
+
+    for _ in range(4):
+        moved = False
+        for i in order:
+            nd = nodes[i]
+            lo = max([nodes[j].level + 1 for j in pred[i]] + [0])
+            hi = min([nodes[j].level - 1 for j in succ[i]] + [nl - 1])
+            if hi <= lo and nd.level == lo:
+                continue
+            cur = nd.level
+            without = [m for m in levels[cur] if m is not nd]
+            base = _level_ns(levels[cur]) - _level_ns(without)  # what the node costs where it is
+            best, best_lv = base, cur
+            for lv in range(lo, hi + 1):
+                if lv == cur or not fits(lv, nd):
+                    continue
+                add = _level_ns(levels[lv] + [nd]) - _level_ns(levels[lv])
+                if add < best - 200:  # (only moves worth more than the model's noise)
+                    best, best_lv = add, lv
+            if best_lv != cur:
+                levels[cur] = without
+                levels[best_lv].append(nd)
+                nd.level = best_lv
+                moved = True
+        if not moved:
+            break
+
+
 def levels_of(descs):
     nodes = expand(descs)
     nl = assign_levels(nodes)
@@ -450,6 +526,8 @@ def pack(descs):
     levels).  Every WorklistDesc carries `.nodes` (its items' Nodes) for reports."""
     nodes = expand_for_worklists(descs)
     nl = assign_levels(nodes)
+    if BALANCE:
+        balance_levels(nodes, nl)
     out = []
     for lv in range(nl):
         members = sorted((n for n in nodes if n.level == lv), key=lambda n: -_cost(n))

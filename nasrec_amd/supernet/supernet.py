@@ -57,6 +57,22 @@ def _make_node(name, use_layernorm, dims, activation, embedding_dim, fixed):
     raise NotImplementedError("Block name {} is not supported in supernet!".format(name))
 
 
+class _tracing_paused:
+    """torch.jit.trace records every torch call it sees, also inside an autograd.Function's forward; the engine's host work (plan
+    buffers carved out of byte arenas with `view(dtype)`, zero fills, copies into static buffers) is not part of the model's graph
+    and trips the tracer's alias analysis.  Inside this block nothing is recorded; the Function itself stays the graph's one node."""
+
+    def __enter__(self):
+        self.state = torch._C._get_tracing_state()
+        if self.state is not None:
+            torch._C._set_tracing_state(None)
+
+    def __exit__(self, *exc):
+        if self.state is not None:
+            torch._C._set_tracing_state(self.state)
+        return False
+
+
 class _SupernetFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward = forward program, backward = backward program."""
 
@@ -66,12 +82,14 @@ class _SupernetFunction(torch.autograd.Function):
         gradient torch carries back to the host tables"""
         eng = model._engine
         B = int(int_x.shape[0])
-        cp = eng.compile(choice, B, train=True)
-        eng.run_forward(cp, int_x, cat_x, rows=rows)
+        with _tracing_paused():
+            cp = eng.compile(choice, B, train=True)
+            eng.run_forward(cp, int_x, cat_x, rows=rows)
+            out = cp.logits.view(B, 1).clone()
         ctx.has_rows = rows is not None
         cp.generation = getattr(cp, "generation", 0) + 1
         ctx.model, ctx.cp, ctx.cat_x, ctx.generation = model, cp, cat_x, cp.generation
-        return cp.logits.view(B, 1).clone()
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
