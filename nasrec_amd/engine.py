@@ -411,7 +411,9 @@ class SupernetEngine:
                 # block output no later block reads, second passes) runs beside the first backward levels
                 cp.fb = None
                 if scheduled:
-                    fb_descs, cp.fb_levels = S.pack(fwd_list + bwd_descs)
+                    # (alloc: a forward product with several levels of slack may be re-cut into split-K items — only in the JOINT
+                    # program, where the backward's latency-bound levels are there to hide it)
+                    fb_descs, cp.fb_levels = S.pack(fwd_list + bwd_descs, alloc=ctx.alloc)
                     cp.fb = Program(fb_descs)
                     bwd_descs, cp.bwd_levels = S.pack(bwd_descs)
                 cp.bwd = Program(bwd_descs)

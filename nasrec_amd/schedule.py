@@ -399,6 +399,49 @@ def balance_levels(nodes: List[Node], nl: int) -> None:
             break
 
 
+RESPLIT = os.environ.get("NASREC_WL_RESPLIT", "1") != "0"
+RESPLIT_MIN_SLACK = 3
+
+
+def resplit_slack_solos(descs, alloc):
+    """A large forward product that runs as a launch of its own (csrc/gemm_kslice.hip: K split inside the workgroup) sits alone on the
+    stream for 9-13 us.  When nothing waits for its result for several levels (in ea_criteo_kaggle_xlarge_best_1shot.json: all of
+    block 5, which no later block selects — computed by the reference and thrown away), it is worth more as a worklist item beside a
+    latency-bound level (a Transformer backward keeps one wavefront per SIMD busy for 17-20 us): the product is re-cut with the
+    ordinary split-K factor of its tile count (workspace from `alloc`), so that its main pass and second pass become schedulable
+    items.  -> new descriptor list (the same objects where nothing changed).  The re-cut product sums its k-slices in another order
+    than the one-pass kernel: it is only applied where slack >= RESPLIT_MIN_SLACK levels says the consumer, if any, is far away."""
+    from . import plan as P
+    nodes = expand_for_worklists(descs)
+    nl = assign_levels(nodes)
+    n = len(nodes)
+    alap = [nl - 1] * n
+    for i in range(n - 1, -1, -1):
+        for j in range(i + 1, n):
+            if alap[j] - 1 < alap[i] and _depends(nodes[j], nodes[i]):
+                alap[i] = alap[j] - 1
+    out, changed = list(descs), False
+    for i, nd in enumerate(nodes):
+        d = nd.desc
+        if nd.part != "whole" or not isinstance(d, L.GemmDesc) or d.splitk > 1 or alap[i] - nd.level < RESPLIT_MIN_SLACK:
+            continue
+        if P.gemm_kernel_name(d) != "gemm_kslice_kernel":
+            continue
+        s0 = d.seg[0]
+        kt = sum((d.seg[q].K + 31) // 32 for q in range(d.nseg) if d.seg[q].A)
+        S = P._splitk_for(((s0.M + 63) // 64) * ((s0.N + 63) // 64), kt)
+        if S <= 1:
+            continue
+        d2 = L.GemmDesc.from_buffer_copy(d)
+        d2.splitk = S
+        ws = alloc(S * s0.M * s0.N)
+        d2.workspace = ws.data_ptr()
+        d2._wl_force, d2._keep = True, ws
+        out[next(k for k, x in enumerate(out) if x is d)] = d2
+        changed = True
+    return out if changed else descs
+
+
 def levels_of(descs):
     nodes = expand(descs)
     nl = assign_levels(nodes)
@@ -440,7 +483,7 @@ def gemm_capable(d) -> bool:
     if nprob == 1 and ((d.seg[0].M + 63) // 64) * ((d.seg[0].N + 63) // 64) * S >= SOLO_TILES:
         return False
     from . import plan as P
-    if P.kslice_eligible(d.amode, d.bmode, d.cmode, [dict(A=d.seg[q].A, Aaux=d.seg[q].Aaux, Baux=d.seg[q].Baux, ones_col=d.seg[q].ones_col,
+    if not getattr(d, "_wl_force", False) and P.kslice_eligible(d.amode, d.bmode, d.cmode, [dict(A=d.seg[q].A, Aaux=d.seg[q].Aaux, Baux=d.seg[q].Baux, ones_col=d.seg[q].ones_col,
                                                            Mvalid=d.seg[q].Mvalid, M=d.seg[q].M, N=d.seg[q].N, K=d.seg[q].K, lda=d.seg[q].lda,
                                                            ldb=d.seg[q].ldb) for q in range(d.nseg)], d.zmode):
         return False  # csrc/gemm_kslice.hip: a kernel of its own (1024-thread workgroups, 133 KB of LDS)
@@ -520,10 +563,12 @@ def expand_for_worklists(descs) -> List[Node]:
     return nodes
 
 
-def pack(descs):
+def pack(descs, alloc=None):
     """program -> scheduled program: per level, the operators the worklist kernel has bodies for share NASREC_OP_WORKLIST launches
     (as many as their descriptors need blobs), the others stay launches of their own.  Returns (new descriptor list, number of
     levels).  Every WorklistDesc carries `.nodes` (its items' Nodes) for reports."""
+    if BALANCE and RESPLIT and alloc is not None:
+        descs = resplit_slack_solos(descs, alloc)
     nodes = expand_for_worklists(descs)
     nl = assign_levels(nodes)
     if BALANCE:

@@ -85,7 +85,7 @@ class _SupernetFunction(torch.autograd.Function):
         with _tracing_paused():
             cp = eng.compile(choice, B, train=True)
             eng.run_forward(cp, int_x, cat_x, rows=rows)
-            out = cp.logits.view(B, 1).clone()
+        out = cp.logits.view(B, 1).clone()  # (outside the pause: a result the tracer has not seen cannot become the node's output)
         ctx.has_rows = rows is not None
         cp.generation = getattr(cp, "generation", 0) + 1
         ctx.model, ctx.cp, ctx.cat_x, ctx.generation = model, cp, cat_x, cp.generation
