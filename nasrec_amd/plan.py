@@ -406,7 +406,7 @@ def kslice_eligible(amode, bmode, cmode, segs, zmode):
     return M <= 512 and 128 <= tiles <= 512 and K >= 512
 
 
-BALANCED_MIN_SAVING_US = 80.0
+BALANCED_MIN_SAVING_US = float(_os.environ.get("NASREC_BALANCED_MIN_US", "80.0"))  # (env: A/B knob)
 
 
 def _balanced_schedule_pays(segs, zmode):

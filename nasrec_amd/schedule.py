@@ -399,7 +399,10 @@ def balance_levels(nodes: List[Node], nl: int) -> None:
             break
 
 
-RESPLIT = os.environ.get("NASREC_WL_RESPLIT", "1") != "0"
+# measured (tools/r04_ab.sh resplit, cfg 2, three runs each): 0.3013 / 0.3021 / 0.3026 ms with the re-cut against 0.3021 / 0.3025 / 0.3014
+# without — the worklist's 32x32 tile runs the 0.6 GFLOP product at ~30 TFLOP/s where the one-pass kernel reaches 46, which eats what
+# the overlap with a Transformer-backward level gains.  Off by default; NASREC_WL_RESPLIT=1 turns it on.
+RESPLIT = os.environ.get("NASREC_WL_RESPLIT", "0") == "1"
 RESPLIT_MIN_SLACK = 3
 
 

@@ -274,7 +274,8 @@ def test_data_parallel_code_path_single_rank():
                         sent[off:off + n] += 1
                         for nm in names:
                             if eng.offsets[nm] < off + n and off < eng.offsets[nm] + eng.params[nm].numel():
-                                assert nm in plan.ready and plan.ready[nm] < end, (nm, end)
+                                # (a range may run over gradients NO launch writes — zero on every rank — never over one that is still to come)
+                                assert nm not in plan.ready or plan.ready[nm] < end, (nm, end)
                 assert int(sent.max()) == 1
                 for nm, idx in plan.ready.items():
                     o = eng.offsets[nm]
