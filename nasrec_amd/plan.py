@@ -171,6 +171,7 @@ class Ctx:
         self.deferred: List = []  # weight-gradient products parked until the end of the backward program
         self.bwd_tail_start = 0
         self.mha_reduce: List = []  # (MHA backward descriptor, [(grad ptr, column offset, length)]) awaiting the shared reduction
+        self.ln_reduce: List = []  # LayerNorm parameter-gradient reductions of a large-batch plan awaiting their shared launch
         self.defer_dw = True
         self.arena = None  # optional Arena (engine.py): where alloc() takes its buffers from
         self.raw_sparse = None  # Buf of the embedding stem's output [B, Fs, 16] (set by the engine): see _flush_raw_dx
@@ -243,6 +244,7 @@ class Ctx:
             fn()
         _flush_raw_dx(self)
         _flush_mha_reduce(self)
+        _flush_ln_reduce(self)
         self.bwd_tail_start = len(self.bwd)  # from here on: only the parked weight-gradient products
         _flush_deferred(self)
         self.out = self.fwd
@@ -658,6 +660,37 @@ def _flush_mha_reduce(ctx):
         ctx.emit(r)
 
 
+_LN_REDUCE_BATCH = _os.environ.get("NASREC_LN_REDUCE_BATCH", "1") != "0"
+
+
+def _flush_ln_reduce(ctx):
+    """the parked LayerNorm parameter-gradient reductions (fixed-order column sums of per-workgroup partials) as items of
+    NASREC_OP_WORKLIST launches, twelve per launch: same body, same order of additions, one launch boundary instead of twelve"""
+    jobs, ctx.ln_reduce = ctx.ln_reduce, []
+    if not jobs:
+        return
+    from . import schedule as S
+    for i0 in range(0, len(jobs), L.WL_MAX_ITEMS):
+        grp = jobs[i0:i0 + L.WL_MAX_ITEMS]
+        if len(grp) == 1:
+            ctx.emit(grp[0])
+            continue
+        w = L.WorklistDesc()
+        w.kind, w.n = L.OP_WORKLIST, len(grp)
+        w.nodes = []
+        off = 0
+        for k, r in enumerate(grp):
+            node = S.Node(r)
+            b = S.item_bytes(node)
+            assert b is not None and off + len(b) <= L.WL_BLOB_BYTES
+            it = w.item[k]
+            it.kind, it.part, it.off = r.kind, L.WL_WHOLE, off
+            C.memmove(C.addressof(w) + L.WorklistDesc.blob.offset + off, b, len(b))
+            w.nodes.append(node)
+            off += (len(b) + 15) & ~15
+        ctx.emit(w)
+
+
 def _flush_deferred(ctx, todo=None):
     final = todo is None  # the flush at the end of the backward program (not an early flush of a few products)
     if todo is None:
@@ -772,7 +805,12 @@ def emit_layernorm(ctx, mode, x_ptr, ldx, R, D, wname, out_ptr, ldy, act, dims, 
         r.ndst = 2
         r.dst[0], r.dst_off[0], r.dst_len[0] = ctx.gparam(wname + ".weight"), 0, D
         r.dst[1], r.dst_off[1], r.dst_len[1] = ctx.gparam(wname + ".bias"), D, D
-        ctx.emit(r)
+        if ctx.B > 256 and _LN_REDUCE_BATCH:
+            # large batch: ~20 of these per step, 6 us each and a launch boundary each, with no consumer before the optimizer — they
+            # wait for the end of the block (data parallel) / of the backward and go out as items of ONE heterogeneous launch
+            ctx.ln_reduce.append(r)
+        else:
+            ctx.emit(r)
         x_grad_cb(dx)
 
     ctx.on_backward(bwd)
@@ -1533,6 +1571,7 @@ def network_walk(ctx, cfg: NetConfig, choice, int_x: DV, sparse0: SV):
             # (with weight-gradient products in backward order, i.e. defer_dw off — the data-parallel bucket boundaries)
             if not ctx.defer_dw:
                 _flush_mha_reduce(ctx)
+                _flush_ln_reduce(ctx)
             ctx.block_marks.append((i, len(ctx.bwd)))
         ctx.on_backward(mark)
         mac = choice["macro"][i]
