@@ -33,6 +33,7 @@
 //     the pieces of each split tile in ascending k order (fixed association: results do not depend on timing) and applies the
 //     epilogue.  No inter-workgroup signalling.
 // fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain (no reduced-precision path exists on gfx950).
+#include <stdlib.h>
 #include "gemm_tile.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -636,7 +637,8 @@ bool gemm_fast_eligible(const nasrec_gemm_desc_t* d, int Mmax, int Nmax) {
   (void)Nmax;
   // skinny problems (a [1024, 13] weight gradient fills a tenth of its 128 x 128 tiles) belong to the small-tile kernel
   if (2 * useful < padded) return false;
-  return tiles >= NASREC_GEMM_FAST_MIN_TILES && kmax >= 64;
+  static const long min_k = getenv("NASREC_FAST_MIN_K") ? atol(getenv("NASREC_FAST_MIN_K")) : 64;  // A/B knob (plan.py mirrors it)
+  return tiles >= NASREC_GEMM_FAST_MIN_TILES && kmax >= min_k;
 }
 
 int launch_gemm_fast(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, int Nmax, int zdim) {

@@ -344,6 +344,8 @@ def _splitk_for(tiles_mn, ktiles, nprob=1):
 
 
 GEMM_FAST_MIN_TILES = 120  # csrc/gemm_tile.h NASREC_GEMM_FAST_MIN_TILES
+_FAST_MIN_K = int(_os.environ.get("NASREC_FAST_MIN_K", "64"))    # A/B knobs (csrc/gemm_fast.hip reads the first one too)
+_FAST_MIN_KT = int(_os.environ.get("NASREC_FAST_MIN_KT", "4"))   # k-tiles of 32 per split of the throughput kernel (8 -> 4, round 4: a 4096x128x1024 product ran on 128 of 256 CUs; cfg 3 5.957 -> 5.930 ms, A/B)
 
 
 def _fast_gemm_splitk(amode, bmode, cmode, segs, zmode):
@@ -372,7 +374,7 @@ def _fast_gemm_splitk(amode, bmode, cmode, segs, zmode):
         kt_sum += kt
         if kt > kt_max:
             kt_max = kt
-    if not any_live or kmax < 64:
+    if not any_live or kmax < _FAST_MIN_K:
         return None
     tiles = area = 0
     for sd in (segs if zmode else segs[:1]):
@@ -383,7 +385,7 @@ def _fast_gemm_splitk(amode, bmode, cmode, segs, zmode):
     kt = kt_max if zmode else kt_sum
     S = 1
     if tiles < 256:
-        S = max(1, min(-(-256 // tiles), kt // 8, 32))
+        S = max(1, min(-(-256 // tiles), kt // _FAST_MIN_KT, 32))
     return S if tiles * S >= GEMM_FAST_MIN_TILES else None
 
 
@@ -450,7 +452,7 @@ def gemm_kernel_name(d) -> str:
         return "token_linear_kernel"  # (csrc/token_linear.hip `token_linear_eligible` has the complete rule)
     if d.cmode != L.CM_PLAIN or (d.amode, d.bmode) not in ((L.AM_KC, L.AM_KC), (L.AM_KC, L.AM_RC), (L.AM_RC, L.AM_RC)) or not live:
         return "gemm_kernel"
-    if any(sd["Aaux"] or sd["Baux"] for sd in segs) or max(sd["K"] for sd in live) < 64:
+    if any(sd["Aaux"] or sd["Baux"] for sd in segs) or max(sd["K"] for sd in live) < _FAST_MIN_K:
         return "gemm_kernel"
     probs = segs if d.zmode else segs[:1]
     tiles = sum(((sd["M"] + 127) // 128) * ((sd["N"] + 127) // 128) for sd in probs)
