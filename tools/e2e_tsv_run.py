@@ -10,6 +10,7 @@ import numpy as np
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=1000000)
 ap.add_argument("--shards", type=int, default=4)
+ap.add_argument("--prof", action="store_true", help="cProfile the epoch call: where the host's per-step time goes")
 a = ap.parse_args()
 tmp = tempfile.mkdtemp(prefix="nasrec_tsv_")
 rng = np.random.default_rng(0)
@@ -43,7 +44,15 @@ def timed(*a_, **k_):
     import torch as _t
     _t.cuda.synchronize()
     t = time.time()
-    r = _orig(*a_, **k_)
+    if a.prof:
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        r = _orig(*a_, **k_)
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    else:
+        r = _orig(*a_, **k_)
     _t.cuda.synchronize()
     epoch_s.append(time.time() - t)
     return r
