@@ -248,6 +248,7 @@ class SuperNet(nn.Module):
     def configure_path_sampling_strategy(self, strategy):
         assert strategy in ["full-path", "single-path", "any-path", "fixed-path", "evo-2shot-path", "default"], \
             "Strategy {} is not found!".format(strategy)
+        self.__dict__.pop("_fixed_resolved", None)
         self._path_sampling_strategy = strategy
         self._macro_path_sampling_strategy = path_sampling_strategy_lib[strategy]["macro"]
         for block in self._blocks:
@@ -337,6 +338,7 @@ class SuperNet(nn.Module):
 
     def configure_choice(self, choice: Any):
         """supernet.py:842-848"""
+        self.__dict__.pop("_fixed_resolved", None)
         self.choice = copy.deepcopy(choice)
         self.macro_last_choice = copy.deepcopy(choice["macro"])
         for idx in range(self._num_blocks):
@@ -492,6 +494,15 @@ class SuperNet(nn.Module):
     # ------------------------------------------------------------------------------------------------ forward
     def _resolve_choice(self, choices):
         """choice bookkeeping of supernet.py:513-529,585 / 605-618,650 without running anything"""
+        d = self.__dict__
+        if self._fixed and choices is None:
+            # a fixed sub-network resolves to the same choice every time: after the first call the step hands back the SAME object
+            # (the engine recognises it by identity and skips the plan-cache key), without walking the seven blocks and without
+            # nn.Module.__setattr__ (2 us per assignment) — the harness calls this once per 0.3 ms training step
+            hit = d.get("_fixed_resolved")
+            if hit is not None and hit[0] is self.macro_last_choice and self._macro_path_sampling_strategy == "fixed-path":
+                d["choice"] = hit[1]
+                return hit[1]
         if not self._fixed:
             self._supernet_train_steps_counter += 1
         self.choice = {"micro": [], "macro": []}
@@ -501,6 +512,8 @@ class SuperNet(nn.Module):
             # the reference hands the *whole* micro list to every block (supernet.py:574,583), which cannot work;
             # an explicit `choices` is honoured per block here
             self.choice["micro"].append(blk._resolve_choice(None if choices is None else choices["micro"][i]))
+        if self._fixed and choices is None and self._macro_path_sampling_strategy == "fixed-path" and self.macro_last_choice is macro:
+            d["_fixed_resolved"] = (macro, self.choice)
         return self.choice
 
     def forward(self, int_feats: torch.Tensor, cat_feats: torch.Tensor, choices=None):
@@ -548,9 +561,10 @@ class SuperNet(nn.Module):
         choice = self._resolve_choice(None)
         self._ensure_engine(int_feats)
         graph = self._fixed if graph is None else graph
-        self._engine_steps = getattr(self, "_engine_steps", 0) + 1
-        self._last_step_batch = int(int_feats.shape[0])
-        self._last_step_key = (choice, clip, eps, graph)
+        d = self.__dict__  # (plain bookkeeping: nn.Module.__setattr__ costs 2 us per assignment)
+        d["_engine_steps"] = d.get("_engine_steps", 0) + 1
+        d["_last_step_batch"] = int(int_feats.shape[0])
+        d["_last_step_key"] = (choice, clip, eps, graph)
         if self._table_sharding == "row":
             from ..sharded_tables import ShardedTableStep
             st = self.__dict__.get("_sharded_step")
