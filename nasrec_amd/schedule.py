@@ -332,6 +332,7 @@ def assign_levels(nodes: List[Node]) -> int:
 # two large products of the step's critical path.  Same bodies on the same operands: bit-identical results.
 # ----------------------------------------------------------------------------------------------------------------
 BALANCE = os.environ.get("NASREC_WL_BALANCE", "1") != "0"
+_PUSH = os.environ.get("NASREC_WL_PUSH", "1") != "0"  # (A/B knob: 0 = a node only moves inside the window its successors leave as they stand)
 _LATENCY_NS = 5000  # what a level costs however little it does (launch, descriptor + operand first touch on cold caches, drain)
 
 
@@ -352,8 +353,11 @@ def _level_ns(members):
 
 
 def balance_levels(nodes: List[Node], nl: int) -> None:
-    """in place: nodes with slack move to the level of their window [last predecessor + 1, first successor - 1] that makes the
-    estimated sum of level durations smallest (local search from the ASAP schedule; the number of levels never grows)"""
+    """in place: nodes with slack move to the level of their window that makes the estimated sum of level durations smallest (local
+    search from the ASAP schedule; the number of levels never grows).  A move to level lv PUSHES the node's successors that sit at
+    or before lv to the level behind their predecessor, recursively, as far as their own successors allow: a Transformer forward
+    (11 us) with one level of slack shares its ASAP level with a critical DotProduct core (6 us) — it can only leave if the
+    token-axis products reading its output step back a level too, which they can."""
     n = len(nodes)
     pred = [[] for _ in range(n)]
     succ = [[] for _ in range(n)]
@@ -362,38 +366,71 @@ def balance_levels(nodes: List[Node], nl: int) -> None:
             if _depends(nodes[i], nodes[j]):
                 pred[i].append(j)
                 succ[j].append(i)
-    movable = [i for i in range(n) if nodes[i].reads is not None and item_bytes(nodes[i]) is not None]
+    idx = {id(nd): i for i, nd in enumerate(nodes)}
+    movable = set(i for i in range(n) if nodes[i].reads is not None and item_bytes(nodes[i]) is not None)
     levels = [[] for _ in range(nl)]
     for i in movable:
         levels[nodes[i].level].append(nodes[i])
     order = sorted(movable, key=lambda i: -_cost(nodes[i]))
     size = {id(nodes[i]): (len(item_bytes(nodes[i])) + 15) & ~15 for i in movable}
 
-    def fits(lv, nd):  # one launch per level: at most WL_MAX_ITEMS items in WL_BLOB_BYTES of descriptors (a second launch would cost a boundary)
-        return len(levels[lv]) < L.WL_MAX_ITEMS and sum(size[id(m)] for m in levels[lv]) + size[id(nd)] <= L.WL_BLOB_BYTES
+    def plan_move(i, lv, moves):
+        """node i to level lv, successors pushed behind it: fills moves {node index: level}; False if some node cannot go"""
+        if lv > nl - 1 or (i not in movable and nodes[i].level != lv):
+            return False
+        moves[i] = lv
+        for j in succ[i]:
+            cur = moves.get(j, nodes[j].level)
+            if cur <= lv and (not _PUSH or not plan_move(j, lv + 1, moves)):
+                return False
+        return True
+
+    def delta(moves):
+        """change of the estimated total if `moves` are applied, or None if a launch would overflow"""
+        touched = {}
+        for i, lv in moves.items():
+            nd = nodes[i]
+            if lv == nd.level:
+                continue
+            touched.setdefault(nd.level, [list(levels[nd.level]), None])
+            touched.setdefault(lv, [list(levels[lv]), None])
+        if not touched:
+            return None
+        for i, lv in moves.items():
+            nd = nodes[i]
+            if lv == nd.level:
+                continue
+            touched[nd.level][0] = [m for m in touched[nd.level][0] if m is not nd]
+            touched[lv][0].append(nd)
+        d = 0
+        for lv, (mem, _) in touched.items():
+            if len(mem) > L.WL_MAX_ITEMS or sum(size[id(m)] for m in mem) > L.WL_BLOB_BYTES:
+                return None  # one launch per level: a second one would cost a boundary
+            d += _level_ns(mem) - _level_ns(levels[lv])
+        return d
 
     for _ in range(4):
         moved = False
         for i in order:
             nd = nodes[i]
             lo = max([nodes[j].level + 1 for j in pred[i]] + [0])
-            hi = min([nodes[j].level - 1 for j in succ[i]] + [nl - 1])
-            if hi <= lo and nd.level == lo:
-                continue
-            cur = nd.level
-            without = [m for m in levels[cur] if m is not nd]
-            base = _level_ns(levels[cur]) - _level_ns(without)  # what the node costs where it is
-            best, best_lv = base, cur
-            for lv in range(lo, hi + 1):
-                if lv == cur or not fits(lv, nd):
+            best, best_moves = -200, None  # (only moves worth more than the model's noise)
+            for lv in range(lo, nl):
+                if lv == nd.level:
                     continue
-                add = _level_ns(levels[lv] + [nd]) - _level_ns(levels[lv])
-                if add < best - 200:  # (only moves worth more than the model's noise)
-                    best, best_lv = add, lv
-            if best_lv != cur:
-                levels[cur] = without
-                levels[best_lv].append(nd)
-                nd.level = best_lv
+                moves = {}
+                if not plan_move(i, lv, moves):
+                    break  # (later levels push even further)
+                d = delta(moves)
+                if d is not None and d < best:
+                    best, best_moves = d, moves
+            if best_moves:
+                for k, lv in best_moves.items():
+                    m = nodes[k]
+                    if lv != m.level:
+                        levels[m.level] = [x for x in levels[m.level] if x is not m]
+                        levels[lv].append(m)
+                        m.level = lv
                 moved = True
         if not moved:
             break
