@@ -51,6 +51,25 @@ static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, i
     it.nblk = per * nprob;
     return 0;
   }
+  // small dense Linear forward (x W^T, binding KC / KC / plain), unsplit, no mask operands / row predicates / ones column, at most
+  // WL_DENSE_STEPS 16-deep k-steps over all segments (a dead segment costs a step): a wavefront per 16 x 16 output tile (wl_dense_small)
+  static const bool dense_body = getenv("NASREC_WL_DENSE_BODY") == nullptr || atoi(getenv("NASREC_WL_DENSE_BODY")) != 0;  // A/B knob
+  if (dense_body && it.part == 0 && !g->zmode && !aux && g->amode == NASREC_AM_KC && g->bmode == NASREC_AM_KC && g->cmode == NASREC_CM_PLAIN) {
+    bool plain = true;
+    int steps = 0;
+    for (int q = 0; q < g->nseg; ++q) {
+      const nasrec_gemm_seg_t& s = g->seg[q];
+      plain = plain && !s.ones_col && !(s.Mvalid > 0 && s.Mvalid < Mmax);
+      steps += (s.A && s.K > 0) ? (s.K + 15) >> 4 : 1;
+    }
+    if (plain && steps <= WL_DENSE_STEPS) {
+      it.geom[0] = (Nmax + 15) / 16;
+      it.geom[1] = (Mmax + 15) / 16;
+      it.geom[2] = WL_TOKS | (3 << 2);
+      it.nblk = (it.geom[0] * it.geom[1] + 3) / 4;
+      return 0;
+    }
+  }
   // token-axis Linear forward (W x, binding KC / TOKR / TOKJ), unsplit, no mask operands / row predicates: a wavefront per (sample,
   // 16 rows of W), operands straight from memory into MFMA registers (wl_token_fwd)
   static const bool tok_body = getenv("NASREC_WL_TOKEN_BODY") == nullptr || atoi(getenv("NASREC_WL_TOKEN_BODY")) != 0;  // A/B knob

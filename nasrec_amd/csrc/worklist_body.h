@@ -159,6 +159,77 @@ __device__ __forceinline__ void wl_token_fwd(unsigned long long blob, int vb_, i
   }
 }
 
+// Small dense Linear forward, the same scheme once more: y[i][n] = sum_k x[i][k] W[n][k] over up to eight 16-deep k-steps in all
+// (binding KC / KC / plain: the 13-, 16-, 32- and 36-wide products of the dense nodes, the 16-wide FM projections; modules.py:171,340,
+// 385,489,515,740).  On the general tile they are the slowest members of several forward levels (6 - 8.4 us as items): 64 x 16 strips
+// staged through LDS behind a barrier, the bias read behind the MFMAs — three dependent trips to a cold L2.  Here a wavefront owns one
+// 16 x 16 output tile: lane (r, g) loads x[16 mt + r][16 s + 4 g .. + 3] and W[16 nt + r][16 s + 4 g .. + 3] for EVERY step up front
+// (one 16-byte load each; a null resource past the last segment), the bias line is touched at the same time, then the MFMAs run
+// (MFMA j of step s sums k = 16 s + 4 g + j: the general tile's grouping, steps and segments in order — bit-identical to it).
+#define WL_DENSE_STEPS 8
+__device__ __forceinline__ void wl_dense_small(unsigned long long blob, int vb_, int NT_, int MT_) {
+  const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
+  const int vb = __builtin_amdgcn_readfirstlane(vb_), NT = __builtin_amdgcn_readfirstlane(NT_), MT = __builtin_amdgcn_readfirstlane(MT_);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int e = lane & 15, fg = lane >> 4;
+  wl_warm_blob(blob, (int)offsetof(nasrec_gemm_desc_t, seg) + g.nseg * (int)sizeof(nasrec_gemm_seg_t));
+  const nasrec_gemm_seg_t& s0 = g.seg[0];
+  const int M = s0.M, N = s0.N;
+  const int unit = vb * 4 + wave;  // (row tile, column tile)
+  if (unit >= MT * NT) return;
+  const int mt = unit / NT, nt = unit - mt * NT;
+  const int row = min(mt * 16 + e, M - 1), col = min(nt * 16 + e, N - 1);  // (lane & 15: row of the A fragment, column of the B fragment)
+  f32x4 fa[WL_DENSE_STEPS], fb[WL_DENSE_STEPS];
+  int lim[WL_DENSE_STEPS];
+  int fq = 0, fk = 0;
+#pragma unroll
+  for (int slot = 0; slot < WL_DENSE_STEPS; ++slot) {  // unconditional loads (see wl_token_fwd): the compiler can count them
+    const bool in = fq < g.nseg;
+    const nasrec_gemm_seg_t& sg = g.seg[in ? fq : 0];
+    const bool live = in && sg.A != nullptr && sg.K > 0;
+    const int K = live ? sg.K : 0, kk = fk + 4 * fg;
+    lim[slot] = K - fk;
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.A), 0, live ? (int)(4 * ((long)(M - 1) * sg.lda + K)) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.B), 0, live ? (int)(4 * ((long)(N - 1) * sg.ldb + K)) : 0, 0x00020000);
+    fa[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, 4 * (row * sg.lda + kk), 0, 0));
+    fb[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, 4 * (col * sg.ldb + kk), 0, 0));
+    fk += 16;
+    const bool next = fk >= K;
+    fq = next ? fq + 1 : fq;
+    fk = next ? 0 : fk;
+  }
+  if (g.bias) {  // pull the bias line in beside the operands (the epilogue reads it behind the MFMAs otherwise: one more cold trip)
+    const float warm = g.bias[g.bias_on_rows ? row : col];
+    asm volatile("" ::"v"(warm));
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int slot = 0; slot < WL_DENSE_STEPS; ++slot) {
+    const int l = lim[slot];
+    if (l > 0) {  // (uniform)
+      f32x4 a = fa[slot], b = fb[slot];
+      if (l < 16) {  // last step of a segment: the 16-byte loads may run into the row's next columns
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool in = 4 * fg + j < l;
+          a[j] = in ? a[j] : 0.f;
+          b[j] = in ? b[j] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+    }
+  }
+  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = mt * 16 + 4 * fg + r, j = nt * 16 + e;
+    if (i < M && j < N) epilogue_store<NASREC_CM_PLAIN>(g, s0, i, j, acc[r]);
+  }
+}
+
 // Token-axis Linear input gradient, the same scheme: dx_q[b][r][e] = sum_i W[i][koff_q + r] dy[b][i][e] for every input segment q of
 // the Linear (binding RC / TOKR / TOKJ, one independent problem per segment: zmode).  A wavefront per (sample, segment, 16 token
 // rows); lane (r, g) of MFMA j of step s needs W[16 s + 4 g + j][r] (four dwords, a row of W apart), lane (e, g) needs
@@ -287,7 +358,8 @@ __global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(unsigned f01
         break;
       }
       const int cfg = it.geom[2];  // tile | binding pair << 2 | mask operand << 4
-      if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 1) wl_token_fwd(blob, vb, it.geom[0]);
+      if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 3) wl_dense_small(blob, vb, it.geom[0], it.geom[1]);
+      else if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 1) wl_token_fwd(blob, vb, it.geom[0]);
       else if ((cfg & 3) == WL_TOKS) wl_token_dx(blob, vb, it.geom[0]);
       else if ((cfg >> 4) & 1) wl_gemm_bind<true>((cfg >> 2) & 3, cfg & 3, blob, vb, it.geom[0], it.geom[1]);
       else wl_gemm_bind<false>((cfg >> 2) & 3, cfg & 3, blob, vb, it.geom[0], it.geom[1]);

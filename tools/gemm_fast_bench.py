@@ -26,6 +26,9 @@ st = torch.cuda.current_stream(dev).cuda_stream
 class _Ctx:
     def __init__(self):
         self.keep = []
+        self.B = 4096            # (plan.gemm_descs reads the batch regime and the shared split-K workspace from its context)
+        self.sk_workspace = None
+        self.shape_only = False
 
     def alloc(self, n):
         t = torch.empty(int(n), dtype=torch.float32, device=dev)
