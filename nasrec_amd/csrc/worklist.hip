@@ -70,6 +70,24 @@ static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, i
       return 0;
     }
   }
+  // small dense input gradients (dy W per problem, binding KC / RC / plain, zmode), unsplit, no mask operands, K <= 16 WL_DENSE_STEPS:
+  // a wavefront per 16 x 16 tile of one problem (wl_dense_small_dx; geom[1] = 0 tells the two bodies apart)
+  if (dense_body && it.part == 0 && g->zmode && !aux && g->amode == NASREC_AM_KC && g->bmode == NASREC_AM_RC && g->cmode == NASREC_CM_PLAIN) {
+    bool plain = true;
+    int TU = 0;
+    for (int q = 0; q < g->nseg; ++q) {
+      const nasrec_gemm_seg_t& s = g->seg[q];
+      plain = plain && !s.ones_col && !(s.Mvalid > 0 && s.Mvalid < s.M) && s.K <= 16 * WL_DENSE_STEPS && s.M > 0 && s.N > 0;
+      TU += ((s.M + 15) / 16) * ((s.N + 15) / 16);
+    }
+    if (plain && TU > 0) {
+      it.geom[0] = TU;
+      it.geom[1] = 0;
+      it.geom[2] = WL_TOKS | (3 << 2);
+      it.nblk = (TU + 3) / 4;
+      return 0;
+    }
+  }
   // token-axis Linear forward (W x, binding KC / TOKR / TOKJ), unsplit, no mask operands / row predicates: a wavefront per (sample,
   // 16 rows of W), operands straight from memory into MFMA registers (wl_token_fwd)
   static const bool tok_body = getenv("NASREC_WL_TOKEN_BODY") == nullptr || atoi(getenv("NASREC_WL_TOKEN_BODY")) != 0;  // A/B knob

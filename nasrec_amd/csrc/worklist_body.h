@@ -230,6 +230,60 @@ __device__ __forceinline__ void wl_dense_small(unsigned long long blob, int vb_,
   }
 }
 
+// ... and the small dense input gradients: dx_q[i][n] = sum_k dy_q[i][k] W_q[k][n] for every problem q of a zmode launch (binding KC / RC /
+// plain; K = the Linear's output width <= 128).  A wavefront per 16 x 16 tile of one problem; lane (r, g) loads dy[16 mt + r][16 s + 4 g
+// .. + 3] (one 16-byte load) and W[16 s + 4 g + j][16 nt + r], j = 0..3 (four dwords, a row of W apart), everything up front.
+__device__ __forceinline__ void wl_dense_small_dx(unsigned long long blob, int vb_, int TU_) {
+  const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
+  const int vb = __builtin_amdgcn_readfirstlane(vb_), TU = __builtin_amdgcn_readfirstlane(TU_);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int e = lane & 15, fg = lane >> 4;
+  wl_warm_blob(blob, (int)offsetof(nasrec_gemm_desc_t, seg) + g.nseg * (int)sizeof(nasrec_gemm_seg_t));
+  int t = vb * 4 + wave, q = 0;
+  if (t >= TU) return;
+  while (q < g.nseg - 1 && t >= ((g.seg[q].M + 15) >> 4) * ((g.seg[q].N + 15) >> 4)) t -= ((g.seg[q].M + 15) >> 4) * ((g.seg[q].N + 15) >> 4), ++q;
+  const nasrec_gemm_seg_t& sg = g.seg[q];
+  const int M = sg.M, N = sg.N, K = sg.K, NT = (N + 15) >> 4;
+  const int mt = t / NT, nt = t - mt * NT;
+  if (!sg.A || K <= 0) {  // a dead problem still owns its output: zero unless it accumulates (what the general tile does)
+    if (!sg.accumulate) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = mt * 16 + 4 * fg + r, j = nt * 16 + e;
+        if (i < M && j < N) epilogue_store<NASREC_CM_PLAIN>(g, sg, i, j, 0.f);
+      }
+    }
+    return;
+  }
+  const int row = min(mt * 16 + e, M - 1), col = min(nt * 16 + e, N - 1);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.A), 0, (int)(4 * ((long)(M - 1) * sg.lda + K)), 0x00020000);
+  const float* wp = sg.B + col;  // B(n, k) = B[k ldb + n]
+  f32x4 fa[WL_DENSE_STEPS];
+  float fb[WL_DENSE_STEPS][4];
+#pragma unroll
+  for (int s = 0; s < WL_DENSE_STEPS; ++s) {
+    fa[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, 4 * (row * sg.lda + 16 * s + 4 * fg), 0, 0));  // (past the extent: zeros)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[s][j] = wp[(long)min(16 * s + 4 * fg + j, K - 1) * sg.ldb];  // (clamped, masked below)
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < WL_DENSE_STEPS; ++s) {
+    if (16 * s < K) {  // (uniform)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = 16 * s + 4 * fg + j < K;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(in ? fa[s][j] : 0.f, in ? fb[s][j] : 0.f, acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = mt * 16 + 4 * fg + r, j = nt * 16 + e;
+    if (i < M && j < N) epilogue_store<NASREC_CM_PLAIN>(g, sg, i, j, acc[r]);
+  }
+}
+
 // Token-axis Linear input gradient, the same scheme: dx_q[b][r][e] = sum_i W[i][koff_q + r] dy[b][i][e] for every input segment q of
 // the Linear (binding RC / TOKR / TOKJ, one independent problem per segment: zmode).  A wavefront per (sample, segment, 16 token
 // rows); lane (r, g) of MFMA j of step s needs W[16 s + 4 g + j][r] (four dwords, a row of W apart), lane (e, g) needs
@@ -358,7 +412,8 @@ __global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(unsigned f01
         break;
       }
       const int cfg = it.geom[2];  // tile | binding pair << 2 | mask operand << 4
-      if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 3) wl_dense_small(blob, vb, it.geom[0], it.geom[1]);
+      if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 3 && it.geom[1] == 0) wl_dense_small_dx(blob, vb, it.geom[0]);
+      else if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 3) wl_dense_small(blob, vb, it.geom[0], it.geom[1]);
       else if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 1) wl_token_fwd(blob, vb, it.geom[0]);
       else if ((cfg & 3) == WL_TOKS) wl_token_dx(blob, vb, it.geom[0]);
       else if ((cfg >> 4) & 1) wl_gemm_bind<true>((cfg >> 2) & 3, cfg & 3, blob, vb, it.geom[0], it.geom[1]);

@@ -336,10 +336,17 @@ _PUSH = os.environ.get("NASREC_WL_PUSH", "1") != "0"  # (A/B knob: 0 = a node on
 _LATENCY_NS = 5000  # what a level costs however little it does (launch, descriptor + operand first touch on cold caches, drain)
 
 
+_BAL_R4 = os.environ.get("NASREC_WL_BAL_COST", "r4") == "r4"  # (A/B knob)
+
+
+def _BAL_COST(node):
+    return _cost_r4(node) if _BAL_R4 else _cost(node)
+
+
 def _work_ns(node):
     """the part of an item's stand-alone duration that occupies the chip (adds up when items share a level), as opposed to latency
     (which overlaps): a product's M*N*K term; a quarter of the sample-per-workgroup bodies (one wavefront per SIMD)"""
-    c = _cost(node)
+    c = _BAL_COST(node)
     if isinstance(node.desc, L.GemmDesc):
         return max(c - _LATENCY_NS, 0) if node.part != "epi" else 400
     return c // 4
@@ -349,7 +356,7 @@ def _level_ns(members):
     """estimated duration of a level's worklist launch"""
     if not members:
         return 0
-    return max(max(_cost(n) for n in members), _LATENCY_NS + sum(_work_ns(n) for n in members))
+    return max(max(_BAL_COST(n) for n in members), _LATENCY_NS + sum(_work_ns(n) for n in members))
 
 
 def balance_levels(nodes: List[Node], nl: int) -> None:
@@ -371,7 +378,7 @@ def balance_levels(nodes: List[Node], nl: int) -> None:
     levels = [[] for _ in range(nl)]
     for i in movable:
         levels[nodes[i].level].append(nodes[i])
-    order = sorted(movable, key=lambda i: -_cost(nodes[i]))
+    order = sorted(movable, key=lambda i: -_BAL_COST(nodes[i]))
     size = {id(nodes[i]): (len(item_bytes(nodes[i])) + 15) & ~15 for i in movable}
 
     def plan_move(i, lv, moves):
@@ -569,6 +576,9 @@ _PART = {"whole": L.WL_WHOLE, "main": L.WL_MAIN, "epi": L.WL_EPI}
 # stand-alone times of the non-GEMM items of the batch-256 step, ns (tools/step_table.py ITEMS=11)
 _ITEM_NS = {L.OP_MHA_BWD: 18000, L.OP_MHA_FWD: 11000, L.OP_DOT_TRI_BWD: 10000, L.OP_DOT_TRI_FWD: 6000, L.OP_REDUCE_ROWS: 4500,
             L.OP_FM_BWD: 3900, L.OP_FM_FWD: 3500}
+# round 4 (ITEMS=7 python tools/step_table.py on the balanced plan): the same items measured again, used by the balancing pass
+_ITEM_NS_R4 = {L.OP_MHA_BWD: 18500, L.OP_MHA_FWD: 10500, L.OP_REDUCE_ROWS: 6000, L.OP_FM_BWD: 7000, L.OP_FM_FWD: 3500, L.OP_FINAL_BWD: 7000,
+               L.OP_FINAL_FWD: 3400, L.OP_GATE_BWD: 3500}
 _COST_MODEL = os.environ.get("NASREC_WL_COST", "time")
 
 
@@ -587,6 +597,23 @@ def _cost(node):
             return 3600
         return 5000 + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A) // 20000
     return _ITEM_NS.get(d.kind, 3000)
+
+
+def _cost_r4(node):
+    """the balancing pass's duration model (the item ORDER inside a launch keeps `_cost`: its A/B stands): products pay ~0.9 us per
+    extra k-segment (a token-axis Linear over four segments 8.7 us, over one 5.7), the DotProduct cores scale with k1^2"""
+    d = node.desc
+    if isinstance(d, L.GemmDesc):
+        if node.part == "epi":
+            return 4000
+        live = [q for q in range(d.nseg) if d.seg[q].A]
+        extra = 0 if d.zmode else 900 * max(len(live) - 1, 0)
+        return 5200 + extra + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in live) // 20000
+    if d.kind == L.OP_DOT_TRI_BWD:
+        return 3500 + int(2.3 * d.k1 * d.k1)
+    if d.kind == L.OP_DOT_TRI_FWD:
+        return 3000 + int(0.2 * d.k1 * d.k1)
+    return _ITEM_NS_R4.get(d.kind, 3000)
 
 
 def expand_for_worklists(descs) -> List[Node]:
