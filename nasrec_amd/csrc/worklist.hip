@@ -62,11 +62,11 @@ static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, i
       plain = plain && !s.ones_col && !(s.Mvalid > 0 && s.Mvalid < Mmax);
       steps += (s.A && s.K > 0) ? (s.K + 15) >> 4 : 1;
     }
-    if (plain && steps <= WL_DENSE_STEPS) {
+    if (plain && steps <= 2 * WL_DENSE_STEPS && (Mmax + 15) / 16 < 0x10000) {
       it.geom[0] = (Nmax + 15) / 16;
-      it.geom[1] = (Mmax + 15) / 16;
+      it.geom[1] = (Mmax + 15) / 16 | (((steps + WL_DENSE_STEPS - 1) / WL_DENSE_STEPS) << 16);  // (never 0: geom[1] == 0 is the dx body)
       it.geom[2] = WL_TOKS | (3 << 2);
-      it.nblk = (it.geom[0] * it.geom[1] + 3) / 4;
+      it.nblk = (it.geom[0] * ((Mmax + 15) / 16) + 3) / 4;
       return 0;
     }
   }

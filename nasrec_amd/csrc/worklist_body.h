@@ -167,9 +167,10 @@ __device__ __forceinline__ void wl_token_fwd(unsigned long long blob, int vb_, i
 // (one 16-byte load each; a null resource past the last segment), the bias line is touched at the same time, then the MFMAs run
 // (MFMA j of step s sums k = 16 s + 4 g + j: the general tile's grouping, steps and segments in order — bit-identical to it).
 #define WL_DENSE_STEPS 8
-__device__ __forceinline__ void wl_dense_small(unsigned long long blob, int vb_, int NT_, int MT_) {
+__device__ __forceinline__ void wl_dense_small(unsigned long long blob, int vb_, int NT_, int MTNB_) {
   const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
-  const int vb = __builtin_amdgcn_readfirstlane(vb_), NT = __builtin_amdgcn_readfirstlane(NT_), MT = __builtin_amdgcn_readfirstlane(MT_);
+  const int vb = __builtin_amdgcn_readfirstlane(vb_), NT = __builtin_amdgcn_readfirstlane(NT_);
+  const int MT = __builtin_amdgcn_readfirstlane(MTNB_) & 0xffff, NB = __builtin_amdgcn_readfirstlane(MTNB_) >> 16;  // row tiles | batches of eight steps << 16
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int e = lane & 15, fg = lane >> 4;
   wl_warm_blob(blob, (int)offsetof(nasrec_gemm_desc_t, seg) + g.nseg * (int)sizeof(nasrec_gemm_seg_t));
@@ -182,6 +183,8 @@ __device__ __forceinline__ void wl_dense_small(unsigned long long blob, int vb_,
   f32x4 fa[WL_DENSE_STEPS], fb[WL_DENSE_STEPS];
   int lim[WL_DENSE_STEPS];
   int fq = 0, fk = 0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int batch = 0; batch < NB; ++batch) {  // (one batch of eight steps for K <= 128; the 160-wide products take a second trip)
 #pragma unroll
   for (int slot = 0; slot < WL_DENSE_STEPS; ++slot) {  // unconditional loads (see wl_token_fwd): the compiler can count them
     const bool in = fq < g.nseg;
@@ -200,11 +203,10 @@ __device__ __forceinline__ void wl_dense_small(unsigned long long blob, int vb_,
     fq = next ? fq + 1 : fq;
     fk = next ? 0 : fk;
   }
-  if (g.bias) {  // pull the bias line in beside the operands (the epilogue reads it behind the MFMAs otherwise: one more cold trip)
+  if (batch == 0 && g.bias) {  // pull the bias line in beside the operands (the epilogue reads it behind the MFMAs otherwise: one more cold trip)
     const float warm = g.bias[g.bias_on_rows ? row : col];
     asm volatile("" ::"v"(warm));
   }
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int slot = 0; slot < WL_DENSE_STEPS; ++slot) {
     const int l = lim[slot];
@@ -221,6 +223,7 @@ __device__ __forceinline__ void wl_dense_small(unsigned long long blob, int vb_,
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
     }
+  }
   }
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
@@ -294,6 +297,7 @@ __device__ __forceinline__ void wl_token_dx(unsigned long long blob, int vb_, in
   const int vb = __builtin_amdgcn_readfirstlane(vb_), TU = __builtin_amdgcn_readfirstlane(TU_);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int e = lane & 15, fg = lane >> 4;
+  wl_warm_blob(blob, (int)offsetof(nasrec_gemm_desc_t, seg) + g.nseg * (int)sizeof(nasrec_gemm_seg_t));  // (the segment walk below reads every segment's fields)
   const int unit = vb * 4 + wave;
   const int b = unit / TU;
   int t = unit - b * TU, q = 0;

@@ -21,7 +21,7 @@ timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACT
 for c in 3 4 5; do timeout 300 python3 $R/tools/host_time_supernet.py $c >> $O/host_time_supernet.txt 2>> $O/log.txt < /dev/null; done
 timeout 300 python3 $R/tools/bench_supernet.py --strategy full-path --steps 10 --warmup 3 > $O/supernet_fullpath_step.txt 2>> $O/log.txt < /dev/null
 timeout 300 python3 $R/tools/parser_bench.py > $O/parser_bench.txt 2>> $O/log.txt < /dev/null
-timeout 600 python3 $R/tools/e2e_tsv_run.py --rows 1000000 > $O/e2e_tsv_run.txt 2>> $O/log.txt < /dev/null
+timeout 900 python3 $R/tools/e2e_tsv_run.py --rows 3000000 > $O/e2e_tsv_run.txt 2>> $O/log.txt < /dev/null
 timeout 300 python3 $R/tools/dedup_cost.py > $O/dedup_cost.txt 2>> $O/log.txt < /dev/null
 # round 4: the data-parallel exchange step on one rank (whole step captured as one graph), what its collectives cost, row-sharded tables
 python3 $R/bench.py --force-dp-path --no-cpu-baseline 2>> $O/log.txt < /dev/null | tail -1 > $O/bench_cfg2_dp_path_result.json
@@ -30,6 +30,9 @@ python3 $R/bench.py --force-dp-path --no-cpu-baseline --no-graph 2>> $O/log.txt 
 python3 $R/bench.py --table-sharding row --no-cpu-baseline 2>> $O/log.txt < /dev/null | tail -1 > $O/bench_cfg2_row_sharded_result.json
 (cd $R && bash tools/r04_ab.sh balance_final NASREC_WL_BALANCE=0 > /dev/null 2>&1; cp gpurun_out/ab/balance_final.txt $O/ab_level_balance.txt)
 CONFIG=3 TOP=60 timeout 300 python3 $R/tools/supernet_step_table.py > $O/supernet_step_table_cfg3.txt 2>> $O/log.txt < /dev/null
+# the throughput GEMM: per-k-tile cycle budget (needs `tools/build_variant.sh ftstamps -DFT_STAMPS` of the same sources) and the vendor library on five products
+[ -f $R/nasrec_amd/lib/variants/ftstamps.so ] && NASREC_HIP_LIB=$R/nasrec_amd/lib/variants/ftstamps.so timeout 300 python3 $R/tools/gemm_fast_stamps.py > $O/gemm_fast_stamps.txt 2>> $O/log.txt < /dev/null
+timeout 300 python3 $R/tools/gemm_vs_vendor.py > $O/gemm_vs_vendor.txt 2>> $O/log.txt < /dev/null
 # keep what travels back small: per-dispatch traces are summarised on the box
 python3 $R/tools/update_profiles_r04.py --summarise $O >> $O/log.txt 2>&1 < /dev/null
 find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete

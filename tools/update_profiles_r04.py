@@ -137,12 +137,13 @@ def install(O):
           ("parser_bench.txt", "r04_parser_bench.txt"), ("e2e_tsv_run.txt", "r04_e2e_tsv_run.txt"), ("dedup_cost.txt", "r04_dedup_cost_global_batch.txt"),
           ("bench_cfg2_dp_path_result.json", "r04_bench_cfg2_dp_path_result.json"), ("bench_cfg2_dp_path_eager_result.json", "r04_bench_cfg2_dp_path_eager_result.json"),
           ("dp_overhead.txt", "r04_dp_overhead.txt"), ("bench_cfg2_row_sharded_result.json", "r04_bench_cfg2_row_sharded_result.json"),
-          ("ab_level_balance.txt", "r04_ab_level_balance.txt"), ("supernet_step_table_cfg3.txt", "r04_supernet_step_table_cfg3.txt")]
+          ("ab_level_balance.txt", "r04_ab_level_balance.txt"), ("supernet_step_table_cfg3.txt", "r04_supernet_step_table_cfg3.txt"),
+          ("gemm_fast_stamps.txt", "r04_gemm_fast_stamps.txt"), ("gemm_vs_vendor.txt", "r04_gemm_vs_vendor.txt")]
     for a, b in cp:
         src = os.path.join(O, a)
         if os.path.exists(src) and os.path.getsize(src) > 0:
             txt = open(src, errors="replace").read()
-            txt = "\n".join(l for l in txt.splitlines() if "amdgpu.ids" not in l and not l.startswith(("ROCm version", "Hostname", "Librccl"))) + "\n"
+            txt = "\n".join(l for l in txt.splitlines() if "amdgpu.ids" not in l and not l.startswith(("ROCm version", "Hostname", "Librccl", "HIP version", "RCCL version"))) + "\n"
             open(os.path.join(P, b), "w").write(txt)
     for c in (2, 3):
         for a, b in (("bench_cfg%d_kernel_stats.csv" % c, "r04_bench_cfg%d_kernel_stats.csv" % c), ("bench_cfg%d_pmc_fetch.csv" % c, "r04_bench_cfg%d_pmc_fetch.csv" % c),
