@@ -64,7 +64,12 @@ __device__ __forceinline__ float bce_term(float z, float y) { return fmaxf(z, 0.
 // With d.y != NULL, dlogits[b] is derived on the fly from logits[b] and y[b] (BCEWithLogits fused into this launch).
 // workgroup vb of nA + nB (+ 1 with the fused loss); lds: 272 floats
 #define FINAL_BWD_LDS_FLOATS 272
-__device__ __forceinline__ void final_bwd_block(const nasrec_final_desc_t& d, int K, int nA, int nB, int vb, float* lds) {
+__device__ __forceinline__ void final_bwd_block(const nasrec_final_desc_t& d, int K, int nA, int nB, int vb_, float* lds) {
+  // dispatch order: the few long-running workgroups first (part C: one workgroup walks the batch; part B: 16 columns x the whole batch
+  // each), the many one-element workgroups of part A behind them — as the item's tail they made a level that holds this item last
+  // 3 us longer than the item itself (workgroups are dispatched in blockIdx order).  Same work per workgroup: same bits.
+  const int nC = d.y != nullptr ? 1 : 0;
+  const int vb = vb_ < nB + nC ? nA + vb_ : vb_ - (nB + nC);  // (below: [0, nA) = part A, [nA, nA + nB) = part B, nA + nB = part C)
   const bool fused = d.y != nullptr;
   auto dl = [&](int b) { return fused ? bce_grad(d.logits[b], d.y[b], d.grad_scale) : d.dlogits[b]; };
   if (vb < nA) {

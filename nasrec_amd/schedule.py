@@ -575,7 +575,7 @@ _PART = {"whole": L.WL_WHOLE, "main": L.WL_MAIN, "epi": L.WL_EPI}
 
 # stand-alone times of the non-GEMM items of the batch-256 step, ns (tools/step_table.py ITEMS=11)
 _ITEM_NS = {L.OP_MHA_BWD: 18000, L.OP_MHA_FWD: 11000, L.OP_DOT_TRI_BWD: 10000, L.OP_DOT_TRI_FWD: 6000, L.OP_REDUCE_ROWS: 4500,
-            L.OP_FM_BWD: 3900, L.OP_FM_FWD: 3500}
+            L.OP_FM_BWD: 3900, L.OP_FM_FWD: 3500, L.OP_FINAL_BWD: 7500}
 # round 4 (ITEMS=7 python tools/step_table.py on the balanced plan): the same items measured again, used by the balancing pass
 _ITEM_NS_R4 = {L.OP_MHA_BWD: 18500, L.OP_MHA_FWD: 10500, L.OP_REDUCE_ROWS: 6000, L.OP_FM_BWD: 7000, L.OP_FM_FWD: 3500, L.OP_FINAL_BWD: 7000,
                L.OP_FINAL_FWD: 3400, L.OP_GATE_BWD: 3500}

@@ -30,7 +30,9 @@ names = {getattr(L, n): n[3:] for n in dir(L) if n.startswith("OP_")}
 tot = 0.0
 rows = []
 with torch.cuda.stream(eng.stream):
-    for phase, prog in (("fwd", cp.fwd), ("bwd", cp.bwd), ("opt", cp.opt)):
+    # FB=1: the program the step really runs (forward and backward scheduled together, cp.fb) instead of the two separately packed ones
+    progs = (("fb", cp.fb), ("opt", cp.opt)) if (os.environ.get("FB") == "1" and getattr(cp, "fb", None) is not None) else (("fwd", cp.fwd), ("bwd", cp.bwd), ("opt", cp.opt))
+    for phase, prog in progs:
         for d in prog.descs:
             us = bench.time_desc(lib, L, sp, d, iters=100) * 1e3
             tot += us
