@@ -598,7 +598,7 @@ class SupernetEngine:
             wctx.arena = None
             wctx.params = wctx.grads = None
         cp.ctx = None
-        del cp, wctx
+        cp = wctx = None  # (not `del`: `cp` is read by the generator expression above, and the module also builds under Cython)
         live = len(self._plans)
         while len(arenas) + live < 4:
             arenas.append(Arena(self.device))
