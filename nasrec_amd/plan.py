@@ -665,13 +665,38 @@ def _flush_mha_reduce(ctx):
 _LN_REDUCE_BATCH = _os.environ.get("NASREC_LN_REDUCE_BATCH", "1") != "0"
 
 
+class _ItemNode:
+    """what reports (bench.py, iter_ops) read of a worklist item — descriptor, part, footprints — with the footprints computed when
+    somebody asks (schedule.desc_io costs ~10 us per descriptor: not on the path of a per-step compile)"""
+    __slots__ = ("desc", "part", "_io", "level", "index")
+
+    def __init__(self, desc, part="whole"):
+        self.desc, self.part, self._io, self.level, self.index = desc, part, None, 0, 0
+
+    def _get(self):
+        if self._io is None:
+            from . import schedule as S
+            io = S.desc_io(self.desc, self.part)
+            self._io = io if io is not None else (None, None)
+        return self._io
+
+    @property
+    def reads(self):
+        return self._get()[0]
+
+    @property
+    def writes(self):
+        return self._get()[1]
+
+
 def _flush_ln_reduce(ctx):
     """the parked LayerNorm parameter-gradient reductions (fixed-order column sums of per-workgroup partials) as items of
     NASREC_OP_WORKLIST launches, twelve per launch: same body, same order of additions, one launch boundary instead of twelve"""
     jobs, ctx.ln_reduce = ctx.ln_reduce, []
     if not jobs:
         return
-    from . import schedule as S
+    size = (C.sizeof(L.WlReduce) + 15) & ~15
+    base = L.WorklistDesc.blob.offset
     for i0 in range(0, len(jobs), L.WL_MAX_ITEMS):
         grp = jobs[i0:i0 + L.WL_MAX_ITEMS]
         if len(grp) == 1:
@@ -679,17 +704,15 @@ def _flush_ln_reduce(ctx):
             continue
         w = L.WorklistDesc()
         w.kind, w.n = L.OP_WORKLIST, len(grp)
-        w.nodes = []
-        off = 0
+        w.nodes = [_ItemNode(r) for r in grp]  # (for reports: footprints are derived on demand, not on the per-step path)
+        assert len(grp) * size <= L.WL_BLOB_BYTES
         for k, r in enumerate(grp):
-            node = S.Node(r)
-            b = S.item_bytes(node)
-            assert b is not None and off + len(b) <= L.WL_BLOB_BYTES
             it = w.item[k]
-            it.kind, it.part, it.off = r.kind, L.WL_WHOLE, off
-            C.memmove(C.addressof(w) + L.WorklistDesc.blob.offset + off, b, len(b))
-            w.nodes.append(node)
-            off += (len(b) + 15) & ~15
+            it.kind, it.part, it.off = r.kind, L.WL_WHOLE, k * size
+            item = L.WlReduce.from_address(C.addressof(w) + base + k * size)  # the item's descriptor, written in place
+            item.kind, item.R, item.C, item.ld, item.in_, item.ndst = r.kind, r.R, r.C, r.ld, r.in_, r.ndst
+            for q in range(r.ndst):
+                item.dst[q], item.dst_off[q], item.dst_len[q] = r.dst[q], r.dst_off[q], r.dst_len[q]
         ctx.emit(w)
 
 
