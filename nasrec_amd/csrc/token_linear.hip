@@ -68,56 +68,28 @@ __global__ __launch_bounds__(1024) void token_linear_kernel(const nasrec_gemm_de
     f32x4 acc[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // The sample's chunks of TL_CHUNK k-steps, segment after segment, SOFTWARE-PIPELINED over two register buffers (round 4): the loads
-    // of chunk t + 1 are in flight while chunk t multiplies.  (One buffer: every chunk exposed a full memory round trip, seven per
-    // sample with three input segments, hidden only by the CU's other 15 wavefronts — 3.5 TB/s.)  The loads are unconditional: past
-    // the last chunk they go against a null resource (no memory traffic, zeros), so the compiler can count what is in flight.
-    // Same MFMAs in the same order: same bits.
-    int cs = s_lo, cc = 0, ckb = 0;  // cursor of the chunk to FETCH next: segment, first k-step, LDS row base of the segment
-    auto skip_dead = [&]() {
-      while (cs < s_hi && (!d.seg[cs].A || d.seg[cs].K <= 0)) ++cs;
-    };
-    skip_dead();
-    struct Chunk {
-      int kb, c0, K4;  // LDS row base, first k-step, k-steps of the segment (K4 = 0: nothing)
-    };
-    auto fetch = [&](float* xv) -> Chunk {
-      const bool in = cs < s_hi;
-      const nasrec_gemm_seg_t& sg = d.seg[in ? cs : s_lo];
-      const int K4 = in ? (sg.K + 3) >> 2 : 0;
+    int kb = 0;
+    for (int s = s_lo; s < s_hi; ++s) {
+      const nasrec_gemm_seg_t& sg = d.seg[s];
+      if (!sg.A || sg.K <= 0) continue;
+      const int K4 = (sg.K + 3) >> 2;
       const __amdgpu_buffer_rsrc_t rs =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.B) + (long)b * sg.ldb, 0, in ? sg.K * 64 : 0, 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.B) + (long)b * sg.ldb, 0, sg.K * 64, 0x00020000);
+      for (int c0 = 0; c0 < K4; c0 += TL_CHUNK) {
+        float xv[TL_CHUNK];
 #pragma unroll
-      for (int u = 0; u < TL_CHUNK; ++u)  // beyond the sample's K rows: zeros (hardware range check)
-        xv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (cc + u) * 256 + lane * 4, 0, 0));
-      const Chunk c = {ckb, cc, K4};
-      cc += TL_CHUNK;
-      if (in && cc >= K4) {
-        ckb += 4 * K4;
-        cc = 0;
-        ++cs;
-        skip_dead();
-      }
-      return c;
-    };
-    auto multiply = [&](const Chunk& c, const float* xv) {
+        for (int u = 0; u < TL_CHUNK; ++u)  // beyond the sample's K rows: zeros (hardware range check)
+          xv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (c0 + u) * 256 + lane * 4, 0, 0));
 #pragma unroll
-      for (int u = 0; u < TL_CHUNK; ++u) {
-        if (c.c0 + u < c.K4) {  // (uniform) LDS rows beyond the staged weights are not zero
-          const float* wrow = Wl + (c.kb + 4 * (c.c0 + u) + g) * MP + e;
+        for (int u = 0; u < TL_CHUNK; ++u) {
+          if (c0 + u < K4) {  // (uniform) LDS rows beyond the staged weights are not zero
+            const float* wrow = Wl + (kb + 4 * (c0 + u) + g) * MP + e;
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[rb * 16], xv[u], acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[rb * 16], xv[u], acc[rb], 0, 0, 0);
+          }
         }
       }
-    };
-    float xa[TL_CHUNK], xb[TL_CHUNK];
-    Chunk ca = fetch(xa);
-    while (ca.K4 > 0) {
-      const Chunk cb = fetch(xb);
-      multiply(ca, xa);
-      if (cb.K4 <= 0) break;
-      ca = fetch(xa);
-      multiply(cb, xb);
+      kb += 4 * K4;
     }
     // ---- epilogue == epilogue_store<NASREC_CM_TOKJ> (gemm_tile.h); D: row = 4 * (lane >> 4) + reg, column = lane & 15 ---------
     float* C = s0.C + (long)b * s0.ldc + e;
