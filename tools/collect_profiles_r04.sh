@@ -33,6 +33,7 @@ CONFIG=3 TOP=60 timeout 300 python3 $R/tools/supernet_step_table.py > $O/superne
 # the throughput GEMM: per-k-tile cycle budget (needs `tools/build_variant.sh ftstamps -DFT_STAMPS` of the same sources) and the vendor library on five products
 [ -f $R/nasrec_amd/lib/variants/ftstamps.so ] && NASREC_HIP_LIB=$R/nasrec_amd/lib/variants/ftstamps.so timeout 300 python3 $R/tools/gemm_fast_stamps.py > $O/gemm_fast_stamps.txt 2>> $O/log.txt < /dev/null
 timeout 300 python3 $R/tools/gemm_vs_vendor.py > $O/gemm_vs_vendor.txt 2>> $O/log.txt < /dev/null
+bash $R/tools/mha_pmc.sh $O/mha_pmc > /dev/null 2>&1
 # keep what travels back small: per-dispatch traces are summarised on the box
 python3 $R/tools/update_profiles_r04.py --summarise $O >> $O/log.txt 2>&1 < /dev/null
 find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete

@@ -190,6 +190,10 @@ def install(O):
                                      "dispatch of the kernel (all instantiations); durations from the rocprofv3 --kernel-trace run of the default bench",
                            "note": "fabric traffic of the 8 private L2s (Infinity Cache included), not HBM reads: every launch starts on cold L2s"},
                           open(os.path.join(P, "dominant_kernel_traffic_cfg%d.json" % c), "w"), indent=1)
+    for ps in ("A", "B"):
+        f = os.path.join(O, "mha_pmc", "mha_pmc_pass%s.csv" % ps)
+        if os.path.exists(f) and os.path.getsize(f) > 0:
+            shutil.copy(f, os.path.join(P, "r04_mha_pmc_pass%s.csv" % ps))
     if os.path.exists(os.path.join(S, "bench_cfg2_pmc_mfma.csv")):
         shutil.copy(os.path.join(S, "bench_cfg2_pmc_mfma.csv"), os.path.join(P, "r04_bench_cfg2_pmc_mfma.csv"))
     print("installed into profiles/ for build", bid)
