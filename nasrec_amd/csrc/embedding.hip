@@ -236,10 +236,6 @@ int launch_opt_reduce(hipStream_t st, const nasrec_opt_reduce_desc_t* d) {
 // NASREC_OP_OPT_APPLY: clip coefficient (re-derived per workgroup) + Adagrad on the dense arena and on the touched rows
 __global__ __launch_bounds__(256) void opt_apply_kernel(const nasrec_opt_apply_desc_t d) {
   __shared__ float sh_coef;
-  // a dense workgroup's first pieces are on their way before the clip coefficient is known (they do not depend on it)
-  const bool dense_flat = (int)blockIdx.x < d.dense_blocks && !d.dense.chunks;
-  AdagradPre pre;
-  if (dense_flat) adagrad_dense_preload(d.dense, blockIdx.x, d.dense_blocks, pre);
   if (threadIdx.x < 64) {
     float total;
     const float c = clip_coef_wave(d.clip, threadIdx.x, &total);
@@ -253,9 +249,7 @@ __global__ __launch_bounds__(256) void opt_apply_kernel(const nasrec_opt_apply_d
   }
   __syncthreads();
   const float coef = sh_coef, lr = *d.dense.lr;
-  if (dense_flat)
-    adagrad_dense_flat(d.dense, blockIdx.x, d.dense_blocks, lr, coef, ADAGRAD_PRE, &pre);
-  else if ((int)blockIdx.x < d.dense_blocks)
+  if ((int)blockIdx.x < d.dense_blocks)
     adagrad_dense_body(d.dense, blockIdx.x, d.dense_blocks, lr, coef);
   else
     adagrad_rows_body(d.rows, (int)blockIdx.x - d.dense_blocks, lr, coef);

@@ -345,7 +345,6 @@ __device__ __forceinline__ void gemm_tile_ring(const nasrec_gemm_desc_t& d, int 
         }
     return;
   }
-  EpiIn ein[FA][FB][4];  // (gemm_tile.h: every read of the lane's elements before the first of their stores)
 #pragma unroll
   for (int a = 0; a < FA; ++a)
 #pragma unroll
@@ -353,15 +352,6 @@ __device__ __forceinline__ void gemm_tile_ring(const nasrec_gemm_desc_t& d, int 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
-        ein[a][b][r] = epilogue_load<CM>(d, s0, i, j, i < M && j < N);
-      }
-#pragma unroll
-  for (int a = 0; a < FA; ++a)
-#pragma unroll
-    for (int b = 0; b < FB; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
-        if (i < M && j < N) epilogue_finish<CM>(d, s0, i, j, acc[a][b][r], ein[a][b][r]);
+        if (i < M && j < N) epilogue_store<CM>(d, s0, i, j, acc[a][b][r]);
       }
 }

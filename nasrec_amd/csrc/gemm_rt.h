@@ -366,7 +366,6 @@ __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mm
         }
     return;
   }
-  EpiIn ein[FA][FB][4];  // (gemm_tile.h: every read of the lane's elements before the first of their stores)
 #pragma unroll
   for (int a = 0; a < FA; ++a)
 #pragma unroll
@@ -374,21 +373,6 @@ __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mm
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
-        const bool ok = i < M && j < N;
-        ein[a][b][r] = CM == NASREC_CM_PLAIN ? epilogue_load<NASREC_CM_PLAIN>(d, s0, i, j, ok) : epilogue_load<NASREC_CM_TOKJ>(d, s0, i, j, ok);
-      }
-#pragma unroll
-  for (int a = 0; a < FA; ++a)
-#pragma unroll
-    for (int b = 0; b < FB; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
-        if (i < M && j < N) {
-          if (CM == NASREC_CM_PLAIN)
-            epilogue_finish<NASREC_CM_PLAIN>(d, s0, i, j, acc[a][b][r], ein[a][b][r]);
-          else
-            epilogue_finish<NASREC_CM_TOKJ>(d, s0, i, j, acc[a][b][r], ein[a][b][r]);
-        }
+        if (i < M && j < N) rt_epilogue_store(CM, d, s0, i, j, acc[a][b][r]);
       }
 }

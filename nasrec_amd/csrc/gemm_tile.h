@@ -94,47 +94,6 @@ __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, cons
   sg.C[o] = v;
 }
 
-// The same epilogue in two halves (round 4): `epilogue_load` reads what element (i, j) needs from memory — residual, bias, gating
-// operand, accumulation target — and `epilogue_finish` does the arithmetic and the stores.  A tile calls the first half for ALL of a
-// lane's elements before the second half of any: written element by element (epilogue_store in a loop) the loads of element k + 1 may
-// not pass the store of element k (the arrays could alias), so a lane paid one dependent memory round trip per element — four to
-// sixteen per tile, on a cold L2 a large part of what a batch-256 item lasts.  Same operations per element in the same order: same bits.
-struct EpiIn {
-  float pre, bia, mul, cc;
-};
-template <int CM>
-__device__ __forceinline__ EpiIn epilogue_load(const nasrec_gemm_desc_t& d, const nasrec_gemm_seg_t& sg, int i, int j, bool valid) {
-  valid = valid && !(sg.ones_col && j == sg.N - 1);  // (the virtual ones column owns no element of C)
-  const int ii = valid ? i : 0, jj = valid ? j : 0;   // (clamped: a lane without an element reads element (0, 0) and drops it)
-  const long o = c_offset<CM>(ii, jj, sg.ldc);
-  EpiIn in;
-  in.pre = d.pre_add ? d.pre_add[o] : 0.f;
-  in.bia = d.bias ? (d.bias_on_rows ? d.bias[ii] : d.bias[jj]) : 0.f;
-  in.mul = d.mul_nseg > 0 ? mul_lookup(d, ii, jj) : 0.f;
-  in.cc = (d.zmode ? sg.accumulate : d.beta) ? sg.C[o] : 0.f;
-  return in;
-}
-template <int CM>
-__device__ __forceinline__ void epilogue_finish(const nasrec_gemm_desc_t& d, const nasrec_gemm_seg_t& sg, int i, int j, float v, const EpiIn& in) {
-  if (sg.ones_col && j == sg.N - 1) {  // virtual column: row sums of A (bias gradient)
-    (sg.rowsum ? sg.rowsum : d.rowsum_out)[i] = v;
-    return;
-  }
-  const long o = c_offset<CM>(i, j, sg.ldc);
-  if (d.pre_add) v += in.pre;
-  if (d.bias) v += in.bia;
-  if (d.save_z) d.save_z[o] = v;
-  v = act_apply(v, d.act);
-  if (d.save_act) d.save_act[o] = v;
-  if (d.mul_nseg > 0) v *= in.mul;
-  if (d.dims_in_use >= 0) {
-    int idx = d.mask_on_rows ? i : j;
-    if (idx >= d.dims_in_use) v = 0.f;
-  }
-  if (d.zmode ? sg.accumulate : d.beta) v += in.cc;
-  sg.C[o] = v;
-}
-
 // second pass of split-K: fixed-order sum of the partial slabs, then the same epilogue (element e of problem z)
 template <int CM>
 __device__ __forceinline__ void splitk_second_pass(const nasrec_gemm_desc_t& d, int Mmax, int Nmax, int z, long e) {
@@ -430,7 +389,6 @@ __device__ __forceinline__ void gemm_tile(const nasrec_gemm_desc_t& d, int Mmax,
         }
     return;
   }
-  EpiIn ein[FA][FB][4];
 #pragma unroll
   for (int a = 0; a < FA; ++a)
 #pragma unroll
@@ -438,16 +396,7 @@ __device__ __forceinline__ void gemm_tile(const nasrec_gemm_desc_t& d, int Mmax,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
-        ein[a][b][r] = epilogue_load<CM>(d, s0, i, j, i < M && j < N);
-      }
-#pragma unroll
-  for (int a = 0; a < FA; ++a)
-#pragma unroll
-    for (int b = 0; b < FB; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
-        if (i < M && j < N) epilogue_finish<CM>(d, s0, i, j, acc[a][b][r], ein[a][b][r]);
+        if (i < M && j < N) epilogue_store<CM>(d, s0, i, j, acc[a][b][r]);
       }
 }
 

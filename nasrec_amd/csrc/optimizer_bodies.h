@@ -72,65 +72,6 @@ __device__ __forceinline__ float clip_coef_wave(const nasrec_clip_coef_desc_t& d
   return coef;
 }
 
-// The flat (no chunk table) arena in 16-byte pieces, piece index = thread + k * (threads of the dense grid).  `pre` (optional): the
-// thread's first ADAGRAD_PRE pieces, loaded by the caller BEFORE it knew the clip coefficient (adagrad_dense_preload) — the operands do
-// not depend on it, so their round trip overlaps the coefficient's.  One float per thread and trip (the round-3 form) was eight to nine
-// DEPENDENT round trips per thread on the bench network (2.2 M parameters over 1024 workgroups): the next trip's loads may not pass
-// this trip's stores.  Per element the same operations in the same order: same bits.
-#define ADAGRAD_PRE 3
-struct AdagradPre {
-  f32x4 g[ADAGRAD_PRE], s[ADAGRAD_PRE], p[ADAGRAD_PRE];
-};
-__device__ __forceinline__ void adagrad_piece(const nasrec_adagrad_dense_desc_t& d, long i, f32x4 g4, f32x4 s4, f32x4 p4, float lr, float coef) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float g = g4[e] * coef;
-    s4[e] = fmaf(g, g, s4[e]);
-    p4[e] = p4[e] - lr * (g / (sqrtf(s4[e]) + d.eps));
-  }
-  *reinterpret_cast<f32x4*>(d.state + 4 * i) = s4;
-  *reinterpret_cast<f32x4*>(d.p + 4 * i) = p4;
-}
-__device__ __forceinline__ void adagrad_dense_preload(const nasrec_adagrad_dense_desc_t& d, int blk, int nblk, AdagradPre& pre) {
-  const long n4 = d.n >> 2, stride = (long)nblk * 256;
-#pragma unroll
-  for (int u = 0; u < ADAGRAD_PRE; ++u) {
-    const long i = min((long)blk * 256 + threadIdx.x + u * stride, n4 > 0 ? n4 - 1 : 0);  // (clamped: unconditional loads)
-    pre.g[u] = *reinterpret_cast<const f32x4*>(d.g + 4 * i);
-    pre.s[u] = *reinterpret_cast<const f32x4*>(d.state + 4 * i);
-    pre.p[u] = *reinterpret_cast<const f32x4*>(d.p + 4 * i);
-  }
-}
-__device__ __forceinline__ void adagrad_dense_flat(const nasrec_adagrad_dense_desc_t& d, int blk, int nblk, float lr, float coef, int npre,
-                                                   const AdagradPre* pre) {
-  const long n4 = d.n >> 2, stride = (long)nblk * 256;
-  long i = (long)blk * 256 + threadIdx.x;
-#pragma unroll
-  for (int u = 0; u < ADAGRAD_PRE; ++u) {
-    if (u < npre) {
-      if (i < n4) adagrad_piece(d, i, pre->g[u], pre->s[u], pre->p[u], lr, coef);
-      i += stride;
-    }
-  }
-  for (; i < n4; i += 2 * stride) {  // two pieces per trip, all six loads ahead of the four stores
-    const long i2 = i + stride;
-    const bool two = i2 < n4;
-    const long j2 = two ? i2 : i;
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(d.g + 4 * i), sa = *reinterpret_cast<const f32x4*>(d.state + 4 * i),
-                pa = *reinterpret_cast<const f32x4*>(d.p + 4 * i);
-    const f32x4 gb = *reinterpret_cast<const f32x4*>(d.g + 4 * j2), sb = *reinterpret_cast<const f32x4*>(d.state + 4 * j2),
-                pb = *reinterpret_cast<const f32x4*>(d.p + 4 * j2);
-    adagrad_piece(d, i, ga, sa, pa, lr, coef);
-    if (two) adagrad_piece(d, i2, gb, sb, pb, lr, coef);
-  }
-  for (long j = 4 * n4 + (long)blk * 256 + threadIdx.x; j < d.n; j += stride) {  // (arena sizes are multiples of 4: normally empty)
-    const float g = d.g[j] * coef;
-    const float s = fmaf(g, g, d.state[j]);
-    d.state[j] = s;
-    d.p[j] = d.p[j] - lr * (g / (sqrtf(s) + d.eps));
-  }
-}
-
 __device__ __forceinline__ void adagrad_dense_body(const nasrec_adagrad_dense_desc_t& d, int blk, int nblk, float lr, float coef) {
   if (d.chunks) {
     for (long c = blk; c < d.nchunks; c += nblk) {
@@ -159,7 +100,12 @@ __device__ __forceinline__ void adagrad_dense_body(const nasrec_adagrad_dense_de
     }
     return;
   }
-  adagrad_dense_flat(d, blk, nblk, lr, coef, 0, nullptr);
+  for (long i = (long)blk * 256 + threadIdx.x; i < d.n; i += (long)nblk * 256) {
+    const float g = d.g[i] * coef;
+    const float s = fmaf(g, g, d.state[i]);
+    d.state[i] = s;
+    d.p[i] = d.p[i] - lr * (g / (sqrtf(s) + d.eps));
+  }
 }
 
 // Row-sparse clip + Adagrad on the touched rows only (4 lanes x float4 per row); workgroup `blk` of 256 threads

@@ -152,13 +152,10 @@ __device__ __forceinline__ void wl_token_fwd(unsigned long long blob, int vb_, i
     }
   }
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15 (e), row = 4 * (lane >> 4) + reg
-  EpiIn ein[4];  // (gemm_tile.h: the four elements' reads before the first store)
-#pragma unroll
-  for (int r = 0; r < 4; ++r) ein[r] = epilogue_load<NASREC_CM_TOKJ>(g, s0, mt * 16 + 4 * fg + r, b * 16 + e, mt * 16 + 4 * fg + r < M);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = mt * 16 + 4 * fg + r;
-    if (i < M) epilogue_finish<NASREC_CM_TOKJ>(g, s0, i, b * 16 + e, acc[r], ein[r]);
+    if (i < M) epilogue_store<NASREC_CM_TOKJ>(g, s0, i, b * 16 + e, acc[r]);
   }
 }
 
@@ -229,13 +226,10 @@ __device__ __forceinline__ void wl_dense_small(unsigned long long blob, int vb_,
   }
   }
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
-  EpiIn ein[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) ein[r] = epilogue_load<NASREC_CM_PLAIN>(g, s0, mt * 16 + 4 * fg + r, nt * 16 + e, mt * 16 + 4 * fg + r < M && nt * 16 + e < N);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = mt * 16 + 4 * fg + r, j = nt * 16 + e;
-    if (i < M && j < N) epilogue_finish<NASREC_CM_PLAIN>(g, s0, i, j, acc[r], ein[r]);
+    if (i < M && j < N) epilogue_store<NASREC_CM_PLAIN>(g, s0, i, j, acc[r]);
   }
 }
 
@@ -286,13 +280,10 @@ __device__ __forceinline__ void wl_dense_small_dx(unsigned long long blob, int v
       }
     }
   }
-  EpiIn ein[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) ein[r] = epilogue_load<NASREC_CM_PLAIN>(g, sg, mt * 16 + 4 * fg + r, nt * 16 + e, mt * 16 + 4 * fg + r < M && nt * 16 + e < N);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = mt * 16 + 4 * fg + r, j = nt * 16 + e;
-    if (i < M && j < N) epilogue_finish<NASREC_CM_PLAIN>(g, sg, i, j, acc[r], ein[r]);
+    if (i < M && j < N) epilogue_store<NASREC_CM_PLAIN>(g, sg, i, j, acc[r]);
   }
 }
 
@@ -347,13 +338,10 @@ __device__ __forceinline__ void wl_token_dx(unsigned long long blob, int vb_, in
       }
     }
   }
-  EpiIn ein[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) ein[r] = epilogue_load<NASREC_CM_TOKJ>(g, sg, t * 16 + 4 * fg + r, b * 16 + e, t * 16 + 4 * fg + r < M);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = t * 16 + 4 * fg + r;
-    if (i < M) epilogue_finish<NASREC_CM_TOKJ>(g, sg, i, b * 16 + e, acc[r], ein[r]);
+    if (i < M) epilogue_store<NASREC_CM_TOKJ>(g, sg, i, b * 16 + e, acc[r]);
   }
 }
 
