@@ -144,61 +144,136 @@ __device__ __forceinline__ void ft_epilogue(const nasrec_gemm_desc_t& d, const n
   // column alone looked up once per lane and column: a lane owns 2 columns x 32 rows, and the gating product's segment search
   // (mul_lookup: a scalar loop over up to 8 k-segments) used to run for each of its 64 elements
   const bool acc_c = d.zmode ? s0.accumulate != 0 : d.beta != 0;
+  const bool has_pre = d.pre_add != nullptr;
+  float* rs = s0.rowsum ? s0.rowsum : d.rowsum_out;
+  // per column of the lane: the gating operand's pointer / stride, the bias, the dead-column flag
+  const float* mp[2] = {nullptr, nullptr};
+  int mld[2] = {0, 0};
+  float bias_c[2];
+  bool dead_c[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int j = min(n0 + wn * 64 + b * 32 + fr, N - 1);
+    if (d.mul_nseg > 0) {
+      for (int q = 0; q < d.mul_nseg; ++q) {
+        const int jj = j - d.mul_off[q];
+        if (jj >= 0 && jj < d.mul_width[q]) {
+          mp[b] = d.mul_ptr[q] ? d.mul_ptr[q] + jj : nullptr;
+          mld[b] = d.mul_ld[q];
+          break;
+        }
+      }
+    }
+    bias_c[b] = d.bias ? d.bias[j] : 0.f;  // (a bias over rows belongs to the token-axis layout: gemm_fast_eligible)
+    dead_c[b] = d.dims_in_use >= 0 && !d.mask_on_rows && j >= d.dims_in_use;
+  }
+  // one element from accumulator to memory: the same operations in the same order whichever way its operands were fetched.  NO load
+  // in here: vmcnt counts loads and stores in one in-order queue, so a load between two stores makes the wave wait for every earlier
+  // store to be acknowledged — once per element
+  float* const Cp = s0.C;
+  float* const zp = d.save_z;
+  float* const ap = d.save_act;
+  const long ldc = s0.ldc;
+  const int act = d.act;
+  const bool has_bias = d.bias != nullptr, has_mulv = d.mul_nseg > 0;
+  const int dead_rows = (d.dims_in_use >= 0 && d.mask_on_rows) ? d.dims_in_use : 0x7fffffff;
+  auto finish = [&](int i, int j, int b, float v, float prevv, float mulv, float cvv) {
+    const long o = (long)i * ldc + j;
+    if (has_pre) v += prevv;
+    if (has_bias) v += bias_c[b];
+    if (zp) zp[o] = v;
+    v = act_apply(v, act);
+    if (ap) ap[o] = v;
+    if (has_mulv) v *= mulv;
+    if (dead_c[b] || i >= dead_rows) v = 0.f;
+    if (acc_c) v += cvv;
+    Cp[o] = v;
+  };
+  const int nread = (d.mul_nseg > 0 ? 1 : 0) + (has_pre ? 1 : 0) + (acc_c ? 1 : 0);
+  if (nread <= 1 && !s0.ones_col) {
+    // ONE array is read (the accumulation target of a dx product, the gating operand, or the residual): all 64 of the lane's values are
+    // in flight before its first store.  Sixteen at a time — load, wait, store, and vmcnt counts loads and stores in one queue, so the next
+    // sixteen loads wait for the previous stores to be acknowledged — a 4096 x 1024 x 128 dx product took 39.7 us with accumulation against
+    // 18.2 us without; a tile alone on its CU (256-tile launches) has nothing to hide four such round trips behind.
+    float rd[2][2][16] = {};
+    bool live_c[2] = {false, false};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if (nread == 0) break;  // (bias / activation / saved planes only: nothing to read)
+      const int j = min(n0 + wn * 64 + b * 32 + fr, N - 1);
+      const float* base = acc_c ? s0.C + j : has_pre ? d.pre_add + j : mp[b];
+      const bool live = base != nullptr;  // (a column outside every gating segment: the loads go to C — unconditional, no branch — and count as 0)
+      live_c[b] = live;
+      const float* bp = live ? base : s0.C + j;
+      const long ld = (acc_c || has_pre || !live) ? s0.ldc : mld[b];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = min(m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3), M - 1);  // (clamped: rows >= M are never stored)
+          rd[a][b][r] = bp[(long)i * ld];  // (straight into its register: a select here and the compiler loads one element at a time)
+        }
+    }
+    // ONE wait for the whole batch, spelled out: the stores below sit behind uniform branches (saved planes present or not), the
+    // compiler cannot count them, and without this it waits with vmcnt(0) — every earlier store acknowledged — at the first use of each
+    // of the 64 loaded registers
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int j = n0 + wn * 64 + b * 32 + fr;
+      if (j >= N) continue;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
+          if (i >= M) continue;
+          const float x = live_c[b] ? rd[a][b][r] : 0.f;
+          finish(i, j, b, i < Mv ? acc[a][b][r] : 0.f, x, x, x);
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int j = n0 + wn * 64 + b * 32 + fr;
     if (j >= N) continue;
     const bool ones_j = s0.ones_col && j == N - 1;
-    const float* mp = nullptr;
-    int mld = 0;
-    if (d.mul_nseg > 0) {
-      for (int q = 0; q < d.mul_nseg; ++q) {
-        const int jj = j - d.mul_off[q];
-        if (jj >= 0 && jj < d.mul_width[q]) {
-          mp = d.mul_ptr[q] ? d.mul_ptr[q] + jj : nullptr;
-          mld = d.mul_ld[q];
-          break;
-        }
-      }
-    }
-    const float bias_j = (d.bias && !d.bias_on_rows) ? d.bias[j] : 0.f;
-    const bool dead_j = d.dims_in_use >= 0 && !d.mask_on_rows && j >= d.dims_in_use;
-    float* rs = s0.rowsum ? s0.rowsum : d.rowsum_out;
     // Everything the 16 rows of a fragment READ (the gating operand, the residual, the accumulation target) is loaded before the first of
     // their stores (round 4): element by element — load, use, store, and the next load may not pass that store, the arrays could
     // alias — a lane paid a dependent memory round trip per element, 64 per tile (the gated 4096 x 5133 x 1024 product: 96 TFLOP/s
     // against 131 for the plain product of the same shape).  Same arithmetic per element: same bits.
-    const bool has_mul = d.mul_nseg > 0 && mp != nullptr, has_pre = d.pre_add != nullptr;
+    const bool has_mul = d.mul_nseg > 0 && mp[b] != nullptr;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      float mulv[16], prev[16], cv[16];
+      float mulv[16] = {}, prev[16] = {}, cv[16] = {};
+      long off[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = min(m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3), M - 1);  // (clamped: rows >= M are never stored)
-        const long o = (long)i * s0.ldc + j;
-        mulv[r] = has_mul ? mp[(long)i * mld] : 0.f;
-        prev[r] = has_pre ? d.pre_add[o] : 0.f;
-        cv[r] = (acc_c && !ones_j) ? s0.C[o] : 0.f;
+      for (int r = 0; r < 16; ++r) off[r] = min(m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3), M - 1);  // (clamped: rows >= M are never stored)
+      // (one uniform branch per ARRAY, sixteen loads inside: a branch per element makes the compiler wait for element r before it issues r + 1)
+      if (has_mul) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mulv[r] = mp[b][off[r] * mld[b]];
       }
+      if (has_pre) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[r] = d.pre_add[off[r] * ldc + j];
+      }
+      if (acc_c) {  // (the ones-column's lanes read a real element too and drop it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cv[r] = Cp[off[r] * ldc + j];
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one wait per batch of sixteen (see above)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = m0 + wm * 64 + a * 32 + 8 * (r >> 2) + 4 * fg + (r & 3);
         if (i >= M) continue;
-        float v = i < Mv ? acc[a][b][r] : 0.f;
+        const float v = i < Mv ? acc[a][b][r] : 0.f;
         if (ones_j) {
           rs[i] = v;
           continue;
         }
-        const long o = (long)i * s0.ldc + j;
-        if (has_pre) v += prev[r];
-        if (d.bias) v += d.bias_on_rows ? d.bias[i] : bias_j;
-        if (d.save_z) d.save_z[o] = v;
-        v = act_apply(v, d.act);
-        if (d.save_act) d.save_act[o] = v;
-        if (d.mul_nseg > 0) v *= mulv[r];
-        if (dead_j || (d.dims_in_use >= 0 && d.mask_on_rows && i >= d.dims_in_use)) v = 0.f;
-        if (acc_c) v += cv[r];
-        s0.C[o] = v;
+        finish(i, j, b, v, prev[r], mulv[r], cv[r]);
       }
     }
   }
@@ -627,6 +702,7 @@ static int launch_fast_t(hipStream_t st, const nasrec_gemm_desc_t* d, int Mmax, 
 // Does this launch belong to the throughput regime?  (plan.py mirrors the rule when it sizes split-K: `_fast_gemm_splitk`.)
 bool gemm_fast_eligible(const nasrec_gemm_desc_t* d, int Mmax, int Nmax) {
   if (d->cmode != NASREC_CM_PLAIN) return false;
+  if (d->bias && d->bias_on_rows) return false;  // (token-axis layouts only; the epilogue here keeps loads out of its store sequence)
   if ((d->amode != NASREC_AM_KC && d->amode != NASREC_AM_RC) || (d->bmode != NASREC_AM_KC && d->bmode != NASREC_AM_RC)) return false;
   if (d->amode == NASREC_AM_RC && d->bmode == NASREC_AM_KC) return false;  // no call site
   const int nprob = d->zmode ? d->nseg : 1;
@@ -652,7 +728,7 @@ bool gemm_fast_eligible(const nasrec_gemm_desc_t* d, int Mmax, int Nmax) {
   (void)Nmax;
   // skinny problems (a [1024, 13] weight gradient fills a tenth of its 128 x 128 tiles) belong to the small-tile kernel
   if (2 * useful < padded) return false;
-  static const long min_k = getenv("NASREC_FAST_MIN_K") ? atol(getenv("NASREC_FAST_MIN_K")) : 64;  // A/B knob (plan.py mirrors it)
+  static const long min_k = getenv("NASREC_FAST_MIN_K") ? atol(getenv("NASREC_FAST_MIN_K")) : 1;  // A/B knob (plan.py mirrors it; 64 until round 4)
   return tiles >= NASREC_GEMM_FAST_MIN_TILES && kmax >= min_k;
 }
 

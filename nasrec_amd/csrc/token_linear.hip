@@ -21,6 +21,7 @@
 #define TL_WAVES 16
 #define TL_CHUNK 8        // k-steps (of 4 k) loaded before their MFMAs
 #define TL_MAX_LDS 147456  // bytes of staged weights per workgroup (one 16-wave workgroup per CU; 160 KB LDS)
+#define TL_BIAS_FLOATS 80  // the row biases sit in front of the weights (M <= 80)
 
 template <int RB>
 struct TlPad {
@@ -29,9 +30,13 @@ struct TlPad {
 
 template <int AM, int RB>
 __global__ __launch_bounds__(1024) void token_linear_kernel(const nasrec_gemm_desc_t d, int wgs) {
-  extern __shared__ __attribute__((aligned(16))) float Wl[];
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  float* const Bl = lds_all;                   // row biases (or zeros)
+  float* const Wl = lds_all + TL_BIAS_FLOATS;  // weights
   constexpr int MP = TlPad<RB>::v;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wave index as a SCALAR: the buffer resources below are built from it, and a resource the compiler takes for lane-dependent is
+  // wrapped in a readfirstlane loop around every load)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int z = d.zmode ? (int)blockIdx.x / wgs : 0;
   const int wg = (int)blockIdx.x - z * wgs;
   const int s_lo = d.zmode ? z : 0, s_hi = d.zmode ? z + 1 : d.nseg;
@@ -60,10 +65,16 @@ __global__ __launch_bounds__(1024) void token_linear_kernel(const nasrec_gemm_de
     }
     kbase += Kp;
   }
+  // the row biases go through LDS too: an LDS read in the epilogue is counted by lgkmcnt, a global one by vmcnt — behind the stores
+  if (tid < TL_BIAS_FLOATS) Bl[tid] = (d.bias && d.bias_on_rows && tid < M) ? d.bias[tid] : 0.f;
   __syncthreads();
 
   const int g = lane >> 4, e = lane & 15;
   const bool acc_c = d.zmode ? s0.accumulate != 0 : d.beta != 0;
+  // what the epilogue needs of the descriptor, once per workgroup (registers)
+  const bool has_bias = d.bias != nullptr, bias_rows = d.bias_on_rows != 0, mask_rows = d.mask_on_rows != 0;
+  const int dims = d.dims_in_use, act = d.act;
+  float* const zbase = d.save_z;
   for (int b = wg * TL_WAVES + wave; b < Bs; b += wgs * TL_WAVES) {
     f32x4 acc[RB];
 #pragma unroll
@@ -92,8 +103,24 @@ __global__ __launch_bounds__(1024) void token_linear_kernel(const nasrec_gemm_de
       kb += 4 * K4;
     }
     // ---- epilogue == epilogue_store<NASREC_CM_TOKJ> (gemm_tile.h); D: row = 4 * (lane >> 4) + reg, column = lane & 15 ---------
+    // Everything the sample's elements READ comes first (the accumulation target: 4 RB loads in flight; the row biases wait in LDS), ONE wait, then nothing but arithmetic and stores: vmcnt counts loads and stores in one in-order queue, so a load
+    // behind a store — element by element: bias, C, store, bias, C, store — makes the wave wait for the store's acknowledgement each time.
     float* C = s0.C + (long)b * s0.ldc + e;
-    float* Z = d.save_z ? d.save_z + (long)b * s0.ldc + e : nullptr;
+    float* Z = zbase ? zbase + (long)b * s0.ldc + e : nullptr;
+    float cv[RB][4];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv[rb][r] = 0.f;
+    if (acc_c) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[rb][r] = C[min(rb * 16 + 4 * g + r, M - 1) * 16];  // (clamped: rows >= M are never stored)
+    }
+    const float bcol = (has_bias && !bias_rows) ? d.bias[b * 16 + e] : 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), spelled out: the compiler cannot count the conditional stores below
+    const bool dead_col = dims >= 0 && !mask_rows && b * 16 + e >= dims;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -101,11 +128,11 @@ __global__ __launch_bounds__(1024) void token_linear_kernel(const nasrec_gemm_de
         const int i = rb * 16 + 4 * g + r;
         if (i >= M) continue;
         float v = acc[rb][r];
-        if (d.bias) v += d.bias_on_rows ? d.bias[i] : d.bias[b * 16 + e];
+        if (has_bias) v += bias_rows ? Bl[i] : bcol;
         if (Z) Z[i * 16] = v;
-        v = act_apply(v, d.act);
-        if (d.dims_in_use >= 0 && (d.mask_on_rows ? i : b * 16 + e) >= d.dims_in_use) v = 0.f;
-        if (acc_c) v += C[i * 16];
+        v = act_apply(v, act);
+        if (dead_col || (dims >= 0 && mask_rows && i >= dims)) v = 0.f;
+        if (acc_c) v += cv[rb][r];
         C[i * 16] = v;
       }
   }
@@ -130,7 +157,7 @@ bool token_linear_eligible(const nasrec_gemm_desc_t* d) {
       if (s.A && s.K > 0) kp += (s.K + 3) & ~3;
       if ((long)s.K * 64 > 0x7fffffffL) return false;
     }
-    if (kp * mp * 4 > TL_MAX_LDS) return false;
+    if (kp * mp * 4 + TL_BIAS_FLOATS * 4 > TL_MAX_LDS) return false;
     if (d->zmode && p > 0 && (s0.N != d->seg[0].N || (s0.M + 15) / 16 != (d->seg[0].M + 15) / 16)) return false;  // one grid, one row-block count
   }
   return true;
@@ -173,7 +200,7 @@ int launch_token_linear(hipStream_t st, const nasrec_gemm_desc_t* d) {
   if (wgs < 64) wgs = 64;
   const int need = (Bs + TL_WAVES - 1) / TL_WAVES;
   if (wgs > need) wgs = need;
-  const size_t lds = (size_t)(kp_max > 0 ? kp_max : 4) * mp * 4;
+  const size_t lds = (size_t)(kp_max > 0 ? kp_max : 4) * mp * 4 + TL_BIAS_FLOATS * 4;
   if (d->amode == NASREC_AM_KC)
     launch_token_linear_t<NASREC_AM_KC>(st, d, rb, wgs * nprob, wgs, lds);
   else
@@ -196,7 +223,9 @@ int launch_token_linear(hipStream_t st, const nasrec_gemm_desc_t* d) {
 template <int RB, int CB>
 __global__ __launch_bounds__(64 * TDW_WAVES) void token_dw_kernel(const nasrec_gemm_desc_t d, int Mmax, int Nmax) {
   __shared__ __attribute__((aligned(16))) float red[4 * RB * CB * 4 * 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wave index as a SCALAR: the buffer resources below are built from it, and a resource the compiler takes for lane-dependent is
+  // wrapped in a readfirstlane loop around every load)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = d.splitk;
   const int z = (int)blockIdx.x / S, ks = (int)blockIdx.x - z * S;
   const nasrec_gemm_seg_t& sg = d.seg[z];

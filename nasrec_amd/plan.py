@@ -344,7 +344,10 @@ def _splitk_for(tiles_mn, ktiles, nprob=1):
 
 
 GEMM_FAST_MIN_TILES = 120  # csrc/gemm_tile.h NASREC_GEMM_FAST_MIN_TILES
-_FAST_MIN_K = int(_os.environ.get("NASREC_FAST_MIN_K", "64"))    # A/B knobs (csrc/gemm_fast.hip reads the first one too)
+_FAST_MIN_K = int(_os.environ.get("NASREC_FAST_MIN_K", "1"))     # A/B knobs (csrc/gemm_fast.hip reads the first one too).  64 -> 1 in round 4: a [B,16] x [16,1024] product is a streaming
+# write of B x 1024 floats, and the throughput kernel's epilogue (full 128-byte rows per store instruction) is the better store path whatever K is: cfg 5 +1.9 %, cfg 3 / 4 +1.1 % (A/B)
+_TOKDW_CAP = int(_os.environ.get("NASREC_TOKDW_CAP", "128"))     # workgroups per problem of the token-axis weight gradient (A/B knob; 32 until round 4: a launch of two problems ran on 64 of
+# the 256 CUs — 64x72x131072 x 2: 108.9 us at 22 TFLOP/s; cfg 5 +1.5 %, cfg 3 +0.6 %)
 _FAST_MIN_KT = int(_os.environ.get("NASREC_FAST_MIN_KT", "4"))   # k-tiles of 32 per split of the throughput kernel (8 -> 4, round 4: a 4096x128x1024 product ran on 128 of 256 CUs; cfg 3 5.957 -> 5.930 ms, A/B)
 
 
@@ -532,8 +535,8 @@ def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, act=0, bias_on_rows=0, mas
                 break
         if ok:
             # token-axis weight gradients at large batch (csrc/token_linear.hip `token_dw_kernel`): S workgroups of 16 wavefronts per
-            # problem, a wavefront per sample — one workgroup per CU, few slabs for the second pass
-            S = max(4, min(32, 256 // nseg, B // 64))
+            # problem, a wavefront per sample — one workgroup per CU whatever the number of problems, few slabs for the second pass
+            S = max(4, min(_TOKDW_CAP, 256 // nseg, B // 64))
     if splitk is not None:
         S = splitk
     elif B <= 512 and S > 1 and kslice_eligible(amode, bmode, cmode, segs, zmode):

@@ -91,7 +91,13 @@ def main():
               ("DW", 1024, 1024, 4096, None), ("DW", 1024, 1024, 8192, None), ("DW", 6157, 6157, 4096, None),
               # ragged: M, N not multiples of 128, K with a partial tile
               ("F", 4000, 1000, 1037, None), ("DX", 4090, 1037, 1000, 1100), ("DW", 1000, 1037, 4090, None)]
-    if quick:
+    custom = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--shape=")]  # --shape=DX,4096,1024,128[,ldw]
+    if custom:
+        shapes = []
+        for c in custom:
+            f = c.split(",")
+            shapes.append((f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]) if len(f) > 4 else None))
+    elif quick:
         shapes = shapes[:2] + shapes[5:6] + shapes[8:9] + shapes[-3:]
     for kind, M, N, K, ldw in shapes:
         d, Cout, ref, ven, keep = desc(kind, M, N, K, ldw)

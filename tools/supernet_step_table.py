@@ -47,6 +47,11 @@ for phase, prog in (("fwd", cp.fwd), ("bwd", cp.bwd), ("opt", cp.opt)):
             info = "%s am=%d bm=%d cm=%d z=%d splitk=%d act=%d %.1f TF/s  %s" % (
                 P.gemm_kernel_name(d), d.amode, d.bmode, d.cmode, d.zmode, d.splitk, d.act, fl / us / 1e6,
                 " ".join("%dx%dx%d%s" % (s[0], s[1], s[2], "+1" if s[3] else "") for s in segs))
+            # epilogue flags + leading dimensions of the first problem (what separates a plain store from the general epilogue)
+            s0 = d.seg[0]
+            info += "  [%s ld=%d/%d/%d]" % ("".join(c for c, on in (("b", bool(d.bias)), ("p", bool(d.pre_add)), ("z", bool(d.save_z)), ("a", bool(d.save_act)),
+                                                                   ("m", d.mul_nseg > 0), ("d", d.dims_in_use >= 0), ("B", d.beta != 0), ("A", bool(s0.accumulate)),
+                                                                   ("r", bool(d.rowsum_out) or bool(s0.rowsum))) if on) or "-", s0.lda, s0.ldb, s0.ldc)
         elif isinstance(d, L.MhaDesc):
             info = "N=%d dims=%d" % (d.N, d.dims_in_use)
         elif isinstance(d, L.LayerNormDesc):
