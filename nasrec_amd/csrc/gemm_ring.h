@@ -348,10 +348,9 @@ __device__ __forceinline__ void gemm_tile_ring(const nasrec_gemm_desc_t& d, int 
 #pragma unroll
   for (int a = 0; a < FA; ++a)
 #pragma unroll
-    for (int b = 0; b < FB; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
-        if (i < M && j < N) epilogue_store<CM>(d, s0, i, j, acc[a][b][r]);
-      }
+    for (int b = 0; b < FB; ++b) {
+      const int i0 = m0 + wm * WTM + a * 16 + 4 * fg, j = n0 + wn * WTN + b * 16 + fr;
+      const float v4[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      if (i0 < M && j < N) epilogue_store_col4<CM>(d, s0, i0, j, M, v4);
+    }
 }

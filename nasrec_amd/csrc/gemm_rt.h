@@ -54,6 +54,13 @@ __device__ __forceinline__ void rt_epilogue_store(int cm, const nasrec_gemm_desc
     epilogue_store<NASREC_CM_TOKJ>(d, sg, i, j, v);
 }
 
+__device__ __forceinline__ void rt_epilogue_store_col4(int cm, const nasrec_gemm_desc_t& d, const nasrec_gemm_seg_t& sg, int i0, int j, int M, const float (&v4)[4]) {
+  if (cm == NASREC_CM_PLAIN)
+    epilogue_store_col4<NASREC_CM_PLAIN>(d, sg, i0, j, M, v4);
+  else
+    epilogue_store_col4<NASREC_CM_TOKJ>(d, sg, i0, j, M, v4);
+}
+
 #define GEMM_RT_LDS_FLOATS(TBM, TBN, TK) (((TBM) + (TBN)) * ((TK) + 4) + 128)
 
 template <bool KCA, bool KCB, int NT, int TK, int TBM, int TBN, bool AUX, int RING>
@@ -369,10 +376,9 @@ __device__ __forceinline__ void gemm_tile_rt(const nasrec_gemm_desc_t& d, int Mm
 #pragma unroll
   for (int a = 0; a < FA; ++a)
 #pragma unroll
-    for (int b = 0; b < FB; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
-        if (i < M && j < N) rt_epilogue_store(CM, d, s0, i, j, acc[a][b][r]);
-      }
+    for (int b = 0; b < FB; ++b) {
+      const int i0 = m0 + wm * WTM + a * 16 + 4 * fg, j = n0 + wn * WTN + b * 16 + fr;
+      const float v4[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      if (i0 < M && j < N) rt_epilogue_store_col4(CM, d, s0, i0, j, M, v4);
+    }
 }

@@ -94,6 +94,87 @@ __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, cons
   sg.C[o] = v;
 }
 
+// The four elements a lane holds of one 16 x 16 MFMA D tile — rows i0 .. i0 + 3 of column j — through the same epilogue, element for
+// element the same arithmetic in the same order as epilogue_store (bit-identical), but laid out for the memory pipeline:
+//   * the descriptor's fields are read ONCE (it lives in global memory: after every store the compiler has to assume it changed and
+//     re-reads each field — a scalar load and a wait per field and element);
+//   * everything the four elements READ (residual, bias, gating operand, accumulation target) is in flight together, ONE explicit wait,
+//     then arithmetic and stores only: vmcnt counts loads and stores in one in-order queue, so a load issued behind a store makes the
+//     wave wait for that store's acknowledgement — element by element that was a store round trip per element; and because the stores
+//     sit behind uniform branches the compiler cannot count them, hence the spelled-out wait.
+template <int CM>
+__device__ __forceinline__ void epilogue_store_col4(const nasrec_gemm_desc_t& d, const nasrec_gemm_seg_t& sg, int i0, int j, int M, const float (&v4)[4]) {
+  if (sg.ones_col && j == sg.N - 1) {  // virtual column: row sums of A (bias gradient)
+    float* rs = sg.rowsum ? sg.rowsum : d.rowsum_out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (i0 + r < M) rs[i0 + r] = v4[r];
+    return;
+  }
+  const float* const pre = d.pre_add;
+  const float* const bias = d.bias;
+  float* const zp = d.save_z;
+  float* const ap = d.save_act;
+  float* const Cp = sg.C;
+  const int act = d.act, dims = d.dims_in_use, ldc = sg.ldc, nmul = d.mul_nseg;
+  const bool brow = d.bias_on_rows != 0, mrow = d.mask_on_rows != 0;
+  const bool acc_c = (d.zmode ? sg.accumulate : d.beta) != 0;
+  const float* mp = nullptr;  // the gating operand's column (mul_lookup's segment search, once)
+  long mld = 0;
+  for (int q = 0; q < nmul; ++q) {
+    const int jj = j - d.mul_off[q];
+    if (jj >= 0 && jj < d.mul_width[q]) {
+      mp = d.mul_ptr[q] ? d.mul_ptr[q] + jj : nullptr;
+      mld = d.mul_ld[q];
+      break;
+    }
+  }
+  long o[4];
+  int ic[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    ic[r] = min(i0 + r, M - 1);  // (clamped: rows >= M are read, never stored)
+    o[r] = c_offset<CM>(ic[r], j, ldc);
+  }
+  float pv[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f}, mv[4] = {0.f, 0.f, 0.f, 0.f}, cv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (pre) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pv[r] = pre[o[r]];
+  }
+  if (bias) {
+    if (brow) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = bias[ic[r]];
+    } else {
+      const float bj = bias[j];
+      bv[0] = bv[1] = bv[2] = bv[3] = bj;
+    }
+  }
+  if (mp) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mv[r] = mp[(long)ic[r] * mld];
+  }
+  if (acc_c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cv[r] = Cp[o[r]];
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (i0 + r >= M) continue;
+    float v = v4[r];
+    if (pre) v += pv[r];
+    if (bias) v += bv[r];
+    if (zp) zp[o[r]] = v;
+    v = act_apply(v, act);
+    if (ap) ap[o[r]] = v;
+    if (nmul > 0) v *= mv[r];
+    if (dims >= 0 && (mrow ? i0 + r : j) >= dims) v = 0.f;
+    if (acc_c) v += cv[r];
+    Cp[o[r]] = v;
+  }
+}
+
 // second pass of split-K: fixed-order sum of the partial slabs, then the same epilogue (element e of problem z)
 template <int CM>
 __device__ __forceinline__ void splitk_second_pass(const nasrec_gemm_desc_t& d, int Mmax, int Nmax, int z, long e) {
@@ -392,11 +473,10 @@ __device__ __forceinline__ void gemm_tile(const nasrec_gemm_desc_t& d, int Mmax,
 #pragma unroll
   for (int a = 0; a < FA; ++a)
 #pragma unroll
-    for (int b = 0; b < FB; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int i = m0 + wm * WTM + a * 16 + 4 * fg + r, j = n0 + wn * WTN + b * 16 + fr;
-        if (i < M && j < N) epilogue_store<CM>(d, s0, i, j, acc[a][b][r]);
-      }
+    for (int b = 0; b < FB; ++b) {
+      const int i0 = m0 + wm * WTM + a * 16 + 4 * fg, j = n0 + wn * WTN + b * 16 + fr;
+      const float v4[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      if (i0 < M && j < N) epilogue_store_col4<CM>(d, s0, i0, j, M, v4);
+    }
 }
 

@@ -152,10 +152,9 @@ __device__ __forceinline__ void wl_token_fwd(unsigned long long blob, int vb_, i
     }
   }
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15 (e), row = 4 * (lane >> 4) + reg
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = mt * 16 + 4 * fg + r;
-    if (i < M) epilogue_store<NASREC_CM_TOKJ>(g, s0, i, b * 16 + e, acc[r]);
+  {
+    const float v4[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (mt * 16 + 4 * fg < M) epilogue_store_col4<NASREC_CM_TOKJ>(g, s0, mt * 16 + 4 * fg, b * 16 + e, M, v4);
   }
 }
 
@@ -226,10 +225,9 @@ __device__ __forceinline__ void wl_dense_small(unsigned long long blob, int vb_,
   }
   }
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = mt * 16 + 4 * fg + r, j = nt * 16 + e;
-    if (i < M && j < N) epilogue_store<NASREC_CM_PLAIN>(g, s0, i, j, acc[r]);
+  {
+    const float v4[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (mt * 16 + 4 * fg < M && nt * 16 + e < N) epilogue_store_col4<NASREC_CM_PLAIN>(g, s0, mt * 16 + 4 * fg, nt * 16 + e, M, v4);
   }
 }
 
@@ -280,10 +278,9 @@ __device__ __forceinline__ void wl_dense_small_dx(unsigned long long blob, int v
       }
     }
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = mt * 16 + 4 * fg + r, j = nt * 16 + e;
-    if (i < M && j < N) epilogue_store<NASREC_CM_PLAIN>(g, sg, i, j, acc[r]);
+  {
+    const float v4[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (mt * 16 + 4 * fg < M && nt * 16 + e < N) epilogue_store_col4<NASREC_CM_PLAIN>(g, sg, mt * 16 + 4 * fg, nt * 16 + e, M, v4);
   }
 }
 
@@ -338,10 +335,9 @@ __device__ __forceinline__ void wl_token_dx(unsigned long long blob, int vb_, in
       }
     }
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = t * 16 + 4 * fg + r;
-    if (i < M) epilogue_store<NASREC_CM_TOKJ>(g, sg, i, b * 16 + e, acc[r]);
+  {
+    const float v4[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (t * 16 + 4 * fg < M) epilogue_store_col4<NASREC_CM_TOKJ>(g, sg, t * 16 + 4 * fg, b * 16 + e, M, v4);
   }
 }
 
