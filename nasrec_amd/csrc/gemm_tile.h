@@ -72,6 +72,8 @@ __device__ __forceinline__ int seg_ld(const nasrec_gemm_desc_t& d, int sq, int w
   return which ? d.seg[sq].ldb : d.seg[sq].lda;
 }
 
+// One element through the epilogue.  Reads first (residual, bias, gating operand, accumulation target), one explicit wait, then arithmetic
+// and stores: see epilogue_store_col4 below for why (the in-order vmcnt queue, and the descriptor in global memory).
 template <int CM>
 __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, const nasrec_gemm_seg_t& sg, int i, int j,
                                                float v) {
@@ -80,18 +82,28 @@ __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, cons
     return;
   }
   const long o = c_offset<CM>(i, j, sg.ldc);
-  if (d.pre_add) v += d.pre_add[o];
-  if (d.bias) v += d.bias_on_rows ? d.bias[i] : d.bias[j];
-  if (d.save_z) d.save_z[o] = v;
-  v = act_apply(v, d.act);
-  if (d.save_act) d.save_act[o] = v;
-  if (d.mul_nseg > 0) v *= mul_lookup(d, i, j);
-  if (d.dims_in_use >= 0) {
-    int idx = d.mask_on_rows ? i : j;
-    if (idx >= d.dims_in_use) v = 0.f;
-  }
-  if (d.zmode ? sg.accumulate : d.beta) v += sg.C[o];
-  sg.C[o] = v;
+  const float* const pre = d.pre_add;
+  const float* const bias = d.bias;
+  float* const zp = d.save_z;
+  float* const ap = d.save_act;
+  float* const Cp = sg.C;
+  const int act = d.act, dims = d.dims_in_use, nmul = d.mul_nseg;
+  const bool mrow = d.mask_on_rows != 0;
+  const bool acc_c = (d.zmode ? sg.accumulate : d.beta) != 0;
+  const float pv = pre ? pre[o] : 0.f;
+  const float bv = bias ? (d.bias_on_rows ? bias[i] : bias[j]) : 0.f;
+  const float mv = nmul > 0 ? mul_lookup(d, i, j) : 0.f;
+  const float cv = acc_c ? Cp[o] : 0.f;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
+  if (pre) v += pv;
+  if (bias) v += bv;
+  if (zp) zp[o] = v;
+  v = act_apply(v, act);
+  if (ap) ap[o] = v;
+  if (nmul > 0) v *= mv;
+  if (dims >= 0 && (mrow ? i : j) >= dims) v = 0.f;
+  if (acc_c) v += cv;
+  Cp[o] = v;
 }
 
 // The four elements a lane holds of one 16 x 16 MFMA D tile — rows i0 .. i0 + 3 of column j — through the same epilogue, element for
