@@ -64,6 +64,8 @@ __device__ __forceinline__ float bce_term(float z, float y) { return fmaxf(z, 0.
 // With d.y != NULL, dlogits[b] is derived on the fly from logits[b] and y[b] (BCEWithLogits fused into this launch).
 // workgroup vb of nA + nB (+ 1 with the fused loss); lds: 272 floats
 #define FINAL_BWD_LDS_FLOATS 272
+#define FINAL_BWD_ROWS 16  // samples per part-A workgroup at large batch
+__host__ __device__ inline int final_bwd_rows(int B) { return B >= 1024 ? FINAL_BWD_ROWS : 1; }
 __device__ __forceinline__ void final_bwd_block(const nasrec_final_desc_t& d, int K, int nA, int nB, int vb_, float* lds) {
   // dispatch order: the few long-running workgroups first (part C: one workgroup walks the batch; part B: 16 columns x the whole batch
   // each), the many one-element workgroups of part A behind them — as the item's tail they made a level that holds this item last
@@ -71,7 +73,70 @@ __device__ __forceinline__ void final_bwd_block(const nasrec_final_desc_t& d, in
   const int nC = d.y != nullptr ? 1 : 0;
   const int vb = vb_ < nB + nC ? nA + vb_ : vb_ - (nB + nC);  // (below: [0, nA) = part A, [nA, nA + nB) = part B, nA + nB = part C)
   const bool fused = d.y != nullptr;
-  auto dl = [&](int b) { return fused ? bce_grad(d.logits[b], d.y[b], d.grad_scale) : d.dlogits[b]; };
+  // the per-sample gradient: both loads unconditional (a branch on `fused` around them, per use, is a branch per load — the compiler then
+  // waits for each before it issues the next: fifteen serial round trips in part B's eight-deep loop); without the fused loss the second
+  // pointer aliases the first and its value is dropped
+  const float* const dl_a = fused ? d.logits : d.dlogits;
+  const float* const dl_b = fused ? d.y : d.dlogits;
+  const float dl_scale = d.grad_scale;
+  auto dl = [&](int b) {
+    const float z = dl_a[b], y = dl_b[b];
+    return fused ? bce_grad(z, y, dl_scale) : z;
+  };
+  if (vb < nA && final_bwd_rows(d.B) > 1) {
+    // part A at large batch: a workgroup = 256 consecutive columns x FINAL_BWD_ROWS samples.  The column's segment search, its weight and
+    // the index arithmetic are done once per thread instead of once per element (one element per thread spent ~40 instructions on t / K,
+    // t % K and the search to move 4 bytes: 1 TB/s at B = 8192); the samples' gradients are the same address in every lane.  Reads
+    // first (gradients, the accumulation targets), one wait, then the stores.  Same value per element: same bits.
+    constexpr int RB = FINAL_BWD_ROWS;
+    const int kblocks = (K + 255) / 256;
+    const int rblk = vb / kblocks, k = (vb - rblk * kblocks) * 256 + (int)threadIdx.x;
+    if (k >= K) return;
+    float* p0 = nullptr;
+    long ldq = 0;
+    bool accq = false;
+    for (int q = 0; q < d.nseg; ++q) {
+      const int jj = final_feat(d, q, k);
+      if (jj >= 0) {
+        if (d.dseg[q]) {
+          p0 = d.dseg[q] + jj;
+          ldq = d.ld[q];
+          accq = d.dseg_accumulate[q] != 0;
+        }
+        break;
+      }
+    }
+    if (!p0) return;
+    const float wk = d.w[k];
+    const int r0 = rblk * RB;
+    float z[RB], y[RB], c[RB], g[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int b = min(r0 + u, d.B - 1);
+      z[u] = dl_a[b];
+      y[u] = dl_b[b];
+      c[u] = 0.f;
+    }
+    if (accq) {
+#pragma unroll
+      for (int u = 0; u < RB; ++u) c[u] = p0[(long)min(r0 + u, d.B - 1) * ldq];
+    }
+    if (fused) {
+#pragma unroll
+      for (int u = 0; u < RB; ++u) g[u] = bce_grad(z[u], y[u], dl_scale);
+    } else {
+#pragma unroll
+      for (int u = 0; u < RB; ++u) g[u] = z[u];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      if (r0 + u >= d.B) break;
+      const float v = g[u] * wk;
+      p0[(long)(r0 + u) * ldq] = accq ? c[u] + v : v;
+    }
+    return;
+  }
   if (vb < nA) {
     const long t = (long)vb * 256 + threadIdx.x;
     if (t >= (long)d.B * K) return;
@@ -127,7 +192,34 @@ __device__ __forceinline__ void final_bwd_block(const nasrec_final_desc_t& d, in
           }
         }
       }
+      const bool has = k < K && src != nullptr;
+      const float* sp = has ? src + jj : d.w;  // (an address that is always valid: the loads below are unconditional)
+      const long sld = has ? ld : 0;
       int b = b0 + w;
+      // eight rows' loads in flight — feature, logit, label: 24 — then ONE branch on the fused loss for the eight.  (Two rows per trip
+      // with the branch per row — the label's load and its wait inside — were serial round trips, the kernel's time at B = 4096 / 8192.)
+      // Rows alternate between the two accumulators exactly as before: same sums, same bits.
+      for (; b + 28 < b1; b += 32) {
+        float f[8], z[8], y[8], g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          f[u] = sp[(long)(b + 4 * u) * sld];
+          z[u] = dl_a[b + 4 * u];
+          y[u] = dl_b[b + 4 * u];
+        }
+        if (fused) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) g[u] = bce_grad(z[u], y[u], dl_scale);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) g[u] = z[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          s0 = fmaf(g[u], (k == K) ? 1.f : (has ? f[u] : 0.f), s0);
+          s1 = fmaf(g[u + 1], (k == K) ? 1.f : (has ? f[u + 1] : 0.f), s1);
+        }
+      }
       for (; b + 4 < b1; b += 8) {
         const float f0 = (k == K) ? 1.f : (src ? src[(long)b * ld + jj] : 0.f);
         const float f1 = (k == K) ? 1.f : (src ? src[(long)(b + 4) * ld + jj] : 0.f);
@@ -163,17 +255,26 @@ __device__ __forceinline__ void final_bwd_block(const nasrec_final_desc_t& d, in
     const float* sp = has ? src + jj : d.w;  // (an address that is always valid: the loads below are unconditional)
     const int sld = has ? ld : 0;
     for (int b0 = bq; b0 < d.B; b0 += 16 * 8) {
-      float f[8], g[8];
+      float f[8], g[8], z[8], y[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 8; ++u) {  // every load of the eight samples, nothing else: 24 in flight
         const int b = min(b0 + 16 * u, d.B - 1);
-        const float v = sp[(long)b * sld];
-        f[u] = (k == K) ? 1.f : (has ? v : 0.f);
-        g[u] = dl(b);
+        f[u] = sp[(long)b * sld];
+        z[u] = dl_a[b];
+        y[u] = dl_b[b];
+      }
+      if (fused) {  // (ONE branch for the eight: inside the loop above it was a branch per sample with the label's load and a wait in it)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g[u] = bce_grad(z[u], y[u], dl_scale);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g[u] = z[u];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (b0 + 16 * u < d.B) s = fmaf(g[u], f[u], s);
+      for (int u = 0; u < 8; ++u) {
+        const float fu = (k == K) ? 1.f : (has ? f[u] : 0.f);
+        if (b0 + 16 * u < d.B) s = fmaf(g[u], fu, s);
+      }
     }
   }
   red[bq][kl] = s;
@@ -195,6 +296,7 @@ __host__ __device__ inline void final_bwd_geometry(const nasrec_final_desc_t& d,
   for (int q = 0; q < d.nseg; ++q) K = K > d.off[q] + final_seg_extent(d, q) ? K : d.off[q] + final_seg_extent(d, q);
   const long tA = (long)d.B * K;
   nA = (int)((tA + 255) / 256);
+  if (final_bwd_rows(d.B) > 1) nA = ((K + 255) / 256) * ((d.B + FINAL_BWD_ROWS - 1) / FINAL_BWD_ROWS);
   nB = (K + 1 + 15) / 16;
   if (d.nsplit > 1) nB = ((K + 1 + 63) / 64) * d.nsplit;
 }

@@ -90,11 +90,24 @@ __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, cons
   const int act = d.act, dims = d.dims_in_use, nmul = d.mul_nseg;
   const bool mrow = d.mask_on_rows != 0;
   const bool acc_c = (d.zmode ? sg.accumulate : d.beta) != 0;
-  const float pv = pre ? pre[o] : 0.f;
-  const float bv = bias ? (d.bias_on_rows ? bias[i] : bias[j]) : 0.f;
-  const float mv = nmul > 0 ? mul_lookup(d, i, j) : 0.f;
-  const float cv = acc_c ? Cp[o] : 0.f;
+  // UNCONDITIONAL loads (an operand that is absent is read at C[o], a valid address, and its value dropped): with `p ? p[o] : 0` the
+  // compiler merges the load, a wait and the later `if (p) v += ...` into one branch per operand — four serial round trips again
+  const float* mp = nullptr;
+  long mo = 0;
+  for (int q = 0; q < nmul; ++q) {
+    const int jj = j - d.mul_off[q];
+    if (jj >= 0 && jj < d.mul_width[q]) {
+      mp = d.mul_ptr[q];
+      mo = (long)i * d.mul_ld[q] + jj;
+      break;
+    }
+  }
+  const float pv = *(pre ? pre + o : Cp + o);
+  const float bv = *(bias ? bias + (d.bias_on_rows ? i : j) : Cp + o);
+  const float mraw = *(mp ? mp + mo : Cp + o);
+  const float cv = Cp[o];
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
+  const float mv = mp ? mraw : 0.f;  // (mul_lookup: a column outside every segment, or a null segment, multiplies by 0)
   if (pre) v += pv;
   if (bias) v += bv;
   if (zp) zp[o] = v;

@@ -695,6 +695,45 @@ def test_layernorm(lib, mode, act):
     close(pw[D:], bd.grad, 2e-5)
 
 
+def test_final_backward_at_large_batch_is_the_elementwise_product_bit_for_bit(lib):
+    """B >= 1024: part A runs 256 columns x 16 samples per workgroup (ragged last row block, a column block that ends inside a segment),
+    part B eight rows per trip: d seg[b, j] = dlogit[b] * w[off + j] (+ what the buffer held) exactly, dw / dbias against fp64"""
+    torch.manual_seed(19)
+    B, D, N = 1030, 300, 7
+    dl, sl = torch.randn(B, D), torch.randn(B, N, 16)
+    K = D + N * 16
+    w, bias = torch.randn(1, K) * 0.05, torch.randn(1)
+    y = (torch.rand(B) < 0.25).float()
+    g = {k: dev(v) for k, v in dict(dl=dl, sl=sl, w=w, bias=bias, y=y).items()}
+    logits = dev(torch.zeros(B))
+    f = L.FinalDesc()
+    f.kind, f.B, f.nseg = L.OP_FINAL_FWD, B, 2
+    f.w, f.bias, f.logits = g["w"].data_ptr(), g["bias"].data_ptr(), logits.data_ptr()
+    f.seg[0], f.width[0], f.ld[0], f.off[0] = g["dl"].data_ptr(), D, D, 0
+    f.seg[1], f.width[1], f.ld[1], f.off[1] = g["sl"].data_ptr(), N * 16, N * 16, D
+    launch(lib, f)
+    nsplit = 4
+    part = dev(torch.full((nsplit * (K + 1),), float("nan")))
+    ddl, dsl = dev(torch.zeros(B, D)), dev(torch.ones(B, N, 16))
+    loss, dlog = dev(torch.zeros(1)), dev(torch.zeros(B))
+    f.kind = L.OP_FINAL_BWD
+    f.y, f.loss, f.dlogits_out, f.grad_scale = g["y"].data_ptr(), loss.data_ptr(), dlog.data_ptr(), 1.0 / B
+    f.nsplit, f.dw, f.dbias = nsplit, part.data_ptr(), None
+    f.dseg[0], f.dseg_accumulate[0] = ddl.data_ptr(), 0
+    f.dseg[1], f.dseg_accumulate[1] = dsl.data_ptr(), 1
+    launch(lib, f)
+    torch.cuda.synchronize()
+    assert torch.equal(ddl, dlog[:, None] * g["w"][0, :D][None, :])
+    assert torch.equal(dsl.reshape(B, -1), 1.0 + dlog[:, None] * g["w"][0, D:][None, :])
+    z = logits.double()
+    ref_dlog = (torch.sigmoid(z) - g["y"].double()) / B
+    close(dlog, ref_dlog, 1e-6)
+    feats = torch.cat([dl, sl.reshape(B, -1)], 1).double()
+    sums = part.view(nsplit, K + 1).double().sum(0).cpu()
+    close(sums[:K], (dlog.double().cpu()[:, None] * feats).sum(0), 1e-5)
+    close(sums[K:], dlog.double().sum().reshape(1), 1e-5)
+
+
 def test_final_bce_and_dense_optimizer(lib):
     torch.manual_seed(9)
     B, D, N = 300, 128, 48

@@ -14,6 +14,9 @@ import sys
 
 def scan(lines, want):
     kern, out = None, {}
+    serial = {}
+    global serial_at
+    serial_at = {}
     q = []  # outstanding vector-memory operations, oldest first: (kind, line)
     label = ""
     for ln, raw in enumerate(lines, 1):
@@ -44,16 +47,24 @@ def scan(lines, want):
             ld = [x for x in done if x[0] == "L"]
             if st and ld and max(x[1] for x in ld) > min(x[1] for x in st):  # a load younger than a store is waited for: the store too
                 out.setdefault(kern, []).append((ln, label, n, len(st), len(ld)))
+            if len(done) == 1 and not q and done[0][0] == "L":  # a wait for ONE load with nothing else in flight: a serial round trip
+                serial[kern] = serial.get(kern, 0) + 1
+                serial_at.setdefault(kern, []).append((ln, label, done[0][1]))
         elif op == "s_endpgm":
             kern = None
-    return out
+    return out, serial
 
 
 def main():
     lines = open(sys.argv[1]).read().splitlines()
     want = sys.argv[2] if len(sys.argv) > 2 else ""
-    for kern, hits in scan(lines, want).items():
-        print("%s: %d waits that include store acknowledgements" % (kern, len(hits)))
+    out, serial = scan(lines, want)
+    for kern in sorted(set(out) | set(serial)):
+        hits = out.get(kern, [])
+        print("%s: %d waits that include store acknowledgements, %d waits for a single load with nothing else in flight" % (kern, len(hits), serial.get(kern, 0)))
+        if len(sys.argv) > 4:  # a fourth argument: list the serial round trips too (line of the wait, label, line of the load)
+            for ln, label, lload in serial_at.get(kern, []):
+                print("   serial: wait at line %6d after %-12s for the load at line %d" % (ln, label, lload))
         for ln, label, n, ns, nl in hits[:int(sys.argv[3]) if len(sys.argv) > 3 else 40]:
             print("   line %6d  after %-12s vmcnt(%d): %d stores, %d loads completed here" % (ln, label, n, ns, nl))
 
