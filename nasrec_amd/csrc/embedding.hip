@@ -236,6 +236,7 @@ int launch_opt_reduce(hipStream_t st, const nasrec_opt_reduce_desc_t* d) {
 // NASREC_OP_OPT_APPLY: clip coefficient (re-derived per workgroup) + Adagrad on the dense arena and on the touched rows
 __global__ __launch_bounds__(256) void opt_apply_kernel(const nasrec_opt_apply_desc_t d) {
   __shared__ float sh_coef;
+  const float lr = *d.dense.lr;  // (beside the partial sums' loads, not behind the barrier: one round trip less on every workgroup's path)
   if (threadIdx.x < 64) {
     float total;
     const float c = clip_coef_wave(d.clip, threadIdx.x, &total);
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void opt_apply_kernel(const nasrec_opt_apply_d
     }
   }
   __syncthreads();
-  const float coef = sh_coef, lr = *d.dense.lr;
+  const float coef = sh_coef;
   if ((int)blockIdx.x < d.dense_blocks)
     adagrad_dense_body(d.dense, blockIdx.x, d.dense_blocks, lr, coef);
   else

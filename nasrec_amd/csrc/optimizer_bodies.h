@@ -60,9 +60,38 @@ __device__ __forceinline__ void sumsq_body(const nasrec_sumsq_desc_t& d, int blk
 
 // one wavefront: lanes take the partials round-robin (fixed assignment), fp64 butterfly -> the same value in every lane
 __device__ __forceinline__ float clip_coef_wave(const nasrec_clip_coef_desc_t& d, int lane, float* total_out) {
+  // eight partials per lane and trip in flight, the first trip of list b beside list a's (a plain loop is load -> wait -> add per
+  // partial: 256 + 26 partials were five dependent round trips at the head of EVERY workgroup of the apply launch).  The additions
+  // per lane are in the same order as before — all of a, then all of b: same bits.
   double s = 0.0;
-  for (int i = lane; i < d.n_a; i += 64) s += (double)d.partial_a[i];
-  for (int i = lane; i < d.n_b; i += 64) s += (double)d.partial_b[i];
+  const int na = d.n_a, nb = d.n_b;
+  if (na > 0 || nb > 0) {
+    const float* pa = na > 0 ? d.partial_a : d.partial_b;  // (an empty list is read at the other list's first element and dropped)
+    const float* pb = nb > 0 ? d.partial_b : d.partial_a;
+    const int ca = max(na - 1, 0), cb = max(nb - 1, 0);
+    float vb0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) vb0[u] = pb[min(lane + 64 * u, cb)];
+    for (int i0 = lane; i0 < na; i0 += 64 * 8) {
+      float va[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) va[u] = pa[min(i0 + 64 * u, ca)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + 64 * u < na) s += (double)va[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (lane + 64 * u < nb) s += (double)vb0[u];
+    for (int i0 = lane + 64 * 8; i0 < nb; i0 += 64 * 8) {
+      float vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) vb[u] = pb[min(i0 + 64 * u, cb)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + 64 * u < nb) s += (double)vb[u];
+    }
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   const float total = (float)sqrt(s);
@@ -114,13 +143,21 @@ __device__ __forceinline__ void adagrad_rows_body(const nasrec_adagrad_rows_desc
   const long pair = t >> 2;
   const int q = (int)(t & 3);
   if (pair >= (long)d.B * d.Fs) return;
-  if (!d.leader[pair]) return;
+  // Two memory round trips instead of five: everything that does not depend on the row id — leader flag, id, the field's row count and
+  // its two base pointers (per-lane loads from the argument arrays: f differs inside a wavefront), the gradient piece — is issued
+  // together; written as `if (!leader) return; row = idx; if (row >= rows[f]) return; ...` every test was a load, a wait and a branch.
   const int f = (int)(pair % d.Fs);
+  const int lead = d.leader[pair];
   const long row = d.idx[pair];
-  if (row < 0 || row >= d.rows[f]) return;  // never write outside a table
+  const long nrows = d.rows[f];
+  float* const sbase = d.state[f];
+  float* const tbase = d.table[f];
   float4 g = *reinterpret_cast<const float4*>(d.gsum + pair * 16 + q * 4);
-  float4* sp = reinterpret_cast<float4*>(d.state[f] + row * 16 + q * 4);
-  float4* pp = reinterpret_cast<float4*>(d.table[f] + row * 16 + q * 4);
+  asm volatile("" ::"v"(lead), "v"((int)row), "v"((int)nrows), "v"(sbase), "v"(tbase), "v"(g.x));  // (all six in flight before the first test)
+  if (!lead) return;
+  if (row < 0 || row >= nrows) return;  // never write outside a table
+  float4* sp = reinterpret_cast<float4*>(sbase + row * 16 + q * 4);
+  float4* pp = reinterpret_cast<float4*>(tbase + row * 16 + q * 4);
   float4 s = *sp, p = *pp;
   float gg[4] = {g.x * coef, g.y * coef, g.z * coef, g.w * coef};
   float ssv[4] = {s.x, s.y, s.z, s.w};
