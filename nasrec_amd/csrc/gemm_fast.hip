@@ -436,21 +436,36 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(const nasrec_gemm_des
     for (int it = 0; it < 4; ++it) {
       f32x4 va, vb;
       int row, k, kmask = 0;
+      float xa[4], xb[4];
+      // the slot's eight dwords in flight together, THEN the selects (the asm pins all eight as live here: left to itself the compiler
+      // — short of registers around this loop — emitted load, wait, select eight times over: 32 dependent round trips per partial
+      // k-tile, and a K = 16 product is nothing but its partial tile)
       ft_slot<AM>(tid, it, row, k);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int kk = k0 + k + (AM == NASREC_AM_KC ? e : 0);
         const int rr = min(m0 + row + (AM == NASREC_AM_KC ? 0 : e), M - 1);
-        const float v = pA[operand_offset<AM>(rr, min(kk, cK - 1), lda)];
-        va[e] = kk < cK ? v : 0.f;
+        xa[e] = pA[operand_offset<AM>(rr, min(kk, cK - 1), lda)];
       }
       ft_slot<BMODE>(tid, it, row, k);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int kk = k0 + k + (BMODE == NASREC_AM_KC ? e : 0);
         const int rr = min(n0 + row + (BMODE == NASREC_AM_KC ? 0 : e), Rb - 1);
-        const float v = pB[operand_offset<BMODE>(rr, min(kk, cK - 1), ldb)];
-        vb[e] = kk < cK ? v : 0.f;
+        xb[e] = pB[operand_offset<BMODE>(rr, min(kk, cK - 1), ldb)];
+      }
+      asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]));
+      ft_slot<AM>(tid, it, row, k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = k0 + k + (AM == NASREC_AM_KC ? e : 0);
+        va[e] = kk < cK ? xa[e] : 0.f;
+      }
+      ft_slot<BMODE>(tid, it, row, k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = k0 + k + (BMODE == NASREC_AM_KC ? e : 0);
+        vb[e] = kk < cK ? xb[e] : 0.f;
         if (kk < cK) kmask |= 1 << e;
       }
       parkA(buf, it, va);
