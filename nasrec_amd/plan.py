@@ -346,6 +346,8 @@ def _splitk_for(tiles_mn, ktiles, nprob=1):
 GEMM_FAST_MIN_TILES = 120  # csrc/gemm_tile.h NASREC_GEMM_FAST_MIN_TILES
 _FAST_MIN_K = int(_os.environ.get("NASREC_FAST_MIN_K", "1"))     # A/B knobs (csrc/gemm_fast.hip reads the first one too).  64 -> 1 in round 4: a [B,16] x [16,1024] product is a streaming
 # write of B x 1024 floats, and the throughput kernel's epilogue (full 128-byte rows per store instruction) is the better store path whatever K is: cfg 5 +1.9 %, cfg 3 / 4 +1.1 % (A/B)
+_LN_NBLK = int(_os.environ.get("NASREC_LN_NBLK", "512"))          # workgroups (of four row-per-wave wavefronts) of the dense LayerNorm backward (A/B knob; 256 until round 4:
+# one workgroup per CU = four wavefronts per CU for a streaming kernel whose rows wait for the previous row's stores: cfg 5 +1.6 %, cfg 3 +0.7 %; 1024 = 512)
 _TOKDW_CAP = int(_os.environ.get("NASREC_TOKDW_CAP", "128"))     # workgroups per problem of the token-axis weight gradient (A/B knob; 32 until round 4: a launch of two problems ran on 64 of
 # the 256 CUs — 64x72x131072 x 2: 108.9 us at 22 TFLOP/s; cfg 5 +1.5 %, cfg 3 +0.6 %)
 _FAST_MIN_KT = int(_os.environ.get("NASREC_FAST_MIN_KT", "4"))   # k-tiles of 32 per split of the throughput kernel (8 -> 4, round 4: a 4096x128x1024 product ran on 128 of 256 CUs; cfg 3 5.957 -> 5.930 ms, A/B)
@@ -813,7 +815,7 @@ def emit_layernorm(ctx, mode, x_ptr, ldx, R, D, wname, out_ptr, ldy, act, dims, 
     def bwd():
         if not ctx.live(out_view):
             return
-        nblk = min((R + 3) // 4, 256) if mode == L.AM_KC else (R + 255) // 256
+        nblk = min((R + 3) // 4, _LN_NBLK) if mode == L.AM_KC else (R + 255) // 256
         part = ctx.alloc(nblk * 2 * D)
         dx = ctx.alloc(_ln_numel(mode, R, D, ldx))
         e = L.LayerNormDesc()

@@ -54,6 +54,8 @@ for phase, prog in (("fwd", cp.fwd), ("bwd", cp.bwd), ("opt", cp.opt)):
                                                                    ("r", bool(d.rowsum_out) or bool(s0.rowsum))) if on) or "-", s0.lda, s0.ldb, s0.ldc)
         elif isinstance(d, L.MhaDesc):
             info = "N=%d dims=%d" % (d.N, d.dims_in_use)
+        elif isinstance(d, L.ReduceRowsDesc):
+            info = "R=%d C=%d ld=%d ndst=%d" % (d.R, d.C, d.ld, d.ndst)
         elif isinstance(d, L.LayerNormDesc):
             info = "mode=%d R=%d D=%d" % (d.mode, d.R, d.D)
         rows.append((us, phase, names.get(d.kind, str(d.kind)), info))
