@@ -415,6 +415,26 @@ def kslice_eligible(amode, bmode, cmode, segs, zmode):
     return M <= 512 and 128 <= tiles <= 512 and K >= 512
 
 
+def skinny_n_eligible(amode, bmode, cmode, segs, zmode):
+    """mirror of csrc/gemm_skinny.hip `gemm_skinny_n_eligible`: a forward Linear with <= 16 outputs at large batch streams x once, K split
+    inside the workgroup (no split-K workspace, no second launch)"""
+    if amode != L.AM_KC or bmode not in (L.AM_KC, L.AM_RC) or cmode != L.CM_PLAIN or (zmode and len(segs) != 1):
+        return False
+    M, N = segs[0]["M"], segs[0]["N"]
+    if N < 1 or N > 16 or M < 1024:
+        return False
+    K = 0
+    for sd in segs:
+        if sd.get("Aaux") or sd.get("Baux") or sd.get("ones_col") or (0 < sd.get("Mvalid", M) < M):
+            return False
+        if sd.get("A") and sd["K"] > 0:
+            K += sd["K"]
+            if M * sd.get("lda", 0) >= (1 << 29) or (sd["K"] if bmode == L.AM_RC else N) * sd.get("ldb", 0) >= (1 << 29):
+                return False
+    return K >= 256 and _SKINNY_N
+
+
+_SKINNY_N = _os.environ.get("NASREC_SKINNY_N", "1") != "0"  # A/B knob: 0 keeps these products on the general template (split-K + second pass)
 BALANCED_MIN_SAVING_US = float(_os.environ.get("NASREC_BALANCED_MIN_US", "80.0"))  # (env: A/B knob)
 
 
@@ -452,6 +472,9 @@ def gemm_kernel_name(d) -> str:
     if d.splitk <= 1 and kslice_eligible(d.amode, d.bmode, d.cmode, [dict(sd, ones_col=d.seg[q].ones_col, Mvalid=d.seg[q].Mvalid, lda=d.seg[q].lda,
                                                                           ldb=d.seg[q].ldb) for q, sd in enumerate(segs)], d.zmode):
         return "gemm_kslice_kernel"
+    if d.splitk <= 1 and skinny_n_eligible(d.amode, d.bmode, d.cmode, [dict(sd, ones_col=d.seg[q].ones_col, Mvalid=d.seg[q].Mvalid, lda=d.seg[q].lda,
+                                                                            ldb=d.seg[q].ldb) for q, sd in enumerate(segs)], d.zmode):
+        return "gemm_skinny_n_kernel"
     if (d.cmode == L.CM_TOKJ and d.bmode == L.AM_TOKR and d.amode in (L.AM_KC, L.AM_RC) and d.splitk <= 1 and not d.pre_add
             and not d.save_act and d.mul_nseg == 0 and all(sd["M"] <= 80 and sd["N"] >= 16 * 1024 and not sd["Aaux"] and not sd["Baux"] for sd in segs)):
         return "token_linear_kernel"  # (csrc/token_linear.hip `token_linear_eligible` has the complete rule)
@@ -543,6 +566,8 @@ def gemm_descs(ctx, amode, bmode, cmode, segs, zmode, act=0, bias_on_rows=0, mas
         S = splitk
     elif B <= 512 and S > 1 and kslice_eligible(amode, bmode, cmode, segs, zmode):
         S = 1  # csrc/gemm_kslice.hip: K is split inside the workgroup
+    elif B >= 1024 and skinny_n_eligible(amode, bmode, cmode, segs, zmode):
+        S = 1  # csrc/gemm_skinny.hip: likewise
     d.splitk = 1
     if fast == 1 and S == 1 and B > 256 and ctx.sk_workspace is not None and _balanced_schedule_pays(segs, zmode):
         d.splitk = L.SPLITK_BALANCED
