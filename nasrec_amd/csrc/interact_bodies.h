@@ -49,8 +49,108 @@ __device__ __forceinline__ void tri_rows_store(float* ts, int k1, int lane, cons
   }
 }
 
+#ifndef TRI_MFMA
+#define TRI_MFMA 1  // 0: the LDS / vector-ALU bodies of rounds 1-3 (A/B builds)
+#endif
+
+// The DotProduct core on the matrix pipe (round 4).  out[p(i, j)] = <T[i], T[j]>, j < i, is the strict lower triangle of the Gram matrix
+// G = T T^T ([k1, 16] x [16, k1]): per 16 x 16 block of G four v_mfma_f32_16x16x4_f32, and BOTH operands are the sample's memory as it
+// lies — lane (r, g) of MFMA j supplies A[i = r][k = g] = T[16 bi + r][4 g + j] and B[k = g][n = r] = T[16 bj + r][4 g + j], i.e. ONE
+// 16-byte load per lane and 16-row block (the 64 lanes read a contiguous 1 KB), no LDS, no barrier.  D: row 4 g + q, column r —
+// sixteen consecutive outputs of a row per store.  k1 = 46: 3 loads, 24 MFMAs, 24 stores per lane against 17 pairs x 8 ds_read_b128 +
+// 16 FMAs.  (Each output is the same 16 products; the matrix pipe adds them in its own order — k = j, 4 + j, 8 + j, 12 + j inside MFMA j.)
+__device__ __forceinline__ void dot_tri_fwd_sample_mfma(const nasrec_dot_tri_desc_t& d, int b, int lane) {
+  const int k1 = d.k1;
+  const int r = lane & 15, g = lane >> 4;
+  const float* Tb = d.T + (long)b * k1 * 16;
+  float* ob = d.out + (long)b * d.ld_out;
+  f32x4 t[TRI_MAXK1 / 16];
+#pragma unroll
+  for (int bi = 0; bi < TRI_MAXK1 / 16; ++bi)
+    if (16 * bi < k1) t[bi] = *reinterpret_cast<const f32x4*>(Tb + min(16 * bi + r, k1 - 1) * 16 + 4 * g);  // (uniform guard; rows >= k1 clamped, never stored)
+#pragma unroll
+  for (int bi = 0; bi < TRI_MAXK1 / 16; ++bi) {
+    if (16 * bi >= k1) break;
+#pragma unroll
+    for (int bj = 0; bj <= bi; ++bj) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t[bi][j], t[bj][j], acc, 0, 0, 0);
+      const int jc = 16 * bj + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 16 * bi + 4 * g + q;
+        if (i < k1 && jc < i) ob[i * (i - 1) / 2 + jc] = acc[q];
+      }
+    }
+  }
+}
+
+// ... and its backward: dT = S T with S the symmetric [k1, k1] matrix of the output gradients (S[i][k] = dO[p(max, min)], zero diagonal).
+// Lane (r, g) of step s supplies A[i = r][k = g] = S[16 bi + r][4 s + g] — a gather from the sample's 4 KB of dO — and
+// B[k = g][n = r] = T[4 s + g][r] — 64 consecutive floats per step.  Every load of the sample is issued before the first MFMA (one round
+// trip); k1 = 46: 12 + 36 dwords per lane, 36 MFMAs, 12 stores, no LDS.
+template <int NB>  // 16-row blocks: k1 <= 16 NB (static trip counts: every load below is unconditional — a guard per load is a branch, a wait and a select per load)
+__device__ __forceinline__ void dot_tri_bwd_sample_mfma_t(const nasrec_dot_tri_desc_t& d, int b, int lane) {
+  constexpr int KS = 4 * NB;
+  const int k1 = d.k1;
+  const int P = k1 * (k1 - 1) / 2;
+  const int r = lane & 15, g = lane >> 4;
+  const float* Tb = d.T + (long)b * k1 * 16;
+  const float* dob = d.dout + (long)b * d.ld_out;
+  float tb[KS], a[NB][KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) tb[s] = Tb[min(4 * s + g, k1 - 1) * 16 + r];  // (a row >= k1 is clamped and meets a zero of S)
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) {
+    const int i = 16 * bi + r;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 4 * s + g;
+      const int hi = max(i, k), lo = min(i, k);
+      a[bi][s] = dob[min(hi * (hi - 1) / 2 + lo, P - 1)];  // (clamped; masked below)
+    }
+  }
+  // every load of the sample has been issued: pin the values here, or the compiler sinks a block's gathers behind the previous block's
+  // stores (and then waits for those stores' acknowledgements, block after block)
+#pragma unroll
+  for (int s = 0; s < KS; s += 4) asm volatile("" ::"v"(tb[s]), "v"(tb[s + 1]), "v"(tb[s + 2]), "v"(tb[s + 3]));
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+    for (int s = 0; s < KS; s += 4) asm volatile("" ::"v"(a[bi][s]), "v"(a[bi][s + 1]), "v"(a[bi][s + 2]), "v"(a[bi][s + 3]));
+  float* dTb = d.dT + (long)b * k1 * 16;
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) {
+    const int i = 16 * bi + r;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 4 * s + g;
+      const float av = (i != k && i < k1 && k < k1) ? a[bi][s] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tb[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int io = 16 * bi + 4 * g + q;
+      if (io < k1) dTb[io * 16 + r] = acc[q];
+    }
+  }
+}
+__device__ __forceinline__ void dot_tri_bwd_sample_mfma(const nasrec_dot_tri_desc_t& d, int b, int lane) {
+  const int nb = (d.k1 + 15) >> 4;  // (uniform)
+  if (nb <= 1) dot_tri_bwd_sample_mfma_t<1>(d, b, lane);
+  else if (nb == 2) dot_tri_bwd_sample_mfma_t<2>(d, b, lane);
+  else if (nb == 3) dot_tri_bwd_sample_mfma_t<3>(d, b, lane);
+  else dot_tri_bwd_sample_mfma_t<4>(d, b, lane);
+}
+
 // one wavefront = one sample b; ts = TRI_MAXK1 * TRI_LD floats of LDS owned by that wavefront
 __device__ __forceinline__ void dot_tri_fwd_sample(const nasrec_dot_tri_desc_t& d, int b, int lane, float* ts) {
+  if (TRI_MFMA) {
+    dot_tri_fwd_sample_mfma(d, b, lane);
+    return;
+  }
   const int k1 = d.k1;
   const float* Tb = d.T + (long)b * k1 * 16;
   TriRows tr;
@@ -127,6 +227,10 @@ __device__ __forceinline__ void copy_segs_element(const nasrec_copy_segs_desc_t&
 // dT[b,i,:] = sum_{j<i} dO[p(i,j)] T[j] + sum_{j>i} dO[p(j,i)] T[j]; one wavefront = one sample; ts / ds = this wavefront's LDS
 // (k1 * TRI_LD and k1 (k1 - 1) / 2 floats)
 __device__ __forceinline__ void dot_tri_bwd_sample(const nasrec_dot_tri_desc_t& d, int b, int lane, float* ts, float* ds) {
+  if (TRI_MFMA) {
+    dot_tri_bwd_sample_mfma(d, b, lane);
+    return;
+  }
   const int k1 = d.k1;
   const int P = k1 * (k1 - 1) / 2;
   const float* Tb = d.T + (long)b * k1 * 16;
