@@ -219,8 +219,16 @@ class ShardedTableStep:
         ss = ops.rows_sumsq(t, own_idx, own_g) if hasattr(ops, "rows_sumsq") else t.grad_sumsq(own_idx, own_g)
         if self.world > 1:
             dist.all_reduce(ss, group=t.group)             # every owner's share of the tables' squared gradient norm
-        total = torch.sqrt(ops.dense_sumsq() + ss)
-        coef = torch.clamp(self.clip / (total + 1e-6), max=1.0) if self.clip is not None else torch.ones_like(total)
+        # the squares are summed in fp64; norm and coefficient then in fp32, operation for operation what torch.nn.utils.clip_grad_norm_
+        # (train_utils.py:285) and the whole-table step's kernel (csrc/optimizer_bodies.h clip_coef_wave) compute: total = float(sqrt(s));
+        # coef = min(max_norm / (total + 1e-6f), 1) — in fp64 throughout, the coefficient could differ from theirs by one ulp
+        # (ops.norm_dtype: fp32 for the HIP engine; the fp64 oracle behind the same protocol keeps fp64 throughout)
+        nd = getattr(ops, "norm_dtype", torch.float64)
+        total = torch.sqrt(ops.dense_sumsq() + ss).to(nd)
+        if self.clip is not None:
+            coef = torch.clamp(torch.tensor(self.clip, dtype=nd, device=total.device) / (total + torch.tensor(1e-6, dtype=nd, device=total.device)), max=1.0)
+        else:
+            coef = torch.ones_like(total)
         self.last_norm = total
         ops.dense_update(coef, lr)
         if hasattr(ops, "rows_update"):
@@ -241,6 +249,7 @@ class EngineShardedOps:
         self.eng, self.eps, self.L, self.C = engine, eps, L, C
         self.flat_g = engine.flat_g
         self.coef_dev = torch.ones(2, dtype=torch.float32, device=engine.device)
+        self.norm_dtype = torch.float32  # the clip coefficient in the arithmetic of the whole-table step's kernel (ShardedTableStep.step)
         self._bufs = {}
 
     def _launch(self, desc):
