@@ -518,7 +518,7 @@ def test_fused_optimizer_tail_is_bit_identical_to_the_stand_alone_ops(lib, B):
     assert torch.equal(a["gsum"].view(-1, 16)[lead], b["gsum"].view(-1, 16)[lead])
 
 
-@pytest.mark.parametrize("k1", [2, 9, 40, 46])
+@pytest.mark.parametrize("k1", [2, 9, 16, 17, 33, 40, 46, 49, 64])  # (one to four 16-row blocks of the MFMA form, block edges, the maximum)
 def test_dot_tri(lib, k1):
     torch.manual_seed(5)
     B = 11
@@ -534,6 +534,7 @@ def test_dot_tri(lib, k1):
     li, lj = torch.tril_indices(k1, k1, offset=-1)
     ref = Z[:, li, lj]
     close(out[:, :P], ref)
+    assert bool((out[:, P:] == 0).all()), "columns beyond the triangle were written"
     dout = torch.randn(B, P + 3)
     ref.backward(dout[:, :P].double())
     gdo, dT = dev(dout), dev(torch.zeros(B, k1, 16))
