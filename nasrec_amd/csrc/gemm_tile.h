@@ -92,8 +92,10 @@ __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, cons
   const int act = d.act, dims = d.dims_in_use, nmul = d.mul_nseg;
   const bool mrow = d.mask_on_rows != 0;
   const bool acc_c = (d.zmode ? sg.accumulate : d.beta) != 0;
-  // UNCONDITIONAL loads (an operand that is absent is read at C[o], a valid address, and its value dropped): with `p ? p[o] : 0` the
-  // compiler merges the load, a wait and the later `if (p) v += ...` into one branch per operand — four serial round trips again
+  // Each operand that is present is loaded behind its own uniform branch; the asm below pins all four values as live at one point, so
+  // the compiler can neither sink a load to its use nor merge `if (p) load` with the later `if (p) v += ...` into one block with a wait in
+  // it (it did: four serial round trips).  (Reading an absent operand at a dummy address instead — C[o] — made the one-pass K = 1565
+  // product's tail wait for a cold line of its own output: 13.4 -> 13.7 us.)
   const float* mp = nullptr;
   long mo = 0;
   for (int q = 0; q < nmul; ++q) {
@@ -104,10 +106,12 @@ __device__ __forceinline__ void epilogue_store(const nasrec_gemm_desc_t& d, cons
       break;
     }
   }
-  const float pv = *(pre ? pre + o : Cp + o);
-  const float bv = *(bias ? bias + (d.bias_on_rows ? i : j) : Cp + o);
-  const float mraw = *(mp ? mp + mo : Cp + o);
-  const float cv = Cp[o];
+  float pv = 0.f, bv = 0.f, mraw = 0.f, cv = 0.f;
+  if (pre) pv = pre[o];
+  if (bias) bv = bias[d.bias_on_rows ? i : j];
+  if (mp) mraw = mp[mo];
+  if (acc_c) cv = Cp[o];
+  asm volatile("" : "+v"(pv), "+v"(bv), "+v"(mraw), "+v"(cv));
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
   const float mv = mp ? mraw : 0.f;  // (mul_lookup: a column outside every segment, or a null segment, multiplies by 0)
   if (pre) v += pv;
