@@ -1,14 +1,14 @@
 // Feature-interaction and glue kernels: DotProduct triangle, FactorizationMachine, SigmoidGating backward,
 // segmented copies, bias-gradient row sums, fixed-order row reductions.
-// All are HBM/latency-bound fp32 work.  The DotProduct core runs on the matrix pipe since round 4 (interact_bodies.h: the Gram matrix
-// T T^T and S T with operands straight from memory, no LDS); rounds 1-3 did the pairwise dots as 16 FMAs on LDS-resident rows
-// (kept behind -DTRI_MFMA=0 for A/B builds: cfg 2 0.2786 -> 0.2771 ms, cfg 5 +1.6 %).
+// All are HBM/latency-bound fp32 work.  The DotProduct core's BACKWARD runs on the matrix pipe since round 4 (interact_bodies.h: S T with
+// operands straight from memory, no LDS: cfg 2 0.2786 -> 0.2771 ms, cfg 5 +1.3 %); the forward keeps the pairwise dots as 16 FMAs on
+// LDS-resident rows (its matrix-pipe form, T T^T, is built and tested — -DTRI_MFMA_FWD=1 — and left off for the logits' accuracy margin).
 #include "common.h"
 #include "interact_bodies.h"
 
 // ---------------------------------------------------------------------------------------------------
 // DotProduct core (modules.py:366-383).  One wavefront per sample, 4 samples per workgroup.
-// (The LDS arrays belong to the -DTRI_MFMA=0 form — T[b] staged with 20-float rows for ds_read_b128 — and vanish from the default build.)
+// (T[b] staged with 20-float rows for ds_read_b128 in the forward; the backward's LDS arrays belong to its -DTRI_MFMA=0 form and vanish from the default build.)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dot_tri_fwd_kernel(const nasrec_dot_tri_desc_t d) {
   __shared__ __attribute__((aligned(16))) float Ts[4][TRI_MAXK1 * TRI_LD];

@@ -52,6 +52,13 @@ __device__ __forceinline__ void tri_rows_store(float* ts, int k1, int lane, cons
 #ifndef TRI_MFMA
 #define TRI_MFMA 1  // 0: the LDS / vector-ALU bodies of rounds 1-3 (A/B builds)
 #endif
+#ifndef TRI_MFMA_FWD
+// The FORWARD keeps the sequential 16-FMA chain on LDS-resident rows by default: it feeds the logits, and on the golden network with the
+// largest logits (fixed_criteo_autoctr, |logit| up to 39.5) the chain is 2.63e-5 from the reference's fp64 evaluation where the matrix
+// pipe's four-term sums land at 3.39e-5 (the reference's own fp32 run: 2.75e-5) — for 0.3 % of a cfg-5 step and
+// nothing measurable at batch 256 (A/B -DTRI_MFMA_FWD=1).  The backward (gradients only) runs on the matrix pipe.
+#define TRI_MFMA_FWD 0
+#endif
 
 // The DotProduct core on the matrix pipe (round 4).  out[p(i, j)] = <T[i], T[j]>, j < i, is the strict lower triangle of the Gram matrix
 // G = T T^T ([k1, 16] x [16, k1]): per 16 x 16 block of G four v_mfma_f32_16x16x4_f32, and BOTH operands are the sample's memory as it
@@ -147,7 +154,7 @@ __device__ __forceinline__ void dot_tri_bwd_sample_mfma(const nasrec_dot_tri_des
 
 // one wavefront = one sample b; ts = TRI_MAXK1 * TRI_LD floats of LDS owned by that wavefront
 __device__ __forceinline__ void dot_tri_fwd_sample(const nasrec_dot_tri_desc_t& d, int b, int lane, float* ts) {
-  if (TRI_MFMA) {
+  if (TRI_MFMA_FWD) {
     dot_tri_fwd_sample_mfma(d, b, lane);
     return;
   }
