@@ -287,6 +287,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-dp-path", action="store_true", help="run the N>1 exchange code path on a single rank")
+    ap.add_argument("--real-collectives", action="store_true",
+                    help="with --force-dp-path on one rank: RCCL's all-gather / all-reduce kernels run inside the captured step (a one-rank gather is a copy kernel otherwise)")
     ap.add_argument("--ids", choices=["uniform", "zipf"], default="uniform",
                     help="id distribution (SURVEY 8d): uniform over each table = the cache-hostile primary case; zipf = Zipf(1.05) with 2 %% zeros")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -378,7 +380,8 @@ def main():
         cfg = P.NetConfig(choice_all["num_blocks"], ops_config_lib[choice_all["config"]], False, "relu", fixed=True)
         eng = SupernetEngine(cfg, Fd, Fs, tables, device=device, warm_choice=choice, world_size=world, host_embedding=sharded)
         eng.init_weights(seed=0)
-        dp = ShardedRun(eng) if sharded else DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=not args.no_graph, force_exchange=args.force_dp_path)
+        dp = ShardedRun(eng) if sharded else DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=not args.no_graph, force_exchange=args.force_dp_path,
+                                                              real_collectives=args.real_collectives)
 
         def one_step(i):
             bx = batches[i % len(batches)]
@@ -401,7 +404,7 @@ def main():
         eng.reserve(B, freeze_gc=True)  # plan slots sized for the largest path: no allocator call inside a step; one engine per process
         model.configure_path_sampling_strategy("default")
         np.random.seed(0)
-        dp = DataParallelStep(eng, None, B, clip=5.0, eps=1e-2, graph=False, force_exchange=args.force_dp_path)
+        dp = DataParallelStep(eng, None, B, clip=5.0, eps=1e-2, graph=False, force_exchange=args.force_dp_path, real_collectives=args.real_collectives)
         if sharded:  # the module built the engine in host_embedding mode and adopted its nn.Embedding weights as this rank's shards
             class _ModuleRun(ShardedRun):
                 def __init__(self):
@@ -423,20 +426,48 @@ def main():
         parallelism = "dp%d dense network (all-reduce of the path's dense grads) + row-sharded tables (all-to-all of ids / rows / row gradients, " \
                       "owner-side dedup + clip + Adagrad)" % world
 
+    # measurement-only ablation (tools/dp_overhead.sh): leave one kind of collective out of the exchange step to see what it costs.  The
+    # results of such a run are wrong by construction; the knob lives HERE, in the harness — nasrec_amd/parallel.py has no way to skip a collective
+    skip = [k for k in os.environ.get("NASREC_BENCH_DP_SKIP", "").split(",") if k]
+    if skip and getattr(dp, "exchange", False):
+        from nasrec_amd.parallel import Collectives
+
+        class Ablated(Collectives):
+            def all_gather(self, out, local, async_op=False):
+                return None if "gather" in skip else Collectives.all_gather(self, out, local, async_op)
+
+            def all_reduce(self, t, async_op=False):
+                return None if "reduce" in skip else Collectives.all_reduce(self, t, async_op)
+        dp.coll = Ablated(args.real_collectives)
+
     def fence():
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    # Setup, not warm-up: the first step compiles the plan and captures the step graph; then the graph is replayed until the GPU has been
+    # busy for ~0.1 s (clocks, TLBs and instruction caches of a box that sat idle through a minute of host-side setup), so that a short
+    # timed region (the driver's --steps 20 --warmup 5 is 7 ms of GPU time) sees the steady state the default 300-step run sees.
+    settle_ms = float(os.environ.get("NASREC_BENCH_SETTLE_MS", "100"))
+    one_step(0)
+    fence()
+    t_s = time.perf_counter()
+    n_settle = 1
+    while (time.perf_counter() - t_s) * 1e3 < settle_ms or n_settle < 4:
+        one_step(n_settle)
+        n_settle += 1
+        if n_settle % 16 == 0:
+            torch.cuda.synchronize(device)
+    fence()
     for i in range(warmup):
-        one_step(i)
+        one_step(n_settle + i)
     fence()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     ev[0].record()
     for i in range(steps):
-        one_step(warmup + i)
+        one_step(n_settle + warmup + i)
         ev[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
@@ -451,7 +482,7 @@ def main():
 
     result = {
         "metric": "supernet samples/sec at batch 256 (Criteo-shape), 1/2/4/8 MI355X",
-        "value": B * world * steps / dt, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "value": B * world * steps / dt, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup, "setup_steps": n_settle,
         "ms_per_step": dt / steps * 1e3, "median_ms_per_step": float(np.median(per_step)), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": w["name"], "baseline_config": args.config, "per_gpu_batch": B, "global_batch": B * world, "graph": dp.graph,
@@ -467,7 +498,10 @@ def main():
             "captured_in_one_graph": bool(getattr(pl, "step_graph", None)),
             "launches_up_to_cut": getattr(pl, "cuts", None),
             "pieces": [{"allreduce_ranges": len(list(rg)), "allreduce_MB": sum(n for _, n in rg) * 4 / 1e6} for _, rg in pl.segments],
-            "allgather_MB": {"ids": B * world * Fs * 8 / 1e6, "row_gradients": B * world * Fs * 64 / 1e6}}
+            "allgather_MB": {"ids": B * world * Fs * 8 / 1e6, "row_gradients": B * world * Fs * 64 / 1e6},
+            # the last pieces' dense gradients ride behind the rows in the row-gradient all-gather (no all-reduce of their own)
+            "packed_tail_floats_per_rank": dp.tail_n, "first_packed_piece": getattr(pl, "first_packed", None),
+            "real_collectives_on_one_rank": bool(args.real_collectives), "id_half_of_the_dedup_beside_the_forward": dp.ids_half is not None}
 
     if rank == 0:  # (N > 1: the roofline of the dominant launch and the step accounting are rank 0's; forward-only and the CPU baseline are N = 1 legs)
         sp = torch.cuda.current_stream(device).cuda_stream
@@ -561,7 +595,21 @@ def main():
         step_descs = [cp.stage] + (list(cp.fb.descs) if getattr(cp, "fb", None) is not None else list(cp.fwd.descs) + list(cp.bwd.descs)) + list(cp.opt.descs)
         if not dp.exchange or fixed:
             n_dense = sum(int(np.prod(eng.shapes[n])) for n in cp.used_params if not n.startswith("_embedding."))
+            # (the table re-launches the optimizer's descriptors a hundred times: what they change — dense parameters and state, the touched
+            # rows and their state, the row gradients that are summed in place — is put back afterwards)
+            with torch.no_grad():
+                ids_now = cp.cat_x.clone()
+                snap = [eng.flat_p.clone(), eng.flat_s.clone(), cp.sparse0.grad_tensor().clone() if not dp.exchange else None,
+                        [t[ids_now[:, f]].clone() for f, t in enumerate(eng.tables)], [t[ids_now[:, f]].clone() for f, t in enumerate(eng.table_state)]]
             rows = launch_table(lib, L, P, S, sp, step_descs, 100 if fixed else 10, n_dense)
+            with torch.no_grad():
+                eng.flat_p.copy_(snap[0])
+                eng.flat_s.copy_(snap[1])
+                if snap[2] is not None:
+                    cp.sparse0.grad_tensor().copy_(snap[2])
+                for f in range(len(eng.tables)):
+                    eng.tables[f][ids_now[:, f]] = snap[3][f]
+                    eng.table_state[f][ids_now[:, f]] = snap[4][f]
             if fixed:  # (a sampled supernet path has ~150 launches: its table stays in roofline_kernels, aggregated by kernel)
                 result["roofline_levels"] = rows
             agg = {}

@@ -79,7 +79,9 @@ enum {
   NASREC_OP_OPT_APPLY = 29,
   NASREC_OP_WORKLIST = 30,
   NASREC_OP_CONST_I64 = 31,
-  NASREC_OP_SPLITK_EPILOGUES = 32
+  NASREC_OP_SPLITK_EPILOGUES = 32,
+  NASREC_OP_DEDUP_IDS = 33,
+  NASREC_OP_OPT_REDUCE2 = 34
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -400,6 +402,9 @@ typedef struct nasrec_adagrad_rows_desc {
   const float* coef;
   int64_t rows[NASREC_MAX_TABLES]; /* rows of table f: an id outside [0, rows) is skipped (the gather has already flagged it;
                                       torch would have raised IndexError in the forward pass) */
+  int32_t rank_B;       /* 0: gsum is one contiguous [B,Fs,16] array.  > 0: gsum is the receive buffer of an all-gather whose per-rank */
+  int32_t _pad;         /*    chunks hold rank_B samples each and start rank_stride floats apart (something else rides behind the rows): */
+  int64_t rank_stride;  /*    row (b,f) lives at gsum + (b / rank_B) * rank_stride + ((b % rank_B) * Fs + f) * 16 */
 } nasrec_adagrad_rows_desc_t;
 
 /* Fused optimizer tail for batch <= 256 (the two grid-wide dependencies of clip_grad_norm_ + Adagrad need two
@@ -424,6 +429,50 @@ typedef struct nasrec_opt_apply_desc {
   nasrec_adagrad_dense_desc_t dense;
   nasrec_adagrad_rows_desc_t rows;
 } nasrec_opt_apply_desc_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * The row-sparse embedding backward in two halves (round 5).  NASREC_OP_EMB_DEDUP above does everything behind the backward pass;
+ * but which sample leads a row, and which samples repeat it, depends on the IDS only — known before the forward pass starts (one
+ * GPU: when the batch is staged; N GPUs: when the ids all-gather lands, nasrec_amd/parallel.py).  So:
+ *   NASREC_OP_DEDUP_IDS   (any time after the ids are known; B <= NASREC_DEDUP_IDS_MAX_B) per field: sort (id, sample) keys; a RUN =
+ *                         the samples of one id in ascending order, a SUB-RUN = the part of a run inside one 256-sample chunk.  Writes
+ *                         leader[b,f] (0 duplicate, 1 leader without duplicates, 2 leader with duplicates), order[f][p] = sample at sorted
+ *                         position p (bit 31: first of its sub-run), list A = sub-runs with >= 2 members, list B = runs with >= 2 sub-runs
+ *                         (entries: start position | length << 16 | bit 31 of an A entry: the sub-run is its whole run), counts[f] = their
+ *                         lengths.  NASREC_OP_STAGE_INPUTS can carry it (stage.dedup_ids.order != NULL).
+ *   NASREC_OP_OPT_REDUCE2 (behind the backward pass) workgroups [0, Fs): per field, IN PLACE over the per-sample row gradients, the sum of
+ *                         every sub-run into its first row in ascending sample order, then of every multi-chunk run's sub-run sums into the
+ *                         leader's row in chunk order — the summation order of NASREC_OP_EMB_DEDUP at every batch size, bit for bit — and
+ *                         the sum of squares of the leaders with duplicates; workgroups [Fs, Fs + row_blocks): sum of squares of the
+ *                         leaders without; the remaining sumsq.nblocks workgroups: NASREC_OP_SUMSQ of the dense gradient arena.
+ * NASREC_OP_OPT_APPLY then reads leader / rows as before (rows.gsum = the same array: a leader's row now holds its sum).
+ * ---------------------------------------------------------------------------------------------- */
+#define NASREC_DEDUP_IDS_MAX_B 4096
+typedef struct nasrec_dedup_ids_desc {
+  int32_t kind; /* NASREC_OP_DEDUP_IDS */
+  int32_t B, Fs;
+  int32_t cap;          /* entries per field of order / of each list: a power of two >= B, 256 <= cap <= NASREC_DEDUP_IDS_MAX_B */
+  const int64_t* idx;   /* [B, Fs] */
+  int32_t* leader;      /* [B, Fs] out */
+  int32_t* order;       /* [Fs, cap] out */
+  int32_t* lists;       /* [Fs, 2, cap / 2] out: list A, list B */
+  int32_t* counts;      /* [Fs, 2] out */
+} nasrec_dedup_ids_desc_t;
+
+typedef struct nasrec_opt_reduce2_desc {
+  int32_t kind; /* NASREC_OP_OPT_REDUCE2 */
+  int32_t B, Fs, cap;
+  int32_t rank_B;        /* layout of `rows` as in nasrec_adagrad_rows_desc_t (0: contiguous) */
+  int32_t row_blocks;    /* workgroups of the pass over leaders without duplicates (>= 1) */
+  int64_t rank_stride;
+  float* rows;           /* [B, Fs, 16] per-sample row gradients, summed in place */
+  const int32_t* leader;
+  const int32_t* order;
+  const int32_t* lists;
+  const int32_t* counts;
+  float* sumsq_partial;  /* [Fs + row_blocks] out */
+  nasrec_sumsq_desc_t sumsq; /* dense arena (sumsq.nblocks workgroups; 0: none) */
+} nasrec_opt_reduce2_desc_t;
 
 typedef struct nasrec_memset_desc {
   int32_t kind; /* NASREC_OP_MEMSET */
@@ -510,6 +559,9 @@ typedef struct nasrec_stage_desc {
   float* lr_dst;                              /* device scalar (may be NULL) */
   nasrec_embed_desc_t gather;                 /* gather.out != NULL: the same launch also runs the embedding stem on
                                                  cat_src (gather.idx and gather.kind are ignored; B, Fs from above) */
+  nasrec_dedup_ids_desc_t dedup_ids;          /* dedup_ids.order != NULL: Fs more workgroups run NASREC_OP_DEDUP_IDS on cat_src (B <= 256;
+                                                 idx / B / Fs / kind are ignored): the id-only half of the optimizer's row dedup, off the
+                                                 step's tail */
 } nasrec_stage_desc_t;
 
 /* ------------------------------------------------------------------------------------------------
@@ -580,6 +632,8 @@ int nasrec_adagrad_dense(void* stream, const nasrec_adagrad_dense_desc_t* d);
 int nasrec_adagrad_rows(void* stream, const nasrec_adagrad_rows_desc_t* d);
 int nasrec_opt_reduce(void* stream, const nasrec_opt_reduce_desc_t* d);
 int nasrec_opt_apply(void* stream, const nasrec_opt_apply_desc_t* d);
+int nasrec_dedup_ids(void* stream, const nasrec_dedup_ids_desc_t* d);
+int nasrec_opt_reduce2(void* stream, const nasrec_opt_reduce2_desc_t* d);
 int nasrec_worklist(void* stream, const nasrec_worklist_desc_t* d);
 
 /* HIP-event timing on an arbitrary stream (bench.py measures kernels on the engine's own stream). */

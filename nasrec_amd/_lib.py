@@ -32,7 +32,8 @@ ACT_BY_NAME = {"identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
 (OP_GEMM, OP_EMBED_GATHER, OP_DOT_TRI_FWD, OP_DOT_TRI_BWD, OP_FM_FWD, OP_FM_BWD, OP_MHA_FWD, OP_MHA_BWD, OP_REDUCE_ROWS,
  OP_COPY_SEGS, OP_GATE_BWD, OP_ROWSUM, OP_FINAL_FWD, OP_BCE, OP_FINAL_BWD, OP_EMB_DEDUP, OP_SUMSQ, OP_CLIP_COEF,
  OP_ADAGRAD_DENSE, OP_ADAGRAD_ROWS, OP_MEMSET, OP_LAYERNORM_FWD, OP_LAYERNORM_BWD, OP_ADD_SEGS, OP_SCALE,
- OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY, OP_WORKLIST, OP_CONST_I64, OP_SPLITK_EPILOGUES) = range(1, 33)
+ OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY, OP_WORKLIST, OP_CONST_I64, OP_SPLITK_EPILOGUES, OP_DEDUP_IDS,
+ OP_OPT_REDUCE2) = range(1, 35)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -130,7 +131,8 @@ class AdagradDenseDesc(C.Structure):
 
 class AdagradRowsDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("Fs", i32), ("eps", f32), ("idx", vp), ("leader", vp), ("gsum", vp),
-                ("table", vp * MAX_TABLES), ("state", vp * MAX_TABLES), ("lr", vp), ("coef", vp), ("rows", i64 * MAX_TABLES)]
+                ("table", vp * MAX_TABLES), ("state", vp * MAX_TABLES), ("lr", vp), ("coef", vp), ("rows", i64 * MAX_TABLES),
+                ("rank_B", i32), ("_pad", i32), ("rank_stride", i64)]
 
 
 class MemsetDesc(C.Structure):
@@ -162,9 +164,21 @@ class ActBwdDesc(C.Structure):
                 ("dims_in_use", i32), ("dy", vp), ("z", vp), ("dz", vp)]
 
 
+DEDUP_IDS_MAX_B = 4096  # NASREC_DEDUP_IDS_MAX_B
+
+
+class DedupIdsDesc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("Fs", i32), ("cap", i32), ("idx", vp), ("leader", vp), ("order", vp), ("lists", vp), ("counts", vp)]
+
+
+class OptReduce2Desc(C.Structure):
+    _fields_ = [("kind", i32), ("B", i32), ("Fs", i32), ("cap", i32), ("rank_B", i32), ("row_blocks", i32), ("rank_stride", i64), ("rows", vp),
+                ("leader", vp), ("order", vp), ("lists", vp), ("counts", vp), ("sumsq_partial", vp), ("sumsq", SumsqDesc)]
+
+
 class StageDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("Fd", i32), ("Fs", i32), ("lr", f32), ("_pad", i32), ("int_src", vp), ("int_dst", vp),
-                ("cat_src", vp), ("cat_dst", vp), ("y_src", vp), ("y_dst", vp), ("lr_dst", vp), ("gather", EmbedDesc)]
+                ("cat_src", vp), ("cat_dst", vp), ("y_src", vp), ("y_dst", vp), ("lr_dst", vp), ("gather", EmbedDesc), ("dedup_ids", DedupIdsDesc)]
 
 
 class OptReduceDesc(C.Structure):
@@ -200,7 +214,8 @@ DESC_BY_KIND = {
     OP_EMB_DEDUP: EmbDedupDesc, OP_SUMSQ: SumsqDesc, OP_CLIP_COEF: ClipCoefDesc, OP_ADAGRAD_DENSE: AdagradDenseDesc,
     OP_ADAGRAD_ROWS: AdagradRowsDesc, OP_MEMSET: MemsetDesc, OP_LAYERNORM_FWD: LayerNormDesc, OP_LAYERNORM_BWD: LayerNormDesc,
     OP_SCALE: ScaleDesc, OP_ACT_BWD: ActBwdDesc, OP_STAGE_INPUTS: StageDesc, OP_OPT_REDUCE: OptReduceDesc, OP_OPT_APPLY: OptApplyDesc,
-    OP_WORKLIST: WorklistDesc, OP_CONST_I64: ConstI64Desc, OP_SPLITK_EPILOGUES: SplitkEpiloguesDesc,
+    OP_WORKLIST: WorklistDesc, OP_CONST_I64: ConstI64Desc, OP_SPLITK_EPILOGUES: SplitkEpiloguesDesc, OP_DEDUP_IDS: DedupIdsDesc,
+    OP_OPT_REDUCE2: OptReduce2Desc,
 }
 
 # every symbol include/nasrec_hip.h declares
@@ -208,7 +223,7 @@ SYMBOLS = [
     "nasrec_launch", "nasrec_program_run", "nasrec_graph_create", "nasrec_graph_launch", "nasrec_graph_destroy", "nasrec_gemm",
     "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm", "nasrec_mha_ffn", "nasrec_layernorm",
     "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense", "nasrec_adagrad_rows", "nasrec_opt_reduce",
-    "nasrec_opt_apply", "nasrec_worklist", "nasrec_event_create",
+    "nasrec_opt_apply", "nasrec_worklist", "nasrec_dedup_ids", "nasrec_opt_reduce2", "nasrec_event_create",
     "nasrec_event_record", "nasrec_event_elapsed_ms", "nasrec_event_destroy", "nasrec_last_error", "nasrec_abi_version",
     "nasrec_desc_sizes", "nasrec_tsv_parse",
 ]
@@ -247,10 +262,10 @@ def load():
     lib.nasrec_tsv_parse.restype = i64
     for name in ("nasrec_gemm", "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm",
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
-                 "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_worklist"):
+                 "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_worklist", "nasrec_dedup_ids", "nasrec_opt_reduce2"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 12:
-        raise EngineError("ABI version mismatch: library %d, binding 12" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 13:
+        raise EngineError("ABI version mismatch: library %d, binding 13" % lib.nasrec_abi_version())
     sizes = (i32 * 40)()
     n = lib.nasrec_desc_sizes(sizes, 40)
     for kind, cls in DESC_BY_KIND.items():

@@ -64,6 +64,8 @@ static int dispatch(hipStream_t st, const void* desc) {
     case NASREC_OP_OPT_REDUCE: return launch_opt_reduce(st, (const nasrec_opt_reduce_desc_t*)desc);
     case NASREC_OP_OPT_APPLY: return launch_opt_apply(st, (const nasrec_opt_apply_desc_t*)desc);
     case NASREC_OP_WORKLIST: return launch_worklist(st, (const nasrec_worklist_desc_t*)desc);
+    case NASREC_OP_DEDUP_IDS: return launch_dedup_ids(st, (const nasrec_dedup_ids_desc_t*)desc);
+    case NASREC_OP_OPT_REDUCE2: return launch_opt_reduce2(st, (const nasrec_opt_reduce2_desc_t*)desc);
     default: return nasrec_set_error(-1, "unknown op kind %d", kind);
   }
 }
@@ -153,6 +155,8 @@ TYPED(nasrec_adagrad_rows, nasrec_adagrad_rows_desc_t, kind == NASREC_OP_ADAGRAD
 TYPED(nasrec_opt_reduce, nasrec_opt_reduce_desc_t, kind == NASREC_OP_OPT_REDUCE)
 TYPED(nasrec_opt_apply, nasrec_opt_apply_desc_t, kind == NASREC_OP_OPT_APPLY)
 TYPED(nasrec_worklist, nasrec_worklist_desc_t, kind == NASREC_OP_WORKLIST)
+TYPED(nasrec_dedup_ids, nasrec_dedup_ids_desc_t, kind == NASREC_OP_DEDUP_IDS)
+TYPED(nasrec_opt_reduce2, nasrec_opt_reduce2_desc_t, kind == NASREC_OP_OPT_REDUCE2)
 
 int nasrec_event_create(void** ev) {
   hipEvent_t e;
@@ -183,7 +187,7 @@ int nasrec_event_destroy(void* ev) {
 
 const char* nasrec_last_error(void) { return g_err; }
 
-int nasrec_abi_version(void) { return 12; }
+int nasrec_abi_version(void) { return 13; }
 
 int nasrec_desc_sizes(int32_t* out, int n) {
   static const int32_t sizes[] = {
@@ -220,6 +224,8 @@ int nasrec_desc_sizes(int32_t* out, int n) {
       (int32_t)sizeof(nasrec_worklist_desc_t),      // 30
       (int32_t)sizeof(nasrec_const_i64_desc_t),     // 31
       (int32_t)sizeof(nasrec_splitk_epilogues_desc_t), // 32
+      (int32_t)sizeof(nasrec_dedup_ids_desc_t),     // 33
+      (int32_t)sizeof(nasrec_opt_reduce2_desc_t),   // 34
   };
   const int total = (int)(sizeof(sizes) / sizeof(sizes[0]));
   int w = 0;

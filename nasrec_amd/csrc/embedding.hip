@@ -6,6 +6,7 @@
 // instruction and the output [B,Fs,16] is written fully coalesced.
 #include "common.h"
 #include "optimizer_bodies.h"
+#include "dedup_bodies.h"
 
 // thread t of the gather: (pair = t >> 2 = (b, f), q = t & 3 = which float4 of the 64-byte row)
 __device__ __forceinline__ void embed_gather_body(const nasrec_embed_desc_t& d, const int64_t* idx, int B, int Fs, long t) {
@@ -28,8 +29,15 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const nasrec_embed_de
 }
 
 // per-step input staging + learning-rate store (one launch instead of three copies and a fill), optionally with the
-// embedding gather of the step riding along
-__global__ __launch_bounds__(256) void stage_inputs_kernel(const nasrec_stage_desc_t d) {
+// embedding gather of the step riding along — and, in `ids_blocks` more workgroups behind them, the id-only half of the optimizer's
+// row dedup (dedup_bodies.h): the ids are in this launch's hands, and nothing reads that half's result before the backward is done
+__global__ __launch_bounds__(256) void stage_inputs_kernel(const nasrec_stage_desc_t d, int base_blocks) {
+  __shared__ unsigned long long dd_key[256];
+  __shared__ int dd_sh[4];
+  if ((int)blockIdx.x >= base_blocks) {
+    dedup_ids_body<256>(d.dedup_ids, d.cat_src, d.B, d.Fs, (int)blockIdx.x - base_blocks, dd_key, dd_sh);
+    return;
+  }
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int n_int = d.B * d.Fd, n_cat = d.B * d.Fs;
   if (t < n_int) d.int_dst[t] = d.int_src[t];
@@ -39,6 +47,14 @@ __global__ __launch_bounds__(256) void stage_inputs_kernel(const nasrec_stage_de
   if (d.gather.out != nullptr) embed_gather_body(d.gather, d.cat_src, d.B, d.Fs, t);
 }
 
+static int dedup_ids_check(const nasrec_dedup_ids_desc_t* d, int B, int Fs, const char* who) {
+  if (B < 1 || B > NASREC_DEDUP_IDS_MAX_B || Fs < 1 || Fs > NASREC_MAX_TABLES) return nasrec_set_error(-2, "%s: B=%d Fs=%d out of range", who, B, Fs);
+  if (d->cap < 256 || d->cap > NASREC_DEDUP_IDS_MAX_B || (d->cap & (d->cap - 1)) || d->cap < B)
+    return nasrec_set_error(-2, "%s: cap=%d must be a power of two in [max(256, B=%d), %d]", who, d->cap, B, NASREC_DEDUP_IDS_MAX_B);
+  if (!d->leader || !d->order || !d->lists || !d->counts) return nasrec_set_error(-2, "%s: null output", who);
+  return 0;
+}
+
 int launch_stage(hipStream_t st, const nasrec_stage_desc_t* d) {
   long n = (long)d->B * (d->Fd > d->Fs ? d->Fd : d->Fs);
   if (d->gather.out != nullptr) {
@@ -46,7 +62,15 @@ int launch_stage(hipStream_t st, const nasrec_stage_desc_t* d) {
     if ((long)d->B * d->Fs * 4 > n) n = (long)d->B * d->Fs * 4;
   }
   if (n < 1) n = 1;
-  hipLaunchKernelGGL(stage_inputs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *d);
+  const int base = (int)((n + 255) / 256);
+  int ids = 0;
+  if (d->dedup_ids.order != nullptr) {
+    if (d->B > 256 || d->dedup_ids.cap != 256) return nasrec_set_error(-2, "stage: the id half of the dedup rides along for B <= 256, cap 256 (B=%d cap=%d)", d->B, d->dedup_ids.cap);
+    const int rc = dedup_ids_check(&d->dedup_ids, d->B, d->Fs, "stage.dedup_ids");
+    if (rc) return rc;
+    ids = d->Fs;
+  }
+  hipLaunchKernelGGL(stage_inputs_kernel, dim3((unsigned)(base + ids)), dim3(256), 0, st, *d, base);
   return nasrec_check_launch("stage_inputs");
 }
 
@@ -393,4 +417,173 @@ int launch_adagrad_rows(hipStream_t st, const nasrec_adagrad_rows_desc_t* d) {
   if (threads == 0) return 0;
   hipLaunchKernelGGL(adagrad_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, *d);
   return nasrec_check_launch("adagrad_rows");
+}
+
+// ---- the two-halves row-sparse backward (dedup_bodies.h) -----------------------------------------------------------
+template <int CAP>
+__global__ __launch_bounds__(256) void dedup_ids_kernel(const nasrec_dedup_ids_desc_t d) {
+  __shared__ unsigned long long key[CAP];
+  __shared__ int sh[4];
+  dedup_ids_body<CAP>(d, d.idx, d.B, d.Fs, blockIdx.x, key, sh);
+}
+
+int launch_dedup_ids(hipStream_t st, const nasrec_dedup_ids_desc_t* d) {
+  const int rc = dedup_ids_check(d, d->B, d->Fs, "dedup_ids");
+  if (rc) return rc;
+  if (!d->idx) return nasrec_set_error(-2, "dedup_ids: null idx");
+  if (d->cap <= 256) hipLaunchKernelGGL(dedup_ids_kernel<256>, dim3(d->Fs), dim3(256), 0, st, *d);
+  else hipLaunchKernelGGL(dedup_ids_kernel<NASREC_DEDUP_IDS_MAX_B>, dim3(d->Fs), dim3(256), 0, st, *d);
+  return nasrec_check_launch("dedup_ids");
+}
+
+// NASREC_OP_OPT_REDUCE2.  R = rows a thread stages per round (1: B <= 256, the one-GPU batch; 4: up to 4096 samples in rounds of 1024).
+// Dynamic LDS: rows [256 R][20] floats | ord [CAP] | lst [CAP] | red [256] | hd [16][16].
+#define OR2_CAP(R) ((R) == 1 ? 256 : NASREC_DEDUP_IDS_MAX_B)
+#define OR2_LDS_BYTES(R) (4 * (256 * (R) * 20 + 2 * OR2_CAP(R) + 256))
+extern __shared__ __attribute__((aligned(16))) float or2_lds[];
+
+template <int R>
+__global__ __launch_bounds__(256) void opt_reduce2_kernel(const nasrec_opt_reduce2_desc_t d) {
+  constexpr int T = 256, ROWS = T * R, CAP = OR2_CAP(R);
+  float* rows = or2_lds;
+  int* ord = reinterpret_cast<int*>(or2_lds + ROWS * 20);
+  int* lst = ord + CAP;
+  float* red = reinterpret_cast<float*>(lst + CAP);
+  const int bid = blockIdx.x, tid = threadIdx.x;
+  const int Fs = d.Fs, B = d.B;
+  if (bid >= Fs + d.row_blocks) {  // dense gradient arena
+    sumsq_body(d.sumsq, bid - Fs - d.row_blocks, d.sumsq.nblocks, red);
+    return;
+  }
+  float ss = 0.f;
+  if (bid >= Fs) {
+    // leaders without duplicates: their row is their own gradient.  4 lanes x float4 per row; flag and row are read together
+    // (one round trip), rows of the other samples are read and dropped
+    const long npair = (long)B * Fs;
+    for (long t = (long)(bid - Fs) * T + tid; t < npair * 4; t += (long)d.row_blocks * T) {
+      const long pair = t >> 2;
+      const int q = (int)(t & 3);
+      const int b = (int)(pair / Fs), f = (int)(pair - (long)b * Fs);
+      const int lead = d.leader[pair];
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dd_row(d.rows, b, f, Fs, d.rank_B, d.rank_stride) + 4 * q);
+      const float s4 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      ss += lead == 1 ? s4 : 0.f;
+    }
+  } else {
+    // field f: the rows of its runs
+    const int f = bid, e = tid & 15, grp = tid >> 4;
+    const int cap = d.cap, half = cap >> 1;
+    const int nA = d.counts[2 * f], nB = d.counts[2 * f + 1];
+    for (int i = tid; i < cap; i += T) {  // (cap / 256 independent loads per array, in flight beside the first round's rows)
+      ord[i] = d.order[(long)f * cap + i];
+      lst[i] = d.lists[(long)f * cap + i];
+    }
+    for (int base = 0; base < B; base += ROWS) {
+      f32x4 g[R][4];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int b = min(base + u * T + tid, B - 1);
+        const f32x4* src = reinterpret_cast<const f32x4*>(dd_row(d.rows, b, f, Fs, d.rank_B, d.rank_stride));
+#pragma unroll
+        for (int v = 0; v < 4; ++v) g[u][v] = src[v];
+      }
+      __syncthreads();  // (the previous round's readers are done; ord / lst of the first round are stored)
+#pragma unroll
+      for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(&rows[(u * T + tid) * 20 + 4 * v]) = g[u][v];
+      __syncthreads();
+      // phase 1: every sub-run of this round's chunks, sixteen lanes per sub-run (lane = one float of the row), ascending sample order
+      for (int k = grp; k < nA; k += T / 16) {
+        const unsigned en = (unsigned)lst[k];
+        const int s = (int)(en & 0xffffu), len = (int)((en >> 16) & 0x7fffu);
+        const int o0 = ord[s] & 0x7fffffff;
+        if (o0 < base || o0 >= base + ROWS) continue;  // (another round's chunk; uniform over the sixteen lanes)
+        float acc = rows[(o0 - base) * 20 + e];
+        int i = 1;
+        for (; i + 4 <= len; i += 4) {
+          const int p0 = ord[s + i] & 0x7fffffff, p1 = ord[s + i + 1] & 0x7fffffff, p2 = ord[s + i + 2] & 0x7fffffff, p3 = ord[s + i + 3] & 0x7fffffff;
+          const float r0 = rows[(p0 - base) * 20 + e], r1 = rows[(p1 - base) * 20 + e], r2 = rows[(p2 - base) * 20 + e], r3 = rows[(p3 - base) * 20 + e];
+          acc += r0;
+          acc += r1;
+          acc += r2;
+          acc += r3;
+        }
+        for (; i < len; ++i) acc += rows[((ord[s + i] & 0x7fffffff) - base) * 20 + e];
+        dd_row(d.rows, o0, f, Fs, d.rank_B, d.rank_stride)[e] = acc;
+        if (en & DD_WHOLE) ss += acc * acc;  // the run ends here: this is the leader's final row
+      }
+    }
+    if (nB > 0) {  // (uniform) phase 2: runs that span chunks — the sub-run sums, in chunk order, into the leader's row
+      __threadfence_block();
+      __syncthreads();  // phase 1's rows (written by other waves of this workgroup) are visible
+      for (int k0 = 0; k0 < nB; k0 += T / 16) {  // (the trip count is uniform: lanes of one wave exchange sub-run heads by shuffles below)
+        const int k = k0 + grp;
+        const bool on = k < nB;
+        const unsigned en = on ? (unsigned)lst[half + k] : 0u;
+        const int s = (int)(en & 0xffffu), len = (int)(en >> 16);
+        // lane c looks for the sub-run of chunk c: the first position of the run whose sample lies in chunk >= c
+        int head = -1;
+        if (on) {
+          int lo = s, hi = s + len;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (((ord[mid] & 0xffff) >> 8) < e) lo = mid + 1;
+            else hi = mid;
+          }
+          if (lo < s + len && ((ord[lo] & 0xffff) >> 8) == e) head = ord[lo] & 0x7fffffff;
+        }
+        float acc = 0.f;
+        bool first = true;
+        int h0 = -1;
+        float v[16];
+        int hs[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {  // all of the run's sub-run rows in flight, then the sums in chunk order
+          hs[c] = __shfl(head, (tid & 48) | c, 64);
+          v[c] = dd_row(d.rows, max(hs[c], 0), f, Fs, d.rank_B, d.rank_stride)[e];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          if (hs[c] >= 0) {
+            acc = first ? v[c] : acc + v[c];
+            if (first) h0 = hs[c];
+            first = false;
+          }
+        }
+        if (on && h0 >= 0) {
+          dd_row(d.rows, h0, f, Fs, d.rank_B, d.rank_stride)[e] = acc;
+          ss += acc * acc;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  red[tid] = ss;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) d.sumsq_partial[bid] = red[0];
+}
+
+int launch_opt_reduce2(hipStream_t st, const nasrec_opt_reduce2_desc_t* d) {
+  if (d->B < 1 || d->B > NASREC_DEDUP_IDS_MAX_B || d->Fs < 1 || d->Fs > NASREC_MAX_TABLES) return nasrec_set_error(-2, "opt_reduce2: B=%d Fs=%d out of range", d->B, d->Fs);
+  if (d->cap < 256 || d->cap > NASREC_DEDUP_IDS_MAX_B || (d->cap & (d->cap - 1)) || d->cap < d->B) return nasrec_set_error(-2, "opt_reduce2: cap=%d", d->cap);
+  if (d->row_blocks < 1 || d->sumsq.nblocks < 0) return nasrec_set_error(-2, "opt_reduce2: row_blocks=%d sumsq.nblocks=%d", d->row_blocks, d->sumsq.nblocks);
+  if (d->rank_B < 0 || (d->rank_B > 0 && d->rank_stride < (int64_t)d->rank_B * d->Fs * 16)) return nasrec_set_error(-2, "opt_reduce2: rank layout %d / %ld", d->rank_B, (long)d->rank_stride);
+  if (!d->rows || !d->leader || !d->order || !d->lists || !d->counts || !d->sumsq_partial) return nasrec_set_error(-2, "opt_reduce2: null pointer");
+  const dim3 grid((unsigned)(d->Fs + d->row_blocks + d->sumsq.nblocks));
+  if (d->cap <= 256) {
+    hipLaunchKernelGGL(opt_reduce2_kernel<1>, grid, dim3(256), OR2_LDS_BYTES(1), st, *d);
+  } else {
+    static unsigned long long attr_mask = 0;
+    if (nasrec_lds_attr_needed(attr_mask)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&opt_reduce2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, OR2_LDS_BYTES(4));
+      if (e != hipSuccess) return nasrec_set_error((int)e, "opt_reduce2: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(opt_reduce2_kernel<4>, grid, dim3(256), OR2_LDS_BYTES(4), st, *d);
+  }
+  return nasrec_check_launch("opt_reduce2");
 }

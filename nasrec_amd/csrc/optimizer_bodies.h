@@ -152,7 +152,12 @@ __device__ __forceinline__ void adagrad_rows_body(const nasrec_adagrad_rows_desc
   const long nrows = d.rows[f];
   float* const sbase = d.state[f];
   float* const tbase = d.table[f];
-  float4 g = *reinterpret_cast<const float4*>(d.gsum + pair * 16 + q * 4);
+  const float* grow = d.gsum + pair * 16;
+  if (d.rank_B > 0) {  // gsum = the receive buffer of an all-gather whose per-rank chunks are rank_stride floats apart
+    const long b = pair / d.Fs, r = b / d.rank_B;
+    grow = d.gsum + r * d.rank_stride + ((b - r * d.rank_B) * d.Fs + f) * 16;
+  }
+  float4 g = *reinterpret_cast<const float4*>(grow + q * 4);
   asm volatile("" ::"v"(lead), "v"((int)row), "v"((int)nrows), "v"(sbase), "v"(tbase), "v"(g.x));  // (all six in flight before the first test)
   if (!lead) return;
   if (row < 0 || row >= nrows) return;  // never write outside a table

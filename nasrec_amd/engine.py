@@ -20,6 +20,8 @@ from . import plan as P
 from . import schedule as S
 
 E = 16
+# largest (global) batch whose row-gradient dedup runs in two halves (csrc/dedup_bodies.h; <= L.DEDUP_IDS_MAX_B); 0 = the one-launch kernels
+DEDUP_SPLIT_MAX_B = min(int(os.environ.get("NASREC_DEDUP_SPLIT_MAX_B", "4096")), L.DEDUP_IDS_MAX_B)
 
 
 def _ptr_array(descs):
@@ -287,12 +289,15 @@ class SupernetEngine:
     # -------------------------------------------------------------------------------------------------------
     @_on_device
     def compile(self, choice, B: int, train: bool, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = False,
-                grad_scale: Optional[float] = None, defer_dw: bool = True) -> CompiledPlan:
-        fast = (id(choice), B, train, clip, eps, graph, grad_scale, defer_dw)
+                grad_scale: Optional[float] = None, defer_dw: bool = True, row_grad_out: Optional[torch.Tensor] = None) -> CompiledPlan:
+        """row_grad_out: storage [B * Fs * 16] the backward writes the per-sample embedding-row gradients into (a data-parallel step
+        hands in the head of its all-gather send buffer: no copy between the backward and the exchange)"""
+        rgo = row_grad_out.data_ptr() if row_grad_out is not None else None
+        fast = (id(choice), B, train, clip, eps, graph, grad_scale, defer_dw, rgo)
         hit = self._last_plan
         if self.cfg.fixed and hit is not None and hit[0] == fast and hit[1] is choice:  # fixed sub-network, same choice object: skip the JSON key
             return hit[2]
-        key = json.dumps([choice, B, train, clip, eps, graph, grad_scale, defer_dw], sort_keys=True, default=_jsonable)
+        key = json.dumps([choice, B, train, clip, eps, graph, grad_scale, defer_dw, rgo], sort_keys=True, default=_jsonable)
         if key in self._plans:
             self._last_plan = (fast, choice, self._plans[key])
             return self._plans[key]
@@ -343,6 +348,9 @@ class SupernetEngine:
             int_buf = P.Buf(ctx, B * self.Fd, need_grad=False, tensor=cp.int_x)
             dense0 = P.DV(int_buf, 0, self.Fd, self.Fd)
             sbuf = ctx.buf(B * self.Fs * E)
+            if row_grad_out is not None:
+                assert row_grad_out.numel() == B * self.Fs * E and row_grad_out.dtype == torch.float32 and row_grad_out.is_contiguous()
+                sbuf.g = row_grad_out
             sparse0 = P.SV(sbuf, 0, self.Fs, self.Fs * E)
             cp.sparse0 = sbuf
             ctx.raw_sparse = sbuf
@@ -427,8 +435,16 @@ class SupernetEngine:
                     last.dseg[q] = None
                 tail = [ctx.bwd[fi + 1]] if plain.nsplit > 1 else []  # (the partial-sum launch of a split final backward)
                 cp.bwd_final_only = Program(pre[1:] + [last] + tail)
-                cp.opt = Program(self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if (sbuf.grad_written and not self.host_embedding)
-                                                       else None, clip, eps))
+                odescs = self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if (sbuf.grad_written and not self.host_embedding)
+                                               else None, clip, eps)
+                cp.ids_on_stage = False
+                if cp.dedup_ids is not None:
+                    if B <= 256:   # the id-only half of the row dedup rides on the staging launch (which holds the caller's ids)
+                        cp.stage.dedup_ids = cp.dedup_ids
+                        cp.ids_on_stage = True
+                    else:          # in-stream programs (large batch): in front of the launch that needs it
+                        odescs = [cp.dedup_ids] + odescs
+                cp.opt = Program(odescs)
                 if graph:
                     cp.step = Program((cp.fb.descs if cp.fb is not None else cp.fwd.descs + cp.bwd.descs) + cp.opt.descs)
                     cp.step.capture(self.stream.cuda_stream)
@@ -498,9 +514,13 @@ class SupernetEngine:
             pre.append(ms)
         cp.bce, cp._pre = bd, pre
 
-    def _optimizer_descs(self, cp, Bg, cat_x, sparse_grad, clip, eps):
-        """clip_grad_norm_ + Adagrad (train_utils.py:285-286): row-sparse on the tables, flat on the dense arena."""
+    def _optimizer_descs(self, cp, Bg, cat_x, sparse_grad, clip, eps, rank_layout=None):
+        """clip_grad_norm_ + Adagrad (train_utils.py:285-286): row-sparse on the tables, flat on the dense arena.
+        rank_layout (data-parallel step): (samples per rank, floats between the ranks' chunks) of `sparse_grad` when it is the receive
+        buffer of an all-gather that carries more than the rows (parallel.py); None = one contiguous [Bg, Fs, 16] array.
+        Leaves `cp.dedup_ids` (the id-only half of the row dedup, to be launched once the ids are in `cat_x`) or None."""
         descs = []
+        cp.dedup_ids = None
         nb = (Bg + 255) // 256
         new = getattr(cp, "arena", None)
         new = (lambda n, dt=torch.float32: cp.arena.alloc(n, dt).tensor()) if new is not None else \
@@ -561,6 +581,38 @@ class SupernetEngine:
             cap = 1024 if self.flat_numel <= (4 << 20) else 2048
             app.dense_blocks = min(cap, ntab if tab is not None else (self.flat_numel + 255) // 256)
             app.clip, app.dense, app.rows = cc, ad, ar
+            if Bg <= DEDUP_SPLIT_MAX_B:
+                # Two halves (csrc/dedup_bodies.h): leaders, duplicate lists and their order depend on the ids only — cp.dedup_ids runs
+                # as soon as the ids are there (B <= 256: on the staging launch; a data-parallel step: behind the ids all-gather, beside the
+                # forward) — and one launch behind the backward sums the duplicate rows IN PLACE and squares what the clip needs.
+                capn = 256
+                while capn < Bg:
+                    capn *= 2
+                if getattr(cp, "dd_order", None) is None:
+                    cp.dd_order = new(self.Fs * capn, torch.int32)
+                    cp.dd_lists = new(self.Fs * capn, torch.int32)
+                    cp.dd_counts = new(self.Fs * 2, torch.int32)
+                row_blocks = max(1, min(512, (Bg * self.Fs * 4 + 255) // 256))
+                if getattr(cp, "emb_partial2", None) is None or cp.emb_partial2.numel() < self.Fs + row_blocks:
+                    cp.emb_partial2 = new(self.Fs + row_blocks)
+                ids = L.DedupIdsDesc()
+                ids.kind, ids.B, ids.Fs, ids.cap = L.OP_DEDUP_IDS, Bg, self.Fs, capn
+                ids.idx, ids.leader = cat_x.data_ptr(), cp.leader.data_ptr()
+                ids.order, ids.lists, ids.counts = cp.dd_order.data_ptr(), cp.dd_lists.data_ptr(), cp.dd_counts.data_ptr()
+                cp.dedup_ids = ids
+                r2 = L.OptReduce2Desc()
+                r2.kind, r2.B, r2.Fs, r2.cap = L.OP_OPT_REDUCE2, Bg, self.Fs, capn
+                r2.rank_B, r2.rank_stride = rank_layout if rank_layout else (0, 0)
+                r2.row_blocks = row_blocks
+                r2.rows, r2.leader = sparse_grad.data_ptr(), cp.leader.data_ptr()
+                r2.order, r2.lists, r2.counts = ids.order, ids.lists, ids.counts
+                r2.sumsq_partial = cp.emb_partial2.data_ptr()
+                r2.sumsq = sq
+                app.clip.partial_b, app.clip.n_b = cp.emb_partial2.data_ptr(), self.Fs + row_blocks
+                app.rows.gsum = sparse_grad.data_ptr()  # summed in place: a leader's row holds its sum
+                app.rows.rank_B, app.rows.rank_stride = r2.rank_B, r2.rank_stride
+                return [r2, app]
+            assert not rank_layout, "the one-launch dedup kernels read a contiguous [B, Fs, 16] array"
             if Bg <= 256:
                 # the five launches collapse into the two that the grid-wide dependencies require
                 red = L.OptReduceDesc()
@@ -647,6 +699,8 @@ class SupernetEngine:
                 self.lr_dev.fill_(float(lr))
             if not self.host_embedding:
                 L.check(L.load().nasrec_launch(sp, C.addressof(cp.gather)))
+            if getattr(cp, "ids_on_stage", False):  # (the staging launch would have carried it)
+                L.check(L.load().nasrec_launch(sp, C.addressof(cp.dedup_ids)))
             return
         d = cp.stage  # prebuilt per plan: only the sources change from step to step
         d.int_src, d.cat_src = int_x.data_ptr(), cat_x.data_ptr()
@@ -692,6 +746,8 @@ class SupernetEngine:
         else:
             self.lr_dev.fill_(float(lr))
             L.check(L.load().nasrec_launch(sp, C.addressof(cp.gather)))
+            if getattr(cp, "ids_on_stage", False):
+                L.check(L.load().nasrec_launch(sp, C.addressof(cp.dedup_ids)))
         if graph:
             cp.step.replay(sp)
         else:

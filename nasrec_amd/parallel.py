@@ -36,31 +36,47 @@ import torch.distributed as dist
 BUCKET_GAP = 16384  # floats: arena ranges closer than this are sent as one all-reduce (fewer, larger collectives)
 
 
+class Collectives:
+    """The step's cross-rank calls behind one object (tools/dp_overhead.py wraps it to leave one kind out and time the rest; the
+    product path never does).  `real_at_world1`: a single-rank group still goes through the library — RCCL's all-gather and
+    all-reduce kernels run (and are captured into the step graph) exactly as on N ranks, which is what a one-GPU box can verify of the
+    N-GPU step; off, a one-rank gather is a copy kernel (the cheapest correct thing)."""
+
+    def __init__(self, real_at_world1: bool = False):
+        self.real = bool(real_at_world1)
+
+    def all_gather(self, out: torch.Tensor, local: torch.Tensor, async_op: bool = False):
+        """out[r*n:(r+1)*n] = local of rank r (n = local.numel()); nccl and gloo.  Returns the work handle of an asynchronous call
+        (None when it completed inline)."""
+        if dist.get_world_size() == 1 and not self.real:
+            # a gather over one rank is a copy: as a kernel on the calling stream, not as the library's device-to-device memcpy (which a
+            # captured graph replays as a memcpy node: ~30 us each on this stack, the whole 62 us the single-rank exchange step cost)
+            out.view(-1).copy_(local.reshape(-1))
+            return None
+        try:
+            w = dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), async_op=async_op)
+        except (RuntimeError, NotImplementedError):
+            n = local.numel()
+            chunks = [out.view(-1)[r * n:(r + 1) * n] for r in range(dist.get_world_size())]
+            w = dist.all_gather(chunks, local.reshape(-1), async_op=async_op)
+        return w if async_op else None
+
+    def all_reduce(self, t: torch.Tensor, async_op: bool = False):
+        w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+        return w if async_op else None
+
+
+_DEFAULT = Collectives()
+
+
 def all_gather_rows(out: torch.Tensor, local: torch.Tensor):
     """out[r*n:(r+1)*n] = local of rank r (n = local.numel()); works on nccl and gloo."""
-    if dist.get_world_size() == 1:
-        # a gather over one rank is a copy: as a kernel on the calling stream, not as the library's device-to-device memcpy (which a
-        # captured graph replays as a memcpy node: ~30 us each on this stack, the whole 62 us the single-rank exchange step cost)
-        out.view(-1).copy_(local.reshape(-1))
-        return
-    try:
-        dist.all_gather_into_tensor(out.view(-1), local.reshape(-1))
-    except (RuntimeError, NotImplementedError):
-        n = local.numel()
-        chunks = [out.view(-1)[r * n:(r + 1) * n] for r in range(dist.get_world_size())]
-        dist.all_gather(chunks, local.reshape(-1))
+    _DEFAULT.all_gather(out, local)
 
 
 def all_gather_rows_async(out: torch.Tensor, local: torch.Tensor):
     """all_gather_rows without blocking the compute stream; returns the work handle (None if it completed inline)"""
-    if dist.get_world_size() == 1:
-        all_gather_rows(out, local)
-        return None
-    try:
-        return dist.all_gather_into_tensor(out.view(-1), local.reshape(-1), async_op=True)
-    except (RuntimeError, NotImplementedError):
-        all_gather_rows(out, local)
-        return None
+    return _DEFAULT.all_gather(out, local, async_op=True)
 
 
 def exchange_gradients(flat_g: torch.Tensor, cat_local: torch.Tensor, sg_local: torch.Tensor, cat_all: torch.Tensor, sg_all: torch.Tensor):
@@ -83,7 +99,11 @@ def coalesce_ranges(ranges: List[Tuple[int, int]], gap: int = BUCKET_GAP) -> Lis
 
 
 DP_SEGMENTS = int(__import__("os").environ.get("NASREC_DP_SEGMENTS", "4"))
-_MEASURE_SKIP = __import__("os").environ.get("NASREC_DP_MEASURE_SKIP", "").split(",")
+# Dense gradients that become final in the LAST pieces of the backward cannot hide behind it: up to this many floats of them ride in the
+# row-gradient all-gather instead of an all-reduce of their own (ONE exposed collective per step), and every rank adds the W copies in
+# rank order.  0 = every piece is all-reduced.
+_DEBUG = __import__("os").environ.get("NASREC_DP_DEBUG", "0") == "1"
+PACK_TAIL_FLOATS = int(__import__("os").environ.get("NASREC_DP_PACK_TAIL", "65536"))
 
 
 def gradient_ready_index(eng, descs):
@@ -173,12 +193,28 @@ class DPPlan:
     loss: torch.Tensor
 
 
+def tail_pieces(segments, budget: int) -> int:
+    """index k such that the ranges of segments[k:] (the LAST pieces of the backward: nothing is left to hide them behind) hold at
+    most `budget` floats in all; len(segments) when nothing fits.  The first piece is never packed when there are several (it is
+    the one that overlaps)."""
+    k, acc = len(segments), 0
+    while k > (1 if len(segments) > 1 else 0):
+        n = sum(m for _, m in segments[k - 1][1])
+        if acc + n > budget:
+            break
+        acc += n
+        k -= 1
+    return k
+
+
 class DataParallelStep:
     def __init__(self, engine, choice, B_local: int, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = True,
-                 force_exchange: bool = False):
+                 force_exchange: bool = False, real_collectives: bool = False):
         """choice: the fixed sub-network's choice, or None for a weight-sharing supernet (the path then comes with every step).
         force_exchange: take the multi-rank code path (all-reduce + all-gather + global-batch optimizer) even in a single-rank
-        process group — lets one GPU exercise exactly what N GPUs run."""
+        process group — lets one GPU exercise exactly what N GPUs run.
+        real_collectives: with it, a single-rank group goes through the communication library too (RCCL's all-gather / all-reduce
+        kernels inside the captured step) instead of the copy a one-rank gather amounts to — adds work, for tests and measurement."""
         self.engine = engine
         self.dp = engine if hasattr(engine, "dp_plan") else EngineDP(engine)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -187,31 +223,75 @@ class DataParallelStep:
         self.graph = bool(graph and self.fixed)
         self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
         self.choice, self.clip, self.eps = choice, clip, eps
+        self.coll = Collectives(real_collectives)
         self._last = None
         self._plans = {}
+        self._last_key = None
         if not self.exchange:
             if self.fixed:
                 self.cp = engine.compile(choice, B_local, True, clip, eps, graph=self.graph)
             return
         Bg = B_local * self.world
         dev = engine.device
+        gdt = getattr(engine, "grad_dtype", torch.float32)
+        self.rows_n = B_local * engine.Fs * 16
         self.cat_all = torch.zeros(Bg, engine.Fs, dtype=torch.int64, device=dev)
-        self.sg_all = torch.zeros(Bg * engine.Fs * 16, dtype=getattr(engine, "grad_dtype", torch.float32), device=dev)
-        self.opt = self.dp.dp_optimizer(Bg, self.cat_all, self.sg_all, clip, eps, False)  # (graph: the whole exchange step is captured as one, _capture)
+        # this rank's share of the row-gradient all-gather: [B, Fs, 16] row gradients | the dense gradients of the backward's last
+        # pieces (fixed sub-networks: `tail`); the receive buffer holds the W shares one after the other
+        cap = PACK_TAIL_FLOATS if self.fixed else 0
+        self.sg_send = torch.zeros(self.rows_n + cap, dtype=gdt, device=dev)
+        self.sg_recv = torch.zeros(self.world * (self.rows_n + cap), dtype=gdt, device=dev)
+        self.tail_n = None  # floats of packed tail per rank: fixed by the first plan (the optimizer's row layout depends on it)
+        self.opt = None
+        self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         if self.fixed:
             self.cp = self._plan(choice)
 
+    # -------------------------------------------------------------------------------------------------------------
     def _plan(self, choice) -> DPPlan:
-        key = id(choice) if self.fixed else json.dumps(choice, sort_keys=True, default=_jsonable)
+        if self.fixed and self._last_key is not None and self._last_key[0] is choice:  # same object as last step: skip the JSON key
+            key = self._last_key[1]
+        else:
+            # keyed on CONTENT: a caller that rebuilds an equal choice dict every step must not re-compile (and re-capture) every step
+            key = json.dumps(choice, sort_keys=True, default=_jsonable)
+            self._last_key = (choice, key)
         hit = self._plans.get(key)
         if hit is not None and getattr(getattr(hit, "cp", None), "evicted", False):
             hit = None  # the engine recycled this plan's slot for another path
         if hit is None:
             if len(self._plans) >= 8:
                 self._plans.pop(next(iter(self._plans)))
-            hit = self.dp.dp_plan(choice, self.B, 1.0 / (self.B * self.world), self.clip, self.eps, False)
+            kw = {}
+            if self.fixed and self.sg_send.numel() > self.rows_n and getattr(self.dp, "accepts_row_grad_out", False):
+                kw["row_grad_out"] = self.sg_send[:self.rows_n]  # the backward writes the row gradients where the gather sends them from
+            hit = self.dp.dp_plan(choice, self.B, 1.0 / (self.B * self.world), self.clip, self.eps, False, **kw)
+            self._layout(hit)
             self._plans[key] = hit
         return hit
+
+    def _layout(self, plan):
+        """which dense-gradient ranges ride in the row-gradient all-gather (plan.tail, plan.first_packed), and the optimizer over
+        the resulting receive-buffer layout (built with the first plan)"""
+        segs = plan.segments
+        plan.tail, plan.first_packed = [], len(segs)
+        if self.fixed and PACK_TAIL_FLOATS > 0:
+            k = tail_pieces(segs, self.sg_send.numel() - self.rows_n)
+            plan.first_packed = k
+            plan.tail = [rg for _, ranges in segs[k:] for rg in ranges]
+        tail_n = sum(n for _, n in plan.tail)
+        if self.tail_n is None:
+            self.tail_n = tail_n
+            stride = self.rows_n + tail_n
+            kw = {"rank_layout": (self.B, stride)} if tail_n else {}
+            self.recv = self.sg_recv[:self.world * stride]
+            self.opt = self.dp.dp_optimizer(self.B * self.world, self.cat_all, self.recv, self.clip, self.eps, False, **kw)  # (graph: the whole exchange step is captured as one, _capture)
+            self.ids_half = getattr(self.dp, "dp_dedup_ids", lambda: None)()
+            self.tail_ops = None
+            if tail_n:
+                mk = getattr(self.dp, "dp_tail_ops", None)
+                self.tail_ops = mk(self.sg_send, self.recv, self.rows_n, plan.tail, self.world) if mk is not None else \
+                    _torch_tail_ops(self.engine.flat_g, self.sg_send, self.recv, self.rows_n, plan.tail, self.world)
+        assert tail_n == self.tail_n, "every plan of one DataParallelStep packs the same number of dense-gradient floats"
 
     def step(self, int_x, cat_x, y, lr: float, choice=None):
         eng = self.engine
@@ -240,27 +320,63 @@ class DataParallelStep:
     def _exchange_step(self, plan):
         """forward, backward in segments, the exchange under it, the optimizer over the global batch — the same sequence for fixed
         sub-networks and sampled paths, eager (work handles) or under graph capture.
-          ids          all-gather right after staging: hidden under the whole forward / backward;
+          ids          all-gather right after staging: hidden under the whole forward / backward; behind it, on a side stream, the
+                       id-only half of the global batch's row dedup (leaders, duplicate lists: csrc/dedup_bodies.h) — beside the
+                       forward, off the step's tail;
           dense grads  one all-reduce per (segment, arena range) as soon as the segment that completes the range has been
                        enqueued — RCCL's stream waits for that point of the compute stream only, the rest of the backward runs
-                       beside the transfer; the last segment's ranges are the exposed part;
-          row grads    all-gather when the backward has reached the embedding stem (its last launch);
+                       beside the transfer.  The LAST pieces' ranges (nothing left to hide them behind; `plan.tail`, a few tens of
+                       KB) are not all-reduced: they ride behind the row gradients in the one all-gather and every rank adds the
+                       W copies in rank order (same bits on every rank);
+          row grads    all-gather when the backward has reached the embedding stem (its last launch): the step's ONE exposed collective;
         the compute stream waits for all of them in front of the optimizer launches, nowhere else."""
         flat_g = self.engine.flat_g
-        skip = _MEASURE_SKIP  # measurement knob (tools/dp_overhead.sh): leave collectives out to see what each kind costs; never set in a run
-        pending = [all_gather_rows_async(self.cat_all, plan.cat_local)] if "gather" not in skip else []
+        coll = self.coll
+        pending = []
+        w_ids = coll.all_gather(self.cat_all, plan.cat_local, async_op=True)
+        ids_done = None
+        if self.ids_half is not None:
+            if self._side is not None:
+                main = torch.cuda.current_stream(self.engine.device)
+                self._side.wait_stream(main)  # (the previous step's optimizer has read the lists this launch rewrites)
+                with torch.cuda.stream(self._side):
+                    if w_ids is not None:
+                        w_ids.wait()
+                    self.ids_half()
+                    ids_done = torch.cuda.Event()
+                    ids_done.record(self._side)
+            else:
+                if w_ids is not None:
+                    w_ids.wait()
+                self.ids_half()
+        elif w_ids is not None:
+            pending.append(w_ids)
         plan.forward()
-        for run, ranges in plan.segments:
+        for k, (run, ranges) in enumerate(plan.segments):
             run()
+            if k >= plan.first_packed:
+                continue
             for off, n in ranges:
-                if "reduce" not in skip:
-                    pending.append(dist.all_reduce(flat_g[off:off + n], op=dist.ReduceOp.SUM, async_op=True))
-        if "gather" not in skip:
-            pending.append(all_gather_rows_async(self.sg_all, plan.sparse_grad))
+                pending.append(coll.all_reduce(flat_g[off:off + n], async_op=True))
+        if self.tail_n:
+            send = self.sg_send[:self.rows_n + self.tail_n]
+            if plan.sparse_grad.data_ptr() != send.data_ptr():
+                send[:self.rows_n].copy_(plan.sparse_grad.view(-1))
+            self.tail_ops[0]()  # dense gradients of the last pieces -> behind the rows
+        else:
+            send = plan.sparse_grad
+        pending.append(coll.all_gather(self.recv, send, async_op=True))
         for w in pending:
             if w is not None:
                 w.wait()  # nccl: the compute stream waits for the collective (no host block)
+        if ids_done is not None:
+            torch.cuda.current_stream(self.engine.device).wait_event(ids_done)
+        if self.tail_n:
+            self.tail_ops[1]()  # flat_g[tail ranges] = sum over ranks, in rank order
         self.opt(plan)
+        if _DEBUG and getattr(plan, "never_written", None) and not torch.cuda.is_current_stream_capturing():
+            for n in plan.never_written:
+                assert float(self.engine.grads[n].abs().max()) == 0.0, "gradient of %s is written by nothing and must stay zero" % n
 
     def _capture(self, plan):
         """the exchange step of a fixed sub-network as ONE graph (torch.cuda.CUDAGraph: ProcessGroupNCCL's collectives are capturable,
@@ -273,7 +389,7 @@ class DataParallelStep:
         w0 = torch.zeros(8, device=dev)
         w1 = torch.zeros(8 * self.world, device=dev)
         dist.all_reduce(w0)
-        all_gather_rows(w1, w0)
+        Collectives(True).all_gather(w1, w0)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         try:
@@ -300,46 +416,112 @@ class DataParallelStep:
         return self.engine.compile(choice, B, True, self.clip, self.eps, graph=self.graph)
 
 
+def _torch_tail_ops(flat_g, send, recv, rows_n, tail, world):
+    """pack / unpack of the packed tail with plain tensor operations (any device; the engine has one launch for each: EngineDP.dp_tail_ops)"""
+    stride = rows_n + sum(n for _, n in tail)
+
+    def pack():
+        pos = rows_n
+        for off, n in tail:
+            send[pos:pos + n].copy_(flat_g[off:off + n])
+            pos += n
+
+    def unpack():
+        R = recv.view(world, stride)
+        pos = rows_n
+        for off, n in tail:
+            acc = R[0, pos:pos + n].clone()
+            for r in range(1, world):  # rank order
+                acc += R[r, pos:pos + n]
+            flat_g[off:off + n].copy_(acc)
+            pos += n
+
+    return pack, unpack
+
+
 class EngineDP:
     """SupernetEngine behind the data-parallel protocol (programs, hipGraph segments, arena ranges per block)."""
+    accepts_row_grad_out = True
 
     def __init__(self, engine):
         self.engine = engine
+        self._holder = None
 
-    def dp_optimizer(self, Bg, cat_all, sg_all, clip, eps, graph):
+    def dp_optimizer(self, Bg, cat_all, sg_all, clip, eps, graph, rank_layout=None):
         from .engine import Program
         eng = self.engine
         with torch.cuda.stream(eng.stream):
-            holder = _Holder()
+            holder = self._holder = _Holder()
             eng._ensure_table_state()
-            prog = Program(eng._optimizer_descs(holder, Bg, cat_all, sg_all, clip, eps))
+            prog = Program(eng._optimizer_descs(holder, Bg, cat_all, sg_all, clip, eps, rank_layout=rank_layout))
             prog.holder = holder
             if graph:
                 prog.capture(eng.stream.cuda_stream)
         eng.stream.synchronize()
         if eng.cfg.fixed:
             return (lambda plan: prog.replay(eng._sp())) if graph else (lambda plan: prog.run(eng._sp()))
+        shared = ("leader", "gsum", "emb_partial", "dense_partial", "dd_order", "dd_lists", "dd_counts", "emb_partial2")
 
         def run(plan):
             # weight-sharing supernet: zero_grad / norm / Adagrad cover the arena ranges of the plan's path only (engine.compile),
             # so the optimizer program is the plan's: same work buffers, the plan's chunk table
             if getattr(plan, "opt_prog", None) is None:
                 h = _Holder()
-                h.leader, h.gsum, h.emb_partial, h.dense_partial = holder.leader, holder.gsum, holder.emb_partial, holder.dense_partial
+                for k in shared:
+                    if hasattr(holder, k):
+                        setattr(h, k, getattr(holder, k))
                 h.chunk_tab, h.nchunks = plan.cp.chunk_tab, plan.cp.nchunks
-                plan.opt_prog = Program(eng._optimizer_descs(h, Bg, cat_all, sg_all, clip, eps))
+                plan.opt_prog = Program(eng._optimizer_descs(h, Bg, cat_all, sg_all, clip, eps, rank_layout=rank_layout))
                 plan.opt_prog.holder = h
             plan.opt_prog.run(eng._sp())
 
         return run
 
-    def dp_plan(self, choice, B, grad_scale, clip, eps, graph) -> DPPlan:
+    def dp_dedup_ids(self):
+        """launcher of the id-only half of the global batch's row dedup (None: this batch size runs the one-launch kernels): to be
+        enqueued once the ids all-gather has landed, anywhere before the optimizer"""
+        import ctypes as C
+        from . import _lib as L
+        d = getattr(self._holder, "dedup_ids", None)
+        if d is None:
+            return None
+        eng, lib = self.engine, L.load()
+        return lambda: L.check(lib.nasrec_launch(eng._sp(), C.addressof(d)))
+
+    def dp_tail_ops(self, send, recv, rows_n, tail, world):
+        """(pack, unpack) of the dense gradients that ride in the row-gradient all-gather, one launch each: COPY_SEGS of the arena ranges
+        behind this rank's rows; REDUCE_ROWS over the W ranks' copies (fixed = rank order) back into the arena"""
+        import ctypes as C
+        from . import _lib as L
+        eng, lib = self.engine, L.load()
+        tail_n = sum(n for _, n in tail)
+        stride = rows_n + tail_n
+        if len(tail) > L.MAX_SEGS or stride >= (1 << 31):
+            return _torch_tail_ops(eng.flat_g, send, recv, rows_n, tail, world)
+        cs = L.CopySegsDesc()
+        cs.kind, cs.B, cs.nseg, cs.ld_dst = L.OP_COPY_SEGS, 1, len(tail), tail_n
+        cs.dst = send.data_ptr() + 4 * rows_n
+        rr = L.ReduceRowsDesc()
+        rr.kind, rr.R, rr.C, rr.ld = L.OP_REDUCE_ROWS, world, tail_n, stride
+        rr.in_ = recv.data_ptr() + 4 * rows_n
+        rr.ndst = len(tail)
+        pos = 0
+        for q, (off, n) in enumerate(tail):
+            cs.seg[q], cs.width[q], cs.ld[q], cs.off[q] = eng.flat_g.data_ptr() + 4 * off, n, n, pos
+            rr.dst[q], rr.dst_off[q], rr.dst_len[q] = eng.flat_g.data_ptr() + 4 * off, pos, n
+            pos += n
+        keep = (cs, rr)
+        return (lambda: L.check(lib.nasrec_launch(eng._sp(), C.addressof(keep[0])))), (lambda: L.check(lib.nasrec_launch(eng._sp(), C.addressof(keep[1]))))
+
+    def dp_plan(self, choice, B, grad_scale, clip, eps, graph, row_grad_out=None) -> DPPlan:
         from .engine import Program
         eng = self.engine
         fixed = eng.cfg.fixed
         # weight-gradient products stay in backward order (never parked behind the backward): a block's gradients are complete when
         # its backward is, and can travel under the blocks that follow
-        cp = eng.compile(choice, B, True, clip, eps, graph=False, grad_scale=grad_scale, defer_dw=False)
+        cp = eng.compile(choice, B, True, clip, eps, graph=False, grad_scale=grad_scale, defer_dw=False, row_grad_out=row_grad_out)
+        cp.ids_on_stage = False  # the optimizer of a data-parallel step runs over the GLOBAL batch: its id half follows the ids all-gather
+        cp.stage.dedup_ids = L_DedupIdsDesc()
         plan = DPPlan()
         plan.cp = cp
         plan.cat_local, plan.loss = cp.cat_x, cp.loss
@@ -360,6 +542,12 @@ class EngineDP:
                 plan.ready, plan.cuts = ready, [end for end, _ in pieces]
                 segs, start = [], 0
                 order = sorted(eng.offsets, key=lambda n: eng.offsets[n])
+                # a merged range runs over gradients NO launch of this step writes.  They must be zero on every rank for ever (an in-place
+                # all-reduce multiplies a leftover by the world size every step, and the whole-arena sum of squares feeds it into the clip):
+                # zeroed here, once — nothing of the plan writes them afterwards (`NASREC_DP_DEBUG=1` checks it after every eager step)
+                plan.never_written = [n for n in order if n not in ready]
+                for n in plan.never_written:
+                    eng.grads[n].zero_()
                 for end, names in pieces:
                     prog = Program(descs[start:end])
                     segs.append(((lambda p: (lambda: p.run(eng._sp())))(prog), merge_over_unwritten(eng, order, set(names), ready)))
@@ -416,6 +604,11 @@ class EngineDP:
 
 class _Holder:
     pass
+
+
+def L_DedupIdsDesc():
+    from . import _lib as L
+    return L.DedupIdsDesc()
 
 
 def _jsonable(o):

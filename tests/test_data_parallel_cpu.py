@@ -179,12 +179,16 @@ class OracleEngine:
             plan.segments = [(fwd_bwd, lazy[0])] + [((lambda: None), r) for r in lazy[1:]]
         return plan
 
-    def dp_optimizer(self, Bg, cat_all, sg_all, clip, eps, graph):
+    def dp_optimizer(self, Bg, cat_all, sg_all, clip, eps, graph, rank_layout=None):
         from oracle import nasrec_oracle as O
         eng, P, Fs = self, self.P, self.Fs
 
         def run(plan=None):
-            sg = sg_all.view(Bg, Fs, 16)
+            if rank_layout is None:
+                sg = sg_all.view(Bg, Fs, 16)
+            else:  # the receive buffer of the all-gather: per rank [Bl, Fs, 16] rows, then the dense gradients that rode along
+                Bl, stride = rank_layout
+                sg = sg_all.view(Bg // Bl, stride)[:, :Bl * Fs * 16].reshape(Bg, Fs, 16)
             uniq = []
             for f in range(Fs):
                 ids, inv = torch.unique(cat_all[:, f], return_inverse=True)
@@ -220,7 +224,7 @@ def _dp_case(name):
     """-> (cfg, P, batches [(int_x, cat_x, y)], choices or None, lr) for the three scenarios"""
     from helpers import GOLDEN, load_golden, oracle_cfg, oracle_params
     from oracle import nasrec_oracle as O
-    if name == "fixed":
+    if name.startswith("fixed"):
         z, meta = load_golden(os.path.join(GOLDEN, "fixed_criteo_autoctr.npz"))
         cfg, P = oracle_cfg(meta), oracle_params(meta)
         b = (torch.tensor(z["int_x"]).double(), torch.tensor(z["cat_x"]), torch.tensor(z["y"]).double().view(-1, 1))
@@ -242,16 +246,22 @@ def _dp_case(name):
 
 
 def _dp_step_worker(rank, port, name, out):
+    from nasrec_amd import parallel
     from nasrec_amd.parallel import DataParallelStep
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     torch.set_num_threads(2)
+    # "fixed": the dense gradients of the backward's last piece ride in the row-gradient all-gather (here: all of them — the stand-in
+    # has one piece) and are added in rank order; "fixed_allreduce": every piece is all-reduced
+    parallel.PACK_TAIL_FLOATS = {"fixed": 1 << 30, "fixed_allreduce": 0}.get(name, parallel.PACK_TAIL_FLOATS)
     cfg, P, batches, choices, lr = _dp_case(name)
     Fs = batches[0][1].shape[1]
     Bl = batches[0][0].shape[0] // WORLD
     eng = OracleEngine(cfg, P, Fs)
     dp = DataParallelStep(eng, choices[0] if cfg.fixed else None, Bl, clip=5.0, eps=1e-2, graph=False)
     assert dp.exchange and dp.world == WORLD
+    if name.startswith("fixed"):
+        assert (dp.tail_n > 0) == (name == "fixed"), dp.tail_n
     sl = slice(rank * Bl, (rank + 1) * Bl)
     losses = []
     for (int_x, cat_x, y), ch in zip(batches, choices):
@@ -267,7 +277,7 @@ import json  # noqa: E402
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("name", ["fixed", "sampled", "large_batch"])
+@pytest.mark.parametrize("name", ["fixed", "fixed_allreduce", "sampled", "large_batch"])
 def test_data_parallel_step_equals_single_process_at_the_global_batch(name):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -289,7 +299,7 @@ def test_data_parallel_step_equals_single_process_at_the_global_batch(name):
     for k in out[0][0]:
         assert torch.equal(out[0][0][k], out[1][0][k]), k  # replicas stay bit-identical
     # the sum of the ranks' losses (each scaled by 1/(B_local*world)) is the global mean loss of the step
-    if name != "fixed":
+    if not name.startswith("fixed"):
         untouched = [k for k in P if k not in touched]
         assert untouched, "a sampled path leaves part of the supernet unused"
         for k in untouched:  # grad None in the reference: neither value nor Adagrad state may move

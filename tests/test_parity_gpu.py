@@ -4,6 +4,7 @@ and against the fp64 oracle, for every committed sub-network / supernet case.  R
 Tolerances (BASELINE.json: "fp32 logits within 1e-5"): |logit_hip - logit_ref_fp64| <= 1e-5 * max(1, max|logit|) AND
 <= max(1e-5, 1.25 x the reference's own |fp32 - fp64| on the same inputs), i.e. absolute 1e-5 wherever the reference's fp32 run meets it;
 gradient checksums within 2e-5 of the gradient norm; three Adagrad steps keep parameters within 2e-5."""
+import json
 import os
 
 import numpy as np
@@ -254,17 +255,25 @@ def test_data_parallel_code_path_single_rank():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         outs = []
-        for force in (False, True):
+        # (plain step; exchange forced on with a one-rank gather as a copy kernel; exchange forced on with RCCL's all-gather / all-reduce
+        # kernels inside the captured step — what N ranks run, as far as one rank can)
+        for force, real in ((False, False), (True, False), (True, True)):
             eng = build_engine(z, meta)
-            dp = DataParallelStep(eng, meta["choice"], int_x.shape[0], clip=5.0, eps=1e-2, graph=True, force_exchange=force)
+            dp = DataParallelStep(eng, dict(meta["choice"]), int_x.shape[0], clip=5.0, eps=1e-2, graph=True, force_exchange=force, real_collectives=real)
             assert dp.exchange == force
             for _ in range(3):
-                dp.step(int_x, cat_x, y, lr=0.05)
+                # an EQUAL choice rebuilt every step must hit the same plan (and the same captured graph): plans are keyed on content
+                dp.step(int_x, cat_x, y, lr=0.05, choice=json.loads(json.dumps(meta["choice"])) if force else None)
             torch.cuda.synchronize()
             outs.append(eng.state_dict())
             if force:
+                assert len(dp._plans) == 1
                 plan = dp._last[1]
                 assert isinstance(plan.step_graph, torch.cuda.CUDAGraph), "the exchange step should be captured as one graph"
+                assert dp.ids_half is not None, "the id-only half of the row dedup should run beside the forward"
+                # the last pieces' dense gradients ride in the row-gradient all-gather: the pieces in front of them are all-reduced
+                assert dp.tail_n == sum(n for _, rg in plan.segments[plan.first_packed:] for _, n in rg) and 0 < dp.tail_n <= 65536
+                assert 1 <= plan.first_packed < len(plan.segments)
                 # the pieces' all-reduce ranges: disjoint, exactly the parameters some launch writes, each final at its cut
                 names = sorted(eng.offsets, key=lambda n: eng.offsets[n])
                 sent = torch.zeros(eng.flat_numel, dtype=torch.int32)
@@ -294,6 +303,7 @@ def test_data_parallel_code_path_single_rank():
                     assert torch.equal(sd2[k], outs[-1][k]), k
         for k in outs[0]:
             assert torch.allclose(outs[0][k], outs[1][k], rtol=0, atol=1e-6), k
+            assert torch.equal(outs[1][k], outs[2][k]), k  # the library's one-rank collectives move the same bits as the copy
     finally:
         if own_pg:
             dist.destroy_process_group()

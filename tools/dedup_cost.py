@@ -26,16 +26,30 @@ for cfgid, world in ((2, 8), (2, 4), (2, 2), (2, 1), (5, 8), (3, 8), (4, 8), (5,
 
     class H:
         pass
-    h = H()
-    descs = eng._optimizer_descs(h, Bg, cat, sg, 5.0, 1e-2)
+    import nasrec_amd.engine as E
     sp = torch.cuda.current_stream().cuda_stream
     names = {getattr(L, n): n[3:] for n in dir(L) if n.startswith("OP_")}
     parts = []
-    for d in descs:
-        us = bench.time_desc(lib, L, sp, d, iters=20) * 1e3
-        parts.append("%s %.0f us" % (names[d.kind], us))
+    for label, cap in (("two halves", E.DEDUP_SPLIT_MAX_B), ("one launch", 0)):
+        if label == "two halves" and Bg > L.DEDUP_IDS_MAX_B:
+            continue
+        keep = E.DEDUP_SPLIT_MAX_B
+        E.DEDUP_SPLIT_MAX_B = cap
+        h = H()
+        sgc = sg.clone()  # (the two-halves launch sums in place)
+        descs = eng._optimizer_descs(h, Bg, cat, sgc, 5.0, 1e-2)
+        E.DEDUP_SPLIT_MAX_B = keep
+        row = []
+        if h.dedup_ids is not None:  # off the tail: beside the forward (N > 1) / on the staging launch (B <= 256)
+            row.append("[hidden: DEDUP_IDS %.1f us]" % (bench.time_desc(lib, L, sp, h.dedup_ids, iters=20) * 1e3))
+        tail = 0.0
+        for d in descs:
+            us = bench.time_desc(lib, L, sp, d, iters=20) * 1e3
+            tail += us
+            row.append("%s %.1f us" % (names[d.kind], us))
+        parts.append("%s: %s = %.1f us behind the backward" % (label, ", ".join(row), tail))
     torch.cuda.synchronize()
     eng.check_indices()
-    print("cfg %d x %d GPUs: global batch %d x %d fields (%.1f MB of row gradients): %s" % (cfgid, world, Bg, Fs, Bg * Fs * 64 / 1e6, ", ".join(parts)))
+    print("cfg %d x %d GPUs: global batch %d x %d fields (%.1f MB of row gradients)\n    %s" % (cfgid, world, Bg, Fs, Bg * Fs * 64 / 1e6, "\n    ".join(parts)))
     del eng, cat, sg
     torch.cuda.empty_cache()

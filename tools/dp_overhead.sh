@@ -9,10 +9,17 @@ run() { name=$1; shift; env "$@" timeout 200 python bench.py --force-dp-path --n
 rm -f $O/result.txt
 timeout 200 python bench.py --no-cpu-baseline --steps 600 --warmup 50 2>/dev/null | grep '^{' | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('plain', round(r['ms_per_step'],4), round(r['median_ms_per_step'],4))" >> $O/result.txt
 run all A=1
-run no_gather NASREC_DP_MEASURE_SKIP=gather
-run no_reduce NASREC_DP_MEASURE_SKIP=reduce
-run none NASREC_DP_MEASURE_SKIP=gather,reduce
+run no_gather NASREC_BENCH_DP_SKIP=gather
+run no_reduce NASREC_BENCH_DP_SKIP=reduce
+run none NASREC_BENCH_DP_SKIP=gather,reduce
 run pieces1 NASREC_DP_SEGMENTS=1
 run pieces2 NASREC_DP_SEGMENTS=2
 run pieces8 NASREC_DP_SEGMENTS=8
+run no_pack NASREC_DP_PACK_TAIL=0
+# ... and with RCCL's own kernels inside the captured step (a one-rank gather is a copy kernel otherwise)
+runreal() { name=$1; shift; env "$@" timeout 200 python bench.py --force-dp-path --real-collectives --no-cpu-baseline --steps 600 --warmup 50 2>/dev/null | grep '^{' | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('$name', round(r['ms_per_step'],4), round(r['median_ms_per_step'],4), r['config'].get('dp_exchange',{}).get('launches_up_to_cut'))" >> $O/result.txt; }
+runreal real_all A=1
+runreal real_no_gather NASREC_BENCH_DP_SKIP=gather
+runreal real_no_reduce NASREC_BENCH_DP_SKIP=reduce
+runreal real_no_pack NASREC_DP_PACK_TAIL=0
 cat $O/result.txt
