@@ -434,20 +434,23 @@ typedef struct nasrec_opt_apply_desc {
  * The row-sparse embedding backward in two halves (round 5).  NASREC_OP_EMB_DEDUP above does everything behind the backward pass;
  * but which sample leads a row, and which samples repeat it, depends on the IDS only — known before the forward pass starts (one
  * GPU: when the batch is staged; N GPUs: when the ids all-gather lands, nasrec_amd/parallel.py).  So:
- *   NASREC_OP_DEDUP_IDS   (any time after the ids are known; B <= NASREC_DEDUP_IDS_MAX_B) per field: sort (id, sample) keys; a RUN =
- *                         the samples of one id in ascending order, a SUB-RUN = the part of a run inside one 256-sample chunk.  Writes
- *                         leader[b,f] (0 duplicate, 1 leader without duplicates, 2 leader with duplicates), order[f][p] = sample at sorted
- *                         position p (bit 31: first of its sub-run), list A = sub-runs with >= 2 members, list B = runs with >= 2 sub-runs
- *                         (entries: start position | length << 16 | bit 31 of an A entry: the sub-run is its whole run), counts[f] = their
- *                         lengths.  NASREC_OP_STAGE_INPUTS can carry it (stage.dedup_ids.order != NULL).
+ *   NASREC_OP_DEDUP_IDS   (any time after the ids are known; B <= NASREC_DEDUP_IDS_MAX_B) per field.  A RUN = the samples of one id in
+ *                         ascending order, a SUB-RUN = the part of a run inside one 256-sample chunk.  Writes leader[b,f] (0 duplicate,
+ *                         1 leader without duplicates, 2 leader with duplicates); order[f][..] = the runs that have duplicates, each run
+ *                         contiguous and ascending (B <= 256: all-pairs match masks, only such runs; above: the whole batch sorted by
+ *                         (id, sample)); list A = the sub-runs with >= 2 members (start in `order` | length << 16 | bit 31: the sub-run is its
+ *                         whole run); list B = the runs with >= 2 sub-runs (start in `heads` | number of sub-runs << 16); heads[f][..] = the
+ *                         first sample of every sub-run of the list-B runs, in chunk order; counts[f] = lengths of the two lists.
+ *                         NASREC_OP_STAGE_INPUTS can carry it (stage.dedup_ids.order != NULL, B <= 256).
  *   NASREC_OP_OPT_REDUCE2 (behind the backward pass) workgroups [0, Fs): per field, IN PLACE over the per-sample row gradients, the sum of
  *                         every sub-run into its first row in ascending sample order, then of every multi-chunk run's sub-run sums into the
  *                         leader's row in chunk order — the summation order of NASREC_OP_EMB_DEDUP at every batch size, bit for bit — and
  *                         the sum of squares of the leaders with duplicates; workgroups [Fs, Fs + row_blocks): sum of squares of the
  *                         leaders without; the remaining sumsq.nblocks workgroups: NASREC_OP_SUMSQ of the dense gradient arena.
+ *                         (256-thread workgroups for B <= 256, 1024-thread workgroups above: a field's rows are staged in LDS at once.)
  * NASREC_OP_OPT_APPLY then reads leader / rows as before (rows.gsum = the same array: a leader's row now holds its sum).
  * ---------------------------------------------------------------------------------------------- */
-#define NASREC_DEDUP_IDS_MAX_B 4096
+#define NASREC_DEDUP_IDS_MAX_B 2048
 typedef struct nasrec_dedup_ids_desc {
   int32_t kind; /* NASREC_OP_DEDUP_IDS */
   int32_t B, Fs;
@@ -457,6 +460,7 @@ typedef struct nasrec_dedup_ids_desc {
   int32_t* order;       /* [Fs, cap] out */
   int32_t* lists;       /* [Fs, 2, cap / 2] out: list A, list B */
   int32_t* counts;      /* [Fs, 2] out */
+  int32_t* heads;       /* [Fs, cap] out (B > 256 only; may be NULL for B <= 256) */
 } nasrec_dedup_ids_desc_t;
 
 typedef struct nasrec_opt_reduce2_desc {
@@ -470,6 +474,7 @@ typedef struct nasrec_opt_reduce2_desc {
   const int32_t* order;
   const int32_t* lists;
   const int32_t* counts;
+  const int32_t* heads;
   float* sumsq_partial;  /* [Fs + row_blocks] out */
   nasrec_sumsq_desc_t sumsq; /* dense arena (sumsq.nblocks workgroups; 0: none) */
 } nasrec_opt_reduce2_desc_t;

@@ -164,16 +164,17 @@ class ActBwdDesc(C.Structure):
                 ("dims_in_use", i32), ("dy", vp), ("z", vp), ("dz", vp)]
 
 
-DEDUP_IDS_MAX_B = 4096  # NASREC_DEDUP_IDS_MAX_B
+DEDUP_IDS_MAX_B = 2048  # NASREC_DEDUP_IDS_MAX_B
 
 
 class DedupIdsDesc(C.Structure):
-    _fields_ = [("kind", i32), ("B", i32), ("Fs", i32), ("cap", i32), ("idx", vp), ("leader", vp), ("order", vp), ("lists", vp), ("counts", vp)]
+    _fields_ = [("kind", i32), ("B", i32), ("Fs", i32), ("cap", i32), ("idx", vp), ("leader", vp), ("order", vp), ("lists", vp), ("counts", vp),
+                ("heads", vp)]
 
 
 class OptReduce2Desc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("Fs", i32), ("cap", i32), ("rank_B", i32), ("row_blocks", i32), ("rank_stride", i64), ("rows", vp),
-                ("leader", vp), ("order", vp), ("lists", vp), ("counts", vp), ("sumsq_partial", vp), ("sumsq", SumsqDesc)]
+                ("leader", vp), ("order", vp), ("lists", vp), ("counts", vp), ("heads", vp), ("sumsq_partial", vp), ("sumsq", SumsqDesc)]
 
 
 class StageDesc(C.Structure):

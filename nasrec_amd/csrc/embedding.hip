@@ -32,10 +32,10 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const nasrec_embed_de
 // embedding gather of the step riding along — and, in `ids_blocks` more workgroups behind them, the id-only half of the optimizer's
 // row dedup (dedup_bodies.h): the ids are in this launch's hands, and nothing reads that half's result before the backward is done
 __global__ __launch_bounds__(256) void stage_inputs_kernel(const nasrec_stage_desc_t d, int base_blocks) {
-  __shared__ unsigned long long dd_key[256];
+  __shared__ __attribute__((aligned(16))) int dd_sidx[256];
   __shared__ int dd_sh[4];
   if ((int)blockIdx.x >= base_blocks) {
-    dedup_ids_body<256>(d.dedup_ids, d.cat_src, d.B, d.Fs, (int)blockIdx.x - base_blocks, dd_key, dd_sh);
+    dedup_ids_small_body(d.dedup_ids, d.cat_src, d.B, d.Fs, (int)blockIdx.x - base_blocks, dd_sidx, dd_sh);
     return;
   }
   const int t = blockIdx.x * 256 + threadIdx.x;
@@ -420,39 +420,95 @@ int launch_adagrad_rows(hipStream_t st, const nasrec_adagrad_rows_desc_t* d) {
 }
 
 // ---- the two-halves row-sparse backward (dedup_bodies.h) -----------------------------------------------------------
-template <int CAP>
-__global__ __launch_bounds__(256) void dedup_ids_kernel(const nasrec_dedup_ids_desc_t d) {
-  __shared__ unsigned long long key[CAP];
+__global__ __launch_bounds__(256) void dedup_ids_small_kernel(const nasrec_dedup_ids_desc_t d) {
+  __shared__ __attribute__((aligned(16))) int sidx[256];
   __shared__ int sh[4];
-  dedup_ids_body<CAP>(d, d.idx, d.B, d.Fs, blockIdx.x, key, sh);
+  dedup_ids_small_body(d, d.idx, d.B, d.Fs, blockIdx.x, sidx, sh);
+}
+
+__global__ __launch_bounds__(256) void dedup_ids_sort_kernel(const nasrec_dedup_ids_desc_t d) {
+  __shared__ unsigned long long key[NASREC_DEDUP_IDS_MAX_B];
+  __shared__ int sh[4];
+  dedup_ids_sort_body<NASREC_DEDUP_IDS_MAX_B>(d, d.idx, d.B, d.Fs, blockIdx.x, key, sh);
 }
 
 int launch_dedup_ids(hipStream_t st, const nasrec_dedup_ids_desc_t* d) {
   const int rc = dedup_ids_check(d, d->B, d->Fs, "dedup_ids");
   if (rc) return rc;
   if (!d->idx) return nasrec_set_error(-2, "dedup_ids: null idx");
-  if (d->cap <= 256) hipLaunchKernelGGL(dedup_ids_kernel<256>, dim3(d->Fs), dim3(256), 0, st, *d);
-  else hipLaunchKernelGGL(dedup_ids_kernel<NASREC_DEDUP_IDS_MAX_B>, dim3(d->Fs), dim3(256), 0, st, *d);
+  if (d->B <= 256 && d->cap == 256) {
+    hipLaunchKernelGGL(dedup_ids_small_kernel, dim3(d->Fs), dim3(256), 0, st, *d);
+  } else {
+    if (!d->heads) return nasrec_set_error(-2, "dedup_ids: B=%d > 256 needs the heads array", d->B);
+    hipLaunchKernelGGL(dedup_ids_sort_kernel, dim3(d->Fs), dim3(256), 0, st, *d);
+  }
   return nasrec_check_launch("dedup_ids");
 }
 
-// NASREC_OP_OPT_REDUCE2.  R = rows a thread stages per round (1: B <= 256, the one-GPU batch; 4: up to 4096 samples in rounds of 1024).
-// Dynamic LDS: rows [256 R][20] floats | ord [CAP] | lst [CAP] | red [256] | hd [16][16].
-#define OR2_CAP(R) ((R) == 1 ? 256 : NASREC_DEDUP_IDS_MAX_B)
-#define OR2_LDS_BYTES(R) (4 * (256 * (R) * 20 + 2 * OR2_CAP(R) + 256))
+// NASREC_OP_OPT_REDUCE2.  T threads per workgroup, RPT rows staged per thread: <256, 1> for B <= 256 (the one-GPU batch), <1024, 2>
+// up to 2048 samples (the global batch of 8 ranks x 256): ALL rows of a field sit in LDS at once (2048 x 64 B = 128 KB), so both
+// summation phases read LDS only.  A run / sub-run is summed by a QUAD of lanes (lane = one float4 of the row): 64 / 256 sums in
+// flight per workgroup.  Dynamic LDS: rows [T RPT][16] floats | ord [T RPT] | lst [T RPT] | hds [T RPT] | red [T].
+#define OR2_LDS_BYTES(T, RPT) (4 * ((T) * (RPT) * 16 + 3 * (T) * (RPT) + (T)))
 extern __shared__ __attribute__((aligned(16))) float or2_lds[];
 
-template <int R>
-__global__ __launch_bounds__(256) void opt_reduce2_kernel(const nasrec_opt_reduce2_desc_t d) {
-  constexpr int T = 256, ROWS = T * R, CAP = OR2_CAP(R);
+// sum of squares of x[0, n) (chunk tables as sumsq_body) with T threads -> partial[blk]; red: T floats
+template <int T>
+__device__ __forceinline__ void or2_dense_sumsq(const nasrec_sumsq_desc_t& d, int blk, int nblk, float* red) {
+  if (T == 256) {
+    sumsq_body(d, blk, nblk, red);
+    return;
+  }
+  const int tid = threadIdx.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (d.chunks) {
+    for (long c = blk; c < d.nchunks; c += nblk) {
+      const float* x = d.x + d.chunks[2 * c];
+      const long n = d.chunks[2 * c + 1], n4 = n >> 2;
+      for (long i = tid; i < n4; i += T) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        s0 += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+      }
+      for (long j = 4 * n4 + tid; j < n; j += T) s1 = fmaf(x[j], x[j], s1);
+    }
+  } else {
+    const long stride = (long)nblk * T, n4 = d.n >> 2;
+    long i = (long)blk * T + tid;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(d.x + 4 * i), b = *reinterpret_cast<const f32x4*>(d.x + 4 * (i + stride));
+      const f32x4 c = *reinterpret_cast<const f32x4*>(d.x + 4 * (i + 2 * stride)), e = *reinterpret_cast<const f32x4*>(d.x + 4 * (i + 3 * stride));
+      s0 += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+      s1 += (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]);
+      s2 += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+      s3 += (e[0] * e[0] + e[1] * e[1]) + (e[2] * e[2] + e[3] * e[3]);
+    }
+    for (; i < n4; i += stride) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(d.x + 4 * i);
+      s0 += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+    }
+    for (long j = 4 * n4 + (long)blk * T + tid; j < d.n; j += stride) s1 = fmaf(d.x[j], d.x[j], s1);
+  }
+  red[tid] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  for (int o = T / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) d.partial[blk] = red[0];
+}
+
+template <int T, int RPT>
+__global__ __launch_bounds__(T) void opt_reduce2_kernel(const nasrec_opt_reduce2_desc_t d) {
+  constexpr int ROWS = T * RPT;
   float* rows = or2_lds;
-  int* ord = reinterpret_cast<int*>(or2_lds + ROWS * 20);
-  int* lst = ord + CAP;
-  float* red = reinterpret_cast<float*>(lst + CAP);
+  int* ord = reinterpret_cast<int*>(or2_lds + ROWS * 16);
+  int* lst = ord + ROWS;
+  int* hds = lst + ROWS;
+  float* red = reinterpret_cast<float*>(hds + ROWS);
   const int bid = blockIdx.x, tid = threadIdx.x;
   const int Fs = d.Fs, B = d.B;
   if (bid >= Fs + d.row_blocks) {  // dense gradient arena
-    sumsq_body(d.sumsq, bid - Fs - d.row_blocks, d.sumsq.nblocks, red);
+    or2_dense_sumsq<T>(d.sumsq, bid - Fs - d.row_blocks, d.sumsq.nblocks, red);
     return;
   }
   float ss = 0.f;
@@ -470,98 +526,78 @@ __global__ __launch_bounds__(256) void opt_reduce2_kernel(const nasrec_opt_reduc
       ss += lead == 1 ? s4 : 0.f;
     }
   } else {
-    // field f: the rows of its runs
-    const int f = bid, e = tid & 15, grp = tid >> 4;
+    // field f: every row of the field into LDS (one round of loads: RPT rows x 4 pieces per thread, beside the lists), then the sums
+    const int f = bid, q = tid & 3, quad = tid >> 2;
     const int cap = d.cap, half = cap >> 1;
     const int nA = d.counts[2 * f], nB = d.counts[2 * f + 1];
-    for (int i = tid; i < cap; i += T) {  // (cap / 256 independent loads per array, in flight beside the first round's rows)
-      ord[i] = d.order[(long)f * cap + i];
-      lst[i] = d.lists[(long)f * cap + i];
+    f32x4 g[RPT][4];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      const int b = min(u * T + tid, B - 1);
+      const f32x4* src = reinterpret_cast<const f32x4*>(dd_row(d.rows, b, f, Fs, d.rank_B, d.rank_stride));
+#pragma unroll
+      for (int v = 0; v < 4; ++v) g[u][v] = src[v];
     }
-    for (int base = 0; base < B; base += ROWS) {
-      f32x4 g[R][4];
+    int ov[RPT], lv[RPT], hv[RPT];
 #pragma unroll
-      for (int u = 0; u < R; ++u) {
-        const int b = min(base + u * T + tid, B - 1);
-        const f32x4* src = reinterpret_cast<const f32x4*>(dd_row(d.rows, b, f, Fs, d.rank_B, d.rank_stride));
+    for (int u = 0; u < RPT; ++u) {
+      const int i = u * T + tid;
+      ov[u] = i < cap ? d.order[(long)f * cap + i] : 0;
+      lv[u] = i < cap ? d.lists[(long)f * cap + i] : 0;
+      hv[u] = (i < cap && d.heads) ? d.heads[(long)f * cap + i] : 0;
+    }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) g[u][v] = src[v];
+    for (int u = 0; u < RPT; ++u) {
+      const int i = u * T + tid;
+      ord[i] = ov[u];
+      lst[i] = lv[u];
+      hds[i] = hv[u];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(&rows[i * 16 + 4 * v]) = g[u][v];
+    }
+    __syncthreads();
+    // phase 1: every sub-run with >= 2 members, a quad per sub-run (lane = one float4 of the row), ascending sample order; the sum
+    // lands in the LDS row of the sub-run's first sample, and in memory
+    for (int k = quad; k < nA; k += T / 4) {
+      const unsigned en = (unsigned)lst[k];
+      const int s = (int)(en & 0xffffu), len = (int)((en >> 16) & 0x7fffu);
+      const int o0 = ord[s];
+      f32x4 acc = *reinterpret_cast<const f32x4*>(&rows[o0 * 16 + 4 * q]);
+      int i = 1;
+      for (; i + 4 <= len; i += 4) {
+        const int p0 = ord[s + i], p1 = ord[s + i + 1], p2 = ord[s + i + 2], p3 = ord[s + i + 3];
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(&rows[p0 * 16 + 4 * q]), r1 = *reinterpret_cast<const f32x4*>(&rows[p1 * 16 + 4 * q]);
+        const f32x4 r2 = *reinterpret_cast<const f32x4*>(&rows[p2 * 16 + 4 * q]), r3 = *reinterpret_cast<const f32x4*>(&rows[p3 * 16 + 4 * q]);
+        acc += r0;
+        acc += r1;
+        acc += r2;
+        acc += r3;
       }
-      __syncthreads();  // (the previous round's readers are done; ord / lst of the first round are stored)
-#pragma unroll
-      for (int u = 0; u < R; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(&rows[(u * T + tid) * 20 + 4 * v]) = g[u][v];
-      __syncthreads();
-      // phase 1: every sub-run of this round's chunks, sixteen lanes per sub-run (lane = one float of the row), ascending sample order
-      for (int k = grp; k < nA; k += T / 16) {
-        const unsigned en = (unsigned)lst[k];
-        const int s = (int)(en & 0xffffu), len = (int)((en >> 16) & 0x7fffu);
-        const int o0 = ord[s] & 0x7fffffff;
-        if (o0 < base || o0 >= base + ROWS) continue;  // (another round's chunk; uniform over the sixteen lanes)
-        float acc = rows[(o0 - base) * 20 + e];
-        int i = 1;
-        for (; i + 4 <= len; i += 4) {
-          const int p0 = ord[s + i] & 0x7fffffff, p1 = ord[s + i + 1] & 0x7fffffff, p2 = ord[s + i + 2] & 0x7fffffff, p3 = ord[s + i + 3] & 0x7fffffff;
-          const float r0 = rows[(p0 - base) * 20 + e], r1 = rows[(p1 - base) * 20 + e], r2 = rows[(p2 - base) * 20 + e], r3 = rows[(p3 - base) * 20 + e];
-          acc += r0;
-          acc += r1;
-          acc += r2;
-          acc += r3;
-        }
-        for (; i < len; ++i) acc += rows[((ord[s + i] & 0x7fffffff) - base) * 20 + e];
-        dd_row(d.rows, o0, f, Fs, d.rank_B, d.rank_stride)[e] = acc;
-        if (en & DD_WHOLE) ss += acc * acc;  // the run ends here: this is the leader's final row
+      for (; i < len; ++i) acc += *reinterpret_cast<const f32x4*>(&rows[ord[s + i] * 16 + 4 * q]);
+      if (en & DD_WHOLE) {  // the run ends here: this is the leader's final row
+        *reinterpret_cast<f32x4*>(dd_row(d.rows, o0, f, Fs, d.rank_B, d.rank_stride) + 4 * q) = acc;
+        ss += (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]);
+      } else {
+        *reinterpret_cast<f32x4*>(&rows[o0 * 16 + 4 * q]) = acc;  // (a sub-run's first row is nobody else's operand in this phase)
       }
     }
     if (nB > 0) {  // (uniform) phase 2: runs that span chunks — the sub-run sums, in chunk order, into the leader's row
-      __threadfence_block();
-      __syncthreads();  // phase 1's rows (written by other waves of this workgroup) are visible
-      for (int k0 = 0; k0 < nB; k0 += T / 16) {  // (the trip count is uniform: lanes of one wave exchange sub-run heads by shuffles below)
-        const int k = k0 + grp;
-        const bool on = k < nB;
-        const unsigned en = on ? (unsigned)lst[half + k] : 0u;
-        const int s = (int)(en & 0xffffu), len = (int)(en >> 16);
-        // lane c looks for the sub-run of chunk c: the first position of the run whose sample lies in chunk >= c
-        int head = -1;
-        if (on) {
-          int lo = s, hi = s + len;
-          while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (((ord[mid] & 0xffff) >> 8) < e) lo = mid + 1;
-            else hi = mid;
-          }
-          if (lo < s + len && ((ord[lo] & 0xffff) >> 8) == e) head = ord[lo] & 0x7fffffff;
-        }
-        float acc = 0.f;
-        bool first = true;
-        int h0 = -1;
-        float v[16];
-        int hs[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {  // all of the run's sub-run rows in flight, then the sums in chunk order
-          hs[c] = __shfl(head, (tid & 48) | c, 64);
-          v[c] = dd_row(d.rows, max(hs[c], 0), f, Fs, d.rank_B, d.rank_stride)[e];
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          if (hs[c] >= 0) {
-            acc = first ? v[c] : acc + v[c];
-            if (first) h0 = hs[c];
-            first = false;
-          }
-        }
-        if (on && h0 >= 0) {
-          dd_row(d.rows, h0, f, Fs, d.rank_B, d.rank_stride)[e] = acc;
-          ss += acc * acc;
-        }
+      __syncthreads();
+      for (int k = quad; k < nB; k += T / 4) {
+        const unsigned en = (unsigned)lst[half + k];
+        const int h0 = (int)(en & 0xffffu), nh = (int)(en >> 16);
+        const int lead = hds[h0];
+        f32x4 acc = *reinterpret_cast<const f32x4*>(&rows[lead * 16 + 4 * q]);
+        for (int i = 1; i < nh; ++i) acc += *reinterpret_cast<const f32x4*>(&rows[hds[h0 + i] * 16 + 4 * q]);
+        *reinterpret_cast<f32x4*>(dd_row(d.rows, lead, f, Fs, d.rank_B, d.rank_stride) + 4 * q) = acc;
+        ss += (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]);
       }
     }
   }
   __syncthreads();
   red[tid] = ss;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = T / 2; o > 0; o >>= 1) {
     if (tid < o) red[tid] += red[tid + o];
     __syncthreads();
   }
@@ -574,16 +610,17 @@ int launch_opt_reduce2(hipStream_t st, const nasrec_opt_reduce2_desc_t* d) {
   if (d->row_blocks < 1 || d->sumsq.nblocks < 0) return nasrec_set_error(-2, "opt_reduce2: row_blocks=%d sumsq.nblocks=%d", d->row_blocks, d->sumsq.nblocks);
   if (d->rank_B < 0 || (d->rank_B > 0 && d->rank_stride < (int64_t)d->rank_B * d->Fs * 16)) return nasrec_set_error(-2, "opt_reduce2: rank layout %d / %ld", d->rank_B, (long)d->rank_stride);
   if (!d->rows || !d->leader || !d->order || !d->lists || !d->counts || !d->sumsq_partial) return nasrec_set_error(-2, "opt_reduce2: null pointer");
+  if (d->B > 256 && !d->heads) return nasrec_set_error(-2, "opt_reduce2: B=%d > 256 needs the heads array", d->B);
   const dim3 grid((unsigned)(d->Fs + d->row_blocks + d->sumsq.nblocks));
   if (d->cap <= 256) {
-    hipLaunchKernelGGL(opt_reduce2_kernel<1>, grid, dim3(256), OR2_LDS_BYTES(1), st, *d);
+    hipLaunchKernelGGL((opt_reduce2_kernel<256, 1>), grid, dim3(256), OR2_LDS_BYTES(256, 1), st, *d);
   } else {
     static unsigned long long attr_mask = 0;
     if (nasrec_lds_attr_needed(attr_mask)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&opt_reduce2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, OR2_LDS_BYTES(4));
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&opt_reduce2_kernel<1024, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, OR2_LDS_BYTES(1024, 2));
       if (e != hipSuccess) return nasrec_set_error((int)e, "opt_reduce2: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(opt_reduce2_kernel<4>, grid, dim3(256), OR2_LDS_BYTES(4), st, *d);
+    hipLaunchKernelGGL((opt_reduce2_kernel<1024, 2>), grid, dim3(1024), OR2_LDS_BYTES(1024, 2), st, *d);
   }
   return nasrec_check_launch("opt_reduce2");
 }

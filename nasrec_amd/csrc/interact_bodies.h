@@ -115,7 +115,7 @@ __device__ __forceinline__ void dot_tri_bwd_sample_mfma_t(const nasrec_dot_tri_d
     for (int s = 0; s < KS; ++s) {
       const int k = 4 * s + g;
       const int hi = max(i, k), lo = min(i, k);
-      a[bi][s] = dob[min(hi * (hi - 1) / 2 + lo, P - 1)];  // (clamped; masked below)
+      a[bi][s] = dob[min(hi * (hi - 1) / 2 + lo, max(P - 1, 0))];  // (clamped; masked below)
     }
   }
   // every load of the sample has been issued: pin the values here, or the compiler sinks a block's gathers behind the previous block's

@@ -60,6 +60,8 @@ static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, i
     for (int q = 0; q < g->nseg; ++q) {
       const nasrec_gemm_seg_t& s = g->seg[q];
       plain = plain && !s.ones_col && !(s.Mvalid > 0 && s.Mvalid < Mmax);
+      // (the body's buffer resources and offsets are 32-bit byte counts: operand extents stay below 2^29 floats, as gemm_kslice / gemm_skinny require)
+      plain = plain && (long)Mmax * s.lda + s.K < (1L << 29) && (long)Nmax * s.ldb + s.K < (1L << 29);
       steps += (s.A && s.K > 0) ? (s.K + 15) >> 4 : 1;
     }
     if (plain && steps <= 2 * WL_DENSE_STEPS && (Mmax + 15) / 16 < 0x10000) {
@@ -78,6 +80,7 @@ static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, i
     for (int q = 0; q < g->nseg; ++q) {
       const nasrec_gemm_seg_t& s = g->seg[q];
       plain = plain && !s.ones_col && !(s.Mvalid > 0 && s.Mvalid < s.M) && s.K <= 16 * WL_DENSE_STEPS && s.M > 0 && s.N > 0;
+      plain = plain && (long)s.M * s.lda + s.K < (1L << 29) && (long)s.K * s.ldb + s.N < (1L << 29);  // (32-bit extents / offsets in the body)
       TU += ((s.M + 15) / 16) * ((s.N + 15) / 16);
     }
     if (plain && TU > 0) {

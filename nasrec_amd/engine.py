@@ -21,7 +21,7 @@ from . import schedule as S
 
 E = 16
 # largest (global) batch whose row-gradient dedup runs in two halves (csrc/dedup_bodies.h; <= L.DEDUP_IDS_MAX_B); 0 = the one-launch kernels
-DEDUP_SPLIT_MAX_B = min(int(os.environ.get("NASREC_DEDUP_SPLIT_MAX_B", "4096")), L.DEDUP_IDS_MAX_B)
+DEDUP_SPLIT_MAX_B = min(int(os.environ.get("NASREC_DEDUP_SPLIT_MAX_B", "2048")), L.DEDUP_IDS_MAX_B)
 
 
 def _ptr_array(descs):
@@ -592,6 +592,7 @@ class SupernetEngine:
                     cp.dd_order = new(self.Fs * capn, torch.int32)
                     cp.dd_lists = new(self.Fs * capn, torch.int32)
                     cp.dd_counts = new(self.Fs * 2, torch.int32)
+                    cp.dd_heads = new(self.Fs * capn, torch.int32) if capn > 256 else None
                 row_blocks = max(1, min(512, (Bg * self.Fs * 4 + 255) // 256))
                 if getattr(cp, "emb_partial2", None) is None or cp.emb_partial2.numel() < self.Fs + row_blocks:
                     cp.emb_partial2 = new(self.Fs + row_blocks)
@@ -599,13 +600,14 @@ class SupernetEngine:
                 ids.kind, ids.B, ids.Fs, ids.cap = L.OP_DEDUP_IDS, Bg, self.Fs, capn
                 ids.idx, ids.leader = cat_x.data_ptr(), cp.leader.data_ptr()
                 ids.order, ids.lists, ids.counts = cp.dd_order.data_ptr(), cp.dd_lists.data_ptr(), cp.dd_counts.data_ptr()
+                ids.heads = cp.dd_heads.data_ptr() if cp.dd_heads is not None else None
                 cp.dedup_ids = ids
                 r2 = L.OptReduce2Desc()
                 r2.kind, r2.B, r2.Fs, r2.cap = L.OP_OPT_REDUCE2, Bg, self.Fs, capn
                 r2.rank_B, r2.rank_stride = rank_layout if rank_layout else (0, 0)
                 r2.row_blocks = row_blocks
                 r2.rows, r2.leader = sparse_grad.data_ptr(), cp.leader.data_ptr()
-                r2.order, r2.lists, r2.counts = ids.order, ids.lists, ids.counts
+                r2.order, r2.lists, r2.counts, r2.heads = ids.order, ids.lists, ids.counts, ids.heads
                 r2.sumsq_partial = cp.emb_partial2.data_ptr()
                 r2.sumsq = sq
                 app.clip.partial_b, app.clip.n_b = cp.emb_partial2.data_ptr(), self.Fs + row_blocks

@@ -107,7 +107,7 @@ def train_and_eval_one_model(model, args):
         save_model_checkpoint(model, ckpt, optimizer)
         dump_pickle_data(os.path.join(args.logging_dir, "train_test_logs.pickle"), epoch_logs)
     elif getattr(model, "_table_sharding", None):  # row-sharded tables: the whole-table state_dict is a collective
-        save_model_checkpoint(model, None, None)
+        save_model_checkpoint(model, None, optimizer)  # (tables and their accumulators are gathered: every rank takes part)
     return epoch_logs
 
 

@@ -103,6 +103,9 @@ DP_SEGMENTS = int(__import__("os").environ.get("NASREC_DP_SEGMENTS", "4"))
 # row-gradient all-gather instead of an all-reduce of their own (ONE exposed collective per step), and every rank adds the W copies in
 # rank order.  0 = every piece is all-reduced.
 _DEBUG = __import__("os").environ.get("NASREC_DP_DEBUG", "0") == "1"
+# where the id-only half of the global batch's row dedup runs in a data-parallel step (A/B knob): side = on a side stream behind the ids
+# all-gather; chain = the gather itself is issued from that side stream; main = on the compute stream in front of the optimizer (exposed)
+_IDS_MODE = __import__("os").environ.get("NASREC_DP_IDS_MODE", "side")
 PACK_TAIL_FLOATS = int(__import__("os").environ.get("NASREC_DP_PACK_TAIL", "65536"))
 
 
@@ -209,12 +212,18 @@ def tail_pieces(segments, budget: int) -> int:
 
 class DataParallelStep:
     def __init__(self, engine, choice, B_local: int, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = True,
-                 force_exchange: bool = False, real_collectives: bool = False):
+                 force_exchange: bool = False, real_collectives: bool = False, paths: str = "shared"):
         """choice: the fixed sub-network's choice, or None for a weight-sharing supernet (the path then comes with every step).
         force_exchange: take the multi-rank code path (all-reduce + all-gather + global-batch optimizer) even in a single-rank
         process group — lets one GPU exercise exactly what N GPUs run.
         real_collectives: with it, a single-rank group goes through the communication library too (RCCL's all-gather / all-reduce
-        kernels inside the captured step) instead of the copy a one-rank gather amounts to — adds work, for tests and measurement."""
+        kernels inside the captured step) instead of the copy a one-rank gather amounts to — adds work, for tests and measurement.
+        paths: "shared" (default) = every rank trains the SAME sampled path per step (shared np.random seed): the reference's
+        one-path-per-step semantics (supernet.py:525-529) at the global batch.  "per-rank" (weight-sharing supernets only; an
+        EXTENSION of the reference) = every rank passes its OWN path to step(): the choices are exchanged first (one small
+        all-gather), the dense gradients are all-reduced over the UNION of the ranks' parameter ranges — a parameter's gradient is the
+        sum over the ranks whose path used it, the others contribute zeros — and clip + Adagrad run over that union on every rank
+        (replicas stay bit-identical); parameters no rank's path touched keep value and state, as `grad is None` does in the reference."""
         self.engine = engine
         self.dp = engine if hasattr(engine, "dp_plan") else EngineDP(engine)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -224,6 +233,9 @@ class DataParallelStep:
         self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
         self.choice, self.clip, self.eps = choice, clip, eps
         self.coll = Collectives(real_collectives)
+        assert paths in ("shared", "per-rank"), paths
+        self.per_rank = paths == "per-rank"
+        assert not (self.per_rank and self.fixed), "a fixed sub-network has one path"
         self._last = None
         self._plans = {}
         self._last_key = None
@@ -300,9 +312,21 @@ class DataParallelStep:
             loss = eng.train_step(int_x, cat_x, y, lr, choice, self.clip, self.eps, graph=self.graph)
             self._last = ("plain", choice, int(int_x.shape[0]))
             return loss
+        union = None
+        if self.per_rank:
+            # the other ranks' paths first (their parameter ranges come from plans of their own, compiled into the engine's few plan
+            # slots): this rank's plan is compiled LAST, so it is the one that stays resident
+            spans = []
+            for r, ch in enumerate(self._all_choices(choice)):
+                if r != (dist.get_rank() if dist.is_initialized() else 0):
+                    spans += list(self.dp.dp_path_spans(ch, self.B, 1.0 / (self.B * self.world), self.clip, self.eps))
+            union = spans
         plan = self._plan(choice)
         plan.stage(int_x, cat_x, y, lr)
         self._last = ("dp", plan)
+        if self.per_rank:
+            self._per_rank_step(plan, coalesce_ranges(union + list(self.dp.dp_path_spans(choice, self.B, 1.0 / (self.B * self.world), self.clip, self.eps)), gap=0))
+            return plan.loss
         if self.graph:
             # Batch-256 regime: the step is a few hundred microseconds and the HOST is what the exchange competes with (a work handle
             # costs ~40 us of host time per collective: 757 us against 609 us for the plain step in round 2).  So the whole exchange —
@@ -333,22 +357,30 @@ class DataParallelStep:
         flat_g = self.engine.flat_g
         coll = self.coll
         pending = []
-        w_ids = coll.all_gather(self.cat_all, plan.cat_local, async_op=True)
         ids_done = None
-        if self.ids_half is not None:
-            if self._side is not None:
-                main = torch.cuda.current_stream(self.engine.device)
-                self._side.wait_stream(main)  # (the previous step's optimizer has read the lists this launch rewrites)
-                with torch.cuda.stream(self._side):
-                    if w_ids is not None:
-                        w_ids.wait()
-                    self.ids_half()
-                    ids_done = torch.cuda.Event()
-                    ids_done.record(self._side)
-            else:
+        mode = _IDS_MODE if (self.ids_half is not None and self._side is not None) else ("main" if self.ids_half is not None else None)
+        if mode == "chain":
+            # the ids all-gather is ISSUED from the side stream (a blocking call there: the side stream waits for the library's stream),
+            # the id half right behind it — one chain beside the compute stream instead of two forks
+            main = torch.cuda.current_stream(self.engine.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                coll.all_gather(self.cat_all, plan.cat_local)
+                self.ids_half()
+                ids_done = torch.cuda.Event()
+                ids_done.record(self._side)
+            w_ids = None
+        else:
+            w_ids = coll.all_gather(self.cat_all, plan.cat_local, async_op=True)
+        if mode == "side":
+            main = torch.cuda.current_stream(self.engine.device)
+            self._side.wait_stream(main)  # (the previous step's optimizer has read the lists this launch rewrites)
+            with torch.cuda.stream(self._side):
                 if w_ids is not None:
                     w_ids.wait()
                 self.ids_half()
+                ids_done = torch.cuda.Event()
+                ids_done.record(self._side)
         elif w_ids is not None:
             pending.append(w_ids)
         plan.forward()
@@ -371,12 +403,56 @@ class DataParallelStep:
                 w.wait()  # nccl: the compute stream waits for the collective (no host block)
         if ids_done is not None:
             torch.cuda.current_stream(self.engine.device).wait_event(ids_done)
+        if mode == "main":
+            self.ids_half()  # (no side stream — CPU stand-ins — or NASREC_DP_IDS_MODE=main: in front of the optimizer, exposed)
         if self.tail_n:
             self.tail_ops[1]()  # flat_g[tail ranges] = sum over ranks, in rank order
         self.opt(plan)
         if _DEBUG and getattr(plan, "never_written", None) and not torch.cuda.is_current_stream_capturing():
             for n in plan.never_written:
                 assert float(self.engine.grads[n].abs().max()) == 0.0, "gradient of %s is written by nothing and must stay zero" % n
+
+    # -------------------------------------------------------------------------------------------------------------
+    CHOICE_BYTES = 16384
+
+    def _all_choices(self, choice):
+        """every rank's path of this step, in rank order (one all-gather of the JSON text, padded)"""
+        raw = json.dumps(choice, sort_keys=True, default=_jsonable).encode()
+        assert len(raw) < self.CHOICE_BYTES - 8, "choice too long for the exchange buffer"
+        dev = self.engine.device
+        buf = torch.zeros(self.CHOICE_BYTES, dtype=torch.uint8)
+        buf[:8] = torch.tensor(list(len(raw).to_bytes(8, "little")), dtype=torch.uint8)
+        buf[8:8 + len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+        buf = buf.to(dev)
+        out = torch.zeros(self.world * self.CHOICE_BYTES, dtype=torch.uint8, device=dev)
+        self.coll.all_gather(out, buf)
+        host = out.cpu().view(self.world, self.CHOICE_BYTES)  # (the host needs them: this mode synchronises once per step)
+        res = []
+        for r in range(self.world):
+            n = int.from_bytes(bytes(host[r, :8].tolist()), "little")
+            res.append(json.loads(bytes(host[r, 8:8 + n].tolist()).decode()))
+        return res
+
+    def _per_rank_step(self, plan, union):
+        """paths="per-rank": own path forward / backward; all-reduce and optimizer over the union of the ranks' parameter ranges"""
+        flat_g = self.engine.flat_g
+        coll = self.coll
+        pending = [coll.all_gather(self.cat_all, plan.cat_local, async_op=True)]
+        # gradients of the union's parameters that THIS rank's path does not write must be zero on this rank (the plan's own
+        # zero_grad covers its path only): zero the union first, the plan then writes its share
+        for off, n in union:
+            flat_g[off:off + n].zero_()
+        plan.forward()
+        for run, _ in plan.segments:
+            run()
+        for off, n in union:
+            pending.append(coll.all_reduce(flat_g[off:off + n], async_op=True))
+        pending.append(coll.all_gather(self.recv, plan.sparse_grad, async_op=True))
+        for w in pending:
+            if w is not None:
+                w.wait()
+        self.opt(plan, spans=union)
+        plan.union = union
 
     def _capture(self, plan):
         """the exchange step of a fixed sub-network as ONE graph (torch.cuda.CUDAGraph: ProcessGroupNCCL's collectives are capturable,
@@ -460,9 +536,26 @@ class EngineDP:
         eng.stream.synchronize()
         if eng.cfg.fixed:
             return (lambda plan: prog.replay(eng._sp())) if graph else (lambda plan: prog.run(eng._sp()))
-        shared = ("leader", "gsum", "emb_partial", "dense_partial", "dd_order", "dd_lists", "dd_counts", "emb_partial2")
+        shared = ("leader", "gsum", "emb_partial", "dense_partial", "dd_order", "dd_lists", "dd_counts", "dd_heads", "emb_partial2")
 
-        def run(plan):
+        def run(plan, spans=None):
+            if spans is not None:
+                # paths="per-rank": norm and Adagrad over the UNION of the ranks' parameter ranges — a chunk table of its own, written
+                # by the program's first launches (stream-ordered, like the plan's)
+                from . import plan as P
+                flat = P.path_chunks(spans)
+                h = _Holder()
+                for k in shared:
+                    if hasattr(holder, k):
+                        setattr(h, k, getattr(holder, k))
+                tab = plan.cp.arena.alloc(len(flat), torch.int64).tensor() if getattr(plan.cp, "arena", None) is not None else \
+                    torch.empty(len(flat), dtype=torch.int64, device=eng.device)
+                h.chunk_tab, h.nchunks = tab, len(flat) // 2
+                prog = Program(P.const_i64_descs(tab.data_ptr(), flat) + eng._optimizer_descs(h, Bg, cat_all, sg_all, clip, eps, rank_layout=rank_layout))
+                prog.holder = h
+                plan.union_opt = prog  # (kept alive until the plan goes)
+                prog.run(eng._sp())
+                return
             # weight-sharing supernet: zero_grad / norm / Adagrad cover the arena ranges of the plan's path only (engine.compile),
             # so the optimizer program is the plan's: same work buffers, the plan's chunk table
             if getattr(plan, "opt_prog", None) is None:
@@ -476,6 +569,12 @@ class EngineDP:
             plan.opt_prog.run(eng._sp())
 
         return run
+
+    def dp_path_spans(self, choice, B, grad_scale, clip, eps):
+        """arena ranges [(offset, numel)] of the dense parameters the path `choice` trains (its plan knows: engine.compile — the
+        arguments are dp_plan's, so this rank's own choice hits the plan it is about to run)"""
+        cp = self.engine.compile(choice, B, True, clip, eps, graph=False, grad_scale=grad_scale, defer_dw=False)
+        return list(cp.path_spans)
 
     def dp_dedup_ids(self):
         """launcher of the id-only half of the global batch's row dedup (None: this batch size runs the one-launch kernels): to be

@@ -167,13 +167,14 @@ class RowShardedTables:
             tot += (g * g).sum()
         return tot
 
-    def whole_table(self, f: int) -> torch.Tensor:
-        """all-gather of table f (tests / checkpoints)"""
+    def whole_table(self, f: int, which: str = "tables") -> torch.Tensor:
+        """all-gather of table f (which = "tables"), or of its Adagrad accumulator ("state") — tests / checkpoints; a collective"""
+        src = self.tables if which == "tables" else self.state
         n, rp = self.num_embeddings[f], self.rp[f]
-        mine = torch.zeros(rp, E, dtype=self.tables[f].dtype, device=self.device)
+        mine = torch.zeros(rp, E, dtype=src[f].dtype, device=self.device)
         k = self.hi[f] - self.lo[f]
         if k > 0:
-            mine[:k] = self.tables[f][:k]
+            mine[:k] = src[f][:k]
         if self.world > 1:
             parts = [torch.empty_like(mine) for _ in range(self.world)]
             dist.all_gather(parts, mine, group=self.group)

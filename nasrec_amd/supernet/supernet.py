@@ -127,6 +127,39 @@ class _SupernetFunction(torch.autograd.Function):
         return (None, None, None, None, drows) + tuple(grads)
 
 
+class ShardEmbedding(nn.Embedding):
+    """This rank's rows [row_lo, row_hi) of a `whole_rows`-row table (SuperNet(table_sharding="row")).  A subclass, so that the type-exact
+    `init_weights` of the reference's harness leaves it alone; its values are always rows of a WHOLE table: drawn chunk by chunk from one
+    generator seeded by (torch.initial_seed(), field) — identical on every rank (utils/dist.init_from_env seeds the ranks alike) and for
+    every world size — of which the rank keeps its range."""
+
+    def __init__(self, rows, dim, whole_rows, row_lo, row_hi, field):
+        self.whole_rows, self.row_lo, self.row_hi, self.field = int(whole_rows), int(row_lo), int(row_hi), int(field)
+        super().__init__(rows, dim)
+
+    def _draw_whole_(self, std: float):
+        g = torch.Generator().manual_seed((torch.initial_seed() + 1000003 * (self.field + 1)) % (1 << 62))
+        dim = self.weight.shape[1]
+        with torch.no_grad():
+            self.weight.zero_()
+            chunk = 1 << 20
+            for r0 in range(0, self.whole_rows, chunk):
+                r1 = min(self.whole_rows, r0 + chunk)
+                part = torch.empty(r1 - r0, dim).normal_(0.0, 1.0, generator=g)  # (every chunk is drawn, kept or not: a rank's rows do not depend on the world size)
+                if r1 <= self.row_lo or r0 >= self.row_hi:
+                    continue
+                a, b = max(r0, self.row_lo), min(r1, self.row_hi)
+                self.weight[a - self.row_lo:b - self.row_lo] = (part[a - r0:b - r0] * std).to(self.weight.device, self.weight.dtype)
+
+    def reset_parameters(self):  # nn.Embedding's constructor default: N(0, 1)
+        if hasattr(self, "whole_rows"):
+            self._draw_whole_(1.0)
+
+    def xavier_normal_whole_(self):
+        """torch.nn.init.xavier_normal_ of the WHOLE table: std = sqrt(2 / (whole_rows + dim))"""
+        self._draw_whole_((2.0 / (self.whole_rows + self.weight.shape[1])) ** 0.5)
+
+
 class SuperNet(nn.Module):
     """Top-level supernet (supernet.py:210-880)."""
 
@@ -207,8 +240,23 @@ class SuperNet(nn.Module):
 
     def _embedding_layers(self, sparse_input_size, num_embeddings, embedding_dim):
         if self._table_sharding == "row":
-            return nn.ModuleList([nn.Embedding(self._shard_rows(num_embeddings[i])[2], embedding_dim) for i in range(sparse_input_size)])
+            out = []
+            for i in range(sparse_input_size):
+                lo, hi, rows = self._shard_rows(num_embeddings[i])
+                out.append(ShardEmbedding(rows, embedding_dim, whole_rows=num_embeddings[i], row_lo=lo, row_hi=hi, field=i))
+            return nn.ModuleList(out)
         return nn.ModuleList([nn.Embedding(num_embeddings[i], embedding_dim) for i in range(sparse_input_size)])
+
+    def apply(self, fn):
+        """nn.Module.apply; with row-sharded tables, the reference's `init_weights` (train_utils.py:70-89: xavier_normal_ on every
+        nn.Embedding, type-exact) also initialises the shards — as rows [lo, hi) of a WHOLE table drawn with the whole table's fan
+        (a shard initialised by itself would take its fan from its own row count: std sqrt(world) times too large, and — every rank
+        seeds alike — the same values on every rank)."""
+        out = super().apply(fn)
+        if self._table_sharding == "row" and getattr(fn, "__name__", "") == "init_weights":
+            for m in self._embedding:
+                m.xavier_normal_whole_()
+        return out
 
     @staticmethod
     def _shard_rows(n):

@@ -179,11 +179,28 @@ class OracleEngine:
             plan.segments = [(fwd_bwd, lazy[0])] + [((lambda: None), r) for r in lazy[1:]]
         return plan
 
+    def dp_path_spans(self, choice, B, grad_scale, clip, eps):
+        """arena ranges of the parameters the path trains: what autograd leaves a gradient for (the real engine reads its plan)"""
+        from oracle import nasrec_oracle as O
+        P = self.P
+        leaves = {k: P[k].detach().requires_grad_(True) for k in self.names}
+        Pl = O.Params(P.dtype, frozen=True)
+        Pl.update(leaves)
+        rows = torch.zeros(2, self.Fs, 16, dtype=P.dtype)
+        for f in range(self.Fs):
+            Pl["_embedding.%d.weight" % f] = rows[:, f]
+        Fd = getattr(self, "Fd", 3)
+        logits = O.supernet_forward(Pl, self.cfg, torch.zeros(2, Fd, dtype=P.dtype), torch.arange(2).view(2, 1).expand(2, self.Fs).contiguous(), choice)
+        grads = torch.autograd.grad(logits.sum(), [leaves[k] for k in self.names], allow_unused=True)
+        return [(self.offsets[k], P[k].numel()) for k, g in zip(self.names, grads) if g is not None]
+
     def dp_optimizer(self, Bg, cat_all, sg_all, clip, eps, graph, rank_layout=None):
         from oracle import nasrec_oracle as O
         eng, P, Fs = self, self.P, self.Fs
 
-        def run(plan=None):
+        def run(plan=None, spans=None):
+            # (spans: the union of the ranks' parameter ranges in per-rank path mode — Adagrad with g = 0 is a no-op, so walking every
+            # parameter is the same update; the real engine restricts norm and update to the ranges)
             if rank_layout is None:
                 sg = sg_all.view(Bg, Fs, 16)
             else:  # the receive buffer of the all-gather: per rank [Bl, Fs, 16] rows, then the dense gradients that rode along
@@ -304,3 +321,95 @@ def test_data_parallel_step_equals_single_process_at_the_global_batch(name):
         assert untouched, "a sampled path leaves part of the supernet unused"
         for k in untouched:  # grad None in the reference: neither value nor Adagrad state may move
             assert torch.equal(out[0][0][k], initial[k]), k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# paths="per-rank" (SURVEY 8e optional mode; north star: "per-sample supernet paths shard data-parallel"): every rank trains its own
+# sampled path; a parameter's gradient is the sum over the ranks whose path used it; clip + Adagrad over the union.  Checked against
+# the fp64 oracle evaluating the two paths on the two half-batches.
+# ------------------------------------------------------------------------------------------------------------------
+def _per_rank_case():
+    from oracle import nasrec_oracle as O
+    tables, Bg, steps = [40, 7, 300, 5], 8, 3
+    cfg = O.NetCfg(3, O.ops_config_lib["autoctr"], True, "relu", fixed=False)
+    P = O.Params(torch.float64)
+    batches = []
+    for s in range(steps):
+        int_x, cat_x, y = O.synthetic_batch(Bg, 3, tables, seed=90 + s)
+        batches.append((int_x.double(), cat_x, y.double().view(-1, 1)))
+    with torch.no_grad():
+        O.supernet_forward(P, cfg, batches[0][0][:4], batches[0][1][:4], O.full_path_choice(cfg), num_embeddings=tables)
+    P.frozen = True
+    choices = []
+    for r in range(WORLD):  # rank r draws from seed + r: different paths on the two ranks
+        np.random.seed(4321 + r)
+        sampler = O.PathSampler(cfg, "default", "binomial-0.5")
+        choices.append([json.loads(json.dumps(sampler.sample(), default=lambda o: o.tolist() if hasattr(o, "tolist") else o.item())) for _ in range(steps)])
+    return cfg, P, batches, choices, 0.02
+
+
+def _per_rank_worker(rank, port, out):
+    from nasrec_amd.parallel import DataParallelStep
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.set_num_threads(2)
+    cfg, P, batches, choices, lr = _per_rank_case()
+    Fs = batches[0][1].shape[1]
+    Bl = batches[0][0].shape[0] // WORLD
+    eng = OracleEngine(cfg, P, Fs)
+    dp = DataParallelStep(eng, None, Bl, clip=5.0, eps=1e-2, graph=False, paths="per-rank")
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    unions = []
+    for s, (int_x, cat_x, y) in enumerate(batches):
+        eng.lr = lr
+        dp.step(int_x[sl], cat_x[sl].contiguous(), y[sl], lr, choice=choices[rank][s])
+        unions.append(list(dp._last[1].union))
+    out[rank] = ({k: v.detach().clone() for k, v in P.items()}, unions)
+    dist.destroy_process_group()
+
+
+def test_per_rank_paths_sum_gradients_over_the_ranks_that_used_a_parameter():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import nasrec_oracle as O
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_per_rank_worker, args=(port, out), nprocs=WORLD, join=True)
+    cfg, P, batches, choices, lr = _per_rank_case()
+    assert any(json.dumps(a) != json.dumps(b) for a, b in zip(choices[0], choices[1])), "the two ranks should train different paths"
+    initial = {k: v.clone() for k, v in P.items()}
+    state, touched = {}, set()
+    names = list(P.keys())
+    Bg = batches[0][0].shape[0]
+    Bl = Bg // WORLD
+    for s, (int_x, cat_x, y) in enumerate(batches):
+        total = {}
+        for r in range(WORLD):  # path r on half r; the loss is the mean over the GLOBAL batch
+            sl = slice(r * Bl, (r + 1) * Bl)
+            leaves = {k: v.detach().requires_grad_(True) for k, v in P.items()}
+            Pl = O.Params(P.dtype, frozen=True)
+            Pl.update(leaves)
+            logits = O.supernet_forward(Pl, cfg, int_x[sl], cat_x[sl], choices[r][s])
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), y[sl].view(-1), reduction="sum") / Bg
+            grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
+            for k, g in zip(names, grads):
+                if g is not None:
+                    total[k] = total[k] + g if k in total else g.clone()
+        norm = torch.sqrt(sum(g.pow(2).sum() for g in total.values()))
+        coef = min(1.0, 5.0 / (float(norm) + 1e-6))
+        with torch.no_grad():
+            for k, g in total.items():
+                st = state.setdefault(k, torch.zeros_like(P[k]))
+                O.adagrad_step_(P[k], g * coef, st, lr, 1e-2)
+        touched |= set(total)
+    for r in range(WORLD):
+        for k, v in P.items():
+            assert torch.allclose(out[r][0][k], v, rtol=0, atol=1e-10), (r, k)
+    for k in out[0][0]:
+        assert torch.equal(out[0][0][k], out[1][0][k]), k  # replicas stay bit-identical
+    assert out[0][1] == out[1][1], "every rank must reduce the same union of ranges"
+    untouched = [k for k in P if k not in touched]
+    assert untouched
+    for k in untouched:
+        assert torch.equal(out[0][0][k], initial[k]), k

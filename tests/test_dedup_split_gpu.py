@@ -39,10 +39,12 @@ def two_halves(lib, idx_d, rows_d, B, Fs, rank=None, nsq=0, g=None):
     """-> (leader [B,Fs] int32, partial sums, descriptors): DEDUP_IDS then OPT_REDUCE2 in place over rows_d"""
     cap = cap_of(B)
     bufs = dict(leader=dev(torch.full((B * Fs,), 9, dtype=torch.int32)), order=dev(torch.zeros(Fs * cap, dtype=torch.int32)),
-                lists=dev(torch.zeros(Fs * cap, dtype=torch.int32)), counts=dev(torch.zeros(Fs * 2, dtype=torch.int32)))
+                lists=dev(torch.zeros(Fs * cap, dtype=torch.int32)), counts=dev(torch.zeros(Fs * 2, dtype=torch.int32)),
+                heads=dev(torch.zeros(Fs * cap, dtype=torch.int32)))
     ids = L.DedupIdsDesc()
     ids.kind, ids.B, ids.Fs, ids.cap = L.OP_DEDUP_IDS, B, Fs, cap
     ids.idx, ids.leader, ids.order, ids.lists, ids.counts = idx_d.data_ptr(), bufs["leader"].data_ptr(), bufs["order"].data_ptr(), bufs["lists"].data_ptr(), bufs["counts"].data_ptr()
+    ids.heads = bufs["heads"].data_ptr() if B > 256 else None
     launch(lib, ids)
     rb = max(1, min(512, (B * Fs * 4 + 255) // 256))
     part = dev(torch.full((Fs + rb,), 7.0))
@@ -50,7 +52,7 @@ def two_halves(lib, idx_d, rows_d, B, Fs, rank=None, nsq=0, g=None):
     r2.kind, r2.B, r2.Fs, r2.cap, r2.row_blocks = L.OP_OPT_REDUCE2, B, Fs, cap, rb
     if rank:
         r2.rank_B, r2.rank_stride = rank
-    r2.rows, r2.leader, r2.order, r2.lists, r2.counts = rows_d.data_ptr(), ids.leader, ids.order, ids.lists, ids.counts
+    r2.rows, r2.leader, r2.order, r2.lists, r2.counts, r2.heads = rows_d.data_ptr(), ids.leader, ids.order, ids.lists, ids.counts, ids.heads
     r2.sumsq_partial = part.data_ptr()
     pd = None
     if nsq:
@@ -81,7 +83,7 @@ def reference_sum(idx, dout, f):
     return first, acc
 
 
-@pytest.mark.parametrize("B", [1, 37, 255, 256, 257, 700, 1024, 2048, 3000, 4096])
+@pytest.mark.parametrize("B", [1, 37, 255, 256, 257, 700, 1024, 1500, 2048])
 def test_two_halves_equal_the_one_launch_dedup_bit_for_bit(lib, B):
     torch.manual_seed(100 + B)
     rows = [4, 1, 7, 50, 3000, 10 ** 6]
@@ -128,9 +130,14 @@ def test_two_halves_equal_the_one_launch_dedup_bit_for_bit(lib, B):
     cap = cap_of(B)
     for f in range(Fs):  # (entries behind a field's counts are stale memory)
         nA, nB = int(bufs["counts"][2 * f]), int(bufs["counts"][2 * f + 1])
-        assert torch.equal(bufs["order"][f * cap:f * cap + B], bufs2["order"][f * cap:f * cap + B])
         assert torch.equal(bufs["lists"][f * cap:f * cap + nA], bufs2["lists"][f * cap:f * cap + nA])
         assert torch.equal(bufs["lists"][f * cap + cap // 2:f * cap + cap // 2 + nB], bufs2["lists"][f * cap + cap // 2:f * cap + cap // 2 + nB])
+        for k in range(nA):  # the sub-runs' samples
+            en = int(bufs["lists"][f * cap + k]) & 0xffffffff
+            s0, ln = en & 0xffff, (en >> 16) & 0x7fff
+            assert torch.equal(bufs["order"][f * cap + s0:f * cap + s0 + ln], bufs2["order"][f * cap + s0:f * cap + s0 + ln])
+            o = bufs["order"][f * cap + s0:f * cap + s0 + ln].cpu().long()
+            assert bool((o[1:] > o[:-1]).all()) and len(set(idx[o, f].tolist())) == 1 and len(set((o >> 8).tolist())) == 1
 
 
 @pytest.mark.parametrize("B,ranks", [(256, 1), (512, 2), (2048, 8), (300, 3)])
@@ -231,10 +238,19 @@ def test_the_id_half_rides_on_the_staging_launch(lib):
     assert torch.equal(a["leader"], b["leader"]) and torch.equal(a["counts"], b["counts"])
     for f in range(Fs):
         nA = int(a["counts"][2 * f])
-        assert torch.equal(a["order"][f * 256:f * 256 + B], b["order"][f * 256:f * 256 + B])
+        assert int(a["counts"][2 * f + 1]) == 0  # one chunk: no run spans chunks
         assert torch.equal(a["lists"][f * 256:f * 256 + nA], b["lists"][f * 256:f * 256 + nA])
-    # the sorted order is (id, sample) ascending and the leaders are the first occurrences
-    for f in range(Fs):
-        o = (a["order"][f * 256:f * 256 + B] & 0x7fffffff).cpu().long()
-        keys = idx[:, f].cpu()[o] * 65536 + o
-        assert bool((keys[1:] > keys[:-1]).all())
+        used, want_lead = 0, {}
+        for bb in range(B):
+            want_lead.setdefault(int(idx[bb, f]), bb)
+        for k in range(nA):  # every run with duplicates: leader first, then its duplicates ascending
+            en = int(a["lists"][f * 256 + k]) & 0xffffffff
+            s0, ln = en & 0xffff, (en >> 16) & 0x7fff
+            assert en >> 31 == 1 and s0 == used
+            used += ln
+            o = a["order"][f * 256 + s0:f * 256 + s0 + ln]
+            assert torch.equal(o, b["order"][f * 256 + s0:f * 256 + s0 + ln])
+            o = o.cpu().long()
+            ids_of = idx[:, f].cpu()[o]
+            assert bool((o[1:] > o[:-1]).all()) and len(set(ids_of.tolist())) == 1 and want_lead[int(ids_of[0])] == int(o[0])
+            assert ln == int((idx[:, f] == ids_of[0]).sum())

@@ -191,3 +191,111 @@ def test_single_process_route_is_the_identity():
     sg = torch.randn(9, len(TABLES), 16, generator=g, dtype=torch.float64)
     own_idx, own_g = t.send_grads(route, sg)
     assert torch.equal(own_idx, cat) and torch.equal(own_g, sg)  # world 1: the owner-side batch is the batch
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 5 (advisor findings): the shards of a drop-in module start as rows of a WHOLE table (whole-table fan, no duplicates across
+# ranks), and an optimizer checkpoint written from sharded tables holds every rank's Adagrad accumulators
+# ------------------------------------------------------------------------------------------------------------------
+INIT_TABLES = [4001, 37, 3, 1200]
+
+
+def _init_worker(rank, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=4)
+    from nasrec_amd.search_space import ops_config_lib
+    from nasrec_amd.supernet.supernet import ShardEmbedding, SuperNet
+    from nasrec_amd.utils.train_utils import init_weights
+    torch.manual_seed(7)  # (utils/dist.init_from_env seeds every rank alike)
+    m = SuperNet(num_blocks=1, ops_config=ops_config_lib["autoctr"], use_layernorm=True, num_embeddings=INIT_TABLES, sparse_input_size=len(INIT_TABLES),
+                 table_sharding="row")
+    assert all(type(e) is ShardEmbedding for e in m._embedding)
+    m.apply(init_weights)
+    out[rank] = [(e.row_lo, e.row_hi, e.weight.detach().clone()) for e in m._embedding]
+    dist.destroy_process_group()
+
+
+def test_sharded_tables_start_as_rows_of_a_whole_table_with_the_whole_table_fan():
+    from nasrec_amd.supernet.supernet import ShardEmbedding
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_init_worker, args=(port, out), nprocs=4, join=True)
+    for f, n in enumerate(INIT_TABLES):
+        parts = [out[r][f] for r in range(4)]
+        whole = torch.cat([w[:hi - lo] for lo, hi, w in parts])
+        assert whole.shape[0] == n and [p[0] for p in parts] == sorted(p[0] for p in parts)
+        if n >= 1000:
+            want = (2.0 / (n + 16)) ** 0.5  # xavier_normal_ of the WHOLE table (train_utils.py:76-77), not of a quarter of it
+            assert abs(float(whole.std()) - want) < 0.03 * want, (f, float(whole.std()), want)
+        # no two rows alike (identically seeded ranks would otherwise hold the same values)
+        assert len({tuple(r.tolist()) for r in whole}) == n
+        # ... and the same table a single rank holding all rows draws: the placement does not change the model
+        torch.manual_seed(7)
+        one = ShardEmbedding(n, 16, n, 0, n, f)
+        one.xavier_normal_whole_()
+        assert torch.equal(one.weight.detach(), whole)
+
+
+class _ShardedStandIn(torch.nn.Module):
+    """what io_utils' checkpoint helpers touch of a row-sharded SuperNet"""
+    _table_sharding = "row"
+
+    def __init__(self, tables):
+        super().__init__()
+        from nasrec_amd.sharded_tables import RowShardedTables
+        from nasrec_amd.supernet.supernet import ShardEmbedding, SuperNet
+        self._num_embeddings = tables
+        self._shard_rows = SuperNet._shard_rows
+        emb = []
+        for f, n in enumerate(tables):
+            lo, hi, rows = SuperNet._shard_rows(n)
+            emb.append(ShardEmbedding(rows, 16, n, lo, hi, f))
+        self._embedding = torch.nn.ModuleList(emb)
+        self._final = torch.nn.Linear(4, 1)
+        self._sharded = RowShardedTables(tables, "cpu", shards=[e.weight.data for e in self._embedding])
+
+
+def _ckpt_worker(rank, port, path, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from nasrec_amd.utils.io_utils import load_model_checkpoint, load_optimizer_state, optimizer_state_for_checkpoint
+    torch.manual_seed(1)
+    m = _ShardedStandIn(TABLES)
+    opt = torch.optim.Adagrad(m.parameters(), lr=0.1, eps=1e-2)
+    for f, e in enumerate(m._embedding):  # accumulators that tell ranks and rows apart (what engine_bind_optimizer aliases)
+        lo, hi = e.row_lo, e.row_hi
+        m._sharded.state[f].zero_()
+        if hi > lo:
+            m._sharded.state[f][:hi - lo] = (torch.arange(lo, hi, dtype=torch.float32).view(-1, 1) + 1000.0 * f + 0.5).expand(hi - lo, 16)
+        opt.state[e.weight]["sum"] = m._sharded.state[f]
+        opt.state[e.weight]["step"] = torch.tensor(3.0)
+    sd = optimizer_state_for_checkpoint(m, opt)  # a collective: both ranks
+    if rank == 0:
+        torch.save({"optimizer_state_dict": sd}, path)
+    dist.barrier()
+    # resume: every rank takes ITS rows of the whole accumulators
+    m2 = _ShardedStandIn(TABLES)
+    opt2 = torch.optim.Adagrad(m2.parameters(), lr=0.1, eps=1e-2)
+    load_optimizer_state(m2, opt2, load_model_checkpoint(path)["optimizer_state_dict"])
+    ok = True
+    for f, e in enumerate(m2._embedding):
+        k = e.row_hi - e.row_lo
+        got = opt2.state[e.weight]["sum"]
+        ok = ok and tuple(got.shape) == tuple(e.weight.shape) and torch.equal(got[:k], m._sharded.state[f][:k])
+    out[rank] = (ok, {i: tuple(v["sum"].shape) for i, v in sd["state"].items() if "sum" in v})
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_checkpoint_holds_every_ranks_accumulators(tmp_path):
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    path = str(tmp_path / "ck.pt")
+    mp.spawn(_ckpt_worker, args=(port, path, out), nprocs=WORLD, join=True)
+    assert out[0][0] and out[1][0], "a rank resumed with accumulators that are not its rows"
+    sd = torch.load(path)["optimizer_state_dict"]
+    for f, n in enumerate(TABLES):  # whole-table accumulators in the checkpoint, row r of table f = r + 1000 f + 0.5
+        s = sd["state"][f]["sum"]
+        assert tuple(s.shape) == (n, 16)
+        assert torch.equal(s[:, 0], torch.arange(n, dtype=torch.float32) + 1000.0 * f + 0.5)
