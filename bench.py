@@ -361,7 +361,8 @@ def main():
             g = torch.Generator(device="cpu").manual_seed(7)
             self.t = RowShardedTables(tables, device, init_fn=lambda f, lo, hi: torch.randn(hi - lo, 16, generator=g) * (2.0 / (tables[f] + 16)) ** 0.5)
             self.ops = EngineShardedOps(eng, clip=5.0, eps=1e-2)
-            self.stepper = ShardedTableStep(self.ops, self.t, B, clip=5.0, eps=1e-2)
+            self.stepper = ShardedTableStep(self.ops, self.t, B, clip=5.0, eps=1e-2, graph=not args.no_graph)
+            self.graph = self.stepper.graph
             self._loss = None
 
         def step(self, int_x, cat_x, y, lr, choice=None):

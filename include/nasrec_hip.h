@@ -174,6 +174,9 @@ typedef struct nasrec_emb_dedup_desc {
   float* sumsq_partial; /* [Fs * ceil(B/256)] out: sum of squares of leader gradients per workgroup */
   int32_t* overflow;    /* optional: set to 1 if a hash partition of the large-batch merge ran out of slots (never seen with
                            real id distributions; the step's result must then be discarded) */
+  int32_t rank_B;       /* layout of `dout` as in nasrec_adagrad_rows_desc_t (0: one contiguous [B,Fs,16] array; > 0: the receive */
+  int32_t _pad2;        /* buffer of an all-gather, rank_B samples per rank chunk, chunks rank_stride floats apart) — gsum stays contiguous */
+  int64_t rank_stride;
 } nasrec_emb_dedup_desc_t;
 
 /* ------------------------------------------------------------------------------------------------

@@ -65,7 +65,7 @@ class EmbedDesc(C.Structure):
 
 class EmbDedupDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("Fs", i32), ("_pad", i32), ("idx", vp), ("dout", vp), ("leader", vp), ("gsum", vp),
-                ("sumsq_partial", vp), ("overflow", vp)]
+                ("sumsq_partial", vp), ("overflow", vp), ("rank_B", i32), ("_pad2", i32), ("rank_stride", i64)]
 
 
 class DotTriDesc(C.Structure):

@@ -107,7 +107,7 @@ __device__ __forceinline__ void dedup_small_body(const nasrec_emb_dedup_desc_t& 
   const long gl = live ? gb : 0;
   f32x4 g[4];
   {
-    const f32x4* src = reinterpret_cast<const f32x4*>(d.dout + (gl * d.Fs + f) * 16);
+    const f32x4* src = reinterpret_cast<const f32x4*>(dd_row(const_cast<float*>(d.dout), (int)gl, f, d.Fs, d.rank_B, d.rank_stride));
 #pragma unroll
     for (int v = 0; v < 4; ++v) g[v] = src[v];
   }

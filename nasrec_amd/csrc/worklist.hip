@@ -231,6 +231,14 @@ int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
         it.nblk = (int)(((long)d->B * d->D + 255) / 256);
         break;
       }
+      case NASREC_OP_DEDUP_IDS: {  // the id-only half of the optimizer's row dedup (B <= 256: the mask form, a workgroup per field)
+        WL_NEED(nasrec_dedup_ids_desc_t);
+        const nasrec_dedup_ids_desc_t* d = reinterpret_cast<const nasrec_dedup_ids_desc_t*>(blob);
+        if (d->B < 1 || d->B > 256 || d->cap != 256 || d->Fs < 1 || d->Fs > NASREC_MAX_TABLES || !d->idx || !d->leader || !d->order || !d->lists || !d->counts)
+          return nasrec_set_error(-2, "worklist: dedup_ids item needs B <= 256, cap 256 and every output (B=%d cap=%d)", d->B, d->cap);
+        it.nblk = d->Fs;
+        break;
+      }
       case NASREC_OP_REDUCE_ROWS: {
         WL_NEED(nasrec_wl_reduce_t);
         const nasrec_wl_reduce_t* d = reinterpret_cast<const nasrec_wl_reduce_t*>(blob);

@@ -4,6 +4,7 @@
 #include "gemm_rt.h"
 #include "final_bodies.h"
 #include "interact_bodies.h"
+#include "dedup_bodies.h"
 
 #define WL_LDS_BIG_FLOATS MHA_BWD_LDS_FLOATS(4)  // 12960 floats = 52 KB
 #define WL_LDS_FLOATS MHA_FWD_LDS_FLOATS(4)  // 7840 floats = 31 KB (5 workgroups per CU): the Transformer forward; a 64x16x64 GEMM tile needs 5568
@@ -464,6 +465,11 @@ __global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(unsigned f01
     case NASREC_OP_REDUCE_ROWS:
       reduce_rows_block(wl_ref<nasrec_wl_reduce_t>(blob), vb, tid, lds);
       break;
+    case NASREC_OP_DEDUP_IDS: {
+      const nasrec_dedup_ids_desc_t& d = wl_ref<nasrec_dedup_ids_desc_t>(blob);
+      dedup_ids_small_body(d, d.idx, d.B, d.Fs, __builtin_amdgcn_readfirstlane(vb), reinterpret_cast<int*>(lds), reinterpret_cast<int*>(lds) + 256);
+      break;
+    }
     case NASREC_OP_FINAL_FWD:
       final_fwd_block(wl_ref<nasrec_final_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb));
       break;

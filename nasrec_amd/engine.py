@@ -21,7 +21,9 @@ from . import schedule as S
 
 E = 16
 # largest (global) batch whose row-gradient dedup runs in two halves (csrc/dedup_bodies.h; <= L.DEDUP_IDS_MAX_B); 0 = the one-launch kernels
-DEDUP_SPLIT_MAX_B = min(int(os.environ.get("NASREC_DEDUP_SPLIT_MAX_B", "2048")), L.DEDUP_IDS_MAX_B)
+DEDUP_SPLIT_MAX_B = min(int(os.environ.get("NASREC_DEDUP_SPLIT_MAX_B", "256")), L.DEDUP_IDS_MAX_B)
+# the id half of a level-scheduled step (B <= 256) as an ITEM of the joint forward + backward program (A/B knob: 0 = on the staging launch)
+_IDS_AS_ITEM = os.environ.get("NASREC_IDS_AS_ITEM", "1") != "0"
 
 
 def _ptr_array(descs):
@@ -289,15 +291,17 @@ class SupernetEngine:
     # -------------------------------------------------------------------------------------------------------
     @_on_device
     def compile(self, choice, B: int, train: bool, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = False,
-                grad_scale: Optional[float] = None, defer_dw: bool = True, row_grad_out: Optional[torch.Tensor] = None) -> CompiledPlan:
+                grad_scale: Optional[float] = None, defer_dw: bool = True, row_grad_out: Optional[torch.Tensor] = None,
+                local_optimizer: bool = True) -> CompiledPlan:
         """row_grad_out: storage [B * Fs * 16] the backward writes the per-sample embedding-row gradients into (a data-parallel step
-        hands in the head of its all-gather send buffer: no copy between the backward and the exchange)"""
+        hands in the head of its all-gather send buffer: no copy between the backward and the exchange); local_optimizer = False: the
+        plan gets no clip + Adagrad program of its own (a data-parallel step runs its optimizer over the GLOBAL batch)"""
         rgo = row_grad_out.data_ptr() if row_grad_out is not None else None
-        fast = (id(choice), B, train, clip, eps, graph, grad_scale, defer_dw, rgo)
+        fast = (id(choice), B, train, clip, eps, graph, grad_scale, defer_dw, rgo, local_optimizer)
         hit = self._last_plan
         if self.cfg.fixed and hit is not None and hit[0] == fast and hit[1] is choice:  # fixed sub-network, same choice object: skip the JSON key
             return hit[2]
-        key = json.dumps([choice, B, train, clip, eps, graph, grad_scale, defer_dw, rgo], sort_keys=True, default=_jsonable)
+        key = json.dumps([choice, B, train, clip, eps, graph, grad_scale, defer_dw, rgo, local_optimizer], sort_keys=True, default=_jsonable)
         if key in self._plans:
             self._last_plan = (fast, choice, self._plans[key])
             return self._plans[key]
@@ -417,11 +421,28 @@ class SupernetEngine:
                 bwd_descs = pre[1:] + ctx.bwd[:fi] + [fused] + ctx.bwd[fi + 1:]
                 # forward + backward of a training step as ONE scheduled program: what the forward leaves off its critical path (a
                 # block output no later block reads, second passes) runs beside the first backward levels
+                # clip + Adagrad (built before the packing: the id-only half of its row dedup is an operator of the step like any other)
+                odescs = []
+                cp.dedup_ids, cp.ids_on_stage = None, False
+                if local_optimizer:
+                    odescs = self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if (sbuf.grad_written and not self.host_embedding)
+                                                   else None, clip, eps)
+                ids_in_program = []
+                if cp.dedup_ids is not None:
+                    if scheduled and _IDS_AS_ITEM:
+                        # ... which depends on nothing but the staged ids and is read by nothing before the optimizer: the level scheduler puts
+                        # it where it costs least (beside a Transformer backward), off both the staging launch and the step's tail
+                        ids_in_program = [cp.dedup_ids]
+                    elif B <= 256:  # on the staging launch (which holds the caller's ids)
+                        cp.stage.dedup_ids = cp.dedup_ids
+                        cp.ids_on_stage = True
+                    else:           # in-stream programs (large batch): in front of the launch that needs it
+                        odescs = [cp.dedup_ids] + odescs
                 cp.fb = None
                 if scheduled:
                     # (alloc: a forward product with several levels of slack may be re-cut into split-K items — only in the JOINT
                     # program, where the backward's latency-bound levels are there to hide it)
-                    fb_descs, cp.fb_levels = S.pack(fwd_list + bwd_descs, alloc=ctx.alloc)
+                    fb_descs, cp.fb_levels = S.pack(ids_in_program + fwd_list + bwd_descs, alloc=ctx.alloc)
                     cp.fb = Program(fb_descs)
                     bwd_descs, cp.bwd_levels = S.pack(bwd_descs)
                 cp.bwd = Program(bwd_descs)
@@ -435,15 +456,6 @@ class SupernetEngine:
                     last.dseg[q] = None
                 tail = [ctx.bwd[fi + 1]] if plain.nsplit > 1 else []  # (the partial-sum launch of a split final backward)
                 cp.bwd_final_only = Program(pre[1:] + [last] + tail)
-                odescs = self._optimizer_descs(cp, B, cp.cat_x, sbuf.grad_tensor() if (sbuf.grad_written and not self.host_embedding)
-                                               else None, clip, eps)
-                cp.ids_on_stage = False
-                if cp.dedup_ids is not None:
-                    if B <= 256:   # the id-only half of the row dedup rides on the staging launch (which holds the caller's ids)
-                        cp.stage.dedup_ids = cp.dedup_ids
-                        cp.ids_on_stage = True
-                    else:          # in-stream programs (large batch): in front of the launch that needs it
-                        odescs = [cp.dedup_ids] + odescs
                 cp.opt = Program(odescs)
                 if graph:
                     cp.step = Program((cp.fb.descs if cp.fb is not None else cp.fwd.descs + cp.bwd.descs) + cp.opt.descs)
@@ -614,7 +626,8 @@ class SupernetEngine:
                 app.rows.gsum = sparse_grad.data_ptr()  # summed in place: a leader's row holds its sum
                 app.rows.rank_B, app.rows.rank_stride = r2.rank_B, r2.rank_stride
                 return [r2, app]
-            assert not rank_layout, "the one-launch dedup kernels read a contiguous [B, Fs, 16] array"
+            if rank_layout:  # (the one-launch kernels read the rows where the all-gather left them; their sums go to the contiguous gsum)
+                dd.rank_B, dd.rank_stride = rank_layout
             if Bg <= 256:
                 # the five launches collapse into the two that the grid-wide dependencies require
                 red = L.OptReduceDesc()

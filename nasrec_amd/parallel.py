@@ -105,7 +105,9 @@ DP_SEGMENTS = int(__import__("os").environ.get("NASREC_DP_SEGMENTS", "4"))
 _DEBUG = __import__("os").environ.get("NASREC_DP_DEBUG", "0") == "1"
 # where the id-only half of the global batch's row dedup runs in a data-parallel step (A/B knob): side = on a side stream behind the ids
 # all-gather; chain = the gather itself is issued from that side stream; main = on the compute stream in front of the optimizer (exposed)
-_IDS_MODE = __import__("os").environ.get("NASREC_DP_IDS_MODE", "side")
+# (measured on one rank, profiles/r05_dp_overhead.txt: a side branch in the captured step costs ~40 us — the graph runs parallel branches
+# through separate hardware queues — against 8 us for the kernel itself on the compute stream: main is the default)
+_IDS_MODE = __import__("os").environ.get("NASREC_DP_IDS_MODE", "main")
 PACK_TAIL_FLOATS = int(__import__("os").environ.get("NASREC_DP_PACK_TAIL", "65536"))
 
 
@@ -573,7 +575,7 @@ class EngineDP:
     def dp_path_spans(self, choice, B, grad_scale, clip, eps):
         """arena ranges [(offset, numel)] of the dense parameters the path `choice` trains (its plan knows: engine.compile — the
         arguments are dp_plan's, so this rank's own choice hits the plan it is about to run)"""
-        cp = self.engine.compile(choice, B, True, clip, eps, graph=False, grad_scale=grad_scale, defer_dw=False)
+        cp = self.engine.compile(choice, B, True, clip, eps, graph=False, grad_scale=grad_scale, defer_dw=False, local_optimizer=False)
         return list(cp.path_spans)
 
     def dp_dedup_ids(self):
@@ -618,9 +620,8 @@ class EngineDP:
         fixed = eng.cfg.fixed
         # weight-gradient products stay in backward order (never parked behind the backward): a block's gradients are complete when
         # its backward is, and can travel under the blocks that follow
-        cp = eng.compile(choice, B, True, clip, eps, graph=False, grad_scale=grad_scale, defer_dw=False, row_grad_out=row_grad_out)
-        cp.ids_on_stage = False  # the optimizer of a data-parallel step runs over the GLOBAL batch: its id half follows the ids all-gather
-        cp.stage.dedup_ids = L_DedupIdsDesc()
+        # (local_optimizer = False: clip + Adagrad of a data-parallel step run over the GLOBAL batch, dp_optimizer)
+        cp = eng.compile(choice, B, True, clip, eps, graph=False, grad_scale=grad_scale, defer_dw=False, row_grad_out=row_grad_out, local_optimizer=False)
         plan = DPPlan()
         plan.cp = cp
         plan.cat_local, plan.loss = cp.cat_x, cp.loss
@@ -703,11 +704,6 @@ class EngineDP:
 
 class _Holder:
     pass
-
-
-def L_DedupIdsDesc():
-    from . import _lib as L
-    return L.DedupIdsDesc()
 
 
 def _jsonable(o):

@@ -262,6 +262,11 @@ def desc_io(d, part="whole") -> Tuple[List[Acc], List[Acc]]:
             v = lambda p, ld: Acc(p, d.R // 16, d.D * E, ld)
         R += [v(d.dy, d.ld_dy), v(d.z, d.ld_z)]
         W.append(v(d.dz, d.ld_dz))
+    elif k == L.OP_DEDUP_IDS:  # ids in; leaders / runs / lists out (the optimizer's launches behind the program read them)
+        R.append(_flat(d.idx, d.B * d.Fs * 2))
+        W += [_flat(d.leader, d.B * d.Fs), _flat(d.order, d.Fs * d.cap), _flat(d.lists, d.Fs * d.cap), _flat(d.counts, d.Fs * 2)]
+        if d.heads:
+            W.append(_flat(d.heads, d.Fs * d.cap))
     elif k == L.OP_MEMSET and not d.chunks:
         W.append(_flat(d.ptr, (d.bytes + 3) // 4))
     else:
@@ -504,7 +509,7 @@ def levels_of(descs):
 _GEMM_HEAD = L.GemmDesc.seg.offset
 _SEG_BYTES = C.sizeof(L.GemmSeg)
 _PLAIN_KINDS = (L.OP_MHA_FWD, L.OP_MHA_BWD, L.OP_FM_FWD, L.OP_FM_BWD, L.OP_DOT_TRI_FWD, L.OP_DOT_TRI_BWD, L.OP_COPY_SEGS, L.OP_GATE_BWD,
-                L.OP_FINAL_FWD, L.OP_FINAL_BWD)
+                L.OP_FINAL_FWD, L.OP_FINAL_BWD, L.OP_DEDUP_IDS)
 WL_LDS_FLOATS = 1696 + 5 * 1024 + 1024  # csrc/worklist_body.h WL_LDS_FLOATS
 
 
@@ -559,6 +564,8 @@ def item_bytes(node):
             return None
     if k in (L.OP_MHA_FWD, L.OP_MHA_BWD) and (d.N < 1 or d.N > 64 or (k == L.OP_MHA_BWD and not d.saved)):
         return None
+    if k == L.OP_DEDUP_IDS and (d.B > 256 or d.cap != 256):
+        return None
     if k in _PLAIN_KINDS:
         return C.string_at(C.addressof(d), C.sizeof(d))
     if k == L.OP_REDUCE_ROWS and 1 <= d.ndst <= L.WL_REDUCE_DST:
@@ -575,10 +582,10 @@ _PART = {"whole": L.WL_WHOLE, "main": L.WL_MAIN, "epi": L.WL_EPI}
 
 # stand-alone times of the non-GEMM items of the batch-256 step, ns (tools/step_table.py ITEMS=11)
 _ITEM_NS = {L.OP_MHA_BWD: 18000, L.OP_MHA_FWD: 11000, L.OP_DOT_TRI_BWD: 10000, L.OP_DOT_TRI_FWD: 6000, L.OP_REDUCE_ROWS: 4500,
-            L.OP_FM_BWD: 3900, L.OP_FM_FWD: 3500, L.OP_FINAL_BWD: 7500}
+            L.OP_FM_BWD: 3900, L.OP_FM_FWD: 3500, L.OP_FINAL_BWD: 7500, L.OP_DEDUP_IDS: 8000}
 # round 4 (ITEMS=7 python tools/step_table.py on the balanced plan): the same items measured again, used by the balancing pass
 _ITEM_NS_R4 = {L.OP_MHA_BWD: 18500, L.OP_MHA_FWD: 10500, L.OP_REDUCE_ROWS: 6000, L.OP_FM_BWD: 7000, L.OP_FM_FWD: 3500, L.OP_FINAL_BWD: 7000,
-               L.OP_FINAL_FWD: 3400, L.OP_GATE_BWD: 3500}
+               L.OP_FINAL_FWD: 3400, L.OP_GATE_BWD: 3500, L.OP_DEDUP_IDS: 8000}
 _COST_MODEL = os.environ.get("NASREC_WL_COST", "time")
 
 

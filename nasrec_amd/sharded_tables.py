@@ -7,17 +7,20 @@ Placement: table f (n_f rows) is cut into `world` contiguous row ranges of rp_f 
 tables side by side).
 
 One training step (the dense network stays data-parallel, `nasrec_amd/parallel.py`):
-  1. route      every (sample b, field f) item goes to the owner of its row; items are sent ordered by (owner, f, b), so that an owner
-                sees each field's items in GLOBAL batch order (source rank, then b) — the order in which duplicate rows are summed;
-  2. lookup     all-to-all of the ids (+ one small all-to-all of the per-field counts), owners gather their rows (bit-exact copy),
-                all-to-all of the rows back: [B, Fs, 16] for the local forward;
+  1. route      every (sample b, field f) item goes to the owner of its row, in the slot [b, f] of the [B, Fs] matrix the owner receives
+                from this rank (PAD_ID in the slots of items other ranks own): the owner's [W B, Fs] matrix is in GLOBAL batch order
+                (source rank, then b) — the order in which duplicate rows are summed;
+  2. lookup     all-to-all of the ids, owners gather their rows (bit-exact copy; zero rows for the pads), all-to-all of the rows back,
+                every item picks its row out of its owner's slot: [B, Fs, 16] for the local forward;
   3. backward   the local row gradients [B, Fs, 16] take the same route to the owners (one all-to-all);
   4. update     every owner runs the row-sparse dedup + clip + Adagrad on ITS rows; the clip coefficient needs the global gradient norm:
                 the owners' partial sums of squares are all-reduced (a few hundred bytes).
 Equivalence target (tests/test_sharded_tables_cpu.py, gloo world 2): the step of a single process at the global batch with whole tables.
 
-The routing is plain torch (sort / bincount / cumsum on whatever device the ids live on); what runs on the rows is pluggable: the HIP
-engine's gather / dedup / Adagrad kernels on the GPU (`ShardedTableOps` in this file binds them), index ops in the CPU tests."""
+Routing (round 5): FIXED-CAPACITY slots — every rank sends every peer a full [B, Fs] slot with PAD_ID where the peer does not own the
+row — so there is no sort, no compaction and no split size for the host to read back: a step enqueues without synchronising with the
+device.  What runs on the rows is pluggable: the HIP engine's gather / dedup / Adagrad kernels on the GPU (`EngineShardedOps` in this
+file binds them), index ops in the CPU tests."""
 import math
 from typing import List, Optional
 
@@ -30,7 +33,7 @@ PAD_ID = -(1 << 30)  # pad of the owner-side id matrix: out of every table's ran
 
 class Route:
     """how the items of one local batch travel: built by RowShardedTables.route(), used for the forward and the backward exchange"""
-    __slots__ = ("B", "order", "send_counts", "recv_counts", "recv_field_counts", "own_idx", "own_pos", "Bp", "nrecv")
+    __slots__ = ("B", "owner", "own_idx", "Bp")
 
 
 class RowShardedTables:
@@ -62,83 +65,78 @@ class RowShardedTables:
             self.tables.append(t.contiguous())
             self.state.append(torch.zeros_like(self.tables[-1]))
         self._rp_t = torch.tensor(self.rp, dtype=torch.int64, device=self.device)
+        self._n_t = torch.tensor(self.num_embeddings, dtype=torch.int64, device=self.device)
+        self._dest = torch.arange(self.world, dtype=torch.int64, device=self.device).view(self.world, 1, 1)
+        self.oob = torch.zeros((), dtype=torch.bool, device=self.device)  # an id outside its table was seen (check_indices)
 
     # ---------------------------------------------------------------------------------------------------------------------
-    def route(self, cat_x: torch.Tensor) -> Route:
-        """cat_x [B, Fs] int64 (global row ids) -> Route.  One host synchronisation (the split sizes of the all-to-alls)."""
-        B, Fs, W = int(cat_x.shape[0]), self.Fs, self.world
-        ids = cat_x.t().contiguous()                       # [Fs, B]: flattened order = (f, b)
-        owner = ids // self._rp_t.view(Fs, 1)
-        local = ids - owner * self._rp_t.view(Fs, 1)
-        flat_owner = owner.reshape(-1)
-        order = torch.sort(flat_owner, stable=True).indices  # items by (owner, f, b)
-        field = torch.arange(Fs, device=ids.device).view(Fs, 1).expand(Fs, B).reshape(-1)
-        counts = torch.bincount(flat_owner * Fs + field, minlength=W * Fs).view(W, Fs)  # [dest, f]
+    # Fixed-capacity exchange (round 5).  Every rank sends every peer a FULL [B, Fs] slot: the entries the peer owns carry the local
+    # row number, the others PAD_ID (ids) / zeros (rows, gradients).  No split sizes, no sort, no compaction — hence nothing for the
+    # host to read back: the whole step enqueues without a synchronisation — and the owner sees source s's sample b at row s B + b of
+    # its [W B, Fs] matrix, i.e. in GLOBAL batch order (the order in which duplicate rows are summed).  The price is W x the bytes of a
+    # compacted exchange (W B Fs 64 B per rank and direction: 3.4 MB at 8 x 256 x 26), which at these sizes is latency, not bandwidth.
+    def route(self, cat_x: torch.Tensor, mask_fn=None) -> Route:
+        """cat_x [B, Fs] int64 (global row ids) -> Route.  No host synchronisation.  mask_fn(cat_x) -> (owner [B, Fs] int64,
+        send_ids [W, B, Fs] int64) runs the masking on the engine (one launch; default: tensor operations)."""
+        B, W = int(cat_x.shape[0]), self.world
         r = Route()
-        r.B, r.order = B, order
-        if W > 1:
-            recv_fc = torch.empty_like(counts)
-            dist.all_to_all_single(recv_fc, counts, group=self.group)  # recv_fc[src, f]
+        r.B, r.Bp = B, W * B
+        if mask_fn is not None:
+            r.owner, send_ids = mask_fn(cat_x)
         else:
-            recv_fc = counts
-        both = torch.stack([counts.sum(1), recv_fc.sum(1)]).cpu()
-        r.send_counts, r.recv_counts = both[0].tolist(), both[1].tolist()
-        r.recv_field_counts = recv_fc
-        r.nrecv = int(sum(r.recv_counts))
-        send_ids = local.reshape(-1)[order]
-        recv_ids = self._a2a(send_ids, r.send_counts, r.recv_counts)
-        # owner side: column f of a padded [Bp, Fs] matrix = field f's items in (source, b) order; pads are PAD_ID (skipped by the update)
-        per_field = recv_fc.sum(0)                          # items of field f over all sources
-        Bp = max(int(per_field.max().item()) if r.nrecv else 0, 1)
-        r.Bp = Bp
-        src_off = torch.cumsum(recv_fc.sum(1), 0) - recv_fc.sum(1)               # start of source s in the received stream
-        in_src = torch.cumsum(recv_fc, 1) - recv_fc                              # start of field f inside source s
-        start = src_off.view(W, 1) + in_src                                      # [src, f] -> position in the received stream
-        col_off = torch.cumsum(recv_fc, 0) - recv_fc                             # [src, f] -> row inside column f
-        # position p of the received stream -> (row, column) of the padded matrix
-        seg_len = recv_fc.reshape(-1)                                            # segments in stream order are (src, f) row-major
-        seg_id = torch.repeat_interleave(torch.arange(W * Fs, device=ids.device), seg_len)
-        within = torch.arange(r.nrecv, device=ids.device) - start.reshape(-1)[seg_id]
-        rows = col_off.reshape(-1)[seg_id] + within
-        cols = seg_id % Fs
-        r.own_pos = rows * Fs + cols                                             # flat index into [Bp, Fs]
-        own_idx = torch.full((Bp * Fs,), PAD_ID, dtype=torch.int64, device=ids.device)
-        own_idx[r.own_pos] = recv_ids
-        r.own_idx = own_idx.view(Bp, Fs)
+            r.owner = torch.div(cat_x, self._rp_t.view(1, self.Fs), rounding_mode="floor")
+            local = cat_x - r.owner * self._rp_t.view(1, self.Fs)
+            self.oob |= ((cat_x < 0) | (cat_x >= self._n_t.view(1, self.Fs))).any()
+            send_ids = torch.where(r.owner.unsqueeze(0) == self._dest, local.unsqueeze(0), torch.full_like(local, PAD_ID).unsqueeze(0))
+        r.own_idx = self._a2a(send_ids.view(W, B * self.Fs)).view(W * B, self.Fs)  # row s B + b = source s, sample b
         return r
 
-    def _a2a(self, send: torch.Tensor, send_counts, recv_counts) -> torch.Tensor:
-        """all_to_all_single along dim 0 with per-rank row counts"""
-        out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        if self.world > 1:
-            dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=self.group)
-        else:
-            out.copy_(send)
+    def _a2a(self, send: torch.Tensor) -> torch.Tensor:
+        """all_to_all_single with equal splits along dim 0 (one [W, ...] slot per peer)"""
+        if self.world == 1:
+            return send
+        out = torch.empty_like(send)
+        dist.all_to_all_single(out, send.contiguous(), group=self.group)
         return out
 
     # ---------------------------------------------------------------------------------------------------------------------
-    def lookup(self, cat_x: torch.Tensor, gather_fn=None):
-        """-> (rows [B, Fs, 16] of the LOCAL batch, Route).  gather_fn(own_idx [Bp, Fs] with pads as 0) -> [Bp, Fs, 16] runs the
-        owner-side gather on this rank's shards (default: torch indexing)."""
-        r = self.route(cat_x)
-        safe = r.own_idx.clamp_min(0)
+    def lookup(self, cat_x: torch.Tensor, gather_fn=None, mask_fn=None, select_fn=None):
+        """-> (rows [B, Fs, 16] of the LOCAL batch, Route).  gather_fn(own_idx [W B, Fs], pads = PAD_ID) -> [W B, Fs, 16] with zero rows
+        for the pads runs the owner-side gather on this rank's shards; select_fn(back [W, B, Fs, 16], owner) -> [B, Fs, 16] picks every
+        item's row out of its owner's slot (defaults: tensor operations)."""
+        r = self.route(cat_x, mask_fn)
+        W, B, Fs = self.world, r.B, self.Fs
         if gather_fn is not None:
-            own_rows = gather_fn(safe)
+            own_rows = gather_fn(r.own_idx)
         else:
-            own_rows = torch.stack([self.tables[f][safe[:, f]] for f in range(self.Fs)], 1)
-        back = own_rows.reshape(-1, E)[r.own_pos]            # received-stream order
-        got = self._a2a(back, r.recv_counts, r.send_counts)  # rows of my items, in my send order
-        rows = torch.empty(self.Fs * r.B, E, dtype=got.dtype, device=got.device)
-        rows[r.order] = got
-        return rows.view(self.Fs, r.B, E).transpose(0, 1).contiguous(), r
+            keep = (r.own_idx >= 0).unsqueeze(-1)
+            safe = r.own_idx.clamp_min(0)
+            own_rows = torch.stack([self.tables[f][safe[:, f].clamp_max(self.tables[f].shape[0] - 1)] for f in range(Fs)], 1) * keep
+        back = self._a2a(own_rows.reshape(W, B * Fs * E)).view(W, B, Fs, E)  # slot o = what owner o holds of my batch
+        if select_fn is not None:
+            rows = select_fn(back, r.owner)
+        else:
+            rows = torch.gather(back, 0, r.owner.clamp(0, W - 1).view(1, B, Fs, 1).expand(1, B, Fs, E)).squeeze(0)
+        return rows.contiguous(), r
 
-    def send_grads(self, r: Route, sg: torch.Tensor):
-        """local row gradients [B, Fs, 16] -> owner-side (own_idx [Bp, Fs] with pads -1, grads [Bp, Fs, 16] with zero pads)"""
-        flat = sg.view(r.B, self.Fs, E).transpose(0, 1).reshape(-1, E)[r.order]
-        got = self._a2a(flat, r.send_counts, r.recv_counts)
-        own = torch.zeros(r.Bp * self.Fs, E, dtype=got.dtype, device=got.device)
-        own[r.own_pos] = got
-        return r.own_idx, own.view(r.Bp, self.Fs, E)
+    def send_grads(self, r: Route, sg: torch.Tensor, mask_fn=None):
+        """local row gradients [B, Fs, 16] -> owner-side (own_idx [W B, Fs] with pads PAD_ID, grads [W B, Fs, 16] with zero pads)"""
+        W, B, Fs = self.world, r.B, self.Fs
+        sg = sg.view(B, Fs, E)
+        if W == 1:
+            return r.own_idx, sg
+        if mask_fn is not None:
+            send = mask_fn(sg, r.owner)
+        else:
+            send = torch.where((r.owner.unsqueeze(0) == self._dest).unsqueeze(-1), sg.unsqueeze(0), torch.zeros((), dtype=sg.dtype, device=sg.device))
+        got = self._a2a(send.reshape(W, B * Fs * E))
+        return r.own_idx, got.view(W * B, Fs, E)
+
+    def check_indices(self):
+        """raise IndexError if any id seen so far was outside its table (torch raises at lookup time; here the flag is read on demand:
+        the step itself never waits for the device)"""
+        if bool(self.oob):
+            raise IndexError("index out of range in embedding lookup (row-sharded tables)")
 
     # ---------------------------------------------------------------------------------------------------------------------
     def reference_update(self, own_idx, own_g, coef: float, lr: float, eps: float):
@@ -192,15 +190,51 @@ class ShardedTableStep:
         ops.forward_backward(int_x, rows [B,Fs,16], y, choice, grad_scale) -> (loss, row gradients [B,Fs,16]); dense gradients in ops.flat_g
         ops.dense_sumsq() -> 0-d float64 tensor (over the step's path only);  ops.dense_update(coef 0-d tensor, lr)
         ops.grad_ranges() -> [(offset, numel)] of ops.flat_g that this step's path wrote, or None for the whole arena (optional)
-        ops.gather(tables, own_idx_safe) -> [Bp,Fs,16] or None (default torch indexing)
+        ops.gather(tables, own_idx) -> [W B, Fs, 16], zero rows where own_idx is PAD_ID (optional; default torch indexing)
         ops.rows_sumsq(tables, own_idx, own_g) -> 0-d float64;  ops.rows_update(tables, own_idx, own_g, coef, lr, eps)"""
 
-    def __init__(self, ops, tables: RowShardedTables, B_local: int, clip: Optional[float] = 5.0, eps: float = 1e-2):
+    def __init__(self, ops, tables: RowShardedTables, B_local: int, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = True):
+        """graph: when the ops say the step is capturable (`ops.capturable`: the HIP engine on a fixed sub-network — one plan, static
+        buffers), the WHOLE step — routing, the three all-to-alls, forward / backward, the all-reduces, owner-side dedup + clip + Adagrad —
+        is captured once (the second call) into one graph and replayed: a step is four small input copies and one graph launch."""
         self.ops, self.tables, self.B, self.clip, self.eps = ops, tables, B_local, clip, eps
         self.world = tables.world
         self.last_norm = None
+        self.graph = bool(graph)
+        self._g = None  # (key, CUDAGraph, static inputs, loss)
+        self._calls = 0
 
-    def step(self, int_x, cat_x, y, lr: float, choice=None):
+    def step(self, int_x, cat_x, y, lr, choice=None):
+        dev = self.tables.device
+        if not (self.graph and dev.type == "cuda" and getattr(self.ops, "capturable", False)):
+            return self._step(int_x, cat_x, y, lr, choice)
+        self._calls += 1
+        if self._calls == 1:  # the first step runs eagerly: plans are compiled, communicators created, work buffers allocated
+            return self._step(int_x, cat_x, y, lr, choice)
+        key = (id(choice), tuple(int_x.shape), tuple(cat_x.shape), int_x.dtype)
+        if self._g is None or self._g[0] != key:
+            static = (torch.empty_like(int_x), torch.empty_like(cat_x), torch.empty_like(y), torch.zeros(1, dtype=torch.float32, device=dev))
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    loss = self._step(static[0], static[1], static[2], static[3], choice)
+                self._g = (key, g, static, loss)
+            except Exception as e:  # noqa: BLE001
+                import warnings
+                warnings.warn("row-sharded step: graph capture failed (%s); running eagerly" % (e,))
+                torch.cuda.synchronize(dev)
+                self.graph = False
+                return self._step(int_x, cat_x, y, lr, choice)
+        _, g, static, loss = self._g
+        static[0].copy_(int_x, non_blocking=True)
+        static[1].copy_(cat_x, non_blocking=True)
+        static[2].copy_(y.reshape(static[2].shape), non_blocking=True)
+        static[3].fill_(float(lr))
+        g.replay()
+        return loss
+
+    def _step(self, int_x, cat_x, y, lr, choice=None):
         t, ops = self.tables, self.ops
         gather = getattr(ops, "gather", None)
         rows, route = t.lookup(cat_x, (lambda idx: gather(t, idx)) if gather is not None else None)
@@ -227,7 +261,10 @@ class ShardedTableStep:
         nd = getattr(ops, "norm_dtype", torch.float64)
         total = torch.sqrt(ops.dense_sumsq() + ss).to(nd)
         if self.clip is not None:
-            coef = torch.clamp(torch.tensor(self.clip, dtype=nd, device=total.device) / (total + torch.tensor(1e-6, dtype=nd, device=total.device)), max=1.0)
+            k = (nd, total.device)
+            if getattr(self, "_consts", (None,))[0] != k:  # (built once: a host scalar turned into a device tensor per step is a copy per step)
+                self._consts = (k, torch.tensor(self.clip, dtype=nd, device=total.device), torch.tensor(1e-6, dtype=nd, device=total.device))
+            coef = torch.clamp(self._consts[1] / (total + self._consts[2]), max=1.0)
         else:
             coef = torch.ones_like(total)
         self.last_norm = total
@@ -252,6 +289,8 @@ class EngineShardedOps:
         self.coef_dev = torch.ones(2, dtype=torch.float32, device=engine.device)
         self.norm_dtype = torch.float32  # the clip coefficient in the arithmetic of the whole-table step's kernel (ShardedTableStep.step)
         self._bufs = {}
+        self.capturable = bool(engine.cfg.fixed)  # one plan, static buffers: the whole step can be captured as one graph
+        self._zero_ids = None
 
     def _launch(self, desc):
         self.L.check(self.L.load().nasrec_launch(self.eng._sp(), self.C.addressof(desc)))
@@ -261,7 +300,9 @@ class EngineShardedOps:
         choice = choice if choice is not None else eng.warm_choice
         cp = eng.compile(choice, int(int_x.shape[0]), train=True, grad_scale=grad_scale)
         sp = eng._sp()
-        eng._stage_inputs(sp, cp, int_x, torch.zeros(int_x.shape[0], eng.Fs, dtype=torch.int64, device=eng.device), y, rows=rows)
+        if self._zero_ids is None or self._zero_ids.shape[0] != int_x.shape[0]:
+            self._zero_ids = torch.zeros(int_x.shape[0], eng.Fs, dtype=torch.int64, device=eng.device)
+        eng._stage_inputs(sp, cp, int_x, self._zero_ids, y.reshape(-1), rows=rows)
         (cp.fb if getattr(cp, "fb", None) is not None else cp.fwd).run(sp)
         if getattr(cp, "fb", None) is None:
             cp.bwd.run(sp)
@@ -296,7 +337,10 @@ class EngineShardedOps:
     def dense_update(self, coef, lr):
         L, eng = self.L, self.eng
         self.coef_dev[0] = coef.to(torch.float32)
-        eng.lr_dev.fill_(float(lr))
+        if torch.is_tensor(lr):
+            eng.lr_dev.copy_(lr.to(torch.float32).reshape(1))  # (a device scalar: the captured step is replayed with a new learning rate)
+        else:
+            eng.lr_dev.fill_(float(lr))
         ad = L.AdagradDenseDesc()
         ad.kind, ad.eps, ad.n = L.OP_ADAGRAD_DENSE, self.eps, eng.flat_numel
         ad.p, ad.g, ad.state = eng.flat_p.data_ptr(), eng.flat_g.data_ptr(), eng.flat_s.data_ptr()
@@ -312,7 +356,7 @@ class EngineShardedOps:
         out = torch.empty(Bp, t.Fs, E, dtype=torch.float32, device=idx_safe.device)
         g = L.EmbedDesc()
         g.kind, g.B, g.Fs = L.OP_EMBED_GATHER, Bp, t.Fs
-        g.idx, g.out, g.oob = idx_safe.data_ptr(), out.data_ptr(), self.eng.oob.data_ptr()
+        g.idx, g.out, g.oob = idx_safe.data_ptr(), out.data_ptr(), None  # (pads are PAD_ID: zero rows, no out-of-range flag — RowShardedTables.oob has the real ones)
         for f in range(t.Fs):
             g.table[f], g.rows[f] = t.tables[f].data_ptr(), t.tables[f].shape[0]
         self._launch(g)

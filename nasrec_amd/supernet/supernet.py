@@ -128,28 +128,25 @@ class _SupernetFunction(torch.autograd.Function):
 
 
 class ShardEmbedding(nn.Embedding):
-    """This rank's rows [row_lo, row_hi) of a `whole_rows`-row table (SuperNet(table_sharding="row")).  A subclass, so that the type-exact
-    `init_weights` of the reference's harness leaves it alone; its values are always rows of a WHOLE table: drawn chunk by chunk from one
-    generator seeded by (torch.initial_seed(), field) — identical on every rank (utils/dist.init_from_env seeds the ranks alike) and for
-    every world size — of which the rank keeps its range."""
+    """This rank's rows [row_lo, row_hi) of a `whole_rows`-row table (SuperNet(table_sharding="row")).  Its values are always rows of a
+    WHOLE table drawn the way the unsharded module draws it — one `normal_` of [whole_rows, dim] from the default generator of the
+    weight's device, at the same point of the initialisation sequence — of which the rank keeps its range: with the ranks seeded alike
+    (utils/dist.init_from_env) a sharded model starts, at any world size, from exactly the unsharded model's tables (and, the random
+    stream having advanced by the same amount, from its dense weights too).  A subclass, so that the type-exact `init_weights` of the
+    harness does not initialise a shard by itself (its fan would be the shard's: std sqrt(world) times too large, the same values on
+    every rank); SuperNet.apply routes that call here."""
 
     def __init__(self, rows, dim, whole_rows, row_lo, row_hi, field):
         self.whole_rows, self.row_lo, self.row_hi, self.field = int(whole_rows), int(row_lo), int(row_hi), int(field)
         super().__init__(rows, dim)
 
     def _draw_whole_(self, std: float):
-        g = torch.Generator().manual_seed((torch.initial_seed() + 1000003 * (self.field + 1)) % (1 << 62))
-        dim = self.weight.shape[1]
         with torch.no_grad():
+            whole = torch.empty(self.whole_rows, self.weight.shape[1], dtype=self.weight.dtype, device=self.weight.device).normal_(0.0, std)
             self.weight.zero_()
-            chunk = 1 << 20
-            for r0 in range(0, self.whole_rows, chunk):
-                r1 = min(self.whole_rows, r0 + chunk)
-                part = torch.empty(r1 - r0, dim).normal_(0.0, 1.0, generator=g)  # (every chunk is drawn, kept or not: a rank's rows do not depend on the world size)
-                if r1 <= self.row_lo or r0 >= self.row_hi:
-                    continue
-                a, b = max(r0, self.row_lo), min(r1, self.row_hi)
-                self.weight[a - self.row_lo:b - self.row_lo] = (part[a - r0:b - r0] * std).to(self.weight.device, self.weight.dtype)
+            k = self.row_hi - self.row_lo
+            if k > 0:
+                self.weight[:k] = whole[self.row_lo:self.row_hi]
 
     def reset_parameters(self):  # nn.Embedding's constructor default: N(0, 1)
         if hasattr(self, "whole_rows"):
@@ -249,14 +246,16 @@ class SuperNet(nn.Module):
 
     def apply(self, fn):
         """nn.Module.apply; with row-sharded tables, the reference's `init_weights` (train_utils.py:70-89: xavier_normal_ on every
-        nn.Embedding, type-exact) also initialises the shards — as rows [lo, hi) of a WHOLE table drawn with the whole table's fan
-        (a shard initialised by itself would take its fan from its own row count: std sqrt(world) times too large, and — every rank
-        seeds alike — the same values on every rank)."""
-        out = super().apply(fn)
+        nn.Embedding, type-exact) initialises the shards too — each as rows [lo, hi) of a WHOLE table drawn with the whole table's fan
+        at the shard's place in the traversal (ShardEmbedding), so the random stream is consumed exactly as by the unsharded model."""
         if self._table_sharding == "row" and getattr(fn, "__name__", "") == "init_weights":
-            for m in self._embedding:
-                m.xavier_normal_whole_()
-        return out
+            def routed(m, _fn=fn):
+                if type(m) is ShardEmbedding:
+                    m.xavier_normal_whole_()
+                else:
+                    _fn(m)
+            return super().apply(routed)
+        return super().apply(fn)
 
     @staticmethod
     def _shard_rows(n):

@@ -211,30 +211,37 @@ def _init_worker(rank, port, out):
                  table_sharding="row")
     assert all(type(e) is ShardEmbedding for e in m._embedding)
     m.apply(init_weights)
-    out[rank] = [(e.row_lo, e.row_hi, e.weight.detach().clone()) for e in m._embedding]
+    out[rank] = [(e.row_lo, e.row_hi, e.weight.detach().clone()) for e in m._embedding] + [torch.rand(4)]  # (the stream behind the initialisation)
     dist.destroy_process_group()
 
 
 def test_sharded_tables_start_as_rows_of_a_whole_table_with_the_whole_table_fan():
-    from nasrec_amd.supernet.supernet import ShardEmbedding
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_init_worker, args=(port, out), nprocs=4, join=True)
     for f, n in enumerate(INIT_TABLES):
         parts = [out[r][f] for r in range(4)]
-        whole = torch.cat([w[:hi - lo] for lo, hi, w in parts])
+        whole = torch.cat([w[:hi - lo] for lo, hi, w in parts])  # (out[r][-1]: the next draws of the rank's random stream)
         assert whole.shape[0] == n and [p[0] for p in parts] == sorted(p[0] for p in parts)
         if n >= 1000:
             want = (2.0 / (n + 16)) ** 0.5  # xavier_normal_ of the WHOLE table (train_utils.py:76-77), not of a quarter of it
             assert abs(float(whole.std()) - want) < 0.03 * want, (f, float(whole.std()), want)
         # no two rows alike (identically seeded ranks would otherwise hold the same values)
         assert len({tuple(r.tolist()) for r in whole}) == n
-        # ... and the same table a single rank holding all rows draws: the placement does not change the model
-        torch.manual_seed(7)
-        one = ShardEmbedding(n, 16, n, 0, n, f)
-        one.xavier_normal_whole_()
-        assert torch.equal(one.weight.detach(), whole)
+    # ... and the tables (and everything initialised after them) are those of the UNSHARDED module from the same seed: the placement does
+    # not change the model
+    from nasrec_amd.search_space import ops_config_lib
+    from nasrec_amd.supernet.supernet import SuperNet
+    from nasrec_amd.utils.train_utils import init_weights
+    torch.manual_seed(7)
+    ref = SuperNet(num_blocks=1, ops_config=ops_config_lib["autoctr"], use_layernorm=True, num_embeddings=INIT_TABLES, sparse_input_size=len(INIT_TABLES))
+    ref.apply(init_weights)
+    for f, n in enumerate(INIT_TABLES):
+        whole = torch.cat([w[:hi - lo] for lo, hi, w in [out[r][f] for r in range(4)]])
+        assert torch.equal(ref._embedding[f].weight.detach(), whole), f
+    nxt = torch.rand(4)  # the random stream has advanced exactly as far: whatever is initialised next gets the unsharded model's values too
+    assert torch.equal(nxt, out[0][-1]) and torch.equal(nxt, out[3][-1])
 
 
 class _ShardedStandIn(torch.nn.Module):
