@@ -75,7 +75,8 @@ def _cview(ptr, cmode, M, N, ldc):
 
 
 def _gemm_io(d, part):
-    """part: 'whole' | 'main' (operands -> split-K slabs) | 'epi' (slabs -> epilogue -> C)"""
+    """part: 'whole' | 'main' (operands -> split-K slabs) | 'epi' (slabs -> epilogue -> C) | 'fused' (a split-K product as one worklist
+    item: operands -> C, the slabs never exist)"""
     R, W = [], []
     nprob = d.nseg if d.zmode else 1
     S = d.splitk if d.splitk > 1 else 1
@@ -84,7 +85,7 @@ def _gemm_io(d, part):
     ws = _flat(d.workspace, S * Mm * Nm * nprob) if (S > 1 and d.workspace) else None
     if d.splitk == L.SPLITK_BALANCED and d.workspace:
         ws = _flat(d.workspace, L.SK_WORKSPACE_FLOATS)  # the engine-wide partial-tile workspace of the balanced schedule: shared by launches
-    if part in ("whole", "main"):
+    if part in ("whole", "main", "fused"):
         for q in range(d.nseg):
             s = d.seg[q]
             if not s.A:
@@ -577,7 +578,7 @@ def item_bytes(node):
     return None
 
 
-_PART = {"whole": L.WL_WHOLE, "main": L.WL_MAIN, "epi": L.WL_EPI}
+_PART = {"whole": L.WL_WHOLE, "main": L.WL_MAIN, "epi": L.WL_EPI, "fused": 3}
 
 
 # stand-alone times of the non-GEMM items of the batch-256 step, ns (tools/step_table.py ITEMS=11)
@@ -602,6 +603,8 @@ def _cost(node):
     if isinstance(d, L.GemmDesc):
         if node.part == "epi":
             return 3600
+        if node.part == "fused":
+            return 6500 + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A) // 20000
         return 5000 + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A) // 20000
     return _ITEM_NS.get(d.kind, 3000)
 
@@ -613,6 +616,8 @@ def _cost_r4(node):
     if isinstance(d, L.GemmDesc):
         if node.part == "epi":
             return 4000
+        if node.part == "fused":
+            return 6500 + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A) // 20000
         live = [q for q in range(d.nseg) if d.seg[q].A]
         extra = 0 if d.zmode else 900 * max(len(live) - 1, 0)
         return 5200 + extra + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in live) // 20000
@@ -623,11 +628,38 @@ def _cost_r4(node):
     return _ITEM_NS_R4.get(d.kind, 3000)
 
 
+FUSE_SPLITK = os.environ.get("NASREC_WL_FUSE_SPLITK", "1") != "0"  # (A/B knob)
+FUSE_MAX_TILES = int(os.environ.get("NASREC_WL_FUSE_TILES", "256"))
+
+
+def fusable(d) -> bool:
+    """mirror of csrc/worklist.hip (part 3): a split-K product with few 16 x 16 output tiles whose main pass + second pass run as ONE
+    worklist item (csrc/worklist_body.h wl_gemm_fused_splitk: bit-identical to the two passes) — the second pass of such a product is a
+    level of its own on the step's critical chain otherwise"""
+    if not FUSE_SPLITK or not isinstance(d, L.GemmDesc) or not (2 <= d.splitk <= 32) or not d.workspace or d.cmode != L.CM_PLAIN or d.amode != L.AM_KC:
+        return False
+    if not ((d.bmode == L.AM_KC and not d.zmode) or (d.bmode == L.AM_RC and d.zmode)):
+        return False
+    tiles = 0
+    for q in range(d.nseg):
+        s = d.seg[q]
+        if s.Aaux or s.Baux or s.ones_col or (0 < s.Mvalid < s.M):
+            return False
+        rc = d.bmode == L.AM_RC
+        if s.A and (s.M * s.lda + s.K >= (1 << 29) or (s.K if rc else s.N) * s.ldb + (s.N if rc else s.K) >= (1 << 29)):
+            return False
+        if d.zmode or q == 0:
+            tiles += ((s.M + 15) // 16) * ((s.N + 15) // 16)
+    return 0 < tiles <= FUSE_MAX_TILES
+
+
 def expand_for_worklists(descs) -> List[Node]:
     """as expand(), but a split-K GEMM is cut in two only when both halves can ride in worklist launches"""
     nodes = []
     for d in descs:
-        if isinstance(d, L.GemmDesc) and d.splitk > 1 and gemm_capable(d):
+        if isinstance(d, L.GemmDesc) and d.splitk > 1 and gemm_capable(d) and fusable(d):
+            nodes.append(Node(d, "fused"))
+        elif isinstance(d, L.GemmDesc) and d.splitk > 1 and gemm_capable(d):
             nodes.append(Node(d, "main"))
             nodes.append(Node(d, "epi"))
         else:
