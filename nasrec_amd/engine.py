@@ -24,6 +24,8 @@ E = 16
 DEDUP_SPLIT_MAX_B = min(int(os.environ.get("NASREC_DEDUP_SPLIT_MAX_B", "256")), L.DEDUP_IDS_MAX_B)
 # the id half of a level-scheduled step (B <= 256) as an ITEM of the joint forward + backward program (A/B knob: 0 = on the staging launch)
 _IDS_AS_ITEM = os.environ.get("NASREC_IDS_AS_ITEM", "1") != "0"
+# clip + Adagrad of a fixed sub-network over the ranges of the parameters its backward reaches, not the whole arena (A/B knob)
+_FIXED_OPT_TABLE = os.environ.get("NASREC_FIXED_OPT_TABLE", "1") != "0"
 
 
 def _ptr_array(descs):
@@ -524,6 +526,21 @@ class SupernetEngine:
             ms = P.memset_desc(self.flat_g)
             ms.chunks, ms.nchunks = cp.chunk_tab.data_ptr(), cp.nchunks
             pre.append(ms)
+        elif _FIXED_OPT_TABLE:
+            # A fixed sub-network can hold parameters no gradient ever reaches (the reference leaves their grad None: in
+            # ea_criteo_kaggle_xlarge_best_1shot.json all of block 5, 1.2 M of the 2.2 M dense parameters — no later block selects it).
+            # Their gradient stays zero, and Adagrad with g = 0 changes neither state nor parameter: the norm and the update walk a chunk
+            # table of the trained ranges only (half the bytes of the optimizer's bandwidth-bound pass).  Written once, here.
+            names = [n for n in list(ctx.grad_params) + ["_final.weight", "_final.bias"] if not n.startswith("_embedding.")]
+            spans = [(self.offsets[n], self.params[n].numel()) for n in dict.fromkeys(names)]
+            if sum(n for _, n in spans) < 0.9 * self.flat_numel:
+                flat = P.path_chunks(spans, chunk=1024)  # (small pieces: a workgroup per piece keeps ~10^3 workgroups on the pass)
+                cp.nchunks = len(flat) // 2
+                cp.chunk_tab = torch.empty(len(flat), dtype=torch.int64, device=self.device)
+                lib = L.load()
+                for dsc in P.const_i64_descs(cp.chunk_tab.data_ptr(), flat):
+                    L.check(lib.nasrec_launch(self.stream.cuda_stream, C.addressof(dsc)))
+                self.stream.synchronize()  # (the descriptors carry the values: they must outlive their launches)
         cp.bce, cp._pre = bd, pre
 
     def _optimizer_descs(self, cp, Bg, cat_x, sparse_grad, clip, eps, rank_layout=None):

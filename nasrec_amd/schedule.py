@@ -630,6 +630,7 @@ def _cost_r4(node):
 
 FUSE_SPLITK = os.environ.get("NASREC_WL_FUSE_SPLITK", "1") != "0"  # (A/B knob)
 FUSE_MAX_TILES = int(os.environ.get("NASREC_WL_FUSE_TILES", "256"))
+FUSE_MIN_TILES = int(os.environ.get("NASREC_WL_FUSE_MIN_TILES", "64"))  # (a 16-wide product is 16 workgroups walking ~7 k-slices each: 14.7 us as an item)
 
 
 def fusable(d) -> bool:
@@ -650,7 +651,7 @@ def fusable(d) -> bool:
             return False
         if d.zmode or q == 0:
             tiles += ((s.M + 15) // 16) * ((s.N + 15) // 16)
-    return 0 < tiles <= FUSE_MAX_TILES
+    return max(FUSE_MIN_TILES, 1) <= tiles <= FUSE_MAX_TILES
 
 
 def expand_for_worklists(descs) -> List[Node]:
