@@ -49,10 +49,7 @@ static int dispatch(hipStream_t st, const void* desc) {
     case NASREC_OP_MEMSET: {
       const nasrec_memset_desc_t* m = (const nasrec_memset_desc_t*)desc;
       if (m->chunks) return launch_memset_chunks(st, m);
-      if (m->bytes == 0) return 0;
-      hipError_t e = hipMemsetAsync(m->ptr, 0, (size_t)m->bytes, st);
-      if (e != hipSuccess) return nasrec_set_error((int)e, "memset: %s", hipGetErrorString(e));
-      return 0;
+      return launch_memset_flat(st, m);
     }
     case NASREC_OP_LAYERNORM_FWD:
     case NASREC_OP_LAYERNORM_BWD: return launch_layernorm(st, (const nasrec_layernorm_desc_t*)desc);

@@ -129,6 +129,7 @@ int launch_stage(hipStream_t s, const nasrec_stage_desc_t* d);
 int launch_opt_reduce(hipStream_t s, const nasrec_opt_reduce_desc_t* d);
 int launch_opt_apply(hipStream_t s, const nasrec_opt_apply_desc_t* d);
 int launch_memset_chunks(hipStream_t s, const nasrec_memset_desc_t* d);
+int launch_memset_flat(hipStream_t s, const nasrec_memset_desc_t* d);
 int launch_const_i64(hipStream_t s, const nasrec_const_i64_desc_t* d);
 int launch_splitk_epilogues(hipStream_t s, const nasrec_splitk_epilogues_desc_t* d);
 int launch_worklist(hipStream_t s, const nasrec_worklist_desc_t* d);

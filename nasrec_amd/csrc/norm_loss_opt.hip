@@ -102,6 +102,30 @@ __global__ __launch_bounds__(256) void memset_chunks_kernel(const nasrec_memset_
   }
 }
 
+// NASREC_OP_MEMSET over one flat range, as a KERNEL (round 5): hipMemsetAsync becomes a memset node of whatever graph captures the step,
+// and inside a torch-captured graph those nodes were not ordered against the kernels around them on this stack (tests/
+// test_sharded_tables_gpu.py: gradients accumulated onto a buffer the memset had not cleared yet, from the second replay on) — a kernel
+// node is ordered like every other launch of the program.  bytes is a multiple of 4 (fp32 / int32 buffers).
+__global__ __launch_bounds__(256) void memset_flat_kernel(float* x, long n) {
+  const long n4 = n >> 2, stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) *reinterpret_cast<f32x4*>(x + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (long j = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) x[j] = 0.f;
+}
+
+int launch_memset_flat(hipStream_t st, const nasrec_memset_desc_t* d) {
+  if (d->bytes <= 0) return 0;
+  if ((d->bytes & 3) || ((unsigned long long)d->ptr & 15)) {  // (not a 16-byte aligned fp32 range: the runtime's memset)
+    hipError_t e = hipMemsetAsync(d->ptr, 0, (size_t)d->bytes, st);
+    if (e != hipSuccess) return nasrec_set_error((int)e, "memset: %s", hipGetErrorString(e));
+    return 0;
+  }
+  const long n = d->bytes >> 2;
+  long blocks = ((n >> 2) + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(memset_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<float*>(d->ptr), n);
+  return nasrec_check_launch("memset");
+}
+
 int launch_memset_chunks(hipStream_t st, const nasrec_memset_desc_t* d) {
   if (d->nchunks < 1) return 0;
   hipLaunchKernelGGL(memset_chunks_kernel, dim3((unsigned)(d->nchunks > 4096 ? 4096 : d->nchunks)), dim3(256), 0, st, *d);

@@ -22,6 +22,7 @@ row — so there is no sort, no compaction and no split size for the host to rea
 device.  What runs on the rows is pluggable: the HIP engine's gather / dedup / Adagrad kernels on the GPU (`EngineShardedOps` in this
 file binds them), index ops in the CPU tests."""
 import math
+import os as _os
 from typing import List, Optional
 
 import torch
@@ -200,7 +201,7 @@ class ShardedTableStep:
         self.ops, self.tables, self.B, self.clip, self.eps = ops, tables, B_local, clip, eps
         self.world = tables.world
         self.last_norm = None
-        self.graph = bool(graph)
+        self.graph = bool(graph) and _os.environ.get("NASREC_SHARDED_GRAPH", "1") != "0"  # (env: A/B knob)
         self._g = None  # (key, CUDAGraph, static inputs, loss)
         self._calls = 0
 
