@@ -108,6 +108,9 @@ _DEBUG = __import__("os").environ.get("NASREC_DP_DEBUG", "0") == "1"
 # (measured on one rank, profiles/r05_dp_overhead.txt: a side branch in the captured step costs ~40 us — the graph runs parallel branches
 # through separate hardware queues — against 8 us for the kernel itself on the compute stream: main is the default)
 _IDS_MODE = __import__("os").environ.get("NASREC_DP_IDS_MODE", "main")
+# NASREC_DP_LATE_IDS=1 (with NASREC_DP_SEGMENTS=1: the LINEAR form of the exchange — nothing beside the forward / backward, every
+# collective behind the backward's last launch): for stacks on which a branch in the captured step costs more than the transfer it hides
+_LATE_IDS = __import__("os").environ.get("NASREC_DP_LATE_IDS", "0") == "1"
 PACK_TAIL_FLOATS = int(__import__("os").environ.get("NASREC_DP_PACK_TAIL", "65536"))
 
 
@@ -252,7 +255,7 @@ class DataParallelStep:
         self.cat_all = torch.zeros(Bg, engine.Fs, dtype=torch.int64, device=dev)
         # this rank's share of the row-gradient all-gather: [B, Fs, 16] row gradients | the dense gradients of the backward's last
         # pieces (fixed sub-networks: `tail`); the receive buffer holds the W shares one after the other
-        cap = PACK_TAIL_FLOATS if self.fixed else 0
+        cap = min(PACK_TAIL_FLOATS, int(engine.flat_numel)) if self.fixed else 0  # (never more than the arena holds)
         self.sg_send = torch.zeros(self.rows_n + cap, dtype=gdt, device=dev)
         self.sg_recv = torch.zeros(self.world * (self.rows_n + cap), dtype=gdt, device=dev)
         self.tail_n = None  # floats of packed tail per rank: fixed by the first plan (the optimizer's row layout depends on it)
@@ -297,6 +300,9 @@ class DataParallelStep:
             self.tail_n = tail_n
             stride = self.rows_n + tail_n
             kw = {"rank_layout": (self.B, stride)} if tail_n else {}
+            cpl = getattr(plan, "cp", None)
+            if self.fixed and getattr(self.dp, "accepts_chunk_table", False) and getattr(cpl, "chunk_tab", None) is not None:
+                kw["chunk_table"] = (cpl.chunk_tab, cpl.nchunks)  # norm + Adagrad over the ranges the sub-network's backward reaches
             self.recv = self.sg_recv[:self.world * stride]
             self.opt = self.dp.dp_optimizer(self.B * self.world, self.cat_all, self.recv, self.clip, self.eps, False, **kw)  # (graph: the whole exchange step is captured as one, _capture)
             self.ids_half = getattr(self.dp, "dp_dedup_ids", lambda: None)()
@@ -372,6 +378,8 @@ class DataParallelStep:
                 ids_done = torch.cuda.Event()
                 ids_done.record(self._side)
             w_ids = None
+        elif _LATE_IDS:
+            w_ids = None  # (issued with the row gradients, behind the backward: no branch beside the forward)
         else:
             w_ids = coll.all_gather(self.cat_all, plan.cat_local, async_op=True)
         if mode == "side":
@@ -399,6 +407,8 @@ class DataParallelStep:
             self.tail_ops[0]()  # dense gradients of the last pieces -> behind the rows
         else:
             send = plan.sparse_grad
+        if _LATE_IDS and mode != "chain":
+            pending.append(coll.all_gather(self.cat_all, plan.cat_local, async_op=True))
         pending.append(coll.all_gather(self.recv, send, async_op=True))
         for w in pending:
             if w is not None:
@@ -520,16 +530,19 @@ def _torch_tail_ops(flat_g, send, recv, rows_n, tail, world):
 class EngineDP:
     """SupernetEngine behind the data-parallel protocol (programs, hipGraph segments, arena ranges per block)."""
     accepts_row_grad_out = True
+    accepts_chunk_table = True
 
     def __init__(self, engine):
         self.engine = engine
         self._holder = None
 
-    def dp_optimizer(self, Bg, cat_all, sg_all, clip, eps, graph, rank_layout=None):
+    def dp_optimizer(self, Bg, cat_all, sg_all, clip, eps, graph, rank_layout=None, chunk_table=None):
         from .engine import Program
         eng = self.engine
         with torch.cuda.stream(eng.stream):
             holder = self._holder = _Holder()
+            if chunk_table is not None:
+                holder.chunk_tab, holder.nchunks = chunk_table
             eng._ensure_table_state()
             prog = Program(eng._optimizer_descs(holder, Bg, cat_all, sg_all, clip, eps, rank_layout=rank_layout))
             prog.holder = holder

@@ -16,10 +16,13 @@ run pieces1 NASREC_DP_SEGMENTS=1
 run pieces2 NASREC_DP_SEGMENTS=2
 run pieces8 NASREC_DP_SEGMENTS=8
 run no_pack NASREC_DP_PACK_TAIL=0
+run linear NASREC_DP_SEGMENTS=1 NASREC_DP_LATE_IDS=1
+run ids_on_side_stream NASREC_DP_IDS_MODE=side
 # ... and with RCCL's own kernels inside the captured step (a one-rank gather is a copy kernel otherwise)
 runreal() { name=$1; shift; env "$@" timeout 200 python bench.py --force-dp-path --real-collectives --no-cpu-baseline --steps 600 --warmup 50 2>/dev/null | grep '^{' | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('$name', round(r['ms_per_step'],4), round(r['median_ms_per_step'],4), r['config'].get('dp_exchange',{}).get('launches_up_to_cut'))" >> $O/result.txt; }
 runreal real_all A=1
 runreal real_no_gather NASREC_BENCH_DP_SKIP=gather
 runreal real_no_reduce NASREC_BENCH_DP_SKIP=reduce
 runreal real_no_pack NASREC_DP_PACK_TAIL=0
+runreal real_linear NASREC_DP_SEGMENTS=1 NASREC_DP_LATE_IDS=1
 cat $O/result.txt
