@@ -77,8 +77,10 @@ def test_two_ranks_on_one_gpu_equal_one_process_at_the_global_batch(case, pack):
         torch.cuda.synchronize()
     ref = {k: v.cpu() for k, v in eng.state_dict().items()}
     r0, r1 = out[0], out[1]
-    if meta["mode"] == "fixed":
-        assert (r0["tail"] > 0) == (pack > 0), r0["tail"]
+    if pack == 0:
+        assert r0["tail"] == 0
+    elif case == "fixed_criteo_xlarge":  # (a network whose backward is one piece has no tail to pack)
+        assert r0["tail"] > 0
     for k in ref:
         assert torch.equal(r0["params"][k], r1["params"][k]), "replicas differ: %s" % k
         scale = max(1.0, float(ref[k].abs().max()))
