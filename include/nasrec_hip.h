@@ -81,7 +81,8 @@ enum {
   NASREC_OP_CONST_I64 = 31,
   NASREC_OP_SPLITK_EPILOGUES = 32,
   NASREC_OP_DEDUP_IDS = 33,
-  NASREC_OP_OPT_REDUCE2 = 34
+  NASREC_OP_OPT_REDUCE2 = 34,
+  NASREC_OP_FINAL_FUSED = 35
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -301,7 +302,7 @@ typedef struct nasrec_rowsum_desc {
 
 /* Final logit (supernet.py:592-598 / 657-664): logits[b] = <feats[b,:], w> + bias, feats = segments. */
 typedef struct nasrec_final_desc {
-  int32_t kind; /* NASREC_OP_FINAL_FWD / _BWD */
+  int32_t kind; /* NASREC_OP_FINAL_FWD / _BWD / _FUSED */
   int32_t B, nseg;
   float grad_scale;    /* bwd with y != NULL: see nasrec_bce_desc_t */
   const float* w;      /* [1, K] */
@@ -323,7 +324,11 @@ typedef struct nasrec_final_desc {
   /* bwd, large batches: nsplit > 1 cuts the batch into nsplit slices, one set of workgroups each; dw is then a partial buffer
      [nsplit, K + 1] (column K = the bias gradient, dbias is unused) that a NASREC_OP_REDUCE_ROWS launch sums in fixed order */
   int32_t nsplit;
-  int32_t _pad;
+  /* NASREC_OP_FINAL_FUSED (round 5; needs y != NULL, nsplit <= 1) = the forward AND the per-sample part of the backward in one launch: the
+     wavefront that has summed sample b's logit writes it, derives (sigmoid(logit) - y[b]) * grad_scale and writes dseg[b, :] — the
+     gradients the rest of the backward pass waits for — one launch boundary earlier.  The parts that need every sample's logit (dw, dbias,
+     the loss, dlogits_out) stay a NASREC_OP_FINAL_BWD with dseg_done = 1: it skips the dseg part.  Same expression per element: same bits. */
+  int32_t dseg_done;
   /* last_n_blocks_out > 1 (supernet.py:592-596 / 657-661): the reference concatenates the last blocks' sparse outputs on the LAST
      dim ([B, N, n*16]) before flattening, so block j's token t sits at weight columns off + t*(n*16) + [0, 16).  tok_stride[q] != 0
      gives such a segment: feature j of the (contiguous [B, N*16]) segment meets weight w[off[q] + (j / 16) * tok_stride[q] + j % 16];
@@ -439,11 +444,14 @@ typedef struct nasrec_opt_apply_desc {
  * GPU: when the batch is staged; N GPUs: when the ids all-gather lands, nasrec_amd/parallel.py).  So:
  *   NASREC_OP_DEDUP_IDS   (any time after the ids are known; B <= NASREC_DEDUP_IDS_MAX_B) per field.  A RUN = the samples of one id in
  *                         ascending order, a SUB-RUN = the part of a run inside one 256-sample chunk.  Writes leader[b,f] (0 duplicate,
- *                         1 leader without duplicates, 2 leader with duplicates); order[f][..] = the runs that have duplicates, each run
- *                         contiguous and ascending (B <= 256: all-pairs match masks, only such runs; above: the whole batch sorted by
- *                         (id, sample)); list A = the sub-runs with >= 2 members (start in `order` | length << 16 | bit 31: the sub-run is its
- *                         whole run); list B = the runs with >= 2 sub-runs (start in `heads` | number of sub-runs << 16); heads[f][..] = the
- *                         first sample of every sub-run of the list-B runs, in chunk order; counts[f] = lengths of the two lists.
+ *                         1 leader without duplicates, 2 leader with duplicates) and
+ *                         B <= 256 (one workgroup per field, all-pairs match masks): order[f][..] = the runs that have duplicates, each
+ *                           contiguous and ascending; lists[f][k] = start in `order` | length << 16 | bit 31; counts[f][0] = their number;
+ *                         B > 256 (one workgroup per field and chunk, all pairs against the field's ids, nothing crosses workgroups):
+ *                           order[f][256 c + ..] = the members of chunk c's sub-runs with >= 2 members; lists[f][b], per SAMPLE = bit 16
+ *                           (b heads such a sub-run) | position inside the chunk's region | (members - 1) << 8 | bit 31 (the sub-run is its
+ *                           whole run) | bit 17 (b leads a run with sub-runs in later chunks); heads[f][b] = the head of the NEXT sub-run
+ *                           of b's run (-1: none): the chain leader -> next -> ... is the run's sub-runs in chunk order.
  *                         NASREC_OP_STAGE_INPUTS can carry it (stage.dedup_ids.order != NULL, B <= 256).
  *   NASREC_OP_OPT_REDUCE2 (behind the backward pass) workgroups [0, Fs): per field, IN PLACE over the per-sample row gradients, the sum of
  *                         every sub-run into its first row in ascending sample order, then of every multi-chunk run's sub-run sums into the
@@ -461,9 +469,9 @@ typedef struct nasrec_dedup_ids_desc {
   const int64_t* idx;   /* [B, Fs] */
   int32_t* leader;      /* [B, Fs] out */
   int32_t* order;       /* [Fs, cap] out */
-  int32_t* lists;       /* [Fs, 2, cap / 2] out: list A, list B */
+  int32_t* lists;       /* [Fs, cap] out */
   int32_t* counts;      /* [Fs, 2] out */
-  int32_t* heads;       /* [Fs, cap] out (B > 256 only; may be NULL for B <= 256) */
+  int32_t* heads;       /* [Fs, cap] out: next-sub-run links (B > 256 only; may be NULL for B <= 256) */
 } nasrec_dedup_ids_desc_t;
 
 typedef struct nasrec_opt_reduce2_desc {
@@ -642,6 +650,7 @@ int nasrec_opt_reduce(void* stream, const nasrec_opt_reduce_desc_t* d);
 int nasrec_opt_apply(void* stream, const nasrec_opt_apply_desc_t* d);
 int nasrec_dedup_ids(void* stream, const nasrec_dedup_ids_desc_t* d);
 int nasrec_opt_reduce2(void* stream, const nasrec_opt_reduce2_desc_t* d);
+int nasrec_final_fused(void* stream, const nasrec_final_desc_t* d);
 int nasrec_worklist(void* stream, const nasrec_worklist_desc_t* d);
 
 /* HIP-event timing on an arbitrary stream (bench.py measures kernels on the engine's own stream). */

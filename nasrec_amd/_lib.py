@@ -33,7 +33,7 @@ ACT_BY_NAME = {"identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
  OP_COPY_SEGS, OP_GATE_BWD, OP_ROWSUM, OP_FINAL_FWD, OP_BCE, OP_FINAL_BWD, OP_EMB_DEDUP, OP_SUMSQ, OP_CLIP_COEF,
  OP_ADAGRAD_DENSE, OP_ADAGRAD_ROWS, OP_MEMSET, OP_LAYERNORM_FWD, OP_LAYERNORM_BWD, OP_ADD_SEGS, OP_SCALE,
  OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY, OP_WORKLIST, OP_CONST_I64, OP_SPLITK_EPILOGUES, OP_DEDUP_IDS,
- OP_OPT_REDUCE2) = range(1, 35)
+ OP_OPT_REDUCE2, OP_FINAL_FUSED) = range(1, 36)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -108,7 +108,7 @@ class FinalDesc(C.Structure):
     _fields_ = [("kind", i32), ("B", i32), ("nseg", i32), ("grad_scale", f32), ("w", vp), ("bias", vp), ("logits", vp), ("dlogits", vp),
                 ("dw", vp), ("dbias", vp), ("seg", vp * MAX_SEGS), ("dseg", vp * MAX_SEGS), ("width", i32 * MAX_SEGS),
                 ("ld", i32 * MAX_SEGS), ("off", i32 * MAX_SEGS), ("dseg_accumulate", i32 * MAX_SEGS), ("y", vp), ("loss", vp),
-                ("dlogits_out", vp), ("nsplit", i32), ("_pad", i32), ("tok_stride", i32 * MAX_SEGS)]
+                ("dlogits_out", vp), ("nsplit", i32), ("dseg_done", i32), ("tok_stride", i32 * MAX_SEGS)]
 
 
 class BceDesc(C.Structure):
@@ -216,7 +216,7 @@ DESC_BY_KIND = {
     OP_ADAGRAD_ROWS: AdagradRowsDesc, OP_MEMSET: MemsetDesc, OP_LAYERNORM_FWD: LayerNormDesc, OP_LAYERNORM_BWD: LayerNormDesc,
     OP_SCALE: ScaleDesc, OP_ACT_BWD: ActBwdDesc, OP_STAGE_INPUTS: StageDesc, OP_OPT_REDUCE: OptReduceDesc, OP_OPT_APPLY: OptApplyDesc,
     OP_WORKLIST: WorklistDesc, OP_CONST_I64: ConstI64Desc, OP_SPLITK_EPILOGUES: SplitkEpiloguesDesc, OP_DEDUP_IDS: DedupIdsDesc,
-    OP_OPT_REDUCE2: OptReduce2Desc,
+    OP_OPT_REDUCE2: OptReduce2Desc, OP_FINAL_FUSED: FinalDesc,
 }
 
 # every symbol include/nasrec_hip.h declares
@@ -224,7 +224,7 @@ SYMBOLS = [
     "nasrec_launch", "nasrec_program_run", "nasrec_graph_create", "nasrec_graph_launch", "nasrec_graph_destroy", "nasrec_gemm",
     "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm", "nasrec_mha_ffn", "nasrec_layernorm",
     "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense", "nasrec_adagrad_rows", "nasrec_opt_reduce",
-    "nasrec_opt_apply", "nasrec_worklist", "nasrec_dedup_ids", "nasrec_opt_reduce2", "nasrec_event_create",
+    "nasrec_opt_apply", "nasrec_worklist", "nasrec_dedup_ids", "nasrec_opt_reduce2", "nasrec_final_fused", "nasrec_event_create",
     "nasrec_event_record", "nasrec_event_elapsed_ms", "nasrec_event_destroy", "nasrec_last_error", "nasrec_abi_version",
     "nasrec_desc_sizes", "nasrec_tsv_parse",
 ]
@@ -263,10 +263,10 @@ def load():
     lib.nasrec_tsv_parse.restype = i64
     for name in ("nasrec_gemm", "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm",
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
-                 "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_worklist", "nasrec_dedup_ids", "nasrec_opt_reduce2"):
+                 "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_worklist", "nasrec_dedup_ids", "nasrec_opt_reduce2", "nasrec_final_fused"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 13:
-        raise EngineError("ABI version mismatch: library %d, binding 13" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 14:
+        raise EngineError("ABI version mismatch: library %d, binding 14" % lib.nasrec_abi_version())
     sizes = (i32 * 40)()
     n = lib.nasrec_desc_sizes(sizes, 40)
     for kind, cls in DESC_BY_KIND.items():

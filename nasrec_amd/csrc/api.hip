@@ -39,6 +39,7 @@ static int dispatch(hipStream_t st, const void* desc) {
     case NASREC_OP_GATE_BWD: return launch_gate_bwd(st, (const nasrec_gate_bwd_desc_t*)desc);
     case NASREC_OP_ROWSUM: return launch_rowsum(st, (const nasrec_rowsum_desc_t*)desc);
     case NASREC_OP_FINAL_FWD:
+    case NASREC_OP_FINAL_FUSED:
     case NASREC_OP_FINAL_BWD: return launch_final(st, (const nasrec_final_desc_t*)desc);
     case NASREC_OP_BCE: return launch_bce(st, (const nasrec_bce_desc_t*)desc);
     case NASREC_OP_EMB_DEDUP: return launch_emb_dedup(st, (const nasrec_emb_dedup_desc_t*)desc);
@@ -154,6 +155,7 @@ TYPED(nasrec_opt_apply, nasrec_opt_apply_desc_t, kind == NASREC_OP_OPT_APPLY)
 TYPED(nasrec_worklist, nasrec_worklist_desc_t, kind == NASREC_OP_WORKLIST)
 TYPED(nasrec_dedup_ids, nasrec_dedup_ids_desc_t, kind == NASREC_OP_DEDUP_IDS)
 TYPED(nasrec_opt_reduce2, nasrec_opt_reduce2_desc_t, kind == NASREC_OP_OPT_REDUCE2)
+TYPED(nasrec_final_fused, nasrec_final_desc_t, kind == NASREC_OP_FINAL_FUSED)
 
 int nasrec_event_create(void** ev) {
   hipEvent_t e;
@@ -184,7 +186,7 @@ int nasrec_event_destroy(void* ev) {
 
 const char* nasrec_last_error(void) { return g_err; }
 
-int nasrec_abi_version(void) { return 13; }
+int nasrec_abi_version(void) { return 14; }
 
 int nasrec_desc_sizes(int32_t* out, int n) {
   static const int32_t sizes[] = {
@@ -223,6 +225,7 @@ int nasrec_desc_sizes(int32_t* out, int n) {
       (int32_t)sizeof(nasrec_splitk_epilogues_desc_t), // 32
       (int32_t)sizeof(nasrec_dedup_ids_desc_t),     // 33
       (int32_t)sizeof(nasrec_opt_reduce2_desc_t),   // 34
+      (int32_t)sizeof(nasrec_final_desc_t),         // 35
   };
   const int total = (int)(sizeof(sizes) / sizeof(sizes[0]));
   int w = 0;

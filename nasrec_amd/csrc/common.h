@@ -117,6 +117,7 @@ int launch_copy_segs(hipStream_t s, const nasrec_copy_segs_desc_t* d);
 int launch_gate_bwd(hipStream_t s, const nasrec_gate_bwd_desc_t* d);
 int launch_rowsum(hipStream_t s, const nasrec_rowsum_desc_t* d);
 int launch_final(hipStream_t s, const nasrec_final_desc_t* d);
+int final_fused_check(const nasrec_final_desc_t* d);
 int launch_bce(hipStream_t s, const nasrec_bce_desc_t* d);
 int launch_sumsq(hipStream_t s, const nasrec_sumsq_desc_t* d);
 int launch_clip_coef(hipStream_t s, const nasrec_clip_coef_desc_t* d);

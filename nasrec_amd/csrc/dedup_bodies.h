@@ -7,9 +7,8 @@
 //   leader     0 duplicate / 1 leader without duplicates / 2 leader with duplicates,
 //   order      the samples of the rows with duplicates, run by run: a RUN = the samples of one id in ascending order; a SUB-RUN = the
 //              part of a run inside one 256-sample chunk of the batch,
-//   list A     the sub-runs with >= 2 members (start position in `order` | length << 16 | DD_WHOLE: the sub-run is its whole run),
-//   list B     the runs with >= 2 sub-runs (start position in `heads` | number of sub-runs << 16),
-//   heads      for the runs of list B: the first sample of every sub-run, in chunk order.
+//   B <= 256 (every run is one sub-run): list A = the runs with >= 2 members (start position in `order` | length << 16 | DD_WHOLE);
+//   above: per-sample entries and a next-sub-run link per sample instead of lists (dedup_ids_pairs_body below).
 // What stays behind the backward pass is the arithmetic: every sub-run summed into its first row in ascending sample order, then the
 // sub-run sums of a multi-chunk run into the leader's row in chunk order — exactly the order of the one-launch kernels
 // (embedding.hip: emb_dedup_small / chunk + merge), so the summed rows are the same bits at every batch size and do not depend on how
@@ -92,121 +91,108 @@ __device__ __forceinline__ void dedup_ids_small_body(const nasrec_dedup_ids_desc
   }
 }
 
-// ---- 256 < B <= NASREC_DEDUP_IDS_MAX_B: sort (id, sample) keys ---------------------------------------------------------------------
-// first position p of the sorted keys [0, n) with key[p] >= t
-__device__ __forceinline__ int dd_lower_bound(const unsigned long long* key, int n, unsigned long long t) {
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (key[mid] < t) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo;
-}
+// ---- 256 < B <= NASREC_DEDUP_IDS_MAX_B: all pairs, one workgroup per (field, 256-sample chunk) ---------------------------------------
+// No workgroup needs another's result, so nothing is sorted, scanned or signalled across workgroups: every array is indexed by SAMPLE
+// (or by the chunk's own region of `order`), and a thread decides everything about its sample from the ids of its field:
+//   earlier chunks   any match  -> not the run's leader                                   (xor + min: 2 instructions per id)
+//   own chunk        256-bit match mask as in the small body -> head of its sub-run? the sub-run's members (ascending)
+//   later chunks     the LOWEST matching sample = the head of the run's next sub-run       (compare + select, descending)
+// Per field:  lists[b]  DD_A | DD_MULTI | DD_WHOLE | (members - 1) << 8 | position of the sub-run inside the chunk's region of `order`
+//             heads[b]  the head of the next sub-run of b's run (-1: none): phase 2 of the sums walks leader -> next -> next ...
+//             order[256 c + ..]  the members of chunk c's sub-runs with >= 2 members;   counts: unused (0)
+#define DD_A 0x10000u      // the sample heads a sub-run with >= 2 members
+#define DD_MULTI 0x20000u  // the sample leads a run with sub-runs in later chunks
 
-// One workgroup of 256 threads per field.  key: CAP 64-bit LDS words; sh: 4 ints.  d.cap (a power of two, 256 <= d.cap <= CAP)
-// entries are sorted; B <= d.cap samples are real.  Here `order` is simply the sorted order (all B samples): runs are contiguous.
-template <int CAP>
-__device__ __forceinline__ void dedup_ids_sort_body(const nasrec_dedup_ids_desc_t& d, const int64_t* idx, int B, int Fs, int f, unsigned long long* key, int* sh) {
-  constexpr int T = 256, PER = CAP / T;
-  const int tid = threadIdx.x;
-  const int n = d.cap, half = n >> 1;
-  // keys (id, sample): ids are row numbers below 2^31 (engine.py), the sample index fits 16 bits; padding sorts last
-  for (int i = tid; i < n; i += T) {
-    unsigned long long k = ~0ull;
-    if (i < B) k = ((unsigned long long)(unsigned)idx[(long)i * Fs + f] << 16) | (unsigned)i;
-    key[i] = k;
-  }
-  // bitonic sort, ascending (a compare-exchange network: the result does not depend on timing)
-  for (int k = 2; k <= n; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      __syncthreads();
-      for (int t = tid; t < half; t += T) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int l = i | j;
-        const unsigned long long a = key[i], b = key[l];
-        const bool up = (i & k) == 0;
-        if ((a > b) == up) {
-          key[i] = b;
-          key[l] = a;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // every thread looks at PER consecutive sorted positions
-  const int per = n / T;  // (>= 1)
-  unsigned ea[PER];   // list A entry that ENDS at this position (0: none)
-  int srun[PER];      // >= 0: a multi-chunk run ends at this position and started at srun
-  int hb[PER];        // the sample, if this position is a sub-run head of a multi-chunk run (else -1)
-  int cnt = 0, cnth = 0;  // list A entries | list B entries << 16; heads
+// sidx: nch * 256 ints of LDS (the field's ids), sh: 4 ints
+__device__ __forceinline__ void dedup_ids_pairs_body(const nasrec_dedup_ids_desc_t& d, const int64_t* idx, int B, int Fs, int f, int c, int* sidx, int* sh) {
+  const int t = threadIdx.x, b = c * 256 + t;
+  const int nch = (B + 255) >> 8;
+  {  // the field's ids: every load first (a loop with a run-time trip count compiles to load -> wait -> store per chunk), then the stores
+    int v[NASREC_DEDUP_IDS_MAX_B / 256];
 #pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    ea[u] = 0u;
-    srun[u] = hb[u] = -1;
-    const int p = tid * per + u;
-    if (u < per && p < B) {
-      const unsigned long long k = key[p];
-      const unsigned id = (unsigned)(k >> 16);
-      const int b = (int)(k & 0xffffu);
-      const unsigned long long kp = p > 0 ? key[p - 1] : ~k, kn = p + 1 < B ? key[p + 1] : ~k;
-      const bool run_start = p == 0 || (unsigned)(kp >> 16) != id, run_end = p + 1 >= B || (unsigned)(kn >> 16) != id;
-      const bool sub_start = run_start || (int)((kp & 0xffffu) >> 8) != (b >> 8), sub_end = run_end || (int)((kn & 0xffffu) >> 8) != (b >> 8);
-      d.order[(long)f * n + p] = b;
-      int s_run = p, e_run = p;
-      if (!run_start) s_run = dd_lower_bound(key, B, (unsigned long long)id << 16);
-      if (!run_end) e_run = dd_lower_bound(key, B, ((unsigned long long)id + 1) << 16) - 1;
-      const bool multi = (int)((key[s_run] & 0xffffu) >> 8) != (int)((key[e_run] & 0xffffu) >> 8);  // the run spans chunks
-      d.leader[(long)b * Fs + f] = run_start ? (e_run > s_run ? 2 : 1) : 0;
-      if (multi && sub_start) {
-        hb[u] = b;
-        ++cnth;
-      }
-      if (multi && run_end) {
-        srun[u] = s_run;
-        cnt += 1 << 16;
-      }
-      if (sub_end && !sub_start) {  // a sub-run with >= 2 members ends here
-        const int s_sub = dd_lower_bound(key, B, ((unsigned long long)id << 16) | (unsigned)(b & ~255));
-        ea[u] = (unsigned)s_sub | ((unsigned)(p - s_sub + 1) << 16) | (multi ? 0u : DD_WHOLE);
-        cnt += 1;
-      }
+    for (int u = 0; u < NASREC_DEDUP_IDS_MAX_B / 256; ++u) {
+      const int i = u * 256 + t;
+      v[u] = i < B ? (int)idx[(long)i * Fs + f] : -1 - i;  // (dead samples: unique negative ids)
+    }
+#pragma unroll
+    for (int u = 0; u < NASREC_DEDUP_IDS_MAX_B / 256; ++u)
+      if (u < nch) sidx[u * 256 + t] = v[u];
+  }
+  __syncthreads();
+  const bool live = b < B;
+  const int my = sidx[b];
+  const int4* s4 = reinterpret_cast<const int4*>(sidx);
+  // earlier chunks: does the id occur at all?
+  unsigned early = 0xffffffffu;
+  for (int cc = 0; cc < c; ++cc) {
+    const int4* p = s4 + cc * 64;
+#pragma unroll 16
+    for (int q = 0; q < 64; ++q) {
+      const int4 v = p[q];
+      early = min(early, min(min((unsigned)(v.x ^ my), (unsigned)(v.y ^ my)), min((unsigned)(v.z ^ my), (unsigned)(v.w ^ my))));
     }
   }
-  int total, totalh;
-  const int pos = dd_block_excl_scan(cnt, sh, &total);
-  const int ph = dd_block_excl_scan(cnth, sh, &totalh);
-  // The heads of one run are consecutive in `heads` (sorted order): a run [s, e] owns heads [hx[s], hx[e] + head(e)), hx[p] = heads at
-  // positions < p.  hx is parked over the keys (every thread is done with them: the scans above end with barriers).
-  int* hx = reinterpret_cast<int*>(key);
-  __syncthreads();
+  // later chunks, from the last id down: the lowest matching sample survives
+  int nxt = -1;
+  for (int cc = nch - 1; cc > c; --cc) {
+    const int4* p = s4 + cc * 64;
+    int loc = -1;
+#pragma unroll 16
+    for (int q = 63; q >= 0; --q) {
+      const int4 v = p[q];
+      loc = v.w == my ? 4 * q + 3 : loc;
+      loc = v.z == my ? 4 * q + 2 : loc;
+      loc = v.y == my ? 4 * q + 1 : loc;
+      loc = v.x == my ? 4 * q : loc;
+    }
+    nxt = loc >= 0 ? cc * 256 + loc : nxt;
+  }
+  // own chunk
+  unsigned mask[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) mask[w] = 0u;
   {
-    int run = ph;
+    const int4* p = s4 + c * 64;
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int p = tid * per + u;
-      if (u < per && p < n) hx[p] = run;
-      if (hb[u] >= 0) {
-        d.heads[(long)f * n + run] = hb[u];
-        ++run;
+    for (int q = 0; q < 64; ++q) {
+      const int4 v = p[q];
+      const unsigned m = (unsigned)(v.x == my) | ((unsigned)(v.y == my) << 1) | ((unsigned)(v.z == my) << 2) | ((unsigned)(v.w == my) << 3);
+      mask[q >> 3] |= m << ((q & 7) * 4);
+    }
+  }
+  bool head = live;  // head of its sub-run
+  int ndup = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const unsigned below = (t >= 32 * (w + 1)) ? 0xffffffffu : (t <= 32 * w ? 0u : ((1u << (t - 32 * w)) - 1u));
+    const unsigned above = (t < 32 * w) ? 0xffffffffu : (t >= 32 * w + 31 ? 0u : ~((2u << (t - 32 * w)) - 1u));
+    if (mask[w] & below) head = false;
+    mask[w] &= above;
+    ndup += __popc(mask[w]);
+  }
+  ndup = head ? ndup : 0;
+  const bool lead = head && early != 0u;
+  if (live) d.leader[(long)b * Fs + f] = lead ? ((ndup || nxt >= 0) ? 2 : 1) : 0;
+  d.heads[(long)f * d.cap + b] = head ? nxt : -1;
+  int total;
+  const int pos = dd_block_excl_scan(ndup ? 1 + ndup : 0, sh, &total);
+  unsigned en = 0u;
+  if (ndup) {
+    en = DD_A | (unsigned)pos | ((unsigned)ndup << 8) | ((lead && nxt < 0) ? DD_WHOLE : 0u);
+    int* o = d.order + (long)f * d.cap + c * 256 + pos;
+    *o++ = b;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      unsigned m = mask[w];
+      while (m) {
+        *o++ = c * 256 + 32 * w + __ffs((int)m) - 1;
+        m &= m - 1;
       }
     }
   }
-  __syncthreads();
-  int pa = pos & 0xffff, pb = pos >> 16;
-#pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    const int p = tid * per + u;
-    if (ea[u]) d.lists[(long)f * n + pa++] = (int)ea[u];
-    if (srun[u] >= 0) {
-      const int h0 = hx[srun[u]], nh = hx[p] + (hb[u] >= 0 ? 1 : 0) - h0;
-      d.lists[(long)f * n + half + pb++] = (int)((unsigned)h0 | ((unsigned)nh << 16));
-    }
-  }
-  if (tid == 0) {
-    d.counts[2 * f] = total & 0xffff;
-    d.counts[2 * f + 1] = total >> 16;
-  }
+  if (lead && nxt >= 0) en |= DD_MULTI;
+  d.lists[(long)f * d.cap + b] = (int)en;
+  if (t == 0 && c == 0) d.counts[2 * f] = d.counts[2 * f + 1] = 0;
 }
 
 // address of row (b, f) of the per-sample row gradients (contiguous, or the receive buffer of an all-gather: nasrec_adagrad_rows_desc_t)

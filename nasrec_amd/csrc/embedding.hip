@@ -426,10 +426,11 @@ __global__ __launch_bounds__(256) void dedup_ids_small_kernel(const nasrec_dedup
   dedup_ids_small_body(d, d.idx, d.B, d.Fs, blockIdx.x, sidx, sh);
 }
 
-__global__ __launch_bounds__(256) void dedup_ids_sort_kernel(const nasrec_dedup_ids_desc_t d) {
-  __shared__ unsigned long long key[NASREC_DEDUP_IDS_MAX_B];
+// grid (chunks of 256 samples, Fs): the chunk index varies fastest, so the workgroups of one field (same ids) sit on neighbouring CUs
+__global__ __launch_bounds__(256) void dedup_ids_pairs_kernel(const nasrec_dedup_ids_desc_t d) {
+  __shared__ __attribute__((aligned(16))) int sidx[NASREC_DEDUP_IDS_MAX_B];
   __shared__ int sh[4];
-  dedup_ids_sort_body<NASREC_DEDUP_IDS_MAX_B>(d, d.idx, d.B, d.Fs, blockIdx.x, key, sh);
+  dedup_ids_pairs_body(d, d.idx, d.B, d.Fs, blockIdx.y, blockIdx.x, sidx, sh);
 }
 
 int launch_dedup_ids(hipStream_t st, const nasrec_dedup_ids_desc_t* d) {
@@ -440,7 +441,7 @@ int launch_dedup_ids(hipStream_t st, const nasrec_dedup_ids_desc_t* d) {
     hipLaunchKernelGGL(dedup_ids_small_kernel, dim3(d->Fs), dim3(256), 0, st, *d);
   } else {
     if (!d->heads) return nasrec_set_error(-2, "dedup_ids: B=%d > 256 needs the heads array", d->B);
-    hipLaunchKernelGGL(dedup_ids_sort_kernel, dim3(d->Fs), dim3(256), 0, st, *d);
+    hipLaunchKernelGGL(dedup_ids_pairs_kernel, dim3((d->B + 255) / 256, d->Fs), dim3(256), 0, st, *d);
   }
   return nasrec_check_launch("dedup_ids");
 }
@@ -528,8 +529,8 @@ __global__ __launch_bounds__(T) void opt_reduce2_kernel(const nasrec_opt_reduce2
   } else {
     // field f: every row of the field into LDS (one round of loads: RPT rows x 4 pieces per thread, beside the lists), then the sums
     const int f = bid, q = tid & 3, quad = tid >> 2;
-    const int cap = d.cap, half = cap >> 1;
-    const int nA = d.counts[2 * f], nB = d.counts[2 * f + 1];
+    const int cap = d.cap;
+    const int nA = d.counts[2 * f];
     f32x4 g[RPT][4];
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {
@@ -557,10 +558,23 @@ __global__ __launch_bounds__(T) void opt_reduce2_kernel(const nasrec_opt_reduce2
     }
     __syncthreads();
     // phase 1: every sub-run with >= 2 members, a quad per sub-run (lane = one float4 of the row), ascending sample order; the sum
-    // lands in the LDS row of the sub-run's first sample, and in memory
-    for (int k = quad; k < nA; k += T / 4) {
+    // lands in the LDS row of the sub-run's first sample, and in memory when the sub-run is the whole run.  B <= 256: list A; above:
+    // one entry per sample (dedup_ids_pairs_body)
+    // (per-sample entries: chunk c's entries start 32 c quads further on — the sub-runs of a few heavy ids sit at the same positions of
+    // every chunk, and would otherwise all queue on the same quads)
+    const int n1 = RPT == 1 ? nA : min(cap, (B + 255) & ~255);
+    for (int k0 = quad; k0 < n1; k0 += T / 4) {
+      const int k = RPT == 1 ? k0 : (k0 & ~255) + ((k0 + 32 * (k0 >> 8)) & 255);
       const unsigned en = (unsigned)lst[k];
-      const int s = (int)(en & 0xffffu), len = (int)((en >> 16) & 0x7fffu);
+      int s, len;
+      if (RPT == 1) {
+        s = (int)(en & 0xffffu);
+        len = (int)((en >> 16) & 0x7fffu);
+      } else {
+        if (!(en & DD_A)) continue;
+        s = (k & ~255) + (int)(en & 0xffu);
+        len = 1 + (int)((en >> 8) & 0xffu);
+      }
       const int o0 = ord[s];
       f32x4 acc = *reinterpret_cast<const f32x4*>(&rows[o0 * 16 + 4 * q]);
       int i = 1;
@@ -581,15 +595,14 @@ __global__ __launch_bounds__(T) void opt_reduce2_kernel(const nasrec_opt_reduce2
         *reinterpret_cast<f32x4*>(&rows[o0 * 16 + 4 * q]) = acc;  // (a sub-run's first row is nobody else's operand in this phase)
       }
     }
-    if (nB > 0) {  // (uniform) phase 2: runs that span chunks — the sub-run sums, in chunk order, into the leader's row
+    if (RPT > 1) {  // phase 2: runs that span chunks — the sub-run sums, in chunk order, into the leader's row
       __syncthreads();
-      for (int k = quad; k < nB; k += T / 4) {
-        const unsigned en = (unsigned)lst[half + k];
-        const int h0 = (int)(en & 0xffffu), nh = (int)(en >> 16);
-        const int lead = hds[h0];
-        f32x4 acc = *reinterpret_cast<const f32x4*>(&rows[lead * 16 + 4 * q]);
-        for (int i = 1; i < nh; ++i) acc += *reinterpret_cast<const f32x4*>(&rows[hds[h0 + i] * 16 + 4 * q]);
-        *reinterpret_cast<f32x4*>(dd_row(d.rows, lead, f, Fs, d.rank_B, d.rank_stride) + 4 * q) = acc;
+      for (int k0 = quad; k0 < n1; k0 += T / 4) {
+        const int k = (k0 & ~255) + ((k0 + 32 * (k0 >> 8)) & 255);
+        if (!((unsigned)lst[k] & DD_MULTI)) continue;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(&rows[k * 16 + 4 * q]);
+        for (int h = hds[k]; h >= 0; h = hds[h]) acc += *reinterpret_cast<const f32x4*>(&rows[h * 16 + 4 * q]);
+        *reinterpret_cast<f32x4*>(dd_row(d.rows, k, f, Fs, d.rank_B, d.rank_stride) + 4 * q) = acc;
         ss += (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]);
       }
     }

@@ -58,6 +58,59 @@ __device__ __forceinline__ void final_fwd_block(const nasrec_final_desc_t& d, in
 __device__ __forceinline__ float bce_grad(float z, float y, float scale) { return (1.f / (1.f + expf(-z)) - y) * scale; }
 __device__ __forceinline__ float bce_term(float z, float y) { return fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z))); }
 
+// NASREC_OP_FINAL_FUSED: final_fwd_block, and behind it — in the wavefront that holds the sample's logit — the part of the backward that
+// needs nothing else: dseg[b, j] (+)= dlogits[b] * w[col(j)], the expression of final_bwd_block's part A.  workgroup vb of (B + 3) / 4.
+__device__ __forceinline__ void final_fused_block(const nasrec_final_desc_t& d, int vb) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = vb * 4 + wave;
+  if (b >= d.B) return;
+  const float yb = d.y[b], bias = d.bias[0];  // (in flight under the sum)
+  float s = 0.f;
+  for (int q = 0; q < d.nseg; ++q) {
+    if (!d.seg[q]) continue;
+    const float* x = d.seg[q] + (long)b * d.ld[q];
+    const float* w = d.w + d.off[q];
+    const int W = d.width[q], ts = d.tok_stride[q];
+    for (int j0 = lane; j0 < W; j0 += 64 * 4) {
+      float xv[4], wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(j0 + 64 * u, W - 1);
+        xv[u] = x[j];
+        wv[u] = w[ts ? (j >> 4) * ts + (j & 15) : j];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + 64 * u < W) s = fmaf(xv[u], wv[u], s);
+    }
+  }
+  const float z = wave_sum(s) + bias;
+  if (lane == 0) d.logits[b] = z;
+  const float g = bce_grad(z, yb, d.grad_scale);
+  for (int q = 0; q < d.nseg; ++q) {
+    float* p = d.dseg[q];
+    if (!p || !d.seg[q]) continue;
+    p += (long)b * d.ld[q];
+    const float* w = d.w + d.off[q];
+    const int W = d.width[q], ts = d.tok_stride[q];
+    const bool acc = d.dseg_accumulate[q] != 0;
+    for (int j0 = lane; j0 < W; j0 += 64 * 4) {  // reads first (weights; the accumulation targets), then the stores
+      float wv[4], cv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(j0 + 64 * u, W - 1);
+        wv[u] = w[ts ? (j >> 4) * ts + (j & 15) : j];
+        cv[u] = acc ? p[j] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float v = g * wv[u];
+        if (j0 + 64 * u < W) p[j0 + 64 * u] = acc ? cv[u] + v : v;
+      }
+    }
+  }
+}
+
 // backward: part A (blocks [0, nA)): dseg[b,j] (+)= dlogits[b] * w[off+j]
 //           part B (blocks [nA, nA+nB)): dw[k] = sum_b dlogits[b] * feat[b,k]; dbias = sum_b dlogits[b]
 //           part C (block nA+nB, only with the fused BCE): loss and the per-sample gradient
@@ -297,6 +350,7 @@ __host__ __device__ inline void final_bwd_geometry(const nasrec_final_desc_t& d,
   const long tA = (long)d.B * K;
   nA = (int)((tA + 255) / 256);
   if (final_bwd_rows(d.B) > 1) nA = ((K + 255) / 256) * ((d.B + FINAL_BWD_ROWS - 1) / FINAL_BWD_ROWS);
+  if (d.dseg_done) nA = 0;  // (NASREC_OP_FINAL_FUSED wrote the per-sample part)
   nB = (K + 1 + 15) / 16;
   if (d.nsplit > 1) nB = ((K + 1 + 63) / 64) * d.nsplit;
 }

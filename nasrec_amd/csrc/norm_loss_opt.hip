@@ -12,9 +12,23 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const nasrec_final_desc_
   final_bwd_block(d, K, nA, nB, blockIdx.x, lds);
 }
 
+__global__ __launch_bounds__(256) void final_fused_kernel(const nasrec_final_desc_t d) { final_fused_block(d, blockIdx.x); }
+
+int final_fused_check(const nasrec_final_desc_t* d) {
+  if (!d->y || !d->logits || !d->bias || !d->w) return nasrec_set_error(-2, "final_fused: needs y, logits, bias and w");
+  if (d->nsplit > 1) return nasrec_set_error(-2, "final_fused: nsplit=%d (the batch-sliced backward keeps its own launch)", d->nsplit);
+  for (int q = 0; q < d->nseg; ++q)
+    if (d->dseg[q] && !d->seg[q]) return nasrec_set_error(-2, "final_fused: segment %d has a gradient destination and no input", q);
+  return 0;
+}
+
 int launch_final(hipStream_t st, const nasrec_final_desc_t* d) {
   if (d->B == 0) return 0;
-  if (d->kind == NASREC_OP_FINAL_FWD) {
+  if (d->kind == NASREC_OP_FINAL_FUSED) {
+    const int rc = final_fused_check(d);
+    if (rc) return rc;
+    hipLaunchKernelGGL(final_fused_kernel, dim3((d->B + 3) / 4), dim3(256), 0, st, *d);
+  } else if (d->kind == NASREC_OP_FINAL_FWD) {
     hipLaunchKernelGGL(final_fwd_kernel, dim3((d->B + 3) / 4), dim3(256), 0, st, *d);
   } else {
     int K, nA, nB;

@@ -231,6 +231,13 @@ int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
         WL_NEED(nasrec_final_desc_t);
         it.nblk = (reinterpret_cast<const nasrec_final_desc_t*>(blob)->B + 3) / 4;
         break;
+      case NASREC_OP_FINAL_FUSED: {
+        WL_NEED(nasrec_final_desc_t);
+        const int rc = final_fused_check(reinterpret_cast<const nasrec_final_desc_t*>(blob));
+        if (rc) return rc;
+        it.nblk = (reinterpret_cast<const nasrec_final_desc_t*>(blob)->B + 3) / 4;
+        break;
+      }
       case NASREC_OP_FINAL_BWD: {
         WL_NEED(nasrec_final_desc_t);
         const nasrec_final_desc_t* d = reinterpret_cast<const nasrec_final_desc_t*>(blob);

@@ -24,6 +24,7 @@ E = 16
 DEDUP_SPLIT_MAX_B = min(int(os.environ.get("NASREC_DEDUP_SPLIT_MAX_B", "256")), L.DEDUP_IDS_MAX_B)
 # the id half of a level-scheduled step (B <= 256) as an ITEM of the joint forward + backward program (A/B knob: 0 = on the staging launch)
 _IDS_AS_ITEM = os.environ.get("NASREC_IDS_AS_ITEM", "1") != "0"
+_FUSE_FINAL = os.environ.get("NASREC_FUSE_FINAL", "1") != "0"  # joint program: final logit + the per-sample part of its backward as one operator
 # clip + Adagrad of a fixed sub-network over the ranges of the parameters its backward reaches, not the whole arena (A/B knob)
 _FIXED_OPT_TABLE = os.environ.get("NASREC_FIXED_OPT_TABLE", "1") != "0"
 
@@ -444,7 +445,8 @@ class SupernetEngine:
                 if scheduled:
                     # (alloc: a forward product with several levels of slack may be re-cut into split-K items — only in the JOINT
                     # program, where the backward's latency-bound levels are there to hide it)
-                    fb_descs, cp.fb_levels = S.pack(ids_in_program + fwd_list + bwd_descs, alloc=ctx.alloc)
+                    jf, jb = self._fuse_final(fwd_list, bwd_descs, fused) if _FUSE_FINAL else (fwd_list, bwd_descs)
+                    fb_descs, cp.fb_levels = S.pack(ids_in_program + jf + jb, alloc=ctx.alloc)
                     cp.fb = Program(fb_descs)
                     bwd_descs, cp.bwd_levels = S.pack(bwd_descs)
                 cp.bwd = Program(bwd_descs)
@@ -711,6 +713,28 @@ class SupernetEngine:
         """Launches go to the CALLER's current stream (no cross-stream event pair per step: each one costs a barrier packet
         and ~10 us of GPU idle); the private stream only builds and captures plans."""
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    @staticmethod
+    def _fuse_final(fwd_list, bwd_descs, fused):
+        """joint forward + backward program: the final logit's forward and the per-sample part of its backward (d loss / d features =
+        (sigmoid(logit) - y) / B * w: supernet.py:592-598 under BCEWithLogitsLoss) become ONE operator (NASREC_OP_FINAL_FUSED: the
+        wavefront that sums a sample's logit writes its feature gradients too), so the backward pass starts one launch boundary
+        earlier; the parts that need every sample's logit (d w, d bias, the loss) stay a FINAL_BWD with dseg_done, which nothing
+        waits for.  Same expressions per element: the bit-identity tests against one launch per operator cover it."""
+        fi = [i for i, d in enumerate(fwd_list) if isinstance(d, L.FinalDesc) and d.kind == L.OP_FINAL_FWD]
+        if len(fi) != 1 or fused.nsplit > 1 or not any(d is fused for d in bwd_descs):
+            return fwd_list, bwd_descs
+        f = fwd_list[fi[0]]
+        same = f.B == fused.B and f.nseg == fused.nseg and f.w == fused.w and f.logits == fused.logits and all(
+            f.seg[q] == fused.seg[q] and f.width[q] == fused.width[q] and f.ld[q] == fused.ld[q] and f.off[q] == fused.off[q]
+            and f.tok_stride[q] == fused.tok_stride[q] and (not fused.dseg[q] or f.seg[q]) for q in range(f.nseg))
+        if not same:
+            return fwd_list, bwd_descs
+        both = L.FinalDesc.from_buffer_copy(fused)
+        both.kind, both.bias = L.OP_FINAL_FUSED, f.bias
+        rest = L.FinalDesc.from_buffer_copy(fused)
+        rest.dseg_done = 1
+        return ([both if i == fi[0] else d for i, d in enumerate(fwd_list)], [rest if d is fused else d for d in bwd_descs])
 
     def _stage_inputs(self, sp, cp, int_x, cat_x, y=None, lr=None, rows=None):
         """one launch: batch -> the plan's static buffers (+ this step's learning rate -> device scalar); host_embedding: the

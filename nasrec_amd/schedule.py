@@ -210,7 +210,7 @@ def desc_io(d, part="whole") -> Tuple[List[Acc], List[Acc]]:
         if d.aux:
             R.append(_operand(d.aux, d.mode, d.R, d.K, d.ld))
         W.append(_flat(d.out, d.R))
-    elif k in (L.OP_FINAL_FWD, L.OP_FINAL_BWD):
+    elif k in (L.OP_FINAL_FWD, L.OP_FINAL_BWD, L.OP_FINAL_FUSED):
         def extent(q):  # weight columns a segment spans (token-strided for last_n_blocks_out > 1: nasrec_final_desc_t.tok_stride)
             ts, Wq = d.tok_stride[q], d.width[q]
             return ((Wq - 1) // 16) * ts + (Wq - 1) % 16 + 1 if (ts and Wq > 0) else Wq
@@ -219,19 +219,23 @@ def desc_io(d, part="whole") -> Tuple[List[Acc], List[Acc]]:
             if d.seg[q]:
                 R.append(Acc(d.seg[q], d.B, d.width[q], d.ld[q]))
         R.append(_flat(d.w, K))
-        if k == L.OP_FINAL_FWD:
+        if k in (L.OP_FINAL_FWD, L.OP_FINAL_FUSED):
             R.append(_flat(d.bias, 1))
             W.append(_flat(d.logits, d.B))
-        else:
+        if k == L.OP_FINAL_FUSED:
+            R.append(_flat(d.y, d.B))
+        if k == L.OP_FINAL_BWD:
             for ptr in (d.dlogits, d.logits, d.y):
                 if ptr:
                     R.append(_flat(ptr, d.B))
+        if k == L.OP_FINAL_FUSED or (k == L.OP_FINAL_BWD and not d.dseg_done):
             for q in range(d.nseg):
                 if d.dseg[q]:
                     a = Acc(d.dseg[q], d.B, d.width[q], d.ld[q])
                     W.append(a)
                     if d.dseg_accumulate[q]:
                         R.append(a)
+        if k == L.OP_FINAL_BWD:
             W.append(_flat(d.dw, (K + 1) * max(d.nsplit, 1)))
             for ptr, n in ((d.dbias, 1), (d.loss, 1), (d.dlogits_out, d.B)):
                 if ptr:
@@ -510,7 +514,7 @@ def levels_of(descs):
 _GEMM_HEAD = L.GemmDesc.seg.offset
 _SEG_BYTES = C.sizeof(L.GemmSeg)
 _PLAIN_KINDS = (L.OP_MHA_FWD, L.OP_MHA_BWD, L.OP_FM_FWD, L.OP_FM_BWD, L.OP_DOT_TRI_FWD, L.OP_DOT_TRI_BWD, L.OP_COPY_SEGS, L.OP_GATE_BWD,
-                L.OP_FINAL_FWD, L.OP_FINAL_BWD, L.OP_DEDUP_IDS)
+                L.OP_FINAL_FWD, L.OP_FINAL_BWD, L.OP_DEDUP_IDS, L.OP_FINAL_FUSED)
 WL_LDS_FLOATS = 1696 + 5 * 1024 + 1024  # csrc/worklist_body.h WL_LDS_FLOATS
 
 
@@ -583,10 +587,10 @@ _PART = {"whole": L.WL_WHOLE, "main": L.WL_MAIN, "epi": L.WL_EPI, "fused": 3}
 
 # stand-alone times of the non-GEMM items of the batch-256 step, ns (tools/step_table.py ITEMS=11)
 _ITEM_NS = {L.OP_MHA_BWD: 18000, L.OP_MHA_FWD: 11000, L.OP_DOT_TRI_BWD: 10000, L.OP_DOT_TRI_FWD: 6000, L.OP_REDUCE_ROWS: 4500,
-            L.OP_FM_BWD: 3900, L.OP_FM_FWD: 3500, L.OP_FINAL_BWD: 7500, L.OP_DEDUP_IDS: 8000}
+            L.OP_FM_BWD: 3900, L.OP_FM_FWD: 3500, L.OP_FINAL_BWD: 7500, L.OP_DEDUP_IDS: 8000, L.OP_FINAL_FUSED: 4500}
 # round 4 (ITEMS=7 python tools/step_table.py on the balanced plan): the same items measured again, used by the balancing pass
 _ITEM_NS_R4 = {L.OP_MHA_BWD: 18500, L.OP_MHA_FWD: 10500, L.OP_REDUCE_ROWS: 6000, L.OP_FM_BWD: 7000, L.OP_FM_FWD: 3500, L.OP_FINAL_BWD: 7000,
-               L.OP_FINAL_FWD: 3400, L.OP_GATE_BWD: 3500, L.OP_DEDUP_IDS: 8000}
+               L.OP_FINAL_FWD: 3400, L.OP_GATE_BWD: 3500, L.OP_DEDUP_IDS: 8000, L.OP_FINAL_FUSED: 4500}
 _COST_MODEL = os.environ.get("NASREC_WL_COST", "time")
 
 
@@ -606,6 +610,8 @@ def _cost(node):
         if node.part == "fused":
             return 6500 + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A) // 20000
         return 5000 + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A) // 20000
+    if d.kind == L.OP_FINAL_BWD and d.dseg_done:
+        return 5000
     return _ITEM_NS.get(d.kind, 3000)
 
 
@@ -625,6 +631,8 @@ def _cost_r4(node):
         return 3500 + int(2.3 * d.k1 * d.k1)
     if d.kind == L.OP_DOT_TRI_FWD:
         return 3000 + int(0.2 * d.k1 * d.k1)
+    if d.kind == L.OP_FINAL_BWD and d.dseg_done:
+        return 5000
     return _ITEM_NS_R4.get(d.kind, 3000)
 
 

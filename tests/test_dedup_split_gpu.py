@@ -128,16 +128,36 @@ def test_two_halves_equal_the_one_launch_dedup_bit_for_bit(lib, B):
     for k in ("leader", "counts"):
         assert torch.equal(bufs[k], bufs2[k]), k
     cap = cap_of(B)
-    for f in range(Fs):  # (entries behind a field's counts are stale memory)
-        nA, nB = int(bufs["counts"][2 * f]), int(bufs["counts"][2 * f + 1])
-        assert torch.equal(bufs["lists"][f * cap:f * cap + nA], bufs2["lists"][f * cap:f * cap + nA])
-        assert torch.equal(bufs["lists"][f * cap + cap // 2:f * cap + cap // 2 + nB], bufs2["lists"][f * cap + cap // 2:f * cap + cap // 2 + nB])
-        for k in range(nA):  # the sub-runs' samples
-            en = int(bufs["lists"][f * cap + k]) & 0xffffffff
-            s0, ln = en & 0xffff, (en >> 16) & 0x7fff
+    for f in range(Fs):
+        if B <= 256:  # compact list of the runs with duplicates (entries behind a field's count are stale memory)
+            nA = int(bufs["counts"][2 * f])
+            assert int(bufs["counts"][2 * f + 1]) == 0
+            assert torch.equal(bufs["lists"][f * cap:f * cap + nA], bufs2["lists"][f * cap:f * cap + nA])
+            entries = [(int(bufs["lists"][f * cap + k]) & 0xffff, (int(bufs["lists"][f * cap + k]) >> 16) & 0x7fff) for k in range(nA)]
+        else:  # one entry and one next-sub-run link per sample
+            nb = (B + 255) // 256 * 256
+            assert torch.equal(bufs["lists"][f * cap:f * cap + nb], bufs2["lists"][f * cap:f * cap + nb])
+            assert torch.equal(bufs["heads"][f * cap:f * cap + nb], bufs2["heads"][f * cap:f * cap + nb])
+            ens = (bufs["lists"][f * cap:f * cap + nb].cpu().long() & 0xffffffff).tolist()
+            entries = [((b & ~255) + (en & 0xff), 1 + ((en >> 8) & 0xff)) for b, en in enumerate(ens) if en & 0x10000]
+            nxt = bufs["heads"][f * cap:f * cap + nb].cpu().tolist()
+            col = idx[:, f].tolist()
+            for b, en in enumerate(ens):
+                if en & 0x20000:  # leader of a run that spans chunks: the chain visits the first sample of every later chunk's part
+                    chain, h = [], nxt[b]
+                    while h >= 0:
+                        chain.append(h)
+                        h = nxt[h]
+                    same = [j for j in range(B) if col[j] == col[b]]
+                    assert same[0] == b
+                    firsts = {}
+                    for j in same:
+                        firsts.setdefault(j >> 8, j)
+                    assert [b] + chain == [firsts[c] for c in sorted(firsts)], (f, b)
+        for s0, ln in entries:  # the sub-runs' samples
             assert torch.equal(bufs["order"][f * cap + s0:f * cap + s0 + ln], bufs2["order"][f * cap + s0:f * cap + s0 + ln])
             o = bufs["order"][f * cap + s0:f * cap + s0 + ln].cpu().long()
-            assert bool((o[1:] > o[:-1]).all()) and len(set(idx[o, f].tolist())) == 1 and len(set((o >> 8).tolist())) == 1
+            assert ln >= 2 and bool((o[1:] > o[:-1]).all()) and len(set(idx[o, f].tolist())) == 1 and len(set((o >> 8).tolist())) == 1
 
 
 @pytest.mark.parametrize("B,ranks", [(256, 1), (512, 2), (2048, 8), (300, 3)])
