@@ -91,74 +91,85 @@ __device__ __forceinline__ void dedup_ids_small_body(const nasrec_dedup_ids_desc
   }
 }
 
-// ---- 256 < B <= NASREC_DEDUP_IDS_MAX_B: all pairs, one workgroup per (field, 256-sample chunk) ---------------------------------------
+// ---- 256 < B <= NASREC_DEDUP_IDS_MAX_B: one workgroup per (field, 256-sample chunk) ----------------------------------------------------
 // No workgroup needs another's result, so nothing is sorted, scanned or signalled across workgroups: every array is indexed by SAMPLE
 // (or by the chunk's own region of `order`), and a thread decides everything about its sample from the ids of its field:
-//   earlier chunks   any match  -> not the run's leader                                   (xor + min: 2 instructions per id)
-//   own chunk        256-bit match mask as in the small body -> head of its sub-run? the sub-run's members (ascending)
-//   later chunks     the LOWEST matching sample = the head of the run's next sub-run       (compare + select, descending)
+//   own chunk      256-bit match mask as in the small body -> head of its sub-run? the sub-run's members (ascending)
+//   other chunks   through an LDS hash table of their ids (open addressing, 4096 slots for <= 1792 ids): per id, "occurs in an earlier
+//                  chunk" (-> the sample does not lead its run) and the LOWEST sample of the later chunks (= the head of the run's next
+//                  sub-run), kept with atomicMin — both independent of the order the table was filled in.  (All pairs against the
+//                  other chunks, 2048 compares per thread, took 37 us at 2048 x 26: the broadcast LDS reads alone are ~8 clocks each.)
 // Per field:  lists[b]  DD_A | DD_MULTI | DD_WHOLE | (members - 1) << 8 | position of the sub-run inside the chunk's region of `order`
 //             heads[b]  the head of the next sub-run of b's run (-1: none): phase 2 of the sums walks leader -> next -> next ...
 //             order[256 c + ..]  the members of chunk c's sub-runs with >= 2 members;   counts: unused (0)
 #define DD_A 0x10000u      // the sample heads a sub-run with >= 2 members
 #define DD_MULTI 0x20000u  // the sample leads a run with sub-runs in later chunks
+#define DD_HASH 4096
+__device__ __forceinline__ int dd_hash(int id) { return (int)(((unsigned)id * 2654435761u) >> 20); }
 
-// sidx: nch * 256 ints of LDS (the field's ids), sh: 4 ints
-__device__ __forceinline__ void dedup_ids_pairs_body(const nasrec_dedup_ids_desc_t& d, const int64_t* idx, int B, int Fs, int f, int c, int* sidx, int* sh) {
+// sidx: 256 ints of LDS (the chunk's ids), sh: 4 ints, hkey / hlo / hearly: DD_HASH ints each
+__device__ __forceinline__ void dedup_ids_pairs_body(const nasrec_dedup_ids_desc_t& d, const int64_t* idx, int B, int Fs, int f, int c, int* sidx, int* sh,
+                                                     int* hkey, int* hlo, int* hearly) {
   const int t = threadIdx.x, b = c * 256 + t;
   const int nch = (B + 255) >> 8;
-  {  // the field's ids: every load first (a loop with a run-time trip count compiles to load -> wait -> store per chunk), then the stores
-    int v[NASREC_DEDUP_IDS_MAX_B / 256];
+  int v[NASREC_DEDUP_IDS_MAX_B / 256];  // the field's ids, sample 256 u + t: every load first
 #pragma unroll
-    for (int u = 0; u < NASREC_DEDUP_IDS_MAX_B / 256; ++u) {
-      const int i = u * 256 + t;
-      v[u] = i < B ? (int)idx[(long)i * Fs + f] : -1 - i;  // (dead samples: unique negative ids)
+  for (int u = 0; u < NASREC_DEDUP_IDS_MAX_B / 256; ++u) {
+    const int i = u * 256 + t;
+    v[u] = i < B ? (int)idx[(long)i * Fs + f] : -1;
+  }
+  for (int i = t; i < DD_HASH; i += 256) {
+    hkey[i] = -1;
+    hlo[i] = 0x7fffffff;
+    hearly[i] = 0;
+  }
+#pragma unroll
+  for (int u = 0; u < NASREC_DEDUP_IDS_MAX_B / 256; ++u)
+    if (u == c) sidx[t] = v[u] >= 0 ? v[u] : -1 - t;  // (samples that do not exist: unique negative ids)
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NASREC_DEDUP_IDS_MAX_B / 256; ++u) {
+    const int id = v[u];
+    if (u < nch && u != c && id >= 0) {
+      int slot = dd_hash(id);
+      for (;;) {
+        const int old = atomicCAS(&hkey[slot], -1, id);
+        if (old == -1 || old == id) break;
+        slot = (slot + 1) & (DD_HASH - 1);
+      }
+      if (u < c) hearly[slot] = 1;
+      else atomicMin(&hlo[slot], u * 256 + t);
     }
-#pragma unroll
-    for (int u = 0; u < NASREC_DEDUP_IDS_MAX_B / 256; ++u)
-      if (u < nch) sidx[u * 256 + t] = v[u];
   }
   __syncthreads();
   const bool live = b < B;
-  const int my = sidx[b];
-  const int4* s4 = reinterpret_cast<const int4*>(sidx);
-  // earlier chunks: does the id occur at all?
-  unsigned early = 0xffffffffu;
-  for (int cc = 0; cc < c; ++cc) {
-    const int4* p = s4 + cc * 64;
-#pragma unroll 16
-    for (int q = 0; q < 64; ++q) {
-      const int4 v = p[q];
-      early = min(early, min(min((unsigned)(v.x ^ my), (unsigned)(v.y ^ my)), min((unsigned)(v.z ^ my), (unsigned)(v.w ^ my))));
-    }
-  }
-  // later chunks, from the last id down: the lowest matching sample survives
+  const int my = sidx[t];
+  bool early = false;
   int nxt = -1;
-  for (int cc = nch - 1; cc > c; --cc) {
-    const int4* p = s4 + cc * 64;
-    int loc = -1;
-#pragma unroll 16
-    for (int q = 63; q >= 0; --q) {
-      const int4 v = p[q];
-      loc = v.w == my ? 4 * q + 3 : loc;
-      loc = v.z == my ? 4 * q + 2 : loc;
-      loc = v.y == my ? 4 * q + 1 : loc;
-      loc = v.x == my ? 4 * q : loc;
+  if (live) {
+    int slot = dd_hash(my);
+    for (;;) {
+      const int k = hkey[slot];
+      if (k == my) {
+        early = hearly[slot] != 0;
+        const int lo = hlo[slot];
+        nxt = lo == 0x7fffffff ? -1 : lo;
+        break;
+      }
+      if (k == -1) break;
+      slot = (slot + 1) & (DD_HASH - 1);
     }
-    nxt = loc >= 0 ? cc * 256 + loc : nxt;
   }
+  const int4* s4 = reinterpret_cast<const int4*>(sidx);
   // own chunk
   unsigned mask[8];
 #pragma unroll
   for (int w = 0; w < 8; ++w) mask[w] = 0u;
-  {
-    const int4* p = s4 + c * 64;
 #pragma unroll
-    for (int q = 0; q < 64; ++q) {
-      const int4 v = p[q];
-      const unsigned m = (unsigned)(v.x == my) | ((unsigned)(v.y == my) << 1) | ((unsigned)(v.z == my) << 2) | ((unsigned)(v.w == my) << 3);
-      mask[q >> 3] |= m << ((q & 7) * 4);
-    }
+  for (int q = 0; q < 64; ++q) {
+    const int4 w4 = s4[q];
+    const unsigned m = (unsigned)(w4.x == my) | ((unsigned)(w4.y == my) << 1) | ((unsigned)(w4.z == my) << 2) | ((unsigned)(w4.w == my) << 3);
+    mask[q >> 3] |= m << ((q & 7) * 4);
   }
   bool head = live;  // head of its sub-run
   int ndup = 0;
@@ -171,7 +182,7 @@ __device__ __forceinline__ void dedup_ids_pairs_body(const nasrec_dedup_ids_desc
     ndup += __popc(mask[w]);
   }
   ndup = head ? ndup : 0;
-  const bool lead = head && early != 0u;
+  const bool lead = head && !early;
   if (live) d.leader[(long)b * Fs + f] = lead ? ((ndup || nxt >= 0) ? 2 : 1) : 0;
   d.heads[(long)f * d.cap + b] = head ? nxt : -1;
   int total;

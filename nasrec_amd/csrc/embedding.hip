@@ -428,9 +428,10 @@ __global__ __launch_bounds__(256) void dedup_ids_small_kernel(const nasrec_dedup
 
 // grid (chunks of 256 samples, Fs): the chunk index varies fastest, so the workgroups of one field (same ids) sit on neighbouring CUs
 __global__ __launch_bounds__(256) void dedup_ids_pairs_kernel(const nasrec_dedup_ids_desc_t d) {
-  __shared__ __attribute__((aligned(16))) int sidx[NASREC_DEDUP_IDS_MAX_B];
+  __shared__ __attribute__((aligned(16))) int sidx[256];
   __shared__ int sh[4];
-  dedup_ids_pairs_body(d, d.idx, d.B, d.Fs, blockIdx.y, blockIdx.x, sidx, sh);
+  __shared__ int htab[3 * DD_HASH];
+  dedup_ids_pairs_body(d, d.idx, d.B, d.Fs, blockIdx.y, blockIdx.x, sidx, sh, htab, htab + DD_HASH, htab + 2 * DD_HASH);
 }
 
 int launch_dedup_ids(hipStream_t st, const nasrec_dedup_ids_desc_t* d) {
@@ -449,8 +450,8 @@ int launch_dedup_ids(hipStream_t st, const nasrec_dedup_ids_desc_t* d) {
 // NASREC_OP_OPT_REDUCE2.  T threads per workgroup, RPT rows staged per thread: <256, 1> for B <= 256 (the one-GPU batch), <1024, 2>
 // up to 2048 samples (the global batch of 8 ranks x 256): ALL rows of a field sit in LDS at once (2048 x 64 B = 128 KB), so both
 // summation phases read LDS only.  A run / sub-run is summed by a QUAD of lanes (lane = one float4 of the row): 64 / 256 sums in
-// flight per workgroup.  Dynamic LDS: rows [T RPT][16] floats | ord [T RPT] | lst [T RPT] | hds [T RPT] | red [T].
-#define OR2_LDS_BYTES(T, RPT) (4 * ((T) * (RPT) * 16 + 3 * (T) * (RPT) + (T)))
+// flight per workgroup.  Dynamic LDS: rows [T RPT][16] floats | ord [T RPT] | lst [T RPT] | hds [T RPT] | red [T] | wave totals [T / 64][2].
+#define OR2_LDS_BYTES(T, RPT) (4 * ((T) * (RPT) * 16 + 3 * (T) * (RPT) + (T) + 2 * ((T) / 64)))
 extern __shared__ __attribute__((aligned(16))) float or2_lds[];
 
 // sum of squares of x[0, n) (chunk tables as sumsq_body) with T threads -> partial[blk]; red: T floats
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(T) void opt_reduce2_kernel(const nasrec_opt_reduce2
     for (int u = 0; u < RPT; ++u) {
       const int i = u * T + tid;
       ov[u] = i < cap ? d.order[(long)f * cap + i] : 0;
-      lv[u] = i < cap ? d.lists[(long)f * cap + i] : 0;
+      lv[u] = i < (RPT == 1 ? cap : min(cap, (B + 255) & ~255)) ? d.lists[(long)f * cap + i] : 0;  // (per-sample entries exist for the chunks of the batch only)
       hv[u] = (i < cap && d.heads) ? d.heads[(long)f * cap + i] : 0;
     }
 #pragma unroll
@@ -557,21 +558,55 @@ __global__ __launch_bounds__(T) void opt_reduce2_kernel(const nasrec_opt_reduce2
       for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(&rows[i * 16 + 4 * v]) = g[u][v];
     }
     __syncthreads();
+    // B > 256: the per-sample entries (dedup_ids_pairs_body) are compacted first — a ballot per staged entry, wave totals through LDS:
+    // a fixed order, so every thread sums the same squares in every run — into the sub-runs with >= 2 members (listA, in `red`'s
+    // storage until the final reduction) and the leaders of multi-chunk runs (listB, over `ord` once phase 1 is done with it)
+    int nA1 = nA, nB1 = 0, posB[RPT];
+    int* listA = reinterpret_cast<int*>(red);
+    if (RPT > 1) {
+      int* wtot = reinterpret_cast<int*>(red + T);  // [T / 64][2]
+      const int lane = tid & 63, wv = tid >> 6;
+      const unsigned long long below = (1ull << lane) - 1ull;
+      int pa[RPT], pb[RPT], ca = 0, cb = 0;
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        const unsigned long long ma = __ballot(((unsigned)lv[u] & DD_A) != 0u), mb = __ballot(((unsigned)lv[u] & DD_MULTI) != 0u);
+        pa[u] = ca + __popcll(ma & below);
+        pb[u] = cb + __popcll(mb & below);
+        ca += __popcll(ma);
+        cb += __popcll(mb);
+      }
+      if (lane == 0) {
+        wtot[2 * wv] = ca;
+        wtot[2 * wv + 1] = cb;
+      }
+      __syncthreads();
+      int ba = 0, bb = 0;
+      nA1 = 0;
+      for (int w = 0; w < T / 64; ++w) {
+        const int xa = wtot[2 * w], xb = wtot[2 * w + 1];
+        ba += w < wv ? xa : 0;
+        bb += w < wv ? xb : 0;
+        nA1 += xa;
+        nB1 += xb;
+      }
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        if ((unsigned)lv[u] & DD_A) listA[ba + pa[u]] = u * T + tid;
+        posB[u] = ((unsigned)lv[u] & DD_MULTI) ? bb + pb[u] : -1;
+      }
+      __syncthreads();
+    }
     // phase 1: every sub-run with >= 2 members, a quad per sub-run (lane = one float4 of the row), ascending sample order; the sum
-    // lands in the LDS row of the sub-run's first sample, and in memory when the sub-run is the whole run.  B <= 256: list A; above:
-    // one entry per sample (dedup_ids_pairs_body)
-    // (per-sample entries: chunk c's entries start 32 c quads further on — the sub-runs of a few heavy ids sit at the same positions of
-    // every chunk, and would otherwise all queue on the same quads)
-    const int n1 = RPT == 1 ? nA : min(cap, (B + 255) & ~255);
-    for (int k0 = quad; k0 < n1; k0 += T / 4) {
-      const int k = RPT == 1 ? k0 : (k0 & ~255) + ((k0 + 32 * (k0 >> 8)) & 255);
+    // lands in the LDS row of the sub-run's first sample, and in memory when the sub-run is the whole run
+    for (int k0 = quad; k0 < nA1; k0 += T / 4) {
+      const int k = RPT == 1 ? k0 : listA[k0];
       const unsigned en = (unsigned)lst[k];
       int s, len;
       if (RPT == 1) {
         s = (int)(en & 0xffffu);
         len = (int)((en >> 16) & 0x7fffu);
       } else {
-        if (!(en & DD_A)) continue;
         s = (k & ~255) + (int)(en & 0xffu);
         len = 1 + (int)((en >> 8) & 0xffu);
       }
@@ -595,11 +630,14 @@ __global__ __launch_bounds__(T) void opt_reduce2_kernel(const nasrec_opt_reduce2
         *reinterpret_cast<f32x4*>(&rows[o0 * 16 + 4 * q]) = acc;  // (a sub-run's first row is nobody else's operand in this phase)
       }
     }
-    if (RPT > 1) {  // phase 2: runs that span chunks — the sub-run sums, in chunk order, into the leader's row
+    if (RPT > 1 && nB1 > 0) {  // (uniform) phase 2: runs that span chunks — the sub-run sums, in chunk order, into the leader's row
       __syncthreads();
-      for (int k0 = quad; k0 < n1; k0 += T / 4) {
-        const int k = (k0 & ~255) + ((k0 + 32 * (k0 >> 8)) & 255);
-        if (!((unsigned)lst[k] & DD_MULTI)) continue;
+#pragma unroll
+      for (int u = 0; u < RPT; ++u)
+        if (posB[u] >= 0) ord[posB[u]] = u * T + tid;
+      __syncthreads();
+      for (int k0 = quad; k0 < nB1; k0 += T / 4) {
+        const int k = ord[k0];
         f32x4 acc = *reinterpret_cast<const f32x4*>(&rows[k * 16 + 4 * q]);
         for (int h = hds[k]; h >= 0; h = hds[h]) acc += *reinterpret_cast<const f32x4*>(&rows[h * 16 + 4 * q]);
         *reinterpret_cast<f32x4*>(dd_row(d.rows, k, f, Fs, d.rank_B, d.rank_stride) + 4 * q) = acc;

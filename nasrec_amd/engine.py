@@ -21,7 +21,7 @@ from . import schedule as S
 
 E = 16
 # largest (global) batch whose row-gradient dedup runs in two halves (csrc/dedup_bodies.h; <= L.DEDUP_IDS_MAX_B); 0 = the one-launch kernels
-DEDUP_SPLIT_MAX_B = min(int(os.environ.get("NASREC_DEDUP_SPLIT_MAX_B", "256")), L.DEDUP_IDS_MAX_B)
+DEDUP_SPLIT_MAX_B = min(int(os.environ.get("NASREC_DEDUP_SPLIT_MAX_B", "2048")), L.DEDUP_IDS_MAX_B)
 # the id half of a level-scheduled step (B <= 256) as an ITEM of the joint forward + backward program (A/B knob: 0 = on the staging launch)
 _IDS_AS_ITEM = os.environ.get("NASREC_IDS_AS_ITEM", "1") != "0"
 _FUSE_FINAL = os.environ.get("NASREC_FUSE_FINAL", "1") != "0"  # joint program: final logit + the per-sample part of its backward as one operator
