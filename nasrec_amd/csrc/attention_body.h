@@ -510,12 +510,14 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   float* F1b = Bf[5];
   float* DOb = Bf[5];   // after the FFN-2 stage
   float* H1b = Bf[6];
-  float* DQb = Bf[6];   // after the FFN-1 stage
   float* DR2b = Bf[7];
-  float* DR1b = Bf[7];  // after the FFN-2 stage
-  float* DKb = Bf[7];   // after the out-projection stage
+  float* DR1b = Bf[7];  // after the FFN-1 stage
   float* DF1b = Bf[8];
-  float* DVb = Bf[8];   // after the FFN-1 stage
+  // dq / dk / dv take the rows of q / k / v once the attention loops are done with them, so that DR1b and Ob (the operands of the
+  // out-projection's weight gradient) live to the last stage, where a wave is free for it
+  float* DQb = Bf[1];
+  float* DKb = Bf[2];
+  float* DVb = Bf[3];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c0 = S * w;
   const int N = d.N;
   const bool active = lane < N;
@@ -611,11 +613,11 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   __syncthreads();
   MHA_STAMP(3);
   // ---- FFN 2: f2 = W2 f1 + c2 ----
-  if (S == 4) {
-    if (w == 0) wgrad_mfma(DR2b, F1b, lane, N, gp + OFF_W2);
-  } else {
-    wgrad_slice<S>(DR2b, F1b, c0, lane, N, gp + OFF_W2);
-  }
+  // (4-wave form: a 16 x 16 weight gradient is one wave's MFMA chain while the others wait at the stage's barrier, and nothing inside the
+  // kernel reads it — so the six chains sit in TWO stages, on different waves, instead of one in each of four: W2 and W1 in the FFN-1
+  // stage (their operands live until LayerNorm 1 writes DR1b), Wout with the three in-projection matrices in the last.  Same operands,
+  // same chains: same bits.)
+  if (S != 4) wgrad_slice<S>(DR2b, F1b, c0, lane, N, gp + OFF_W2);
   bgrad_slice<S>(dr2, c0, lane, gp + OFF_C2);
   float row[16];
   ld_row(DR2b + lane * 16, row);
@@ -628,6 +630,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   MHA_STAMP(4);
   // ---- FFN 1: f1 = relu(W1 h1 + c1) ----
   if (S == 4) {
+    if (w == 0) wgrad_mfma(DR2b, F1b, lane, N, gp + OFF_W2);
     if (w == 1) wgrad_mfma(DF1b, H1b, lane, N, gp + OFF_W1);
   } else {
     wgrad_slice<S>(DF1b, H1b, c0, lane, N, gp + OFF_W1);
@@ -660,11 +663,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   __syncthreads();
   MHA_STAMP(6);
   // ---- out-projection: a = Wout o + bout ----
-  if (S == 4) {
-    if (w == 2) wgrad_mfma(DR1b, Ob, lane, N, gp + OFF_WOUT);
-  } else {
-    wgrad_slice<S>(DR1b, Ob, c0, lane, N, gp + OFF_WOUT);
-  }
+  if (S != 4) wgrad_slice<S>(DR1b, Ob, c0, lane, N, gp + OFF_WOUT);
   bgrad_slice<S>(dr1, c0, lane, gp + OFF_BOUT);
   ld_row(DR1b + lane * 16, row);
   Vec<S> dO = vzero<S>();
@@ -762,7 +761,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
     dk = vzero<S>();
     dv = vzero<S>();
   }
-  __syncthreads();  // every wave is done with Qb/DOb (DQb aliases H1b, DKb aliases DR1b, DVb aliases DF1b: all dead)
+  __syncthreads();  // every wave is done with Qb / Kb / Vb / DOb
   stv<S>(DQb + lane * 16 + c0, dq);
   stv<S>(DKb + lane * 16 + c0, dk);
   stv<S>(DVb + lane * 16 + c0, dv);
@@ -773,6 +772,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
     if (w == 0) wgrad_mfma(DQb, Xb, lane, N, gp + OFF_WIN);
     if (w == 1) wgrad_mfma(DKb, Xb, lane, N, gp + OFF_WIN + 256);
     if (w == 2) wgrad_mfma(DVb, Xb, lane, N, gp + OFF_WIN + 512);
+    if (w == 3) wgrad_mfma(DR1b, Ob, lane, N, gp + OFF_WOUT);
   } else {
     wgrad_slice<S>(DQb, Xb, c0, lane, N, gp + OFF_WIN);
     wgrad_slice<S>(DKb, Xb, c0, lane, N, gp + OFF_WIN + 256);
