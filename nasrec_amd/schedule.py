@@ -636,7 +636,7 @@ def _cost_r4(node):
     return _ITEM_NS_R4.get(d.kind, 3000)
 
 
-FUSE_SPLITK = os.environ.get("NASREC_WL_FUSE_SPLITK", "0") != "0"  # A/B knob, off: measured +4.5 us per cfg-2 step (profiles/r05_ab_fused_splitk.txt) — the fused item is 1/S of the parallelism of its two passes
+FUSE_SPLITK = os.environ.get("NASREC_WL_FUSE_SPLITK", "0") != "0"  # A/B knob, off: measured +11 us per cfg-2 step, +4.5 us from 64 tiles up (profiles/r05_ab_fused_splitk.txt) — the fused item is 1/S of the parallelism of its two passes
 FUSE_MAX_TILES = int(os.environ.get("NASREC_WL_FUSE_TILES", "256"))
 FUSE_MIN_TILES = int(os.environ.get("NASREC_WL_FUSE_MIN_TILES", "64"))  # (a 16-wide product is 16 workgroups walking ~7 k-slices each: 14.7 us as an item)
 
