@@ -33,6 +33,11 @@ def test_bench_cli_takes_the_spawn_route_without_touching_a_gpu():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=600)
     import torch
-    if not torch.cuda.is_available():
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        # no GPU, or one GPU for two ranks (RCCL refuses two ranks on one device): the failure must come back as a failure
         assert p.returncode != 0 and '"metric"' not in p.stdout
         assert "rank of the 2-rank run failed" in p.stderr
+    else:  # a multi-GPU host: the spawned ranks deliver exactly one result line, for two GPUs
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2

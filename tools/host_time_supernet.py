@@ -52,3 +52,14 @@ print("cfg %d: wall %.2f ms/step; path sampling + plan compile %.2f ms/step mean
       "host is several steps ahead) %.2f mean %.2f median %.2f max; GPU span per step median %.2f ms; sum of GPU spans / wall = %.3f" % (
     cfgid, wall / N * 1e3, np.mean(comp) * 1e3, np.median(comp) * 1e3, np.max(comp) * 1e3, np.mean(host) * 1e3, np.median(host) * 1e3, np.max(host) * 1e3,
     np.median(gpu), gpu.sum() / (wall * 1e3)))
+# the same host call with an EMPTY queue in front of it (a synchronise before every step: no back-pressure from the launch queue in the
+# numbers) — what the host itself costs per step, enqueue included
+host2 = []
+for i in range(N):
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()
+    model.engine_train_step(*batches[i % 2], lr=1e-3)
+    host2.append(time.perf_counter() - h0)
+torch.cuda.synchronize()
+print("cfg %d, empty queue before every step: whole host call %.2f ms mean, %.2f median, %.2f max (compiled host modules: %s)" % (
+    cfgid, np.mean(host2) * 1e3, np.median(host2) * 1e3, np.max(host2) * 1e3, __import__("nasrec_amd").host_modules_compiled()))
