@@ -286,6 +286,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--steps-only", action="store_true",
+                    help="profiler passes: only the set-up and the timed steps (no live roofline timing, forward-only / ablation legs or CPU baseline), "
+                         "so that a rocprofv3 window holds nothing but real steps; the printed line then has no `roofline`")
     ap.add_argument("--force-dp-path", action="store_true", help="run the N>1 exchange code path on a single rank")
     ap.add_argument("--real-collectives", action="store_true",
                     help="with --force-dp-path on one rank: RCCL's all-gather / all-reduce kernels run inside the captured step (a one-rank gather is a copy kernel otherwise)")
@@ -504,7 +507,7 @@ def main():
             "packed_tail_floats_per_rank": dp.tail_n, "first_packed_piece": getattr(pl, "first_packed", None),
             "real_collectives_on_one_rank": bool(args.real_collectives), "id_half_of_the_dedup_beside_the_forward": dp.ids_half is not None}
 
-    if rank == 0:  # (N > 1: the roofline of the dominant launch and the step accounting are rank 0's; forward-only and the CPU baseline are N = 1 legs)
+    if rank == 0 and not args.steps_only:  # (N > 1: the roofline of the dominant launch and the step accounting are rank 0's; forward-only and the CPU baseline are N = 1 legs)
         sp = torch.cuda.current_stream(device).cuda_stream
         cp = dp.last_plan()
         allg = [d for d in P.iter_ops(cp.fwd.descs + cp.bwd.descs) if isinstance(d, L.GemmDesc)]

@@ -25,7 +25,22 @@ def _free_port():
     return p
 
 
-def _worker(rank, port, case, steps, pack, out):
+def _inputs(z, meta, rows):
+    """the golden batch, or (rows > 0) a seeded synthetic batch of that many samples over the golden network's tables: global batches
+    above 256 samples take the per-(field, chunk) id half of the row dedup and the LDS-resident sums (csrc/dedup_bodies.h)"""
+    import numpy as np
+    if not rows:
+        return z["int_x"], z["cat_x"], z["y"].reshape(-1)
+    g = np.random.default_rng(7)
+    Fd = z["int_x"].shape[1]
+    int_x = g.standard_normal((rows, Fd)).astype(z["int_x"].dtype) * 0.5
+    tabs = np.asarray(meta["tables"], dtype=np.int64)
+    cat_x = (g.integers(0, 1 << 40, size=(rows, len(tabs))) % np.minimum(tabs, 97)[None, :]).astype(np.int64)  # (few distinct ids: duplicates within and across chunks and ranks)
+    y = (g.random(rows) < 0.3).astype(z["y"].dtype)
+    return int_x, cat_x, y
+
+
+def _worker(rank, port, case, steps, pack, out, rows=0):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -40,7 +55,7 @@ def _worker(rank, port, case, steps, pack, out):
     from test_parity_gpu import build_engine
     parallel.PACK_TAIL_FLOATS = pack
     z, meta = load_golden(os.path.join(GOLDEN, case + ".npz"))
-    int_x, cat_x, y = torch.tensor(z["int_x"]).cuda(), torch.tensor(z["cat_x"]).cuda(), torch.tensor(z["y"]).cuda().view(-1)
+    int_x, cat_x, y = (torch.tensor(a).cuda() for a in _inputs(z, meta, rows))
     Bl = int_x.shape[0] // WORLD
     sl = slice(rank * Bl, (rank + 1) * Bl)
     eng = build_engine(z, meta)
@@ -58,8 +73,9 @@ def _worker(rank, port, case, steps, pack, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,pack", [("fixed_criteo_xlarge", 65536), ("fixed_criteo_xlarge", 0), ("fixed_kdd_autoctr", 65536), ("supernet_xlarge_any", 0)])
-def test_two_ranks_on_one_gpu_equal_one_process_at_the_global_batch(case, pack):
+@pytest.mark.parametrize("case,pack,rows", [("fixed_criteo_xlarge", 65536, 0), ("fixed_criteo_xlarge", 0, 0), ("fixed_kdd_autoctr", 65536, 0),
+                                            ("supernet_xlarge_any", 0, 0), ("fixed_criteo_xlarge", 65536, 600), ("supernet_xlarge_any", 0, 300)])
+def test_two_ranks_on_one_gpu_equal_one_process_at_the_global_batch(case, pack, rows):
     from helpers import GOLDEN, load_golden
     from test_parity_gpu import build_engine
     z, meta = load_golden(os.path.join(GOLDEN, case + ".npz"))
@@ -67,9 +83,9 @@ def test_two_ranks_on_one_gpu_equal_one_process_at_the_global_batch(case, pack):
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(port, case, steps, pack, out), nprocs=WORLD, join=True)
+    mp.spawn(_worker, args=(port, case, steps, pack, out, rows), nprocs=WORLD, join=True)
     # one process, whole batch
-    int_x, cat_x, y = torch.tensor(z["int_x"]).cuda(), torch.tensor(z["cat_x"]).cuda(), torch.tensor(z["y"]).cuda().view(-1)
+    int_x, cat_x, y = (torch.tensor(a).cuda() for a in _inputs(z, meta, rows))
     eng = build_engine(z, meta)
     ref_losses = []
     for _ in range(steps):

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-end measurement run (one gpurun call, ~15 min of box time): everything profiles/r05_* is derived from, written under
 # gpurun_out/r05/.  tools/update_profiles_r05.py turns it into the committed summaries.  PMC passes run `bench.py --no-graph` (cfg 2; the
-# supernet configs never capture) under `timeout` and never together with a trace domain other than kernel-trace.
+# supernet configs never capture) with `--steps-only` (the counter window holds real steps only: no repeated timing launches of the live
+# roofline measurement) under `timeout`, and never together with a trace domain other than kernel-trace.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/r05
 mkdir -p $O
@@ -16,12 +17,17 @@ for c in 3 4 5; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg$c -- python3 $R/bench.py --config $c --no-cpu-baseline > $O/bench_cfg${c}_under_profiler.out 2>&1 < /dev/null
 done
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_cfg2_$ctr -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-graph > /dev/null 2>&1 < /dev/null
+  timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_cfg2_$ctr -- python3 $R/bench.py --steps 12 --warmup 3 --steps-only --no-graph > /dev/null 2>&1 < /dev/null
   for c in 3 4 5; do
-    timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_cfg${c}_$ctr -- python3 $R/bench.py --config $c --steps 12 --warmup 3 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+    timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_cfg${c}_$ctr -- python3 $R/bench.py --config $c --steps 12 --warmup 3 --steps-only > /dev/null 2>&1 < /dev/null
   done
 done
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_cfg2_mfma -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-graph > /dev/null 2>&1 < /dev/null
+# the largest GEMM launch's own rows: windows that also hold the live roofline timing (cfg 2 and 3)
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmcfull_cfg2_$ctr -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-graph > /dev/null 2>&1 < /dev/null
+  timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmcfull_cfg3_$ctr -- python3 $R/bench.py --config 3 --steps 12 --warmup 3 --no-cpu-baseline > /dev/null 2>&1 < /dev/null
+done
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_cfg2_mfma -- python3 $R/bench.py --steps 12 --warmup 3 --steps-only --no-graph > /dev/null 2>&1 < /dev/null
 # keep what travels back small: per-dispatch traces are summarised on the box, right away (the rest of the run may be cut short)
 python3 $R/tools/update_profiles_r05.py --summarise $O >> $O/log.txt 2>&1 < /dev/null
 find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete
@@ -39,5 +45,5 @@ CONFIG=3 TOP=60 timeout 300 python3 $R/tools/supernet_step_table.py > $O/superne
 timeout 300 python3 $R/tools/gemm_vs_vendor.py > $O/gemm_vs_vendor.txt 2>> $O/log.txt < /dev/null
 timeout 300 python3 $R/tools/parser_bench.py > $O/parser_bench.txt 2>> $O/log.txt < /dev/null
 timeout 900 python3 $R/tools/e2e_tsv_run.py --rows 3000000 > $O/e2e_tsv_run.txt 2>> $O/log.txt < /dev/null
-(cd $R && timeout 2400 python3 -m pytest tests -q -m gpu 2>&1 | tail -5 > $O/gpu_tests.txt)
+(cd $R && timeout 2400 python3 -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/gpu_tests.txt)
 du -sh $O | tail -1

@@ -81,10 +81,14 @@ def summarise(O):
         rec = {"kernel": name, "grid_size": grid, "dispatches": len(dur), "mean_us": statistics.mean(dur), "median_us": statistics.median(dur),
                "min_us": min(dur), "max_us": max(dur), "durations_us": [round(x, 2) for x in dur]}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            # per-kernel means: the window of real steps (`--steps-only`); the rows of the LARGEST GEMM launch: the window that also holds
+            # the live roofline timing (that launch thirty times over — a sampled path's largest launch hardly repeats otherwise)
             cc = one(os.path.join(O, "pmc_cfg%d_%s" % (c, ctr), "**", "*counter_collection.csv"))
+            ccf = one(os.path.join(O, "pmcfull_cfg%d_%s" % (c, ctr), "**", "*counter_collection.csv")) or cc
             if not cc:
                 continue
             rows = list(csv.DictReader(open(cc)))
+            rows_full = rows if ccf == cc else list(csv.DictReader(open(ccf)))
             agg = collections.defaultdict(list)
             for r in rows:
                 agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
@@ -92,7 +96,7 @@ def summarise(O):
                 f.write("kernel,counter,dispatches,mean_per_dispatch_kb,total_kb\n")
                 for n in sorted(agg, key=lambda n: -sum(agg[n])):
                     f.write("%s,%s,%d,%.1f,%.0f\n" % (n, ctr, len(agg[n]), sum(agg[n]) / len(agg[n]), sum(agg[n])))
-            v = [float(r["Counter_Value"]) for r in rows if short(r["Kernel_Name"]) == name and r["Grid_Size"] == grid]
+            v = [float(r["Counter_Value"]) for r in rows_full if short(r["Kernel_Name"]) == name and r["Grid_Size"] == grid]
             v = split_upper(v) if ctr == "FETCH_SIZE" else v
             rec[ctr.lower() + "_kb_raw"] = {"dispatches": len(v), "mean": statistics.mean(v) if v else None, "values": [round(x, 1) for x in v[:400]]}
         out[c] = rec
@@ -167,7 +171,7 @@ def install(O):
             if f is not None and w is not None:
                 big = r.get("roofline_largest_gemm", r["roofline"])
                 j = {"build_id": bid, "kernel": big["kernel"], "kernels_of_the_launch": "%s, grid size %s threads" % (d["kernel"], d["grid_size"]),
-                     "source": "tools/collect_profiles_r05.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python3 bench.py%s --steps 12 --warmup 3 --no-cpu-baseline%s`; per-dispatch rows of this launch in profiles/r05_dominant_launch_cfg%d_dispatches.json" % (
+                     "source": "tools/collect_profiles_r05.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python3 bench.py%s --steps 12 --warmup 3 --steps-only%s`; per-dispatch rows of this launch in profiles/r05_dominant_launch_cfg%d_dispatches.json" % (
                          "" if c == 2 else " --config %d" % c, " --no-graph" if c == 2 else "", c),
                      "fetch_size_kb_raw": f, "fetch_correction": 2.0,
                      "fetch_correction_source": "MI355X_MICROARCH.md HBM section (gfx950 FETCH_SIZE tallies 128-B requests at 64 B); confirmed on known byte counts in round 1 (profiles/r01_pmc_fetch_calibration_loadrate.csv)",
