@@ -362,11 +362,18 @@ def _work_ns(node):
     return c // 4
 
 
+_MHA_PAIR = os.environ.get("NASREC_WL_MHA_PAIR", "1") != "0"  # (A/B knob)
+
+
 def _level_ns(members):
-    """estimated duration of a level's worklist launch"""
+    """estimated duration of a level's worklist launch.  A Transformer forward beside a Transformer backward is nearly free: both are one
+    wavefront per SIMD walking barrier-separated stages, two such workgroups per CU fill each other's waits — whereas in a short level
+    of products the forward's own 9-11 us become the level's duration."""
     if not members:
         return 0
-    return max(max(_BAL_COST(n) for n in members), _LATENCY_NS + sum(_work_ns(n) for n in members))
+    pair = _MHA_PAIR and any(n.desc.kind == L.OP_MHA_BWD for n in members)
+    work = sum((_BAL_COST(n) // 12 if pair and n.desc.kind == L.OP_MHA_FWD else _work_ns(n)) for n in members)
+    return max(max(_BAL_COST(n) for n in members), _LATENCY_NS + work)
 
 
 def balance_levels(nodes: List[Node], nl: int) -> None:
@@ -398,8 +405,14 @@ def balance_levels(nodes: List[Node], nl: int) -> None:
         moves[i] = lv
         for j in succ[i]:
             cur = moves.get(j, nodes[j].level)
-            if cur <= lv and (not _PUSH or not plan_move(j, lv + 1, moves)):
-                return False
+            if cur <= lv:
+                if not _PUSH:
+                    return False
+                # a Transformer forward that found its place beside a Transformer backward stays there (see _level_ns)
+                if _MHA_PAIR and nodes[j].desc.kind == L.OP_MHA_FWD and any(m.desc.kind == L.OP_MHA_BWD for m in levels[nodes[j].level]):
+                    return False
+                if not plan_move(j, lv + 1, moves):
+                    return False
         return True
 
     def delta(moves):
