@@ -47,6 +47,8 @@ with torch.cuda.stream(eng.stream):
                     d.splitk, d.act, fl / us / 1e6)
             if isinstance(d, L.WorklistDesc):
                 info = "worklist of " + " || ".join(names.get(n.desc.kind, "?") + ("[%s]" % n.part if n.part != "whole" else "") for n in d.nodes)
+                if os.environ.get("MODEL") == "1":  # the balancing pass's estimate of this level (schedule._level_ns) beside the measurement
+                    info = "[model %.1f us] " % (S._level_ns(d.nodes) / 1e3) + info
             rows.append((phase, names.get(d.kind, str(d.kind)), us, info))
             if isinstance(d, L.WorklistDesc) and ITEMS and us >= ITEMS:
                 # every item as a one-item worklist of its own (same body, same descriptor): what it costs without the others
@@ -65,6 +67,8 @@ with torch.cuda.stream(eng.stream):
                         what += " am=%d bm=%d cm=%d z=%d S=%d %s" % (dd.amode, dd.bmode, dd.cmode, dd.zmode, dd.splitk, segs[:4])
                         if n.part != "epi":
                             what += "   [stand-alone kernel%s: %.2f us]" % (" + second pass" if dd.splitk > 1 else "", bench.time_desc(lib, L, sp, dd, iters=50) * 1e3)
+                    if os.environ.get("MODEL") == "1":
+                        what = "[model %.1f us, work %.1f] " % (S._BAL_COST(n) / 1e3, S._work_ns(n) / 1e3) + what
                     rows.append(("   ", "  item", ius, what))
 for r in rows:
     print("%s %-14s %7.2f us  %s" % r)
