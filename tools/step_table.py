@@ -65,6 +65,9 @@ with torch.cuda.stream(eng.stream):
                     if isinstance(dd, L.GemmDesc):
                         segs = [(dd.seg[q].M, dd.seg[q].N, dd.seg[q].K) for q in range(dd.nseg) if dd.seg[q].A]
                         what += " am=%d bm=%d cm=%d z=%d S=%d %s" % (dd.amode, dd.bmode, dd.cmode, dd.zmode, dd.splitk, segs[:4])
+                        if os.environ.get("MODEL") == "1":  # (operand strides / accumulation / pointer alignment of the first live problem)
+                            s0 = next(dd.seg[q] for q in range(dd.nseg) if dd.seg[q].A)
+                            what += " ld=%d/%d/%d acc=%s act=%d A%%256=%d B%%256=%d C%%256=%d" % (s0.lda, s0.ldb, s0.ldc, [int(dd.seg[q].accumulate) for q in range(dd.nseg)] if dd.zmode else int(dd.beta != 0), dd.act, s0.A % 256, s0.B % 256, s0.C % 256)
                         if n.part != "epi":
                             what += "   [stand-alone kernel%s: %.2f us]" % (" + second pass" if dd.splitk > 1 else "", bench.time_desc(lib, L, sp, dd, iters=50) * 1e3)
                     if os.environ.get("MODEL") == "1":
