@@ -418,9 +418,12 @@ def main():
                     self._loss = None
             dp = _ModuleRun()
 
+        seen_choices = []  # every sampled path of the run (the live roofline below averages the dominant kernel's algorithmic bytes over them)
+
         def one_step(i):
             bx = batches[i % len(batches)]
             ch = model._resolve_choice(None)  # the sampler of the drop-in module: global np.random, reference call order
+            seen_choices.append(ch)
             dp.step(bx[0], bx[1], bx[2], sched.get_lr(), choice=ch)
             sched.step()
         parallelism = "dp%d (same sampled path on every rank; bucketed RCCL all-reduce of the path's dense grads overlapped with the " \
@@ -648,6 +651,20 @@ def main():
                 "note": "aggregate over this kernel's launches in one step (sum of flops / sum of isolated launch durations); a launch of this "
                         "kernel is one dependency level of the step, latency-bound at batch 256 (DESIGN.md 3); per-launch rows in roofline_levels"}
             result["roofline_kernels"] = {k: dict(v, share=v["us"] / tot_us) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"])}
+            if not fixed and not dp.exchange:
+                # a supernet step runs a different sampled path every time: `traffic` (a counter mean over the launches of MANY paths) is only
+                # comparable with algorithmic bytes averaged over many paths too — the launches of the last path alone can be twice or half that
+                tb, tn = 0.0, 0
+                for chs in seen_choices[-(steps + warmup):]:
+                    cpi = eng.compile(chs, B, True, 5.0, 1e-2, graph=False)
+                    for dsc in list(cpi.fwd.descs) + list(cpi.bwd.descs) + list(cpi.opt.descs):
+                        if launch_kernel_name(L, P, dsc).split("<")[0] == name:
+                            tb += launch_work(L, S, dsc, n_dense)[1]
+                            tn += 1
+                if tn:
+                    result["roofline"]["algorithmic_bytes_last_path"] = result["roofline"]["algorithmic_bytes"]
+                    result["roofline"]["algorithmic_bytes"] = tb / tn
+                    result["roofline"]["algorithmic_bytes_note"] = "mean per launch over the %d sampled paths of the warm-up and timed steps (%d launches of this kernel)" % (len(seen_choices[-(steps + warmup):]), tn)
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic_cfg%d.json" % args.config)))
                 if tj.get("build_id") == csrc_build_id() and tj.get("kernel") == name:
