@@ -160,6 +160,49 @@ def test_two_halves_equal_the_one_launch_dedup_bit_for_bit(lib, B):
             assert ln >= 2 and bool((o[1:] > o[:-1]).all()) and len(set(idx[o, f].tolist())) == 1 and len(set((o >> 8).tolist())) == 1
 
 
+def _dd_hash(i):
+    return ((i * 2654435761) & 0xffffffff) >> 20  # csrc/dedup_bodies.h dd_hash
+
+
+@pytest.mark.parametrize("case", ["one_id", "all_distinct", "one_hash_bucket", "pairs_across_chunks"])
+def test_id_half_on_adversarial_ids(lib, case):
+    """the id half above 256 samples goes through an LDS hash table of the other chunks' ids (open addressing): one id everywhere (a
+    single run of 8 sub-runs of 256), no duplicates at all, every id in the same bucket (a probe chain as long as the table is full),
+    and every id exactly twice, 1024 samples apart"""
+    B, Fs = 2048, 2
+    g = torch.Generator().manual_seed(11)
+    if case == "one_id":
+        col = torch.full((B,), 12345, dtype=torch.int64)
+    elif case == "all_distinct":
+        col = torch.randperm(10 ** 6, generator=g)[:B]
+    elif case == "one_hash_bucket":
+        pool, i = [], 1
+        while len(pool) < 600:  # 600 distinct ids with dd_hash == 77, each about 3.4 times
+            if _dd_hash(i) == 77:
+                pool.append(i)
+            i += 1
+        col = torch.tensor(pool)[torch.randint(0, len(pool), (B,), generator=g)]
+    else:
+        half = torch.randperm(10 ** 6, generator=g)[:B // 2]
+        col = torch.cat([half, half])
+    idx = torch.stack([col, torch.randint(0, 50, (B,), generator=g)], 1)
+    dout = torch.randn(B, Fs, 16, generator=g)
+    gi, rows_d = dev(idx), dev(dout.clone())
+    bufs, part, _, _ = two_halves(lib, gi, rows_d, B, Fs)
+    torch.cuda.synchronize()
+    lead, got = bufs["leader"].cpu().view(B, Fs), rows_d.cpu().view(B, Fs, 16)
+    total = 0.0
+    for f in range(Fs):
+        first, acc = reference_sum(idx, dout, f)
+        assert int((lead[:, f] > 0).sum()) == len(first)
+        counts = torch.bincount(idx[:, f])
+        for i, b in first.items():
+            assert int(lead[b, f]) == (2 if int(counts[i]) > 1 else 1), (f, i)
+            assert torch.equal(got[b, f], acc[i]), (case, f, i)
+            total += float(acc[i].double().pow(2).sum())
+    assert abs(float(part.double().sum()) - total) <= 2e-6 * total
+
+
 @pytest.mark.parametrize("B,ranks", [(256, 1), (512, 2), (2048, 8), (300, 3)])
 def test_two_halves_tail_equals_the_dense_reference_step(lib, B, ranks):
     """OPT_REDUCE2 + OPT_APPLY == embedding_dense_backward + clip_grad_norm_ + torch.optim.Adagrad (dense, fp64), two steps, with the

@@ -781,6 +781,21 @@ def test_final_bce_and_dense_optimizer(lib):
     launch(lib, f2)
     assert torch.equal(dlog2, dlog) and torch.equal(ddl2, ddl) and torch.equal(dsl2, dsl) and torch.equal(dw2, dw) and torch.equal(db2, db)
     close(loss2, ref_loss.reshape(1), 1e-6)
+    # NASREC_OP_FINAL_FUSED (forward + the per-sample part of the backward) followed by the rest (FINAL_BWD with dseg_done): the same
+    # bits as forward, then backward with the fused loss — logits, feature gradients (overwrite and accumulate), d w, d bias, loss
+    logits4, loss4, dlog4 = dev(torch.full((B,), 7.0)), dev(torch.zeros(1)), dev(torch.zeros(B))
+    ddl4, dsl4, dw4, db4 = dev(torch.zeros(B, D)), dev(torch.ones(B, N, 16)), dev(torch.zeros(K)), dev(torch.zeros(1))
+    f4 = L.FinalDesc.from_buffer_copy(f2)
+    f4.kind, f4.logits, f4.loss, f4.dlogits_out = L.OP_FINAL_FUSED, logits4.data_ptr(), loss4.data_ptr(), dlog4.data_ptr()
+    f4.dw, f4.dbias, f4.dseg[0], f4.dseg[1] = dw4.data_ptr(), db4.data_ptr(), ddl4.data_ptr(), dsl4.data_ptr()
+    launch(lib, f4)
+    assert torch.equal(logits4, logits) and torch.equal(ddl4, ddl) and torch.equal(dsl4, dsl)
+    assert float(dw4.abs().max()) == 0.0  # (the fused operator leaves the parts that need every sample's logit alone)
+    f5 = L.FinalDesc.from_buffer_copy(f4)
+    f5.kind, f5.dseg_done = L.OP_FINAL_BWD, 1
+    launch(lib, f5)
+    assert torch.equal(dw4, dw) and torch.equal(db4, db) and torch.equal(dlog4, dlog) and torch.equal(loss4, loss2)
+    assert torch.equal(ddl4, ddl) and torch.equal(dsl4, dsl)  # (dseg_done: the second launch does not touch them again)
     # large-batch form: the batch in nsplit slices -> partial [nsplit, K + 1] (column K = bias gradient), summed by REDUCE_ROWS
     for nsplit in (2, 5):
         part = dev(torch.full((nsplit * (K + 1),), float("nan")))
