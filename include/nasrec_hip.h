@@ -325,7 +325,7 @@ typedef struct nasrec_final_desc {
      [nsplit, K + 1] (column K = the bias gradient, dbias is unused) that a NASREC_OP_REDUCE_ROWS launch sums in fixed order */
   int32_t nsplit;
   /* NASREC_OP_FINAL_FUSED (round 5; needs y != NULL, nsplit <= 1) = the forward AND the per-sample part of the backward in one launch: the
-     wavefront that has summed sample b's logit writes it, derives (sigmoid(logit) - y[b]) * grad_scale and writes dseg[b, :] — the
+     workgroup that has summed sample b's logit writes it, derives (sigmoid(logit) - y[b]) * grad_scale and writes dseg[b, :] — the
      gradients the rest of the backward pass waits for — one launch boundary earlier.  The parts that need every sample's logit (dw, dbias,
      the loss, dlogits_out) stay a NASREC_OP_FINAL_BWD with dseg_done = 1: it skips the dseg part.  Same expression per element: same bits. */
   int32_t dseg_done;

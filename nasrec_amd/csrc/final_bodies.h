@@ -24,69 +24,60 @@ __host__ __device__ inline int final_seg_extent(const nasrec_final_desc_t& d, in
 }
 
 // ---------------------------------------------------------------------------------------------------
-// final logit: one wavefront per sample, lanes stride the (segmented) feature axis
+// final logit: one WORKGROUP per sample (round 5), its four wavefronts take every fourth 64-feature trip of the (segmented) feature axis
+// — four trips each in flight — and meet through four floats of LDS: z = ((s0 + s1) + (s2 + s3)) + bias.  (One wavefront per sample
+// walked the ~1.6 k features of the bench network in 25 trips of 64, four in flight: 3.5 us for the forward at batch 256, 5.7 us
+// with the per-sample backward behind it — on the step's critical path, alone in its level.)
 // ---------------------------------------------------------------------------------------------------
-// workgroup vb of (B + 3) / 4: one wavefront per sample
-__device__ __forceinline__ void final_fwd_block(const nasrec_final_desc_t& d, int vb) {
+// -> the sample's logit in every thread; red: 4 floats of LDS
+__device__ __forceinline__ float final_logit(const nasrec_final_desc_t& d, int b, float* red) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = vb * 4 + wave;
-  if (b >= d.B) return;
   float s = 0.f;
   for (int q = 0; q < d.nseg; ++q) {
     if (!d.seg[q]) continue;
     const float* x = d.seg[q] + (long)b * d.ld[q];
     const float* w = d.w + d.off[q];
-    // four trips' loads in flight (same summation order as the plain loop, which compiles to load -> wait -> fma per trip)
     const int W = d.width[q], ts = d.tok_stride[q];
-    for (int j0 = lane; j0 < W; j0 += 64 * 4) {
+    for (int j0 = lane + 64 * wave; j0 < W; j0 += 256 * 4) {
       float xv[4], wv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int j = min(j0 + 64 * u, W - 1);
+        const int j = min(j0 + 256 * u, W - 1);
         xv[u] = x[j];
         wv[u] = w[ts ? (j >> 4) * ts + (j & 15) : j];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (j0 + 64 * u < W) s = fmaf(xv[u], wv[u], s);
+        if (j0 + 256 * u < W) s = fmaf(xv[u], wv[u], s);
     }
   }
   s = wave_sum(s);
-  if (lane == 0) d.logits[b] = s + d.bias[0];
+  __syncthreads();  // (red may still be read from an earlier use of the buffer)
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  return ((red[0] + red[1]) + (red[2] + red[3])) + d.bias[0];
+}
+
+// workgroup vb of B
+__device__ __forceinline__ void final_fwd_block(const nasrec_final_desc_t& d, int vb, float* red) {
+  if (vb >= d.B) return;
+  const float z = final_logit(d, vb, red);
+  if (threadIdx.x == 0) d.logits[vb] = z;
 }
 
 __device__ __forceinline__ float bce_grad(float z, float y, float scale) { return (1.f / (1.f + expf(-z)) - y) * scale; }
 __device__ __forceinline__ float bce_term(float z, float y) { return fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z))); }
 
-// NASREC_OP_FINAL_FUSED: final_fwd_block, and behind it — in the wavefront that holds the sample's logit — the part of the backward that
-// needs nothing else: dseg[b, j] (+)= dlogits[b] * w[col(j)], the expression of final_bwd_block's part A.  workgroup vb of (B + 3) / 4.
-__device__ __forceinline__ void final_fused_block(const nasrec_final_desc_t& d, int vb) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = vb * 4 + wave;
+// NASREC_OP_FINAL_FUSED: final_fwd_block, and behind it — in the workgroup that holds the sample's logit — the part of the backward that
+// needs nothing else: dseg[b, j] (+)= dlogits[b] * w[col(j)], the expression of final_bwd_block's part A.  workgroup vb of B.
+__device__ __forceinline__ void final_fused_block(const nasrec_final_desc_t& d, int vb, float* red) {
+  const int b = vb;
   if (b >= d.B) return;
-  const float yb = d.y[b], bias = d.bias[0];  // (in flight under the sum)
-  float s = 0.f;
-  for (int q = 0; q < d.nseg; ++q) {
-    if (!d.seg[q]) continue;
-    const float* x = d.seg[q] + (long)b * d.ld[q];
-    const float* w = d.w + d.off[q];
-    const int W = d.width[q], ts = d.tok_stride[q];
-    for (int j0 = lane; j0 < W; j0 += 64 * 4) {
-      float xv[4], wv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = min(j0 + 64 * u, W - 1);
-        xv[u] = x[j];
-        wv[u] = w[ts ? (j >> 4) * ts + (j & 15) : j];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (j0 + 64 * u < W) s = fmaf(xv[u], wv[u], s);
-    }
-  }
-  const float z = wave_sum(s) + bias;
-  if (lane == 0) d.logits[b] = z;
+  const float yb = d.y[b];  // (in flight under the sum)
+  const float z = final_logit(d, b, red);
+  if (threadIdx.x == 0) d.logits[b] = z;
   const float g = bce_grad(z, yb, d.grad_scale);
+  const int tid = threadIdx.x;
   for (int q = 0; q < d.nseg; ++q) {
     float* p = d.dseg[q];
     if (!p || !d.seg[q]) continue;
@@ -94,18 +85,18 @@ __device__ __forceinline__ void final_fused_block(const nasrec_final_desc_t& d, 
     const float* w = d.w + d.off[q];
     const int W = d.width[q], ts = d.tok_stride[q];
     const bool acc = d.dseg_accumulate[q] != 0;
-    for (int j0 = lane; j0 < W; j0 += 64 * 4) {  // reads first (weights; the accumulation targets), then the stores
+    for (int j0 = tid; j0 < W; j0 += 256 * 4) {  // reads first (weights; the accumulation targets), then the stores
       float wv[4], cv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int j = min(j0 + 64 * u, W - 1);
+        const int j = min(j0 + 256 * u, W - 1);
         wv[u] = w[ts ? (j >> 4) * ts + (j & 15) : j];
         cv[u] = acc ? p[j] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float v = g * wv[u];
-        if (j0 + 64 * u < W) p[j0 + 64 * u] = acc ? cv[u] + v : v;
+        if (j0 + 256 * u < W) p[j0 + 256 * u] = acc ? cv[u] + v : v;
       }
     }
   }

@@ -5,14 +5,20 @@
 
 #include "final_bodies.h"
 
-__global__ __launch_bounds__(256) void final_fwd_kernel(const nasrec_final_desc_t d) { final_fwd_block(d, blockIdx.x); }
+__global__ __launch_bounds__(256) void final_fwd_kernel(const nasrec_final_desc_t d) {
+  __shared__ float red[4];
+  final_fwd_block(d, blockIdx.x, red);
+}
 
 __global__ __launch_bounds__(256) void final_bwd_kernel(const nasrec_final_desc_t d, int K, int nA, int nB) {
   __shared__ float lds[FINAL_BWD_LDS_FLOATS];
   final_bwd_block(d, K, nA, nB, blockIdx.x, lds);
 }
 
-__global__ __launch_bounds__(256) void final_fused_kernel(const nasrec_final_desc_t d) { final_fused_block(d, blockIdx.x); }
+__global__ __launch_bounds__(256) void final_fused_kernel(const nasrec_final_desc_t d) {
+  __shared__ float red[4];
+  final_fused_block(d, blockIdx.x, red);
+}
 
 int final_fused_check(const nasrec_final_desc_t* d) {
   if (!d->y || !d->logits || !d->bias || !d->w) return nasrec_set_error(-2, "final_fused: needs y, logits, bias and w");
@@ -27,9 +33,9 @@ int launch_final(hipStream_t st, const nasrec_final_desc_t* d) {
   if (d->kind == NASREC_OP_FINAL_FUSED) {
     const int rc = final_fused_check(d);
     if (rc) return rc;
-    hipLaunchKernelGGL(final_fused_kernel, dim3((d->B + 3) / 4), dim3(256), 0, st, *d);
+    hipLaunchKernelGGL(final_fused_kernel, dim3(d->B), dim3(256), 0, st, *d);
   } else if (d->kind == NASREC_OP_FINAL_FWD) {
-    hipLaunchKernelGGL(final_fwd_kernel, dim3((d->B + 3) / 4), dim3(256), 0, st, *d);
+    hipLaunchKernelGGL(final_fwd_kernel, dim3(d->B), dim3(256), 0, st, *d);
   } else {
     int K, nA, nB;
     final_bwd_geometry(*d, K, nA, nB);

@@ -229,13 +229,13 @@ int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
       }
       case NASREC_OP_FINAL_FWD:
         WL_NEED(nasrec_final_desc_t);
-        it.nblk = (reinterpret_cast<const nasrec_final_desc_t*>(blob)->B + 3) / 4;
+        it.nblk = reinterpret_cast<const nasrec_final_desc_t*>(blob)->B;  // (a workgroup per sample)
         break;
       case NASREC_OP_FINAL_FUSED: {
         WL_NEED(nasrec_final_desc_t);
         const int rc = final_fused_check(reinterpret_cast<const nasrec_final_desc_t*>(blob));
         if (rc) return rc;
-        it.nblk = (reinterpret_cast<const nasrec_final_desc_t*>(blob)->B + 3) / 4;
+        it.nblk = reinterpret_cast<const nasrec_final_desc_t*>(blob)->B;  // (a workgroup per sample)
         break;
       }
       case NASREC_OP_FINAL_BWD: {

@@ -633,10 +633,10 @@ __global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(unsigned f01
       break;
     }
     case NASREC_OP_FINAL_FWD:
-      final_fwd_block(wl_ref<nasrec_final_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb));
+      final_fwd_block(wl_ref<nasrec_final_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), lds);
       break;
     case NASREC_OP_FINAL_FUSED:
-      final_fused_block(wl_ref<nasrec_final_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb));
+      final_fused_block(wl_ref<nasrec_final_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), lds);
       break;
     case NASREC_OP_FINAL_BWD:
       final_bwd_block(wl_ref<nasrec_final_desc_t>(blob), it.geom[0], it.geom[1], it.geom[2], __builtin_amdgcn_readfirstlane(vb), lds);
