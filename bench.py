@@ -285,7 +285,8 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step's program instead of replaying a captured graph")
+    ap.add_argument("--graph", action="store_true", help="replay the captured step even where launching its program is faster (default: the engine decides)")
     ap.add_argument("--steps-only", action="store_true",
                     help="profiler passes: only the set-up and the timed steps (no live roofline timing, forward-only / ablation legs or CPU baseline), "
                          "so that a rocprofv3 window holds nothing but real steps; the printed line then has no `roofline`")
@@ -384,8 +385,8 @@ def main():
         cfg = P.NetConfig(choice_all["num_blocks"], ops_config_lib[choice_all["config"]], False, "relu", fixed=True)
         eng = SupernetEngine(cfg, Fd, Fs, tables, device=device, warm_choice=choice, world_size=world, host_embedding=sharded)
         eng.init_weights(seed=0)
-        dp = ShardedRun(eng) if sharded else DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=not args.no_graph, force_exchange=args.force_dp_path,
-                                                              real_collectives=args.real_collectives)
+        dp = ShardedRun(eng) if sharded else DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=False if args.no_graph else True if args.graph else None,
+                                                              force_exchange=args.force_dp_path, real_collectives=args.real_collectives)
 
         def one_step(i):
             bx = batches[i % len(batches)]
@@ -493,6 +494,7 @@ def main():
         "ms_per_step": dt / steps * 1e3, "median_ms_per_step": float(np.median(per_step)), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": w["name"], "baseline_config": args.config, "per_gpu_batch": B, "global_batch": B * world, "graph": dp.graph,
+                   "step_submission": ("one graph replay per step" if dp.graph else "the step's program launched by one host call per step (nasrec_program_run)") if fixed else "programs launched per sampled path",
                    "parallelism": parallelism,
                    "ids": "%s over each table; %d pre-generated id batches = %.0f MB of distinct-ish table rows per lap of the pool (Infinity Cache: 256 MB)"
                           % (args.ids, len(batches), len(batches) * B * Fs * 64 / 1e6),
@@ -533,7 +535,7 @@ def main():
             eng.dead_code_elimination = True
             eng._plans.clear()
             eng._last_plan = None
-            dp2 = DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=not args.no_graph)
+            dp2 = DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=False if args.no_graph else True if args.graph else None)
             for i in range(20):
                 dp2.step(*batches[i], sched.get_lr())
             torch.cuda.synchronize(device)

@@ -782,11 +782,23 @@ class SupernetEngine:
         return cp.logits.view(B, 1)
 
     @_on_device
-    def train_step(self, int_x, cat_x, y, lr: float, choice=None, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = False,
+    def prefers_graph(self, B: int) -> bool:
+        """graph = None: replay the captured step, or launch its program?  A level-scheduled step (fixed sub-network, batch <= 256) is
+        ~27 launches issued by ONE host call (nasrec_program_run: ~3 us each, the host stays far ahead of a 0.25 ms step), and every
+        graph launch ends on a ~8.5 us bubble before the next command starts (rocprofv3 kernel trace, tools/launch_gaps.py: graph's last
+        kernel -> next launch 8.4 - 8.7 us, 0.0 between eagerly launched kernels): 0.2575 ms replayed, 0.2515 ms launched.  Plans
+        of 60+ launches (no level schedule; larger batches) keep the graph: there the host call is what bounds the step.  (A host that
+        has more to do between steps — the training harness with its data pipe — is better off replaying: SuperNet.engine_train_step.)"""
+        return not (self.level_schedule and self.cfg.fixed and B <= 256) or os.environ.get("NASREC_STEP_GRAPH", "auto") == "1"
+
+    def train_step(self, int_x, cat_x, y, lr: float, choice=None, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: Optional[bool] = False,
                    staged: bool = False):
         """zero_grad -> forward -> BCE -> backward -> clip_grad_norm_ -> Adagrad (train_utils.py:262-286).
-        Returns the (device) loss tensor of this step.  `staged`: inputs are already in the plan's static buffers."""
+        Returns the (device) loss tensor of this step.  `staged`: inputs are already in the plan's static buffers.  graph: True = replay
+        the captured step, False = launch its program, None = whichever is faster for this plan (prefers_graph)."""
         choice = choice if choice is not None else self.warm_choice
+        if graph is None:
+            graph = self.cfg.fixed and self.prefers_graph(int(int_x.shape[0]) if int_x is not None else int(self._last_plan[2].cat_x.shape[0]))
         if self.host_embedding:
             raise L.EngineError("the fused training step needs the embedding tables on the device (place_embedding_on_cpu keeps them "
                                 "on the host): use the nn.Module path (forward / backward / torch optimizer)")

@@ -216,7 +216,7 @@ def tail_pieces(segments, budget: int) -> int:
 
 
 class DataParallelStep:
-    def __init__(self, engine, choice, B_local: int, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: bool = True,
+    def __init__(self, engine, choice, B_local: int, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: Optional[bool] = True,
                  force_exchange: bool = False, real_collectives: bool = False, paths: str = "shared"):
         """choice: the fixed sub-network's choice, or None for a weight-sharing supernet (the path then comes with every step).
         force_exchange: take the multi-rank code path (all-reduce + all-gather + global-batch optimizer) even in a single-rank
@@ -234,8 +234,12 @@ class DataParallelStep:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.B = B_local
         self.fixed = bool(engine.cfg.fixed)
-        self.graph = bool(graph and self.fixed)
         self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
+        # graph = None: the exchange step is always captured (work handles cost more than a 0.3 ms step hides); the plain step of one
+        # rank replays or launches, whichever is faster for its plan (engine.prefers_graph)
+        if graph is None:
+            graph = self.fixed and (self.exchange or not hasattr(engine, "prefers_graph") or engine.prefers_graph(B_local))
+        self.graph = bool(graph and self.fixed)
         self.choice, self.clip, self.eps = choice, clip, eps
         self.coll = Collectives(real_collectives)
         assert paths in ("shared", "per-rank"), paths

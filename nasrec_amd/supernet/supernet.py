@@ -607,6 +607,9 @@ class SuperNet(nn.Module):
                               "and a torch optimizer")
         choice = self._resolve_choice(None)
         self._ensure_engine(int_feats)
+        # (graph=None: a fixed sub-network's step is replayed as a graph.  Launching the level-scheduled program instead is ~6 us faster per
+        # step when the host does nothing else — bench.py, engine.prefers_graph — but this harness's host has a data pipe and a Python
+        # loop to run: measured on TSV shards 832 k rows/s launched against 896 k replayed)
         graph = self._fixed if graph is None else graph
         d = self.__dict__  # (plain bookkeeping: nn.Module.__setattr__ costs 2 us per assignment)
         d["_engine_steps"] = d.get("_engine_steps", 0) + 1
