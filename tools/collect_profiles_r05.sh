@@ -41,6 +41,14 @@ python3 $R/bench.py --force-dp-path --no-cpu-baseline --no-graph 2>> $O/log.txt 
 (cd $R && bash tools/dp_overhead.sh > /dev/null 2>&1; cp gpurun_out/dp_overhead/result.txt $O/dp_overhead.txt)
 python3 $R/bench.py --table-sharding row --no-cpu-baseline 2>> $O/log.txt < /dev/null | tail -1 > $O/bench_cfg2_row_sharded_result.json
 (cd $R && rm -f gpurun_out/ab/fuse_final.txt && bash tools/r04_ab.sh fuse_final NASREC_FUSE_FINAL=0 > /dev/null 2>&1; cp gpurun_out/ab/fuse_final.txt $O/ab_fuse_final.txt)
+# program launch against graph replay of the cfg-2 step (bench.py decides by engine.prefers_graph; --graph forces the replay), and the gaps between kernels in both
+for i in 1 2 3; do for a in "" "--graph"; do
+  python3 $R/bench.py --no-cpu-baseline --steps 1000 --warmup 100 --steps-only $a 2>> $O/log.txt < /dev/null | tail -1 | python3 -c "import sys,json; r=json.loads(sys.stdin.read()); print('bench.py --steps 1000 --warmup 100 $a:', round(r['value']), 'samples/s', round(r['ms_per_step'],4), 'ms mean', round(r['median_ms_per_step'],4), 'median;', r['config']['step_submission'])" >> $O/ab_graph_vs_launch.txt
+done; done
+for a in "" "--graph"; do
+  rm -rf /tmp/gaps; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/gaps -- python3 $R/bench.py --steps 200 --warmup 20 --steps-only $a > /dev/null 2>&1 < /dev/null
+  echo "== rocprofv3 --kernel-trace -- python3 bench.py --steps 200 --warmup 20 --steps-only $a" >> $O/launch_gaps.txt; python3 $R/tools/launch_gaps.py /tmp/gaps >> $O/launch_gaps.txt 2>&1
+done
 CONFIG=3 TOP=60 timeout 300 python3 $R/tools/supernet_step_table.py > $O/supernet_step_table_cfg3.txt 2>> $O/log.txt < /dev/null
 timeout 300 python3 $R/tools/gemm_vs_vendor.py > $O/gemm_vs_vendor.txt 2>> $O/log.txt < /dev/null
 timeout 300 python3 $R/tools/parser_bench.py > $O/parser_bench.txt 2>> $O/log.txt < /dev/null

@@ -147,7 +147,8 @@ def install(O):
           ("gemm_fast_stamps.txt", TAG + "_gemm_fast_stamps.txt"), ("gemm_vs_vendor.txt", TAG + "_gemm_vs_vendor.txt"),
           ("bench_cfg2_driver_flags_result.json", TAG + "_bench_cfg2_driver_flags_result.json"),
           ("bench_cfg2_dp_path_real_result.json", TAG + "_bench_cfg2_dp_path_real_collectives_result.json"), ("ab_fuse_final.txt", TAG + "_ab_fuse_final.txt"),
-          ("gpu_tests.txt", TAG + "_gpu_tests.txt")]
+          ("gpu_tests.txt", TAG + "_gpu_tests.txt"),
+          ("ab_graph_vs_launch.txt", TAG + "_ab_graph_vs_launch.txt"), ("launch_gaps.txt", TAG + "_launch_gaps.txt")]
     for a, b in cp:
         src = os.path.join(O, a)
         if os.path.exists(src) and os.path.getsize(src) > 0:
