@@ -518,7 +518,7 @@ def main():
         allg = [d for d in P.iter_ops(cp.fwd.descs + cp.bwd.descs) if isinstance(d, L.GemmDesc)]
         if fixed and world == 1 and not sharded:
             # ---- forward-only throughput (eval path) ---------------------------------------------------------------
-            fgraph = not args.no_graph  # (--no-graph: nothing is graph-replayed — counter collection hangs on replays now and then)
+            fgraph = False if args.no_graph else True if args.graph else eng.prefers_graph(B)  # (replay or launch: engine.prefers_graph)
             eng.compile(choice, B, train=False, graph=fgraph)
             for _ in range(20):
                 eng.forward(batches[0][0], batches[0][1], graph=fgraph)
