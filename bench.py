@@ -460,6 +460,10 @@ def main():
     settle_ms = float(os.environ.get("NASREC_BENCH_SETTLE_MS", "100"))
     one_step(0)
     fence()
+    import gc
+    gc.collect()
+    gc.disable()  # (a launched — not replayed — step needs the host on time: no collector pause from here to the end of the timed region; a
+    #                serving loop would do the same.  Before the settle phase: a collection between warm-up and timing idles the GPU for tens of ms)
     t_s = time.perf_counter()
     n_settle = 1
     while (time.perf_counter() - t_s) * 1e3 < settle_ms or n_settle < 4:
@@ -472,9 +476,6 @@ def main():
         one_step(n_settle + i)
     fence()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    import gc
-    gc.collect()
-    gc.disable()  # (a launched — not replayed — step needs the host on time: no collector pause inside the timed region; a serving loop would do the same)
     t0 = time.perf_counter()
     ev[0].record()
     for i in range(steps):

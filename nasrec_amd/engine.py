@@ -736,9 +736,10 @@ class SupernetEngine:
         rest.dseg_done = 1
         return ([both if i == fi[0] else d for i, d in enumerate(fwd_list)], [rest if d is fused else d for d in bwd_descs])
 
-    def _stage_inputs(self, sp, cp, int_x, cat_x, y=None, lr=None, rows=None):
+    def _stage_inputs(self, sp, cp, int_x, cat_x, y=None, lr=None, rows=None, launch=True):
         """one launch: batch -> the plan's static buffers (+ this step's learning rate -> device scalar); host_embedding: the
-        looked-up rows [B, Fs, 16] come with the batch"""
+        looked-up rows [B, Fs, 16] come with the batch.  launch=False: only patch the prebuilt staging descriptor (the caller launches it
+        as the head of a program) — returns True when that is what happened, False when the inputs went another way and are staged"""
         if self.host_embedding:
             if rows is None:
                 raise L.EngineError("this engine holds no embedding table (place_embedding_on_cpu): pass the looked-up rows")
@@ -757,7 +758,7 @@ class SupernetEngine:
                 L.check(L.load().nasrec_launch(sp, C.addressof(cp.gather)))
             if getattr(cp, "ids_on_stage", False):  # (the staging launch would have carried it)
                 L.check(L.load().nasrec_launch(sp, C.addressof(cp.dedup_ids)))
-            return
+            return False
         d = cp.stage  # prebuilt per plan: only the sources change from step to step
         d.int_src, d.cat_src = int_x.data_ptr(), cat_x.data_ptr()
         d.y_src = y.data_ptr() if y is not None else None
@@ -765,7 +766,10 @@ class SupernetEngine:
             d.lr, d.lr_dst = float(lr), self.lr_dev.data_ptr()
         else:
             d.lr_dst = None
+        if not launch:
+            return True
         L.check(L.load().nasrec_launch(sp, C.addressof(d)))
+        return False
 
     @_on_device
     def forward(self, int_x, cat_x, choice=None, graph=False, rows=None):
@@ -810,7 +814,13 @@ class SupernetEngine:
         cp = self.compile(choice, B, train=True, clip=clip, eps=eps, graph=graph)
         sp = self._sp()
         if not staged:
-            self._stage_inputs(sp, cp, int_x, cat_x, y, lr)
+            whole = not graph and getattr(cp, "fb", None) is not None and not self.host_embedding
+            if self._stage_inputs(sp, cp, int_x, cat_x, y, lr, launch=not whole):
+                # a launched (not replayed) step: staging launch + joint program + optimizer as ONE host call
+                if getattr(cp, "whole", None) is None:
+                    cp.whole = Program([cp.stage] + list(cp.fb.descs) + list(cp.opt.descs))
+                cp.whole.run(sp)
+                return cp.loss
         else:
             self.lr_dev.fill_(float(lr))
             L.check(L.load().nasrec_launch(sp, C.addressof(cp.gather)))
