@@ -589,6 +589,13 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
     rstd2 = rs2[1];
     if (!(d.dims_in_use >= 0 && lane >= d.dims_in_use)) dout = dout_in;
   }
+  // The attention loops recompute p = exp(s - max) / sum as ONE exponential: exp2(s' - m'), s' = (q log2 e) . k and m' = (max + ln sum) log2 e
+  // (round 5: the loops are 42 % of this body and issue-bound; the multiply by 1 / sum and the log2 e scaling inside expf were three
+  // of ~15 vector instructions per key and head pair).  mq: the lane's own rows as queries; Mb below: every row, for the lanes as keys.
+  constexpr float LOG2E = 1.44269504088896340736f;
+  float mq[HP];
+#pragma unroll
+  for (int h = 0; h < HP; ++h) mq[h] = (mx[h] - __logf(li[h])) * LOG2E;
   MHA_STAMP(2);
   // ---- LayerNorm 2 ----
   bgrad_slice<S>(vmul<S>(dout, xh2), c0, lane, gp + OFF_L2W);
@@ -603,7 +610,8 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
   }
   red[0][w * 64 + lane] = sa;
   red[1][w * 64 + lane] = sb;
-  __syncthreads();
+  __syncthreads();  // (also: every lane has its own max / 1 / sum in registers)
+  for (int i = tid; i < N * 8; i += NT) Mb[i] = (Mb[i] - __logf(Lb[i])) * LOG2E;  // m' per (row, head): read by the key-side loop, several barriers on
   float c1 = slice_sum<NW>(red[0], lane) * (1.f / 16.f);
   float c2 = slice_sum<NW>(red[1], lane) * (1.f / 16.f);
   Vec<S> dr2;
@@ -687,15 +695,15 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
     // Two heads per wave = one packed-fp32 lane pair (v_pk_mul / v_pk_fma: 2 heads per instruction), on rows parked as (h0c0, h1c0,
     // h0c1, h1c1); every element sees the operations of the scalar form below in the same order (same bits).  q4 / k4 / v4 hold
     // their rows in that pair order here.
-    const f32x2 qa = {q4[0], q4[1]}, qb = {q4[2 % S], q4[3 % S]}, doa = {dO[0], dO[2 % S]}, dob = {dO[1], dO[3 % S]};
-    const f32x2 m2 = {mx[0], mx[1 % HP]}, l2 = {li[0], li[1 % HP]}, dd2 = {dd[0], dd[1 % HP]};
+    const f32x2 qa = {q4[0] * LOG2E, q4[1] * LOG2E}, qb = {q4[2 % S] * LOG2E, q4[3 % S] * LOG2E}, doa = {dO[0], dO[2 % S]}, dob = {dO[1], dO[3 % S]};
+    const f32x2 m2 = {mq[0], mq[1 % HP]}, dd2 = {dd[0], dd[1 % HP]};
     f32x2 dqa = {0.f, 0.f}, dqb = {0.f, 0.f};  // phase A: lane = query
 #pragma unroll 4
     for (int j = 0; j < N; ++j) {
       const f32x4 kj = ld4(Kb + j * 16 + c0), vj = ld4(Vb + j * 16 + c0);
       const f32x2 ka = {kj[0], kj[1]}, kb = {kj[2], kj[3]}, va = {vj[0], vj[1]}, vb = {vj[2], vj[3]};
       const f32x2 t = __builtin_elementwise_fma(qa, ka, qb * kb) - m2;
-      const f32x2 p = (f32x2){__expf(t[0]), __expf(t[1])} * l2;
+      const f32x2 p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
       const f32x2 ds = p * (__builtin_elementwise_fma(doa, va, dob * vb) - dd2);
       dqa = __builtin_elementwise_fma(ds, ka, dqa);
       dqb = __builtin_elementwise_fma(ds, kb, dqb);
@@ -705,16 +713,15 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
     dq[2 % S] = dqa[1] * MHA_SCALE;
     dq[3 % S] = dqb[1] * MHA_SCALE;
     MHA_STAMP(8);
-    const f32x2 ka = {k4[0], k4[1]}, kb = {k4[2 % S], k4[3 % S]}, va = {v4[0], v4[1]}, vb = {v4[2 % S], v4[3 % S]};
-    f32x2 dka = {0.f, 0.f}, dkb = {0.f, 0.f}, dva = {0.f, 0.f}, dvb = {0.f, 0.f};  // phase B: lane = key
+    const f32x2 ka = {k4[0] * LOG2E, k4[1] * LOG2E}, kb = {k4[2 % S] * LOG2E, k4[3 % S] * LOG2E}, va = {v4[0], v4[1]}, vb = {v4[2 % S], v4[3 % S]};
+    f32x2 dka = {0.f, 0.f}, dkb = {0.f, 0.f}, dva = {0.f, 0.f}, dvb = {0.f, 0.f};  // phase B: lane = key (ka / kb: the scores' side only)
 #pragma unroll 4
     for (int i = 0; i < N; ++i) {
       const f32x4 qi = ld4(Qb + i * 16 + c0), doi = ld4(DOb + i * 16 + c0);
       const f32x2 qia = {qi[0], qi[1]}, qib = {qi[2], qi[3]}, da = {doi[0], doi[1]}, db = {doi[2], doi[3]};
-      const f32x2 mi = *reinterpret_cast<const f32x2*>(Mb + i * 8 + HP * w), l_ = *reinterpret_cast<const f32x2*>(Lb + i * 8 + HP * w),
-                  di = *reinterpret_cast<const f32x2*>(Db + i * 8 + HP * w);
+      const f32x2 mi = *reinterpret_cast<const f32x2*>(Mb + i * 8 + HP * w), di = *reinterpret_cast<const f32x2*>(Db + i * 8 + HP * w);
       const f32x2 t = __builtin_elementwise_fma(qia, ka, qib * kb) - mi;
-      const f32x2 p = (f32x2){__expf(t[0]), __expf(t[1])} * l_;
+      const f32x2 p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
       dva = __builtin_elementwise_fma(p, da, dva);
       dvb = __builtin_elementwise_fma(p, db, dvb);
       const f32x2 ds = p * (__builtin_elementwise_fma(da, va, db * vb) - di);
@@ -730,7 +737,7 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
     const Vec<S> vj = ldv<S>(Vb + j * 16 + c0);
 #pragma unroll
     for (int h = 0; h < HP; ++h) {
-      const float p = __expf(fmaf(q4[2 * h], kj[2 * h], q4[2 * h + 1] * kj[2 * h + 1]) - mx[h]) * li[h];
+      const float p = __builtin_amdgcn_exp2f(fmaf(q4[2 * h] * LOG2E, kj[2 * h], (q4[2 * h + 1] * LOG2E) * kj[2 * h + 1]) - mq[h]);
       const float ds = p * (fmaf(dO[2 * h], vj[2 * h], dO[2 * h + 1] * vj[2 * h + 1]) - dd[h]);
       dq[2 * h] = fmaf(ds, kj[2 * h], dq[2 * h]);
       dq[2 * h + 1] = fmaf(ds, kj[2 * h + 1], dq[2 * h + 1]);
@@ -745,8 +752,8 @@ __device__ __forceinline__ void mha_bwd_sample(const nasrec_mha_desc_t& d, const
     const Vec<S> doi = ldv<S>(DOb + i * 16 + c0);
 #pragma unroll
     for (int h = 0; h < HP; ++h) {
-      const float mi = Mb[i * 8 + HP * w + h], l_ = Lb[i * 8 + HP * w + h], di = Db[i * 8 + HP * w + h];
-      const float p = __expf(fmaf(qi[2 * h], k4[2 * h], qi[2 * h + 1] * k4[2 * h + 1]) - mi) * l_;
+      const float mi = Mb[i * 8 + HP * w + h], di = Db[i * 8 + HP * w + h];
+      const float p = __builtin_amdgcn_exp2f(fmaf(qi[2 * h], k4[2 * h] * LOG2E, qi[2 * h + 1] * (k4[2 * h + 1] * LOG2E)) - mi);
       dv[2 * h] = fmaf(p, doi[2 * h], dv[2 * h]);
       dv[2 * h + 1] = fmaf(p, doi[2 * h + 1], dv[2 * h + 1]);
       const float ds = p * (fmaf(doi[2 * h], v4[2 * h], doi[2 * h + 1] * v4[2 * h + 1]) - di);
