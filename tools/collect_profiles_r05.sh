@@ -30,7 +30,7 @@ done
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_cfg2_mfma -- python3 $R/bench.py --steps 12 --warmup 3 --steps-only --no-graph > /dev/null 2>&1 < /dev/null
 # keep what travels back small: per-dispatch traces are summarised on the box, right away (the rest of the run may be cut short)
 python3 $R/tools/update_profiles_r05.py --summarise $O >> $O/log.txt 2>&1 < /dev/null
-find $O -name "*kernel_trace.csv" -size +8M -delete; find $O -name "*counter_collection.csv" -size +8M -delete
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete  # (gpurun copies back at most 64 MiB; the summaries hold what is kept)
 for c in 3 4 5; do timeout 300 python3 $R/tools/host_time_supernet.py $c >> $O/host_time_supernet.txt 2>> $O/log.txt < /dev/null; done
 timeout 300 python3 $R/tools/bench_supernet.py --strategy full-path --steps 10 --warmup 3 > $O/supernet_fullpath_step.txt 2>> $O/log.txt < /dev/null
 timeout 300 python3 $R/tools/dedup_cost.py > $O/dedup_cost.txt 2>> $O/log.txt < /dev/null
