@@ -20,22 +20,6 @@ static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, i
   const int S = g->splitk > 1 ? g->splitk : 1;
   if (g->splitk == NASREC_SPLITK_BALANCED) return nasrec_set_error(-2, "worklist: the balanced schedule is a throughput-regime launch");
   if ((it.part == 0) != (S == 1)) return nasrec_set_error(-2, "worklist: gemm part %d with splitk %d", it.part, g->splitk);
-  if (it.part == 3) {
-    // main pass + second pass of a split-K product in one workgroup per 16 x 16 output tile (wl_gemm_fused_splitk; schedule.py `fusable`)
-    const bool kckc = g->amode == NASREC_AM_KC && g->bmode == NASREC_AM_KC && !g->zmode, kcrc = g->amode == NASREC_AM_KC && g->bmode == NASREC_AM_RC && g->zmode;
-    if (!(kckc || kcrc) || g->cmode != NASREC_CM_PLAIN || S > 32) return nasrec_set_error(-2, "worklist: fused split-K item with binding a=%d b=%d z=%d S=%d", g->amode, g->bmode, g->zmode, S);
-    long tiles = 0;
-    for (int q = 0; q < g->nseg; ++q) {
-      const nasrec_gemm_seg_t& s = g->seg[q];
-      if (s.Aaux || s.Baux || s.ones_col || (s.Mvalid > 0 && s.Mvalid < s.M)) return nasrec_set_error(-2, "worklist: fused split-K item with mask operands / row predicates");
-      if (s.A && ((long)s.M * s.lda + s.K >= (1L << 29) || (long)(kcrc ? s.K : s.N) * s.ldb + (kcrc ? s.N : s.K) >= (1L << 29)))
-        return nasrec_set_error(-2, "worklist: fused split-K item: operand extent beyond 2^29 floats");
-      if (q < nprob) tiles += (long)((s.M + 15) / 16) * ((s.N + 15) / 16);
-    }
-    it.geom[0] = it.geom[1] = it.geom[2] = 0;
-    it.nblk = (int)tiles;
-    return 0;
-  }
   if (S > 1 && !g->workspace) return nasrec_set_error(-3, "worklist: splitk=%d needs a workspace", S);
   int Mmax = 0, Nmax = 0, Kmax = 0;
   long wgs = 0;

@@ -342,164 +342,6 @@ __device__ __forceinline__ void wl_token_dx(unsigned long long blob, int vb_, in
   }
 }
 
-// A split-K product whose second pass would sit on the step's critical path, as ONE item (nasrec_wl_item_t.part == 3, round 5): a
-// workgroup owns one 16 x 16 output tile and computes ALL S k-slices of it — wave w the slices of chain w of the second pass
-// (gemm_tile.h splitk_second_pass sums the slabs as four interleaved chains, v_w = p_w + p_{w+4} + ..., the tail of S mod 4 slabs on
-// chain 0, then (v0 + v1) + (v2 + v3)) — each slice from zeroed accumulators over the tiles [T q / S, T (q + 1) / S) of 64 k the main
-// pass gives it, MFMA j of 16-deep step kb summing k = 64 t + 16 kb + 4 g + j (gemm_tile_rt's order, dead k as zeros).  The chains meet
-// in LDS, wave 0 runs the epilogue.  Every partial sum is the main pass's, every addition the second pass's: BIT-identical to the two
-// launches (tests/test_parity_gpu.py: the level-scheduled step against one launch per operator), without the slabs' round trip through
-// memory and without the level the second pass cost.  Bindings: KC / KC (x W^T) and KC / RC per problem (dy W, zmode); operands straight
-// to MFMA registers (16-byte loads along k; four dwords a row of W apart for RC), the next tile's loads in flight under this tile's MFMAs.
-__device__ __forceinline__ void wl_gemm_fused_splitk(unsigned long long blob, int vb_, float* lds) {
-  const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
-  const int vb = __builtin_amdgcn_readfirstlane(vb_);
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int fr = lane & 15, fg = lane >> 4;
-  wl_warm_blob(blob, (int)offsetof(nasrec_gemm_desc_t, seg) + g.nseg * (int)sizeof(nasrec_gemm_seg_t));
-  const bool rcb = g.bmode == NASREC_AM_RC;
-  const int S = g.splitk;
-  int t = vb, z = 0;
-  if (g.zmode)
-    while (z < g.nseg - 1 && t >= ((g.seg[z].M + 15) >> 4) * ((g.seg[z].N + 15) >> 4)) t -= ((g.seg[z].M + 15) >> 4) * ((g.seg[z].N + 15) >> 4), ++z;
-  const nasrec_gemm_seg_t& s0 = g.seg[z];
-  const int M = s0.M, N = s0.N, NT = (N + 15) >> 4;
-  const int mt = t / NT, nt = t - mt * NT;
-  int T = 0;
-  if (g.zmode) {
-    T = (s0.A && s0.K > 0) ? (s0.K + 63) >> 6 : 0;
-  } else {
-    for (int q = 0; q < g.nseg; ++q)
-      if (g.seg[q].A && g.seg[q].K > 0) T += (g.seg[q].K + 63) >> 6;
-  }
-  const int row = min(mt * 16 + fr, M - 1), col = min(nt * 16 + fr, N - 1);  // (lane & 15: row of the A fragment, column of the B fragment)
-  // the wave's work as one list of tiles: slices of its chain in ascending order, a slice's tiles in order
-  const int S4 = S & ~3;
-  int q = wave < S4 ? wave : (wave == 0 ? S4 : S);  // current slice (S: none left)
-  int tt = 0, t1 = 0, sg_i = 0, kt = 0;              // tile cursor inside the slice: global tile tt < t1 = segment sg_i, k-tile kt
-  auto advance_q = [&]() {  // chain order: q, q + 4, ... below S4; wave 0 then takes the tail S4 .. S - 1
-    if (q < S4) q = (q + 4 < S4) ? q + 4 : (wave == 0 ? S4 : S);
-    else q = (wave == 0 && q + 1 < S) ? q + 1 : S;
-  };
-  auto seek = [&]() {  // position the cursor on the first tile of slice q (an empty slice adds nothing: skipped)
-    while (q < S) {
-      tt = (int)((long)T * q / S);
-      t1 = (int)((long)T * (q + 1) / S);
-      if (tt < t1) break;
-      advance_q();
-    }
-    if (q >= S) return;
-    if (g.zmode) {
-      sg_i = z;
-      kt = tt;
-    } else {
-      int skip = tt;
-      sg_i = 0;
-      for (;;) {
-        const int n = (g.seg[sg_i].A && g.seg[sg_i].K > 0) ? (g.seg[sg_i].K + 63) >> 6 : 0;
-        if (skip < n) break;
-        skip -= n;
-        ++sg_i;
-      }
-      kt = skip;
-    }
-  };
-  auto next_slice = [&]() {
-    advance_q();
-    seek();
-  };
-  // Units of 32 k (half a tile: two 16-deep steps), double-buffered in registers: the next unit's four loads are in flight under this
-  // unit's eight MFMAs (whole tiles in flight took 64 registers and pushed the kernel's other bodies into scratch).
-  f32x4 fa[2][2], fb[2][2];
-  int kv[2];        // valid k of the unit in the buffer, counted from the unit's first k (<= -32 ... : see `on`)
-  bool on_[2];      // the buffer holds a unit
-  bool last[2];     // the unit ends its slice
-  int half = 0;     // which half of the cursor's tile the next fetch takes
-  auto fetch = [&](int buf) {
-    const bool on = q < S;
-    const nasrec_gemm_seg_t& sg = g.seg[on ? sg_i : z];
-    const int K = on ? sg.K : 0, k0 = (kt << 6) + 32 * half;
-    kv[buf] = K - k0;
-    on_[buf] = on;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.A), 0, on ? (int)(4 * ((long)(M - 1) * sg.lda + K)) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(sg.B), 0, on ? (int)(4 * (rcb ? ((long)(K - 1) * sg.ldb + N) : ((long)(N - 1) * sg.ldb + K))) : 0, 0x00020000);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int kk = k0 + 16 * kb + 4 * fg;
-      fa[buf][kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, 4 * (row * sg.lda + kk), 0, 0));
-      if (!rcb) {
-        fb[buf][kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, 4 * (col * sg.ldb + kk), 0, 0));
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[buf][kb][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, 4 * ((kk + j) * sg.ldb + col), 0, 0));
-      }
-    }
-    last[buf] = false;
-    if (on) {  // advance the cursor
-      if (half == 0) {
-        half = 1;
-      } else {
-        half = 0;
-        ++tt;
-        last[buf] = tt >= t1;
-        if (last[buf]) {
-          next_slice();
-        } else if (g.zmode) {
-          ++kt;
-        } else if (++kt >= ((sg.K + 63) >> 6)) {
-          do {
-            ++sg_i;
-          } while (!(g.seg[sg_i].A && g.seg[sg_i].K > 0));
-          kt = 0;
-        }
-      }
-    }
-  };
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, vsum = {0.f, 0.f, 0.f, 0.f};
-  seek();
-  fetch(0);
-  auto multiply = [&](int buf) {  // (buf is a constant at every call: the buffers stay in registers)
-    const int l = kv[buf];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x4 a = fa[buf][kb], b = fb[buf][kb];
-      if (l < 16 * kb + 16) {  // (uniform) the segment's last live step, or a step beyond K: dead k as zeros (the staged tile's padding)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bool in = 16 * kb + 4 * fg + j < l;
-          a[j] = in ? a[j] : 0.f;
-          b[j] = in ? b[j] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
-    }
-    if (last[buf]) {  // the slice is complete: its partial sum joins the chain (what the second pass adds: v_w += slab_q)
-      vsum += acc;
-      acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  for (;;) {  // (uniform exits: the wave's list is exhausted)
-    if (!on_[0]) break;
-    fetch(1);  // the next unit's loads under this unit's MFMAs (a null resource past the end)
-    multiply(0);
-    if (!on_[1]) break;
-    fetch(0);
-    multiply(1);
-  }
-  // (v0 + v1) + (v2 + v3), then the epilogue — on wave 0
-  f32x4* part = reinterpret_cast<f32x4*>(lds);
-  part[wave * 64 + lane] = vsum;
-  __syncthreads();
-  if (wave == 0 && mt * 16 + 4 * fg < M && nt * 16 + fr < N) {
-    const f32x4 v0 = part[lane], v1 = part[64 + lane], v2 = part[128 + lane], v3 = part[192 + lane];
-    const f32x4 v = (v0 + v1) + (v2 + v3);
-    const float v4[4] = {v[0], v[1], v[2], v[3]};
-    epilogue_store_col4<NASREC_CM_PLAIN>(g, s0, mt * 16 + 4 * fg, nt * 16 + fr, M, v4);
-  }
-}
-
 __device__ __forceinline__ void wl_gemm_second_pass(unsigned long long blob, int vb_, int per_) {
   const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
   const int vb = __builtin_amdgcn_readfirstlane(vb_), per = __builtin_amdgcn_readfirstlane(per_);
@@ -568,10 +410,6 @@ __global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(unsigned f01
     case NASREC_OP_GEMM: {
       if (it_part == 2) {
         wl_gemm_second_pass(blob, vb, it.geom[0]);
-        break;
-      }
-      if (it_part == 3) {
-        wl_gemm_fused_splitk(blob, vb, lds);
         break;
       }
       const int cfg = it.geom[2];  // tile | binding pair << 2 | mask operand << 4

@@ -75,8 +75,7 @@ def _cview(ptr, cmode, M, N, ldc):
 
 
 def _gemm_io(d, part):
-    """part: 'whole' | 'main' (operands -> split-K slabs) | 'epi' (slabs -> epilogue -> C) | 'fused' (a split-K product as one worklist
-    item: operands -> C, the slabs never exist)"""
+    """part: 'whole' | 'main' (operands -> split-K slabs) | 'epi' (slabs -> epilogue -> C)"""
     R, W = [], []
     nprob = d.nseg if d.zmode else 1
     S = d.splitk if d.splitk > 1 else 1
@@ -85,7 +84,7 @@ def _gemm_io(d, part):
     ws = _flat(d.workspace, S * Mm * Nm * nprob) if (S > 1 and d.workspace) else None
     if d.splitk == L.SPLITK_BALANCED and d.workspace:
         ws = _flat(d.workspace, L.SK_WORKSPACE_FLOATS)  # the engine-wide partial-tile workspace of the balanced schedule: shared by launches
-    if part in ("whole", "main", "fused"):
+    if part in ("whole", "main"):
         for q in range(d.nseg):
             s = d.seg[q]
             if not s.A:
@@ -595,7 +594,7 @@ def item_bytes(node):
     return None
 
 
-_PART = {"whole": L.WL_WHOLE, "main": L.WL_MAIN, "epi": L.WL_EPI, "fused": 3}
+_PART = {"whole": L.WL_WHOLE, "main": L.WL_MAIN, "epi": L.WL_EPI}
 
 
 # stand-alone times of the non-GEMM items of the batch-256 step, ns (tools/step_table.py ITEMS=11)
@@ -620,8 +619,6 @@ def _cost(node):
     if isinstance(d, L.GemmDesc):
         if node.part == "epi":
             return 3600
-        if node.part == "fused":
-            return 6500 + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A) // 20000
         return 5000 + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A) // 20000
     if d.kind == L.OP_FINAL_BWD and d.dseg_done:
         return 5000
@@ -635,8 +632,6 @@ def _cost_r4(node):
     if isinstance(d, L.GemmDesc):
         if node.part == "epi":
             return 4000
-        if node.part == "fused":
-            return 6500 + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A) // 20000
         live = [q for q in range(d.nseg) if d.seg[q].A]
         extra = 0 if d.zmode else 900 * max(len(live) - 1, 0)
         return 5200 + extra + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in live) // 20000
@@ -649,39 +644,11 @@ def _cost_r4(node):
     return _ITEM_NS_R4.get(d.kind, 3000)
 
 
-FUSE_SPLITK = os.environ.get("NASREC_WL_FUSE_SPLITK", "0") != "0"  # A/B knob, off: measured +11 us per cfg-2 step, +4.5 us from 64 tiles up (profiles/r05_ab_fused_splitk.txt) — the fused item is 1/S of the parallelism of its two passes
-FUSE_MAX_TILES = int(os.environ.get("NASREC_WL_FUSE_TILES", "256"))
-FUSE_MIN_TILES = int(os.environ.get("NASREC_WL_FUSE_MIN_TILES", "64"))  # (a 16-wide product is 16 workgroups walking ~7 k-slices each: 14.7 us as an item)
-
-
-def fusable(d) -> bool:
-    """mirror of csrc/worklist.hip (part 3): a split-K product with few 16 x 16 output tiles whose main pass + second pass run as ONE
-    worklist item (csrc/worklist_body.h wl_gemm_fused_splitk: bit-identical to the two passes) — the second pass of such a product is a
-    level of its own on the step's critical chain otherwise"""
-    if not FUSE_SPLITK or not isinstance(d, L.GemmDesc) or not (2 <= d.splitk <= 32) or not d.workspace or d.cmode != L.CM_PLAIN or d.amode != L.AM_KC:
-        return False
-    if not ((d.bmode == L.AM_KC and not d.zmode) or (d.bmode == L.AM_RC and d.zmode)):
-        return False
-    tiles = 0
-    for q in range(d.nseg):
-        s = d.seg[q]
-        if s.Aaux or s.Baux or s.ones_col or (0 < s.Mvalid < s.M):
-            return False
-        rc = d.bmode == L.AM_RC
-        if s.A and (s.M * s.lda + s.K >= (1 << 29) or (s.K if rc else s.N) * s.ldb + (s.N if rc else s.K) >= (1 << 29)):
-            return False
-        if d.zmode or q == 0:
-            tiles += ((s.M + 15) // 16) * ((s.N + 15) // 16)
-    return max(FUSE_MIN_TILES, 1) <= tiles <= FUSE_MAX_TILES
-
-
 def expand_for_worklists(descs) -> List[Node]:
     """as expand(), but a split-K GEMM is cut in two only when both halves can ride in worklist launches"""
     nodes = []
     for d in descs:
-        if isinstance(d, L.GemmDesc) and d.splitk > 1 and gemm_capable(d) and fusable(d):
-            nodes.append(Node(d, "fused"))
-        elif isinstance(d, L.GemmDesc) and d.splitk > 1 and gemm_capable(d):
+        if isinstance(d, L.GemmDesc) and d.splitk > 1 and gemm_capable(d):
             nodes.append(Node(d, "main"))
             nodes.append(Node(d, "epi"))
         else:
