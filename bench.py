@@ -147,6 +147,15 @@ def launch_kernel_name(L, P, d):
     return names.get(d.kind, "kind%d" % d.kind) + "_kernel"
 
 
+def dense_floats_walked(eng, cp):
+    """floats of the dense arena the optimizer's launches (square sum, Adagrad) actually walk: the plan's chunk table when it has one
+    (the ranges a gradient reaches: engine.compile), else the whole arena"""
+    tab = getattr(cp, "chunk_tab", None)
+    if tab is None:
+        return int(eng.flat_numel)
+    return int(tab.view(-1)[1:2 * cp.nchunks:2].sum().item())  # (offset, count) pairs
+
+
 def launch_work(L, S, d, n_dense=0):
     """(MFMA flops, algorithmic bytes, item summary) of one launch: flops = the products' 2·M·N·K (split-K second passes and the
     vector-ALU bodies — Transformer, FM, DotProduct cores — count 0: the MFMA roof is about the matrix pipe); bytes = every operand
@@ -162,10 +171,12 @@ def launch_work(L, S, d, n_dense=0):
     elif k in (L.OP_OPT_REDUCE, L.OP_EMB_DEDUP):  # ids + row gradients read, summed rows + leaders written (+ the gradient arena read once)
         dd = d.dedup if k == L.OP_OPT_REDUCE else d
         by = dd.B * dd.Fs * (8 + 64 + 64 + 4) + (n_dense * 4 if k == L.OP_OPT_REDUCE else 0)
+    elif k == L.OP_OPT_REDUCE2:  # row gradients read once (duplicates' sums written back in place: counted once more), leaders + lists read, the arena's gradients read once
+        by = d.B * d.Fs * (64 + 64 + 12) + n_dense * 4
     elif k == L.OP_SUMSQ:
         by = n_dense * 4
-    elif k == L.OP_OPT_APPLY:    # dense: g read, state and parameter read + written; rows: summed gradient read, table row + state row r/w
-        by = n_dense * 20 + d.rows.B * d.rows.Fs * (64 + 4 * 64)
+    elif k == L.OP_OPT_APPLY:    # dense (n_dense = the floats of the chunk table the launch walks): g read, state and parameter read + written; rows: leader flag + id + summed gradient read, table row + state row r/w
+        by = n_dense * 20 + d.rows.B * d.rows.Fs * (12 + 64 + 4 * 64)
     for n in nodes:
         if isinstance(n.desc, L.GemmDesc) and n.part != "epi":
             fl += gemm_flops(n.desc)
@@ -184,6 +195,36 @@ def launch_table(lib, L, P, S, sp, descs, iters, n_dense=0):
         us = time_desc(lib, L, sp, d, iters=iters) * 1e3
         rows.append({"kernel": launch_kernel_name(L, P, d), "items": items, "mflop": fl / 1e6, "alg_KB": by / 1e3, "us": us})
     return rows
+
+
+def launch_table_in_step(lib, L, sp, descs, reps, blocker, warm=None):
+    """duration of every launch of the step IN THE STEP'S OWN ORDER (HIP events on the launch stream between consecutive launches of one
+    real step): each kernel sees the caches as its predecessors left them, not the warm state of a back-to-back relaunch of the same
+    descriptor.  Ahead of each timed step a blocker (a few ms of unrelated GPU work) lets the host enqueue the whole step before the first
+    launch starts, and `warm` (one untimed step) puts the step's own working set back into the Infinity Cache.  The event packet
+    between two launches is inside the measured interval: these durations are upper bounds of the kernels' own."""
+    n = len(descs)
+    evs = []
+    for _ in range(n + 1):
+        e = C.c_void_p()
+        L.check(lib.nasrec_event_create(C.byref(e)))
+        evs.append(e)
+    acc = np.zeros(n)
+    ms = C.c_float()
+    for _ in range(reps):
+        blocker()
+        if warm is not None:
+            warm()
+        L.check(lib.nasrec_event_record(evs[0], sp))
+        for i, d in enumerate(descs):
+            L.check(lib.nasrec_launch(sp, C.addressof(d)))
+            L.check(lib.nasrec_event_record(evs[i + 1], sp))
+        for i in range(n):
+            L.check(lib.nasrec_event_elapsed_ms(evs[i], evs[i + 1], C.byref(ms)))
+            acc[i] += ms.value
+    for e in evs:
+        lib.nasrec_event_destroy(e)
+    return acc / reps * 1e3  # us
 
 
 def csrc_build_id():
@@ -330,12 +371,23 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d, but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DRY RUN of the N-rank launch path on a box without GPUs (tests/test_bench_dry_gloo_cpu.py; never a measurement): the ranks form a
+    # gloo group on the CPU and the engine behind DataParallelStep is a stand-in built by NASREC_BENCH_DRY_ENGINE = "file.py:factory"
+    # (test infrastructure; bench.py itself provides none) — the rendezvous, the step loop, the fences, the max over ranks and the
+    # result line are the ones the GPUs run
+    dry = os.environ.get("NASREC_BENCH_DRY_ENGINE")
+    if dry:
+        device = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     if world > 1 or args.force_dp_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from nasrec_amd import _lib as L
     from nasrec_amd import plan as P
@@ -349,7 +401,10 @@ def main():
     ds = DATASETS[w["dataset"]]
     tables = [min(n, w["cap"]) if w.get("cap") else n for n in ds["tables"]]
     Fd, Fs = ds["Fd"], ds["Fs"]
-    n_pool = args.id_pool if args.id_pool is not None else max(4, -(-(280 << 20) // (B * Fs * 64)))  # touched rows > 256 MiB per lap
+    if dry:
+        B = int(os.environ.get("NASREC_BENCH_DRY_BATCH", "4"))
+        tables = [min(n, 50) for n in tables]
+    n_pool = 4 if dry else args.id_pool if args.id_pool is not None else max(4, -(-(280 << 20) // (B * Fs * 64)))  # touched rows > 256 MiB per lap
     batches = BatchPool(n_pool, 16 if fixed else 4, B, Fd, tables, device, 1234 + rank, w["dataset"] == "avazu", args.ids)
     steps_per_epoch = w["train_limit"] // B
     sched = CosineAnnealingWarmupRestarts(steps_per_epoch, max_lr=LR_MAX if fixed else 0.12, min_lr=LR_MIN, warmup_steps=steps_per_epoch // 10)
@@ -383,8 +438,16 @@ def main():
         choice = {"macro": choice_all["macro"], "micro": choice_all["micro"]}
         # main_train.py:258-269: best-1shot sub-networks are built WITHOUT LayerNorm (use_layernorm hard-coded False)
         cfg = P.NetConfig(choice_all["num_blocks"], ops_config_lib[choice_all["config"]], False, "relu", fixed=True)
-        eng = SupernetEngine(cfg, Fd, Fs, tables, device=device, warm_choice=choice, world_size=world, host_embedding=sharded)
-        eng.init_weights(seed=0)
+        if dry:
+            import importlib.util
+            path, fn = dry.rsplit(":", 1)
+            spec = importlib.util.spec_from_file_location("_bench_dry_engine", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            eng = getattr(mod, fn)(choice_all, choice, Fd, Fs, tables)
+        else:
+            eng = SupernetEngine(cfg, Fd, Fs, tables, device=device, warm_choice=choice, world_size=world, host_embedding=sharded)
+            eng.init_weights(seed=0)
         dp = ShardedRun(eng) if sharded else DataParallelStep(eng, choice, B, clip=5.0, eps=1e-2, graph=False if args.no_graph else True if args.graph else None,
                                                               force_exchange=args.force_dp_path, real_collectives=args.real_collectives)
 
@@ -449,15 +512,17 @@ def main():
         dp.coll = Ablated(args.real_collectives)
 
     def fence():
-        torch.cuda.synchronize(device)
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize(device)
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
 
     # Setup, not warm-up: the first step compiles the plan and captures the step graph; then the graph is replayed until the GPU has been
     # busy for ~0.1 s (clocks, TLBs and instruction caches of a box that sat idle through a minute of host-side setup), so that a short
     # timed region (the driver's --steps 20 --warmup 5 is 7 ms of GPU time) sees the steady state the default 300-step run sees.
-    settle_ms = float(os.environ.get("NASREC_BENCH_SETTLE_MS", "100"))
+    settle_ms = 0.0 if dry else float(os.environ.get("NASREC_BENCH_SETTLE_MS", "100"))
     one_step(0)
     fence()
     import gc
@@ -469,7 +534,7 @@ def main():
     while (time.perf_counter() - t_s) * 1e3 < settle_ms or n_settle < 4:
         one_step(n_settle)
         n_settle += 1
-        if n_settle % 16 == 0:
+        if n_settle % 16 == 0 and device.type == "cuda":
             torch.cuda.synchronize(device)
     fence()
     for i in range(warmup):
@@ -483,9 +548,10 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     # per-step durations (median_ms_per_step, the step-level roofline) from a second, untimed pass with an event behind every step
-    nper = min(steps, 300)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(nper + 1)]
-    ev[0].record()
+    nper = 0 if dry else min(steps, 300)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(nper + 1)] if nper else []
+    if nper:
+        ev[0].record()
     for i in range(nper):
         one_step(n_settle + warmup + steps + i)
         ev[i + 1].record()
@@ -495,7 +561,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    per_step = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(nper)])
+    per_step = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(nper)]) if nper else np.array([dt / steps * 1e3])
     loss = float(dp.last_loss().item())
     if not (loss == loss):
         raise SystemExit("loss is NaN")
@@ -513,18 +579,27 @@ def main():
                    "embedding_update": "row-sparse clip+Adagrad (== dense reference update for weight_decay 0)", "table_sharding": args.table_sharding},
         "final_loss": loss,
     }
+    if dry:
+        result["data"] = "synthetic; DRY RUN of the launch path on the CPU (gloo, stand-in engine, batch %d, 50-row tables): NOT a measurement" % B
+        result["config"]["dry_run"] = True
     if dp.exchange:
         pl = dp._last[1]
         result["config"]["dp_exchange"] = {
+            "backend": dist.get_backend() + (" (= RCCL on ROCm)" if dist.get_backend() == "nccl" else ""), "world_size": dist.get_world_size(),
             "captured_in_one_graph": bool(getattr(pl, "step_graph", None)),
             "launches_up_to_cut": getattr(pl, "cuts", None),
             "pieces": [{"allreduce_ranges": len(list(rg)), "allreduce_MB": sum(n for _, n in rg) * 4 / 1e6} for _, rg in pl.segments],
             "allgather_MB": {"ids": B * world * Fs * 8 / 1e6, "row_gradients": B * world * Fs * 64 / 1e6},
             # the last pieces' dense gradients ride behind the rows in the row-gradient all-gather (no all-reduce of their own)
             "packed_tail_floats_per_rank": dp.tail_n, "first_packed_piece": getattr(pl, "first_packed", None),
-            "real_collectives_on_one_rank": bool(args.real_collectives), "id_half_of_the_dedup_beside_the_forward": dp.ids_half is not None}
+            "real_collectives_on_one_rank": bool(args.real_collectives),
+            # where the id-only half of the global-batch row dedup runs (parallel._exchange_step): "main" = on the compute stream in front of
+            # the optimizer (exposed; the default: a fork to a second stream inside a captured graph costs more than the launch),
+            # "side" / "chain" = beside the forward on a second stream; None = the one-launch dedup kernels (no separate id half)
+            "id_half_split_from_the_row_sums": dp.ids_half is not None,
+            "id_half_mode": (__import__("nasrec_amd.parallel", fromlist=["_IDS_MODE"])._IDS_MODE if getattr(dp, "_side", None) is not None else "main") if dp.ids_half is not None else None}
 
-    if rank == 0 and not args.steps_only:  # (N > 1: the roofline of the dominant launch and the step accounting are rank 0's; forward-only and the CPU baseline are N = 1 legs)
+    if rank == 0 and not args.steps_only and not dry:  # (N > 1: the roofline of the dominant launch and the step accounting are rank 0's; forward-only and the CPU baseline are N = 1 legs)
         sp = torch.cuda.current_stream(device).cuda_stream
         cp = dp.last_plan()
         allg = [d for d in P.iter_ops(cp.fwd.descs + cp.bwd.descs) if isinstance(d, L.GemmDesc)]
@@ -604,6 +679,7 @@ def main():
             if tj.get("build_id") == csrc_build_id() and tj.get("kernel") == big["kernel"]:
                 big["traffic"] = tj["traffic_bytes_per_launch"]
                 big["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % tj.get("source", "profiles/")
+                big["traffic_source"] = "profiles/dominant_gemm_traffic_cfg%d.json (%s; not this run)" % (args.config, tj.get("source", "rocprofv3 --pmc"))
                 big["algorithmic_bytes"] = tj["algorithmic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -615,7 +691,7 @@ def main():
         from nasrec_amd import schedule as S
         step_descs = [cp.stage] + (list(cp.fb.descs) if getattr(cp, "fb", None) is not None else list(cp.fwd.descs) + list(cp.bwd.descs)) + list(cp.opt.descs)
         if not dp.exchange or fixed:
-            n_dense = sum(int(np.prod(eng.shapes[n])) for n in cp.used_params if not n.startswith("_embedding."))
+            n_dense = dense_floats_walked(eng, cp)  # (what the optimizer's launches walk: the plan's chunk table)
             # (the table re-launches the optimizer's descriptors a hundred times: what they change — dense parameters and state, the touched
             # rows and their state, the row gradients that are summed in place — is put back afterwards)
             with torch.no_grad():
@@ -623,6 +699,22 @@ def main():
                 snap = [eng.flat_p.clone(), eng.flat_s.clone(), cp.sparse0.grad_tensor().clone() if not dp.exchange else None,
                         [t[ids_now[:, f]].clone() for f, t in enumerate(eng.tables)], [t[ids_now[:, f]].clone() for f, t in enumerate(eng.table_state)]]
             rows = launch_table(lib, L, P, S, sp, step_descs, 100 if fixed else 10, n_dense)
+            # ... and every launch once more IN THE STEP'S ORDER (the durations the roofline is built from: a back-to-back relaunch of one
+            # descriptor runs 5 - 30 % faster than the same launch inside the step, whose operands were just written by other kernels)
+            blk = torch.empty(4096, 4096, device=device).normal_()
+            blk_out = torch.empty_like(blk)
+
+            def blocker():
+                for _ in range(4 if fixed else 6):
+                    torch.mm(blk, blk, out=blk_out)
+
+            def warm_step():
+                for dsc in step_descs:
+                    L.check(lib.nasrec_launch(sp, C.addressof(dsc)))
+            us_in = launch_table_in_step(lib, L, sp, step_descs, 30 if fixed else 5, blocker, warm_step)
+            for r, u in zip(rows, us_in):
+                r["us_isolated"], r["us"] = r["us"], float(u)
+            del blk, blk_out
             with torch.no_grad():
                 eng.flat_p.copy_(snap[0])
                 eng.flat_s.copy_(snap[1])
@@ -635,8 +727,9 @@ def main():
                 result["roofline_levels"] = rows
             agg = {}
             for r in rows:
-                a = agg.setdefault(r["kernel"], {"us": 0.0, "mflop": 0.0, "alg_KB": 0.0, "launches": 0})
+                a = agg.setdefault(r["kernel"], {"us": 0.0, "us_isolated": 0.0, "mflop": 0.0, "alg_KB": 0.0, "launches": 0})
                 a["us"] += r["us"]
+                a["us_isolated"] += r["us_isolated"]
                 a["mflop"] += r["mflop"]
                 a["alg_KB"] += r["alg_KB"]
                 a["launches"] += 1
@@ -645,8 +738,8 @@ def main():
             # Transformer backward and its LDS)
             fam = {}
             for k, a in agg.items():
-                f = fam.setdefault(k.split("<")[0], {"us": 0.0, "mflop": 0.0, "alg_KB": 0.0, "launches": 0, "variants": []})
-                for key in ("us", "mflop", "alg_KB", "launches"):
+                f = fam.setdefault(k.split("<")[0], {"us": 0.0, "us_isolated": 0.0, "mflop": 0.0, "alg_KB": 0.0, "launches": 0, "variants": []})
+                for key in ("us", "us_isolated", "mflop", "alg_KB", "launches"):
                     f[key] += a[key]
                 f["variants"].append(k)
             name, a = max(fam.items(), key=lambda kv: kv[1]["us"])
@@ -660,9 +753,12 @@ def main():
                 "traffic": None, "kernel": name, "variants": sorted(a["variants"]), "launches_per_step": a["launches"],
                 "share_of_step_time": a["us"] / tot_us if tot_us else None,
                 "flops_per_launch": a["mflop"] * 1e6 / a["launches"], "avg_launch_us": a["us"] / a["launches"],
+                "avg_launch_us_isolated": a["us_isolated"] / a["launches"],
+                "duration_source": "HIP events between consecutive launches of real steps, in the step's own order (mean of %d steps; the event packet "
+                                   "is inside the interval); `avg_launch_us_isolated` = back-to-back relaunches of each descriptor" % (30 if fixed else 5),
                 "algorithmic_bytes": a["alg_KB"] * 1e3 / a["launches"],
                 "mfma_achieved_TFLOPs": tf, "mfma_frac": mf, "hbm_achieved_GBps": gbs, "hbm_frac": hf,
-                "note": "aggregate over this kernel's launches in one step (sum of flops / sum of isolated launch durations); a launch of this "
+                "note": "aggregate over this kernel's launches in one step (sum of flops / sum of in-step launch durations); a launch of this "
                         "kernel is one dependency level of the step, latency-bound at batch 256 (DESIGN.md 3); per-launch rows in roofline_levels"}
             result["roofline_kernels"] = {k: dict(v, share=v["us"] / tot_us) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"])}
             if not fixed and not dp.exchange:
@@ -684,6 +780,11 @@ def main():
                 if tj.get("build_id") == csrc_build_id() and tj.get("kernel") == name:
                     result["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
                     result["roofline"]["traffic_unit"] = "bytes per launch, mean over the kernel's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % tj.get("source", "profiles/")
+                    # the counters cannot be read from inside this process: the figure is a committed artefact of a rocprofv3 --pmc run of this
+                    # same command on this same build (csrc hash checked above), NOT a measurement of this run
+                    result["roofline"]["traffic_source"] = "profiles/dominant_kernel_traffic_cfg%d.json (%s; not this run)" % (args.config, tj.get("source", "rocprofv3 --pmc"))
+                else:
+                    result["roofline"]["traffic_source"] = "none for this build (profiles/dominant_kernel_traffic_cfg%d.json is from build %s)" % (args.config, tj.get("build_id"))
             except (OSError, KeyError, ValueError):
                 pass
         else:

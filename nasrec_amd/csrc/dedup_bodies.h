@@ -43,7 +43,11 @@ __device__ __forceinline__ int dd_block_excl_scan(int v, int* sh, int* total) {
 __device__ __forceinline__ void dedup_ids_small_body(const nasrec_dedup_ids_desc_t& d, const int64_t* idx, int B, int Fs, int f, int* sidx, int* sh) {
   const int b = threadIdx.x;
   const bool live = b < B;
-  const int my = live ? (int)idx[(long)b * Fs + f] : -1 - b;  // dead lanes get unique negative ids
+  // ids are compared as 32-bit values (tables have < 2^31 rows: engine.py).  An id outside [0, 2^31) is out of range for every table —
+  // the gather has raised the oob flag and the apply never writes outside a table — but narrowed it could collide with a valid id, with
+  // a dead lane's synthetic id or with -1: such a sample gets a unique negative id of its own (a run of one that the apply skips).
+  const int64_t raw = live ? idx[(long)b * Fs + f] : 0;
+  const int my = !live ? -1 - b : ((raw >= 0 && raw <= 0x7fffffffL) ? (int)raw : (int)0x80000000u + b);  // dead lanes get unique negative ids
   sidx[b] = my;
   __syncthreads();
   const int4* s4 = reinterpret_cast<const int4*>(sidx);
@@ -116,7 +120,8 @@ __device__ __forceinline__ void dedup_ids_pairs_body(const nasrec_dedup_ids_desc
 #pragma unroll
   for (int u = 0; u < NASREC_DEDUP_IDS_MAX_B / 256; ++u) {
     const int i = u * 256 + t;
-    v[u] = i < B ? (int)idx[(long)i * Fs + f] : -1;
+    const int64_t raw = i < B ? idx[(long)i * Fs + f] : -1;
+    v[u] = (raw >= 0 && raw <= 0x7fffffffL) ? (int)raw : -1;  // (an id outside [0, 2^31) is in no table: treated like a sample that does not exist, see dedup_ids_small_body)
   }
   for (int i = t; i < DD_HASH; i += 256) {
     hkey[i] = -1;

@@ -785,7 +785,6 @@ class SupernetEngine:
             cp.fwd.run(sp)
         return cp.logits.view(B, 1)
 
-    @_on_device
     def prefers_graph(self, B: int) -> bool:
         """graph = None: replay the captured step, or launch its program?  A level-scheduled step (fixed sub-network, batch <= 256) is
         ~27 launches issued by ONE host call (nasrec_program_run: ~3 us each, the host stays far ahead of a 0.25 ms step), and every
@@ -795,6 +794,7 @@ class SupernetEngine:
         has more to do between steps — the training harness with its data pipe — is better off replaying: SuperNet.engine_train_step.)"""
         return not (self.level_schedule and self.cfg.fixed and B <= 256) or os.environ.get("NASREC_STEP_GRAPH", "auto") == "1"
 
+    @_on_device
     def train_step(self, int_x, cat_x, y, lr: float, choice=None, clip: Optional[float] = 5.0, eps: float = 1e-2, graph: Optional[bool] = False,
                    staged: bool = False):
         """zero_grad -> forward -> BCE -> backward -> clip_grad_norm_ -> Adagrad (train_utils.py:262-286).

@@ -356,8 +356,10 @@ class DataParallelStep:
     def _exchange_step(self, plan):
         """forward, backward in segments, the exchange under it, the optimizer over the global batch — the same sequence for fixed
         sub-networks and sampled paths, eager (work handles) or under graph capture.
-          ids          all-gather right after staging: hidden under the whole forward / backward; behind it, on a side stream, the
-                       id-only half of the global batch's row dedup (leaders, duplicate lists: csrc/dedup_bodies.h) — beside the
+          ids          all-gather right after staging: hidden under the whole forward / backward.  The id-only half of the global
+                       batch's row dedup (leaders, duplicate lists: csrc/dedup_bodies.h) runs where NASREC_DP_IDS_MODE says: "main"
+                       (the default) = on the compute stream right in front of the optimizer, exposed (a fork to a second stream inside a
+                       captured graph cost ~40 us on this stack, more than the launch); "side" / "chain" = on a side stream beside the
                        forward, off the step's tail;
           dense grads  one all-reduce per (segment, arena range) as soon as the segment that completes the range has been
                        enqueued — RCCL's stream waits for that point of the compute stream only, the rest of the backward runs
@@ -467,6 +469,10 @@ class DataParallelStep:
         for w in pending:
             if w is not None:
                 w.wait()
+        if self.ids_half is not None:
+            # global batch <= NASREC_DEDUP_SPLIT_MAX_B: the optimizer program is [OPT_REDUCE2, OPT_APPLY] only and reads the leaders /
+            # run lists the id half writes for THIS batch — it is the caller's launch (as in _exchange_step), behind the ids all-gather
+            self.ids_half()
         self.opt(plan, spans=union)
         plan.union = union
 
@@ -567,8 +573,12 @@ class EngineDP:
                 for k in shared:
                     if hasattr(holder, k):
                         setattr(h, k, getattr(holder, k))
-                tab = plan.cp.arena.alloc(len(flat), torch.int64).tensor() if getattr(plan.cp, "arena", None) is not None else \
-                    torch.empty(len(flat), dtype=torch.int64, device=eng.device)
+                # ONE table per plan, reused by every step (the union changes with the other ranks' paths: the table is rewritten in
+                # stream order by the program's first launches) and regrown only when a larger union arrives — never out of the plan's
+                # bump arena, which lives as long as the cached plan and would grow by a table per step
+                tab = getattr(plan, "union_tab", None)
+                if tab is None or tab.numel() < len(flat):
+                    tab = plan.union_tab = torch.empty(max(len(flat), 2 * (tab.numel() if tab is not None else 0)), dtype=torch.int64, device=eng.device)
                 h.chunk_tab, h.nchunks = tab, len(flat) // 2
                 prog = Program(P.const_i64_descs(tab.data_ptr(), flat) + eng._optimizer_descs(h, Bg, cat_all, sg_all, clip, eps, rank_layout=rank_layout))
                 prog.holder = h

@@ -202,7 +202,7 @@ class ShardedTableStep:
         self.world = tables.world
         self.last_norm = None
         self.graph = bool(graph) and _os.environ.get("NASREC_SHARDED_GRAPH", "1") != "0"  # (env: A/B knob)
-        self._g = None  # (key, CUDAGraph, static inputs, loss)
+        self._g = None  # (key, CUDAGraph, static inputs, loss, the choice object it was captured for)
         self._calls = 0
 
     def step(self, int_x, cat_x, y, lr, choice=None):
@@ -212,22 +212,39 @@ class ShardedTableStep:
         self._calls += 1
         if self._calls == 1:  # the first step runs eagerly: plans are compiled, communicators created, work buffers allocated
             return self._step(int_x, cat_x, y, lr, choice)
-        key = (id(choice), tuple(int_x.shape), tuple(cat_x.shape), int_x.dtype)
+        # keyed on the CONTENT of the choice (a caller that rebuilds an equal dict every step must not re-capture every step, and a
+        # recycled id() after a collection must not replay another choice's graph); `is` = the fast path of an unchanged object
+        if self._g is not None and self._g[4] is choice and self._g[0][1:] == (tuple(int_x.shape), tuple(cat_x.shape), int_x.dtype):
+            key = self._g[0]
+        else:
+            import json
+            from .engine import _jsonable
+            key = (json.dumps(choice, sort_keys=True, default=_jsonable), tuple(int_x.shape), tuple(cat_x.shape), int_x.dtype)
         if self._g is None or self._g[0] != key:
             static = (torch.empty_like(int_x), torch.empty_like(cat_x), torch.empty_like(y), torch.zeros(1, dtype=torch.float32, device=dev))
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
+            ok, loss = True, None
             try:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     loss = self._step(static[0], static[1], static[2], static[3], choice)
-                self._g = (key, g, static, loss)
             except Exception as e:  # noqa: BLE001
                 import warnings
                 warnings.warn("row-sharded step: graph capture failed (%s); running eagerly" % (e,))
                 torch.cuda.synchronize(dev)
+                ok = False
+            if self.world > 1:
+                # every rank replays or every rank runs eagerly: a rank that fell back alone would issue its collectives from the host
+                # while the others issue theirs from a graph replay — the same sequence, but a capture that failed HALFWAY has already
+                # left the ranks' communicators out of step; agree on the outcome (MIN) before anybody chooses
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.tables.group)
+                ok = bool(int(flag.item()))
+            if not ok:
                 self.graph = False
                 return self._step(int_x, cat_x, y, lr, choice)
-        _, g, static, loss = self._g
+            self._g = (key, g, static, loss, choice)
+        _, g, static, loss, _ = self._g
         static[0].copy_(int_x, non_blocking=True)
         static[1].copy_(cat_x, non_blocking=True)
         static[2].copy_(y.reshape(static[2].shape), non_blocking=True)

@@ -105,3 +105,123 @@ def test_two_ranks_on_one_gpu_equal_one_process_at_the_global_batch(case, pack, 
     # the rank's own mean): their average is the global mean
     for t in range(steps):
         assert abs(0.5 * (r0["losses"][t] + r1["losses"][t]) - ref_losses[t]) <= 1e-4 * max(1.0, abs(ref_losses[t])), (t, r0["losses"][t], r1["losses"][t], ref_losses[t])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# paths="per-rank" on the REAL engine (round 6; the advisor's finding on round 5: `_per_rank_step` never launched the id half of the
+# row dedup, so at global batches <= NASREC_DEDUP_SPLIT_MAX_B the optimizer read leaders / run lists of an earlier batch — the mode
+# had only ever run with the CPU stand-in, whose `ids_half` is None).  Two ranks on one GPU, each with its own sampled path per step;
+# expected: the fp64 oracle evaluating path r on half r, gradients summed over the ranks, clip + Adagrad over the union.
+# ------------------------------------------------------------------------------------------------------------------
+PER_RANK_CASE, PER_RANK_STEPS = "supernet_xlarge_any", 3
+
+
+def _per_rank_choices(meta, same):
+    import json
+    import numpy as np
+    from helpers import oracle_cfg
+    from oracle import nasrec_oracle as O
+    cfg = oracle_cfg(meta)
+    out = []
+    for r in range(WORLD):
+        np.random.seed(977 + (0 if same else r))
+        sampler = O.PathSampler(cfg, "default", "binomial-0.5")
+        out.append([json.loads(json.dumps(sampler.sample(), default=lambda o: o.tolist() if hasattr(o, "tolist") else o.item()))
+                    for _ in range(PER_RANK_STEPS)])
+    return out
+
+
+def _per_rank_worker(rank, port, same, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from helpers import GOLDEN, load_golden
+    from nasrec_amd.parallel import DataParallelStep
+    from test_parity_gpu import build_engine
+    z, meta = load_golden(os.path.join(GOLDEN, PER_RANK_CASE + ".npz"))
+    int_x, cat_x, y = (torch.tensor(a).cuda() for a in _inputs(z, meta, 0))
+    Bl = int_x.shape[0] // WORLD
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    eng = build_engine(z, meta)
+    dp = DataParallelStep(eng, None, Bl, clip=5.0, eps=1e-2, graph=False, paths="per-rank")
+    choices = _per_rank_choices(meta, same)
+    arena0 = None
+    arena_sizes = []
+    for s in range(PER_RANK_STEPS):
+        dp.step(int_x[sl].contiguous(), cat_x[sl].contiguous(), y[sl].contiguous(), meta["lr"], choice=choices[rank][s])
+        torch.cuda.synchronize()
+    # a cached plan's arena must not grow with the number of steps it has run (the union's chunk table is allocated once per plan)
+    plan = dp._last[1]
+    arena = getattr(plan.cp, "arena", None)
+    used = (lambda: int(arena.used_bytes()) if arena is not None else None)
+    before = used()
+    for _ in range(4):
+        dp.step(int_x[sl].contiguous(), cat_x[sl].contiguous(), y[sl].contiguous(), 0.0, choice=choices[rank][PER_RANK_STEPS - 1])
+    torch.cuda.synchronize()
+    eng.check_indices()
+    out[rank] = dict(params={k: v.cpu() for k, v in eng.state_dict().items()}, ids_half=dp.ids_half is not None, arena=(before, used()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("same", [True, False])
+def test_per_rank_paths_on_the_engine_match_the_fp64_oracle(same):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import GOLDEN, load_golden, oracle_cfg, oracle_params
+    from oracle import nasrec_oracle as O
+    z, meta = load_golden(os.path.join(GOLDEN, PER_RANK_CASE + ".npz"))
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_per_rank_worker, args=(port, same, out), nprocs=WORLD, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["ids_half"], "a global batch this small takes the two-halves row dedup: the id half is the caller's launch"
+    assert r0["arena"][0] == r0["arena"][1], "the plan's arena grew while a cached plan was re-run: %s" % (r0["arena"],)
+    for k in r0["params"]:
+        assert torch.equal(r0["params"][k], r1["params"][k]), "replicas differ: %s" % k
+    # fp64 oracle: path r on half r, loss = mean over the GLOBAL batch
+    cfg = oracle_cfg(meta)
+    P = oracle_params(meta)
+    choices = _per_rank_choices(meta, same)
+    if not same:
+        import json
+        assert any(json.dumps(a) != json.dumps(b) for a, b in zip(choices[0], choices[1])), "the two ranks should train different paths"
+    int_x, cat_x, y = (torch.tensor(a) for a in _inputs(z, meta, 0))
+    int_x, y = int_x.double(), y.double().view(-1)
+    Bg = int_x.shape[0]
+    Bl = Bg // WORLD
+    names = list(P.keys())
+    state = {}
+    for s in range(PER_RANK_STEPS):
+        total = {}
+        for r in range(WORLD):
+            sl = slice(r * Bl, (r + 1) * Bl)
+            leaves = {k: v.detach().requires_grad_(True) for k, v in P.items()}
+            Pl = O.Params(P.dtype, frozen=True)
+            Pl.update(leaves)
+            logits = O.supernet_forward(Pl, cfg, int_x[sl], cat_x[sl], choices[r][s], num_embeddings=meta["tables"])
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), y[sl], reduction="sum") / Bg
+            grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
+            for k, g in zip(names, grads):
+                if g is not None:
+                    total[k] = total[k] + g if k in total else g.clone()
+        norm = torch.sqrt(sum(g.pow(2).sum() for g in total.values()))
+        coef = min(1.0, 5.0 / (float(norm) + 1e-6))
+        with torch.no_grad():
+            for k, g in total.items():
+                st = state.setdefault(k, torch.zeros_like(P[k]))
+                O.adagrad_step_(P[k], g * coef, st, meta["lr"], 1e-2)
+    bad = []
+    for k, v in P.items():
+        got = r0["params"][k].double().reshape(v.shape)
+        scale = max(1.0, float(v.abs().max()))
+        err = float((got - v).abs().max())
+        if err > 1e-4 * scale:
+            bad.append((k, err))
+    assert not bad, bad[:8]

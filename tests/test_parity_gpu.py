@@ -270,7 +270,7 @@ def test_data_parallel_code_path_single_rank():
                 assert len(dp._plans) == 1
                 plan = dp._last[1]
                 assert isinstance(plan.step_graph, torch.cuda.CUDAGraph), "the exchange step should be captured as one graph"
-                assert dp.ids_half is not None, "the id-only half of the row dedup should run beside the forward"
+                assert dp.ids_half is not None, "a global batch this small takes the two-halves row dedup (its id half is a launch of the exchange step: NASREC_DP_IDS_MODE)"
                 # the last pieces' dense gradients ride in the row-gradient all-gather: the pieces in front of them are all-reduced
                 assert dp.tail_n == sum(n for _, rg in plan.segments[plan.first_packed:] for _, n in rg) and 0 < dp.tail_n <= 65536
                 assert 1 <= plan.first_packed < len(plan.segments)
@@ -304,6 +304,58 @@ def test_data_parallel_code_path_single_rank():
         for k in outs[0]:
             assert torch.allclose(outs[0][k], outs[1][k], rtol=0, atol=1e-6), k
             assert torch.equal(outs[1][k], outs[2][k]), k  # the library's one-rank collectives move the same bits as the copy
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
+
+
+def test_exchange_step_falls_back_to_eager_when_the_capture_is_refused(monkeypatch):
+    """The N-rank batch-256 step is captured into ONE graph with RCCL's collectives inside (parallel._capture); whether RCCL on N
+    ranks accepts that capture has never been observed (no multi-GPU box in six rounds).  If the platform refuses, the step must
+    run eagerly — work handles, the same sequence — and land on the SAME bits.  Here the refusal is forced: torch.cuda.graph raises
+    inside the capture, with the real collectives on."""
+    import warnings
+    import torch.distributed as dist
+    from helpers import GOLDEN
+    from nasrec_amd import parallel
+    from nasrec_amd.parallel import DataParallelStep
+    z, meta = load_golden(os.path.join(GOLDEN, "fixed_criteo_xlarge.npz"))
+    int_x, cat_x, y = torch.tensor(z["int_x"]).cuda(), torch.tensor(z["cat_x"]).cuda(), torch.tensor(z["y"]).cuda().view(-1)
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29543", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        outs = []
+        for refuse in (False, True):
+            eng = build_engine(z, meta)
+            if refuse:
+                class Refused:
+                    def __init__(self, *a, **kw):
+                        pass
+
+                    def __enter__(self):
+                        raise RuntimeError("capture refused (forced by the test)")
+
+                    def __exit__(self, *a):
+                        return False
+                monkeypatch.setattr(parallel.torch.cuda, "graph", Refused)
+            dp = DataParallelStep(eng, dict(meta["choice"]), int_x.shape[0], clip=5.0, eps=1e-2, graph=True, force_exchange=True, real_collectives=True)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                for _ in range(3):
+                    dp.step(int_x, cat_x, y, lr=0.05)
+            torch.cuda.synchronize()
+            plan = dp._last[1]
+            if refuse:
+                monkeypatch.undo()
+                assert plan.step_graph is False, "the refused capture must leave the plan on the eager exchange"
+                assert any("capture" in str(w.message) for w in caught), "the fallback must be announced, not silent"
+            else:
+                assert isinstance(plan.step_graph, torch.cuda.CUDAGraph)
+            eng.check_indices()
+            outs.append(eng.state_dict())
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]), "eager fallback differs from the captured step: %s" % k
     finally:
         if own_pg:
             dist.destroy_process_group()
