@@ -200,3 +200,46 @@ def test_supernet_sampled_path_forward_and_backward_against_the_oracle(name):
     _compare(name, eng, cp, B, Fs, cat_x, *ref, floor=floor)
     del model, eng, cp
     torch.cuda.empty_cache()
+
+
+def test_search_point_batch_512_last_layer_only_against_the_oracle():
+    """The search loop's operating point (scripts/run_ea/criteo_run_ea_from_supernet_xlarge.sh; eval_subnet_from_supernet.py:114-120): the
+    Criteo xlarge supernet with LayerNorm, one pinned candidate path, batch 512, `set_mode_to_finelune_last_only` — through the drop-in
+    module exactly as the harness drives it (forward, BCEWithLogitsLoss, backward).  Against the fp64 oracle on the same batch: logits of
+    all 512 samples, the loss, d loss / d `_final.weight` and `_final.bias`; every other parameter's .grad stays None (the engine launches
+    only the weight part of the final-logit backward: `cp.bwd_final_only`)."""
+    from test_supernet_fullsize_gpu import _build, _jsonable
+    model, c, ds, tables, _, _, _ = _build("cfg3_criteo_xlarge_b4096", seed=5)
+    eng = model._engine
+    Fs, B = ds["Fs"], 512
+    int_x, cat_x, y = O.synthetic_batch(B, ds["Fd"], tables, seed=97531)
+    int_x, cat_x, y = int_x.cuda(), cat_x.cuda(), y.view(-1, 1).cuda()
+    model.configure_path_sampling_strategy("fixed-path")  # the candidate: one path, drawn once and pinned
+    choice = _jsonable(model._resolve_choice(None))
+    assert _jsonable(model._resolve_choice(None)) == choice, "fixed-path: the same candidate at every step"
+    model.set_mode_to_finelune_last_only()
+    model.zero_grad()
+    logits = model(int_x, cat_x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    cp = eng._last_plan[2]
+    ocfg = O.NetCfg(7, O.ops_config_lib[c["space"]], True, "relu", fixed=False)
+    ref_logits, ref_loss, ref_dense, _, _ = _oracle_step(eng, cp.used_params, ocfg, int_x, cat_x, y.view(-1), choice, Fs)
+    scale = max(1.0, float(ref_logits.abs().max()))
+    lerr = float((logits.detach().double().cpu().view(-1) - ref_logits).abs().max())
+    assert lerr <= 1e-5 * scale, "logit err %.3e (scale %.2f)" % (lerr, scale)
+    assert abs(float(loss) - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if name.startswith("_final."):
+            g = ref_dense[name]
+            assert p.grad is not None, name
+            rel = float((p.grad.detach().double().cpu().reshape(g.shape) - g).abs().max()) / max(float(g.abs().max()), 1e-30)
+            worst = max(worst, rel)
+            assert rel <= GRAD_REL[256] * 4, "%s: %.3e of its largest entry" % (name, rel)
+        else:
+            assert p.grad is None, "last-layer-only mode wrote a gradient for %s" % name
+    _report("search_point_criteo_xlarge_b512_last_only", dict(B=B, logit_err=lerr, logit_scale=scale, worst_final_grad_rel=worst))
+    del model, eng, cp
+    torch.cuda.empty_cache()

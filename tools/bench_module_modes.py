@@ -7,12 +7,12 @@ sys.path.insert(0, ROOT)
 import torch
 from nasrec_amd.supernet.supernet import SuperNet, ops_config_lib
 from nasrec_amd.utils.config import NUM_EMBEDDINGS_CRITEO
-from oracle import nasrec_oracle as O
+import bench
 
 ca = json.load(open(os.path.join(ROOT, "nasrec_amd", "configs", "criteo", "ea_criteo_kaggle_xlarge_best_1shot.json")))
 m = SuperNet(num_blocks=ca["num_blocks"], ops_config=ops_config_lib[ca["config"]], use_layernorm=False, num_embeddings=NUM_EMBEDDINGS_CRITEO,
              sparse_input_size=26, path_sampling_strategy="fixed-path", fixed=True, fixed_choice=ca).cuda()
-int_x, cat_x, y = [t.cuda() for t in O.synthetic_batch(256, 13, NUM_EMBEDDINGS_CRITEO, seed=1)]
+int_x, cat_x, y = bench.synthetic_batches(1, 256, 13, NUM_EMBEDDINGS_CRITEO, "cuda", 1)[0]
 y = y.view(-1, 1)
 with torch.no_grad():
     m(int_x, cat_x)

@@ -10,6 +10,10 @@
 //              reached G (sc1 poll by one lane + barrier), handed-off bytes are stored write-through (sc0 sc1) and loaded sc1
 //   fine       ONE launch; a workgroup waits for the flags of ITS two producers only (a dependency DAG instead of levels)
 //   fence      as `level`, with plain loads / stores and agent-scope release / acquire fences instead of sc1 accesses
+//   item       as `level` (a workgroup waits for ALL of phase p-1), but nobody polls the counter: every finishing workgroup adds to it,
+//              the one whose add returns G - 1 (the last arriver) stores the epoch into REPL replica flags on lines of their own, and
+//              a waiting workgroup polls ONE replica (w % REPL): the completion mechanism a dependency DAG of ITEMS would use
+//              (per-item arrival counter + replicated done flags; here with the coarsest possible dependencies)
 // `--skew S`: every 8th workgroup does S x the arithmetic (a level is as slow as its slowest item; only `fine` can run ahead of it).
 // Forward progress of the one-launch forms relies on in-order dispatch of workgroup ids (a workgroup only waits for lower ids); every
 // spin is bounded by a wall-clock budget and raises a flag instead of hanging.  All four forms must produce the same bits.
@@ -21,7 +25,8 @@
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-enum { M_LAUNCHES = 0, M_LEVEL = 1, M_FINE = 2, M_FENCE = 3 };
+enum { M_LAUNCHES = 0, M_LEVEL = 1, M_FINE = 2, M_FENCE = 3, M_ITEM = 4 };
+#define REPL 32  // replica flags per phase in the `item` form, one 128-byte line each
 #define TM 32
 #define TK 128
 #define TN 64
@@ -32,6 +37,7 @@ struct Args {
   const float* W;      // [TK][TN]
   unsigned* cnt;       // [P + 1] per-phase arrival counters (monotonic over runs)
   unsigned* flag;      // [P + 1][G] per-workgroup epochs
+  unsigned* rep;       // [P + 1][REPL][32] replica flags of the `item` form
   unsigned* err;       // spin budget exceeded
   int P, G, rows, skew;
   unsigned epoch;      // run number + 1
@@ -71,6 +77,12 @@ __global__ __launch_bounds__(256, 3) void seam_kernel(const Args a) {
           __builtin_amdgcn_s_sleep(2);
           if (wall_clock64() - t0 > SPIN_BUDGET_TICKS) { atomicExch(a.err, 1u); break; }
         }
+      } else if (MODE == M_ITEM) {
+        const unsigned* f0 = a.rep + ((size_t)(p - 1) * REPL + (w % REPL)) * 32;
+        while (__hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+          __builtin_amdgcn_s_sleep(2);
+          if (wall_clock64() - t0 > SPIN_BUDGET_TICKS) { atomicExch(a.err, 1u); break; }
+        }
       } else {
         const unsigned want = a.epoch * (unsigned)G;
         while (__hip_atomic_load(a.cnt + (p - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -92,7 +104,7 @@ __global__ __launch_bounds__(256, 3) void seam_kernel(const Args a) {
     for (int i = 0; i < TM * TK / 4 / 256; ++i) {
       const int e = tid + 256 * i, row = e / (TK / 4), c4 = e % (TK / 4);
       f32x4 v;
-      if (MODE == M_LEVEL || MODE == M_FINE)
+      if (MODE == M_LEVEL || MODE == M_FINE || MODE == M_ITEM)
         v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, 16 * e, 0, 16));
       else
         v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, 16 * e, 0, 0));
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(256, 3) void seam_kernel(const Args a) {
       v0[j] = tanhf(acc[j]);  // (bounded values through 24 phases)
       v1[j] = tanhf(acc[4 + j]);
     }
-    const int aux = (MODE == M_LEVEL || MODE == M_FINE) ? 17 : 0;  // sc0 sc1: write-through
+    const int aux = (MODE == M_LEVEL || MODE == M_FINE || MODE == M_ITEM) ? 17 : 0;  // sc0 sc1: write-through
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v0), ro, 4 * (r * TK + c), 0, aux);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v1), ro, 4 * (r * TK + c + 4), 0, aux);
   }
@@ -141,8 +153,15 @@ __global__ __launch_bounds__(256, 3) void seam_kernel(const Args a) {
       }
       if (MODE == M_FINE)
         __hip_atomic_store(a.flag + (size_t)p * G + w, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else
+      else if (MODE != M_ITEM)
         __hip_atomic_fetch_add(a.cnt + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (MODE == M_ITEM && tid < 64) {  // (wave 0: lane 0 arrives; if it was the last one, lanes 0 .. REPL-1 publish the replicas with one store instruction)
+      unsigned old = 0;
+      if (tid == 0) old = __hip_atomic_fetch_add(a.cnt + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if (old == a.epoch * (unsigned)G - 1u && tid < REPL)
+        __hip_atomic_store(a.rep + ((size_t)p * REPL + tid) * 32, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -197,6 +216,8 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&a.cnt, (P + 1) * 4));
   CK(hipMalloc(&a.flag, (size_t)(P + 1) * G * 4));
   CK(hipMalloc(&a.err, 4));
+  CK(hipMalloc(&a.rep, (size_t)(P + 1) * REPL * 32 * 4));
+  CK(hipMemset(a.rep, 0, (size_t)(P + 1) * REPL * 32 * 4));
   CK(hipMemset(a.cnt, 0, (P + 1) * 4));
   CK(hipMemset(a.flag, 0, (size_t)(P + 1) * G * 4));
   CK(hipMemset(a.err, 0, 4));
@@ -210,10 +231,10 @@ int main(int argc, char** argv) {
   hipStream_t st;
   CK(hipStreamCreate(&st));
   std::vector<float> ref, got((size_t)rows * TK);
-  const char* names[4] = {"launches", "level", "fine", "fence"};
+  const char* names[5] = {"launches", "level", "fine", "fence", "item"};
   printf("seam probe: %d phases x %d workgroups of 256 threads, skew %d, %d timed runs each\n", P, G, skew, reps);
   unsigned epoch = 0;
-  for (int mode = 0; mode < 4; ++mode) {
+  for (int mode = 0; mode < 5; ++mode) {
     // poison everything but phase 0, so that a stale or early read shows
     CK(hipMemset(a.X, 0xff, xn * 4));
     CK(hipMemcpy(a.X, h0.data(), h0.size() * 4, hipMemcpyHostToDevice));
@@ -221,8 +242,9 @@ int main(int argc, char** argv) {
     int bad_runs = 0;
     for (int r = 0; r < reps + 5; ++r) {
       a.epoch = ++epoch;
-      if (mode == M_LEVEL || mode == M_FENCE) {  // the counters are per form: reset them so that epoch * G is the target
+      if (mode == M_LEVEL || mode == M_FENCE || mode == M_ITEM) {  // the counters are per form: reset them so that epoch * G is the target
         CK(hipMemsetAsync(a.cnt, 0, (P + 1) * 4, st));
+        if (mode == M_ITEM) CK(hipMemsetAsync(a.rep, 0, (size_t)(P + 1) * REPL * 32 * 4, st));
         a.epoch = 1;
       }
       CK(hipMemsetAsync(a.X + (size_t)rows * TK, 0xff, (xn - (size_t)rows * TK) * 4, st));  // poison every phase's output before every run: a stale or early read shows as NaN bits
@@ -231,6 +253,7 @@ int main(int argc, char** argv) {
         case M_LAUNCHES: us = run_once<M_LAUNCHES>(a, st); break;
         case M_LEVEL: us = run_once<M_LEVEL>(a, st); break;
         case M_FINE: us = run_once<M_FINE>(a, st); break;
+        case M_ITEM: us = run_once<M_ITEM>(a, st); break;
         default: us = run_once<M_FENCE>(a, st); break;
       }
       if (r >= 5) {

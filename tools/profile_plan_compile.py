@@ -9,7 +9,7 @@ import torch
 from nasrec_amd import _lib as L, plan as P
 from nasrec_amd.engine import Arena
 from nasrec_amd.search_space import ops_config_lib
-from oracle import nasrec_oracle as O
+from nasrec_amd.supernet.supernet import SuperNet
 
 space = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "xlarge"
 B, Fd, Fs = 4096, 13, 26
@@ -28,9 +28,14 @@ params = {n: flat_p[o:o + int(np.prod(shapes[n]))].view(shapes[n]) for n, o in o
 grads = {n: flat_g[o:o + int(np.prod(shapes[n]))].view(shapes[n]) for n, o in offsets.items()}
 arena = Arena("cpu")
 PCACHE = {}
-ocfg = O.NetCfg(7, O.ops_config_lib[space], True, "relu", fixed=False)
+# paths from the drop-in module's own sampler (host-side bookkeeping: no engine, no GPU)
+_m = SuperNet(num_blocks=7, ops_config=ops_config_lib[space], use_layernorm=True, num_embeddings=[10] * Fs, sparse_input_size=Fs,
+              path_sampling_strategy="default", fixed=False, anypath_choice="binomial-0.5")
 np.random.seed(0)
-sampler = O.PathSampler(ocfg, "default", "binomial-0.5")
+
+
+class sampler:
+    sample = staticmethod(lambda: _m._resolve_choice(None))
 
 
 def compile_once(choice):
