@@ -653,6 +653,11 @@ int nasrec_opt_reduce2(void* stream, const nasrec_opt_reduce2_desc_t* d);
 int nasrec_final_fused(void* stream, const nasrec_final_desc_t* d);
 int nasrec_worklist(void* stream, const nasrec_worklist_desc_t* d);
 
+/* Uncached device memory (hipExtMallocWithFlags(hipDeviceMallocUncached)): the plan arena of a persistent step (NASREC_OP_PERSIST) —
+ * buffers that one workgroup of a launch writes and another workgroup of the SAME launch reads.  The caller owns the memory. */
+int nasrec_alloc_uncached(int64_t bytes, void** out);
+int nasrec_free_uncached(void* p);
+
 /* HIP-event timing on an arbitrary stream (bench.py measures kernels on the engine's own stream). */
 int nasrec_event_create(void** ev);
 int nasrec_event_record(void* ev, void* stream);

@@ -226,7 +226,7 @@ SYMBOLS = [
     "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense", "nasrec_adagrad_rows", "nasrec_opt_reduce",
     "nasrec_opt_apply", "nasrec_worklist", "nasrec_dedup_ids", "nasrec_opt_reduce2", "nasrec_final_fused", "nasrec_event_create",
     "nasrec_event_record", "nasrec_event_elapsed_ms", "nasrec_event_destroy", "nasrec_last_error", "nasrec_abi_version",
-    "nasrec_desc_sizes", "nasrec_tsv_parse",
+    "nasrec_desc_sizes", "nasrec_tsv_parse", "nasrec_alloc_uncached", "nasrec_free_uncached",
 ]
 
 _lib = None
@@ -259,14 +259,16 @@ def load():
     lib.nasrec_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(f32)]
     lib.nasrec_event_destroy.argtypes = [vp]
     lib.nasrec_desc_sizes.argtypes = [C.POINTER(i32), C.c_int]
+    lib.nasrec_alloc_uncached.argtypes = [i64, C.POINTER(vp)]
+    lib.nasrec_free_uncached.argtypes = [vp]
     lib.nasrec_tsv_parse.argtypes = [vp, i64, i32, i32, vp, i64, vp, vp, vp, C.POINTER(i64), C.POINTER(i32)]
     lib.nasrec_tsv_parse.restype = i64
     for name in ("nasrec_gemm", "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm",
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
                  "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_worklist", "nasrec_dedup_ids", "nasrec_opt_reduce2", "nasrec_final_fused"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 14:
-        raise EngineError("ABI version mismatch: library %d, binding 14" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 15:
+        raise EngineError("ABI version mismatch: library %d, binding 15" % lib.nasrec_abi_version())
     sizes = (i32 * 40)()
     n = lib.nasrec_desc_sizes(sizes, 40)
     for kind, cls in DESC_BY_KIND.items():

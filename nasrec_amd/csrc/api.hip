@@ -157,6 +157,23 @@ TYPED(nasrec_dedup_ids, nasrec_dedup_ids_desc_t, kind == NASREC_OP_DEDUP_IDS)
 TYPED(nasrec_opt_reduce2, nasrec_opt_reduce2_desc_t, kind == NASREC_OP_OPT_REDUCE2)
 TYPED(nasrec_final_fused, nasrec_final_desc_t, kind == NASREC_OP_FINAL_FUSED)
 
+// Device memory that the XCDs' L2 caches do not hold (MTYPE uncached): plain stores go through to memory, and a plain load behind an
+// agent-scope acquire (buffer_inv sc1: the CU's L1) reads what another workgroup of the SAME launch stored — what the persistent step
+// kernel (csrc/persist.hip) needs of every buffer that one of its items writes and another reads (tools/micro/seam_probe.hip `uc`).
+int nasrec_alloc_uncached(int64_t bytes, void** out) {
+  void* p = nullptr;
+  hipError_t rc = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
+  if (rc != hipSuccess) return nasrec_set_error((int)rc, "hipExtMallocWithFlags(%lld, uncached): %s", (long long)bytes, hipGetErrorString(rc));
+  *out = p;
+  return 0;
+}
+
+int nasrec_free_uncached(void* p) {
+  hipError_t rc = hipFree(p);
+  if (rc != hipSuccess) return nasrec_set_error((int)rc, "hipFree: %s", hipGetErrorString(rc));
+  return 0;
+}
+
 int nasrec_event_create(void** ev) {
   hipEvent_t e;
   hipError_t rc = hipEventCreate(&e);
@@ -186,7 +203,7 @@ int nasrec_event_destroy(void* ev) {
 
 const char* nasrec_last_error(void) { return g_err; }
 
-int nasrec_abi_version(void) { return 14; }
+int nasrec_abi_version(void) { return 15; }
 
 int nasrec_desc_sizes(int32_t* out, int n) {
   static const int32_t sizes[] = {

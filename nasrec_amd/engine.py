@@ -98,6 +98,20 @@ class ArenaRef:
         return getattr(self.tensor(), name)
 
 
+class _RawDeviceBytes:
+    """n bytes of device memory at ptr, as the CUDA array interface torch.as_tensor understands (zero-copy; the tensor keeps this object
+    alive).  The memory is the arena's: freed by Arena.__del__ through free()."""
+
+    def __init__(self, ptr, n):
+        self.ptr, self.n = int(ptr), int(n)
+        self.__cuda_array_interface__ = {"shape": (self.n,), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def free(self):
+        if self.ptr:
+            L.load().nasrec_free_uncached(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+
 class Arena:
     """Device memory of one plan slot: buffers are bump-allocated out of a few large chunks that live as long as the engine, so
     compiling a plan costs no allocator calls (a sampled supernet path almost never repeats: every step compiles a plan with
@@ -106,19 +120,45 @@ class Arena:
 
     CHUNK = 256 << 20  # bytes
 
-    def __init__(self, device):
+    def __init__(self, device, uncached: bool = False):
+        """uncached: the chunks are UNCACHED device memory (nasrec_alloc_uncached; wrapped as torch tensors through the CUDA array
+        interface, freed with the arena): the arena of a persistent step, whose items hand buffers to each other inside one launch"""
         self.device = device
+        self.uncached = bool(uncached)
         self.chunks: List[torch.Tensor] = []
         self.base: List[int] = []
         self.cur, self.off = 0, 0
+        self._owned = []
 
     def reset(self):
         self.cur, self.off = 0, 0
 
     def _grow(self, nbytes):
-        c = torch.empty(max(self.CHUNK, nbytes), dtype=torch.uint8, device=self.device)
+        n = max(self.CHUNK, nbytes) if not self.uncached else max(64 << 20, (nbytes + (1 << 20) - 1) & ~((1 << 20) - 1))
+        if self.uncached:
+            with torch.cuda.device(self.device):
+                ptr = C.c_void_p()
+                L.check(L.load().nasrec_alloc_uncached(n, C.byref(ptr)))
+            holder = _RawDeviceBytes(ptr.value, n)
+            self._owned.append(holder)
+            c = torch.as_tensor(holder, device=self.device)
+            assert c.data_ptr() == ptr.value and c.numel() == n and c.dtype == torch.uint8
+        else:
+            c = torch.empty(n, dtype=torch.uint8, device=self.device)
         self.chunks.append(c)
         self.base.append(c.data_ptr())
+
+    def ranges(self):
+        """[(first byte, one past the last)] of the arena's chunks"""
+        return [(b, b + c.numel()) for b, c in zip(self.base, self.chunks)]
+
+    def __del__(self):
+        try:
+            self.chunks = []
+            for h in self._owned:
+                h.free()
+        except Exception:
+            pass
 
     def alloc(self, numel: int, dtype=torch.float32) -> ArenaRef:
         numel = int(numel)
@@ -142,6 +182,9 @@ class Arena:
         """grow to at least nbytes now (one allocator call per chunk, outside any timed or latency-sensitive region)"""
         while sum(c.numel() for c in self.chunks) < nbytes:
             self._grow(self.CHUNK)
+
+
+_UC_ARENA = os.environ.get("NASREC_UC_ARENA", "0") == "1"
 
 
 def _on_device(fn):
@@ -309,6 +352,8 @@ class SupernetEngine:
             self._last_plan = (fast, choice, self._plans[key])
             return self._plans[key]
         arena = None
+        if self.cfg.fixed and _UC_ARENA and B <= 256 and train:
+            arena = Arena(self.device, uncached=True)  # (A/B knob NASREC_UC_ARENA=1: the fixed plan's buffers in uncached memory)
         if not self.cfg.fixed:
             # Sampled paths rarely repeat: a small cache of plan slots, each with its own arena.  Evicting a plan needs no device
             # synchronisation: its slot is reused by a plan whose kernels are enqueued, in stream order, behind the evicted one's
@@ -466,7 +511,7 @@ class SupernetEngine:
                     cp.step.capture(self.stream.cuda_stream)
             elif graph:
                 cp.fwd.capture(self.stream.cuda_stream)
-        if graph or arena is None:
+        if graph or arena is None or cfg.fixed:
             self.stream.synchronize()  # these plans are built (zero-filled, captured) on the private stream, and replayed on the caller's
         self._plans[key] = cp
         self._last_plan = (fast, choice, cp)

@@ -363,9 +363,14 @@ class SyntheticPipe:
         g = torch.Generator().manual_seed(self.seed)
         B, s = self.batch_size, self.spec
         for _ in range(self.steps):
-            int_x = torch.zeros(B, s.Fd) if s.dense_is_zero else torch.log(torch.randint(0, 1000, (B, s.Fd), generator=g).float() + 1.0)
-            cat_x = torch.stack([torch.randint(0, int(n), (B,), generator=g) for n in s.tables], dim=1)
-            y = (torch.rand(B, 1, generator=g) < 0.25).float()
+            # (the float math in numpy: on a many-core host a torch CPU elementwise op over a few thousand elements costs milliseconds —
+            # `torch.log` of a [512, 13] tensor took 15 ms per batch on the 1-GPU boxes, 10 s of a 12 s candidate fine-tune of the search loop)
+            if s.dense_is_zero:
+                int_x = torch.zeros(B, s.Fd)
+            else:
+                int_x = torch.from_numpy(np.log(torch.randint(0, 1000, (B, s.Fd), generator=g).numpy().astype(np.float32) + np.float32(1.0)))
+            cat_x = torch.from_numpy(np.stack([torch.randint(0, int(n), (B,), generator=g).numpy() for n in s.tables], axis=1))
+            y = torch.from_numpy((torch.rand(B, 1, generator=g).numpy() < 0.25).astype(np.float32))
             yield int_x, cat_x, y
 
 

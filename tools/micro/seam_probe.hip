@@ -14,10 +14,19 @@
 //              the one whose add returns G - 1 (the last arriver) stores the epoch into REPL replica flags on lines of their own, and
 //              a waiting workgroup polls ONE replica (w % REPL): the completion mechanism a dependency DAG of ITEMS would use
 //              (per-item arrival counter + replicated done flags; here with the coarsest possible dependencies)
+//   inv        as `fine`, write-through (sc0 sc1) stores but PLAIN loads behind an agent-scope acquire (buffer_inv sc1: this CU's L1)
+//   uc         as `fine` on UNCACHED device memory (hipExtMallocWithFlags(hipDeviceMallocUncached)): plain stores, plain loads behind
+//              the acquire — the form that would need no change to the operator bodies at all
+//   uc_sc1     uncached memory, plain stores, sc1 loads, no acquire
+//   flags      coarse dependencies like `item` (wait for ALL of phase p-1) without any atomic: every finishing workgroup stores ITS flag,
+//              a waiting workgroup's wave 0 sweeps all G flags of the phase with 64-lane sc1 loads until every one carries the epoch
+// Every one-launch form PRE-READS its input tile with plain loads before it waits (values discarded): the tile then still holds the
+// poison of the memset, so this CU's L1 and this XCD's L2 hold stale lines of exactly the bytes the hand-off must deliver — a form that
+// returns them shows up in `wrong bits`.
 // `--skew S`: every 8th workgroup does S x the arithmetic (a level is as slow as its slowest item; only `fine` can run ahead of it).
 // Forward progress of the one-launch forms relies on in-order dispatch of workgroup ids (a workgroup only waits for lower ids); every
-// spin is bounded by a wall-clock budget and raises a flag instead of hanging.  All four forms must produce the same bits.
-//   hipcc -O3 --offload-arch=gfx950 -o seam_probe seam_probe.hip && ./seam_probe [--skew 3] [--phases 24] [--groups 512]
+// spin is bounded by a wall-clock budget and raises a flag instead of hanging.  All forms must produce the same bits.
+//   hipcc -O3 --offload-arch=gfx950 -o seam_probe seam_probe.hip && ./seam_probe [--skew 3] [--phases 24] [--groups 512] [--modes 0,2,4,5,6,7]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -25,7 +34,7 @@
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-enum { M_LAUNCHES = 0, M_LEVEL = 1, M_FINE = 2, M_FENCE = 3, M_ITEM = 4 };
+enum { M_LAUNCHES = 0, M_LEVEL = 1, M_FINE = 2, M_FENCE = 3, M_ITEM = 4, M_INV = 5, M_UC = 6, M_UC_SC1 = 7, M_FLAGS = 8, M_COUNT = 9 };
 #define REPL 32  // replica flags per phase in the `item` form, one 128-byte line each
 #define TM 32
 #define TK 128
@@ -35,10 +44,11 @@ enum { M_LAUNCHES = 0, M_LEVEL = 1, M_FINE = 2, M_FENCE = 3, M_ITEM = 4 };
 struct Args {
   float* X;            // [P + 1][rows][TK]
   const float* W;      // [TK][TN]
-  unsigned* cnt;       // [P + 1] per-phase arrival counters (monotonic over runs)
+  unsigned* cnt;       // [P + 1] per-phase arrival counters
   unsigned* flag;      // [P + 1][G] per-workgroup epochs
   unsigned* rep;       // [P + 1][REPL][32] replica flags of the `item` form
   unsigned* err;       // spin budget exceeded
+  float* sink;         // pre-read results land here (never true)
   int P, G, rows, skew;
   unsigned epoch;      // run number + 1
   int phase0;          // M_LAUNCHES: the phase this launch runs
@@ -50,6 +60,10 @@ template <int MODE>
 __global__ __launch_bounds__(256, 3) void seam_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) float sx[TM * (TK + 4)];
   __shared__ __attribute__((aligned(16))) float sw[TK * TN];
+  constexpr bool SC1_LD = MODE == M_LEVEL || MODE == M_FINE || MODE == M_ITEM || MODE == M_UC_SC1 || MODE == M_FLAGS;
+  constexpr bool SC1_ST = MODE == M_LEVEL || MODE == M_FINE || MODE == M_ITEM || MODE == M_INV || MODE == M_FLAGS;
+  constexpr bool ACQ = MODE == M_FENCE || MODE == M_INV || MODE == M_UC;
+  constexpr bool PER_WG = MODE == M_FINE || MODE == M_INV || MODE == M_UC || MODE == M_UC_SC1;  // per-producer flags
   const int tid = threadIdx.x;
   const int G = a.G, nrb = G / 2;
   int p, w;
@@ -68,9 +82,26 @@ __global__ __launch_bounds__(256, 3) void seam_kernel(const Args a) {
   // the weight panel does not depend on anybody: stage it before waiting
   for (int i = tid; i < TK * TN / 4; i += 256) reinterpret_cast<f32x4*>(sw)[i] = reinterpret_cast<const f32x4*>(a.W)[i];
   if (MODE != M_LAUNCHES && p > 1) {
-    if (tid == 0) {
+    {  // pre-read: plant (possibly stale) lines of the input tile in this CU's L1 and this XCD's L2
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < TM * TK / 4 / 256; ++i) s += reinterpret_cast<const f32x4*>(xin)[tid + 256 * i];
+      if (s[0] == 123456.f && s[1] == 654321.f) a.sink[tid] = s[2] + s[3];
+    }
+    if (MODE == M_FLAGS && tid < 64) {  // wave 0 sweeps the G flags of phase p - 1, 64 at a time
       const unsigned long long t0 = wall_clock64();
-      if (MODE == M_FINE) {
+      const unsigned* fl = a.flag + (size_t)(p - 1) * G;
+      for (;;) {
+        bool ok = true;
+        for (int i = tid; i < G; i += 64) ok = ok && __hip_atomic_load(fl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > SPIN_BUDGET_TICKS) { if (tid == 0) atomicExch(a.err, 1u); break; }
+      }
+    }
+    if (tid == 0 && MODE != M_FLAGS) {
+      const unsigned long long t0 = wall_clock64();
+      if (PER_WG) {
         const unsigned* f0 = a.flag + (size_t)(p - 1) * G + 2 * irb;
         while (__hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch ||
                __hip_atomic_load(f0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
@@ -90,24 +121,20 @@ __global__ __launch_bounds__(256, 3) void seam_kernel(const Args a) {
           if (wall_clock64() - t0 > SPIN_BUDGET_TICKS) { atomicExch(a.err, 1u); break; }
         }
       }
-      if (MODE == M_FENCE) {
+      if (ACQ) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
     __syncthreads();
   }
-  // stage the input tile: 32 x 128 floats, 16-byte loads (sc1 in the one-launch sc1 forms: every load of handed-off bytes)
+  // stage the input tile: 32 x 128 floats, 16-byte loads (sc1 in the sc1 forms: every load of handed-off bytes)
   {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, TM * TK * 4, 0x00020000);
 #pragma unroll
     for (int i = 0; i < TM * TK / 4 / 256; ++i) {
       const int e = tid + 256 * i, row = e / (TK / 4), c4 = e % (TK / 4);
-      f32x4 v;
-      if (MODE == M_LEVEL || MODE == M_FINE || MODE == M_ITEM)
-        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, 16 * e, 0, 16));
-      else
-        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, 16 * e, 0, 0));
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, 16 * e, 0, SC1_LD ? 16 : 0));
       *reinterpret_cast<f32x4*>(&sx[row * (TK + 4) + 4 * c4]) = v;
     }
   }
@@ -139,7 +166,7 @@ __global__ __launch_bounds__(256, 3) void seam_kernel(const Args a) {
       v0[j] = tanhf(acc[j]);  // (bounded values through 24 phases)
       v1[j] = tanhf(acc[4 + j]);
     }
-    const int aux = (MODE == M_LEVEL || MODE == M_FINE || MODE == M_ITEM) ? 17 : 0;  // sc0 sc1: write-through
+    constexpr int aux = SC1_ST ? 17 : 0;  // sc0 sc1: write-through
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v0), ro, 4 * (r * TK + c), 0, aux);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v1), ro, 4 * (r * TK + c + 4), 0, aux);
   }
@@ -151,7 +178,7 @@ __global__ __launch_bounds__(256, 3) void seam_kernel(const Args a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      if (MODE == M_FINE)
+      if (PER_WG || MODE == M_FLAGS)
         __hip_atomic_store(a.flag + (size_t)p * G + w, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else if (MODE != M_ITEM)
         __hip_atomic_fetch_add(a.cnt + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -200,22 +227,37 @@ static float run_once(Args a, hipStream_t st) {
 
 int main(int argc, char** argv) {
   int P = 24, G = 512, skew = 1, reps = 200;
+  bool on[M_COUNT];
+  for (int m = 0; m < M_COUNT; ++m) on[m] = true;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--skew")) skew = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--phases")) P = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--groups")) G = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--modes")) {
+      for (int m = 0; m < M_COUNT; ++m) on[m] = false;
+      for (char* t = strtok(argv[++i], ","); t; t = strtok(nullptr, ",")) on[atoi(t) % M_COUNT] = true;
+      on[M_LAUNCHES] = true;  // (the reference bits)
+    }
   }
   const int rows = G / 2 * TM;
   const size_t xn = (size_t)(P + 1) * rows * TK;
   Args a{};
   a.P = P, a.G = G, a.rows = rows, a.skew = skew;
-  CK(hipMalloc(&a.X, xn * 4));
+  float *Xc = nullptr, *Xu = nullptr;
+  CK(hipMalloc(&Xc, xn * 4));
+  if (hipExtMallocWithFlags((void**)&Xu, xn * 4, hipDeviceMallocUncached) != hipSuccess) {
+    printf("hipExtMallocWithFlags(hipDeviceMallocUncached) is refused on this box: the uc forms are skipped\n");
+    Xu = nullptr;
+    (void)hipGetLastError();
+    on[M_UC] = on[M_UC_SC1] = false;
+  }
   float* W;
   CK(hipMalloc(&W, TK * TN * 4));
   CK(hipMalloc(&a.cnt, (P + 1) * 4));
   CK(hipMalloc(&a.flag, (size_t)(P + 1) * G * 4));
   CK(hipMalloc(&a.err, 4));
+  CK(hipMalloc(&a.sink, 256 * 4));
   CK(hipMalloc(&a.rep, (size_t)(P + 1) * REPL * 32 * 4));
   CK(hipMemset(a.rep, 0, (size_t)(P + 1) * REPL * 32 * 4));
   CK(hipMemset(a.cnt, 0, (P + 1) * 4));
@@ -231,10 +273,12 @@ int main(int argc, char** argv) {
   hipStream_t st;
   CK(hipStreamCreate(&st));
   std::vector<float> ref, got((size_t)rows * TK);
-  const char* names[5] = {"launches", "level", "fine", "fence", "item"};
-  printf("seam probe: %d phases x %d workgroups of 256 threads, skew %d, %d timed runs each\n", P, G, skew, reps);
+  const char* names[M_COUNT] = {"launches", "level", "fine", "fence", "item", "inv", "uc", "uc_sc1", "flags"};
+  printf("seam probe: %d phases x %d workgroups of 256 threads, skew %d, %d timed runs each (one-launch forms pre-read their inputs)\n", P, G, skew, reps);
   unsigned epoch = 0;
-  for (int mode = 0; mode < 5; ++mode) {
+  for (int mode = 0; mode < M_COUNT; ++mode) {
+    if (!on[mode]) continue;
+    a.X = (mode == M_UC || mode == M_UC_SC1) ? Xu : Xc;
     // poison everything but phase 0, so that a stale or early read shows
     CK(hipMemset(a.X, 0xff, xn * 4));
     CK(hipMemcpy(a.X, h0.data(), h0.size() * 4, hipMemcpyHostToDevice));
@@ -254,6 +298,10 @@ int main(int argc, char** argv) {
         case M_LEVEL: us = run_once<M_LEVEL>(a, st); break;
         case M_FINE: us = run_once<M_FINE>(a, st); break;
         case M_ITEM: us = run_once<M_ITEM>(a, st); break;
+        case M_INV: us = run_once<M_INV>(a, st); break;
+        case M_UC: us = run_once<M_UC>(a, st); break;
+        case M_UC_SC1: us = run_once<M_UC_SC1>(a, st); break;
+        case M_FLAGS: us = run_once<M_FLAGS>(a, st); break;
         default: us = run_once<M_FENCE>(a, st); break;
       }
       if (r >= 5) {

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--train_batch_size", type=int, default=512)
     ap.add_argument("--test_batch_size", type=int, default=8192)
     ap.add_argument("--cap", type=int, default=0, help="cap the tables (0 = the full 33.76 M rows)")
+    ap.add_argument("--profile", action="store_true", help="cProfile of the LAST candidate's call (host time by function)")
     a = ap.parse_args()
 
     from nasrec_amd import eval_subnet_from_supernet as E
@@ -97,7 +98,19 @@ def main():
         phase.clear()
         torch.cuda.synchronize()
         t = time.perf_counter()
+        prof = None
+        if a.profile and c == a.candidates - 1:
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         res = SU._create_model_train_and_get_results(argparse.Namespace(**vars(args)), 0, E.finetune_and_eval_one_model, tok, choice, ckpt, {"beta": 0.0})
+        if prof is not None:
+            prof.disable()
+            import io
+            import pstats
+            buf = io.StringIO()
+            pstats.Stats(prof, stream=buf).sort_stats("cumulative").print_stats(45)
+            print(buf.getvalue())
         torch.cuda.synchronize()
         total = time.perf_counter() - t
         tr = phase.get("train_and_test", 0.0) - phase.get("test", 0.0)
