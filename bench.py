@@ -139,6 +139,8 @@ def time_desc(lib, L, stream_ptr, desc, iters=200):
 
 def launch_kernel_name(L, P, d):
     """the device kernel a descriptor launches (as rocprofv3 names it, template arguments shortened)"""
+    if isinstance(d, L.PersistDesc):
+        return "persist_kernel<%s>" % ("true" if d.big else "false")
     if isinstance(d, L.WorklistDesc):
         return "worklist_kernel<%s>" % ("true" if any(n.desc.kind == L.OP_MHA_BWD for n in d.nodes) else "false")  # csrc/worklist.hip:143-146
     if isinstance(d, L.GemmDesc):
@@ -161,7 +163,7 @@ def launch_work(L, S, d, n_dense=0):
     vector-ALU bodies — Transformer, FM, DotProduct cores — count 0: the MFMA roof is about the matrix pipe); bytes = every operand
     / result window of every item once (schedule.desc_io, the footprints the level scheduler itself trusts; split-K slabs written by the
     main pass and read back by the second pass included)"""
-    nodes = d.nodes if isinstance(d, L.WorklistDesc) else [S.Node(d)]
+    nodes = d.nodes if isinstance(d, (L.WorklistDesc, L.PersistDesc)) else [S.Node(d)]
     names = {getattr(L, n): n[3:] for n in dir(L) if n.startswith("OP_")}
     fl, by, items = 0.0, 0, []
     # kinds outside the scheduler's model (they are never reordered): staging + gather, the optimizer's launches
@@ -729,6 +731,7 @@ def main():
                                                "frac_of_hbm_peak": B * Fs * 128 / us / 1e3 / HBM_PEAK_GBS}
 
         # ---- the largest GEMM launch of the (last) step's plan, fp32 MFMA bound ---------------------------------------------
+        allg = [d for d in P.iter_ops(cp.fwd.descs + cp.bwd.descs) if isinstance(d, L.GemmDesc)]  # (of the CURRENT plan: the leg above re-compiled it)
         dom = max(allg, key=gemm_flops)
         ms = time_desc(lib, L, sp, dom, iters=200 if fixed else 30)
         fl = gemm_flops(dom)

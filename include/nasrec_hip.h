@@ -82,7 +82,8 @@ enum {
   NASREC_OP_SPLITK_EPILOGUES = 32,
   NASREC_OP_DEDUP_IDS = 33,
   NASREC_OP_OPT_REDUCE2 = 34,
-  NASREC_OP_FINAL_FUSED = 35
+  NASREC_OP_FINAL_FUSED = 35,
+  NASREC_OP_PERSIST = 36
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -622,8 +623,64 @@ typedef struct nasrec_worklist_desc {
 } nasrec_worklist_desc_t;
 
 /* ------------------------------------------------------------------------------------------------
+ * Persistent step (batch <= 256, round 6): the worklist items of MANY levels in ONE launch, ordered topologically, with the
+ * dependencies between them resolved inside the kernel instead of by kernel boundaries.  A level launch lasts as long as its slowest
+ * item; here an item starts as soon as the items it depends on (read-after-write, write-after-read, write-after-write on the
+ * scheduler's footprints) have finished, whatever else is still running.
+ *   * item k owns the workgroups [first_k, first_k + nblk_k) of the launch; workgroups are dispatched in index order, and a workgroup
+ *     only ever waits for items with smaller workgroup indices, so every wait ends (a bounded spin raises `err[0]` instead of hanging);
+ *   * completion: every finishing workgroup drains its stores and adds to one of up to 8 arrival counters of its item (shard = its index
+ *     in the item mod 8); the last arriver of a shard adds to the item's top counter; the last of those stores the step's epoch into
+ *     NASREC_PS_REPL replica flags (one 128-byte line each); a waiting workgroup polls ONE replica of each of its <= NASREC_PS_MAX_DEPS
+ *     dependencies (one lane per dependency).  No counter is ever reset: the epoch is the item's own counter divided by its size;
+ *   * visibility: every buffer an item hands to another item of the same launch must live in UNCACHED device memory
+ *     (nasrec_alloc_uncached: plain stores go through to memory), and a workgroup that waited runs an agent-scope acquire (its CU's L1)
+ *     before its body — the bodies are the worklist's, unchanged (tools/micro/seam_probe.hip form `uc`).  The caller (schedule.py)
+ *     checks the footprints of every dependency edge against the arena's address ranges.
+ * The item table, the descriptor blob and the chunk index live in device memory (written by nasrec_persist_prepare, once per plan);
+ * descriptors have the worklist's formats and truncation rule.
+ * ---------------------------------------------------------------------------------------------- */
+#define NASREC_PS_MAX_DEPS 8
+#define NASREC_PS_REPL 16
+#define NASREC_PS_SHARDS 8
+#define NASREC_PS_COUNTER_STRIDE 16   /* uint64 per counter line (128 bytes) */
+#define NASREC_PS_FLAG_STRIDE 32      /* uint32 per flag line (128 bytes) */
+typedef struct nasrec_persist_item {
+  int32_t kind, part, off;   /* as nasrec_wl_item_t; off = byte offset of the descriptor in the blob (multiple of 16) */
+  int32_t first, nblk;       /* prepare: workgroup range */
+  int32_t geom[3];           /* prepare: as nasrec_wl_item_t */
+  int32_t ndeps;
+  int32_t deps[NASREC_PS_MAX_DEPS];  /* item indices, all smaller than the item's own */
+  int32_t _pad[3];
+} nasrec_persist_item_t;     /* 80 bytes */
+
+typedef struct nasrec_persist_desc {
+  int32_t kind;          /* NASREC_OP_PERSIST */
+  int32_t n;             /* items */
+  int32_t total_blocks;  /* prepare */
+  int32_t blob_bytes;
+  /* device memory, owned by the caller, filled by nasrec_persist_prepare */
+  nasrec_persist_item_t* items;     /* [n] */
+  char* blob;                       /* [blob_bytes] */
+  uint16_t* chunk_item;             /* [chunk_cap]: the item that owns workgroup 16 c */
+  unsigned long long* counters;     /* [n][NASREC_PS_SHARDS + 1][NASREC_PS_COUNTER_STRIDE], zero-filled by prepare, never reset */
+  uint32_t* flags;                  /* [n][NASREC_PS_REPL][NASREC_PS_FLAG_STRIDE], zero-filled by prepare */
+  uint32_t* err;                    /* [4]: err[0] != 0 = a wait ran out of its budget (results invalid); [1] the item, [2] its dependency */
+  int32_t chunk_cap, big;           /* capacity of chunk_item (entries); prepare: big = a Transformer backward is among the items */
+  unsigned long long* trace;        /* device [total_blocks][4] or NULL: per workgroup the 100 MHz wall clock at entry, with its dependencies
+                                       satisfied, behind its body, behind its arrival (tools/persist_timeline.py) */
+  /* host memory, read by nasrec_persist_prepare only */
+  const nasrec_persist_item_t* host_items;
+  const char* host_blob;
+} nasrec_persist_desc_t;
+
+/* ------------------------------------------------------------------------------------------------
  * Entry points
  * ---------------------------------------------------------------------------------------------- */
+/* geometry of every item, workgroup ranges, chunk index; copies tables and descriptors to the device buffers of `d` and zero-fills its
+ * counters and flags (synchronous copies: once per plan, not per step).  Fills d->total_blocks / d->big. */
+int nasrec_persist_prepare(nasrec_persist_desc_t* d);
+
 /* Launch one op (any descriptor above) on `stream`. */
 int nasrec_launch(void* stream, const void* desc);
 /* Launch a program: n descriptors in order on `stream` (one host call per training step). */

@@ -33,7 +33,7 @@ ACT_BY_NAME = {"identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
  OP_COPY_SEGS, OP_GATE_BWD, OP_ROWSUM, OP_FINAL_FWD, OP_BCE, OP_FINAL_BWD, OP_EMB_DEDUP, OP_SUMSQ, OP_CLIP_COEF,
  OP_ADAGRAD_DENSE, OP_ADAGRAD_ROWS, OP_MEMSET, OP_LAYERNORM_FWD, OP_LAYERNORM_BWD, OP_ADD_SEGS, OP_SCALE,
  OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY, OP_WORKLIST, OP_CONST_I64, OP_SPLITK_EPILOGUES, OP_DEDUP_IDS,
- OP_OPT_REDUCE2, OP_FINAL_FUSED) = range(1, 36)
+ OP_OPT_REDUCE2, OP_FINAL_FUSED, OP_PERSIST) = range(1, 37)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -208,6 +208,19 @@ class WorklistDesc(C.Structure):
                 ("blob", C.c_char * WL_BLOB_BYTES)]
 
 
+PS_MAX_DEPS, PS_REPL, PS_SHARDS, PS_COUNTER_STRIDE, PS_FLAG_STRIDE = 8, 16, 8, 16, 32  # NASREC_PS_*
+
+
+class PersistItem(C.Structure):
+    _fields_ = [("kind", i32), ("part", i32), ("off", i32), ("first", i32), ("nblk", i32), ("geom", i32 * 3), ("ndeps", i32),
+                ("deps", i32 * PS_MAX_DEPS), ("_pad", i32 * 3)]
+
+
+class PersistDesc(C.Structure):
+    _fields_ = [("kind", i32), ("n", i32), ("total_blocks", i32), ("blob_bytes", i32), ("items", vp), ("blob", vp), ("chunk_item", vp),
+                ("counters", vp), ("flags", vp), ("err", vp), ("chunk_cap", i32), ("big", i32), ("trace", vp), ("host_items", vp), ("host_blob", vp)]
+
+
 DESC_BY_KIND = {
     OP_GEMM: GemmDesc, OP_EMBED_GATHER: EmbedDesc, OP_DOT_TRI_FWD: DotTriDesc, OP_DOT_TRI_BWD: DotTriDesc, OP_FM_FWD: FmDesc,
     OP_FM_BWD: FmDesc, OP_MHA_FWD: MhaDesc, OP_MHA_BWD: MhaDesc, OP_REDUCE_ROWS: ReduceRowsDesc, OP_COPY_SEGS: CopySegsDesc,
@@ -216,7 +229,7 @@ DESC_BY_KIND = {
     OP_ADAGRAD_ROWS: AdagradRowsDesc, OP_MEMSET: MemsetDesc, OP_LAYERNORM_FWD: LayerNormDesc, OP_LAYERNORM_BWD: LayerNormDesc,
     OP_SCALE: ScaleDesc, OP_ACT_BWD: ActBwdDesc, OP_STAGE_INPUTS: StageDesc, OP_OPT_REDUCE: OptReduceDesc, OP_OPT_APPLY: OptApplyDesc,
     OP_WORKLIST: WorklistDesc, OP_CONST_I64: ConstI64Desc, OP_SPLITK_EPILOGUES: SplitkEpiloguesDesc, OP_DEDUP_IDS: DedupIdsDesc,
-    OP_OPT_REDUCE2: OptReduce2Desc, OP_FINAL_FUSED: FinalDesc,
+    OP_OPT_REDUCE2: OptReduce2Desc, OP_FINAL_FUSED: FinalDesc, OP_PERSIST: PersistDesc,
 }
 
 # every symbol include/nasrec_hip.h declares
@@ -226,7 +239,7 @@ SYMBOLS = [
     "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense", "nasrec_adagrad_rows", "nasrec_opt_reduce",
     "nasrec_opt_apply", "nasrec_worklist", "nasrec_dedup_ids", "nasrec_opt_reduce2", "nasrec_final_fused", "nasrec_event_create",
     "nasrec_event_record", "nasrec_event_elapsed_ms", "nasrec_event_destroy", "nasrec_last_error", "nasrec_abi_version",
-    "nasrec_desc_sizes", "nasrec_tsv_parse", "nasrec_alloc_uncached", "nasrec_free_uncached",
+    "nasrec_desc_sizes", "nasrec_tsv_parse", "nasrec_alloc_uncached", "nasrec_free_uncached", "nasrec_persist_prepare",
 ]
 
 _lib = None
@@ -261,6 +274,7 @@ def load():
     lib.nasrec_desc_sizes.argtypes = [C.POINTER(i32), C.c_int]
     lib.nasrec_alloc_uncached.argtypes = [i64, C.POINTER(vp)]
     lib.nasrec_free_uncached.argtypes = [vp]
+    lib.nasrec_persist_prepare.argtypes = [vp]
     lib.nasrec_tsv_parse.argtypes = [vp, i64, i32, i32, vp, i64, vp, vp, vp, C.POINTER(i64), C.POINTER(i32)]
     lib.nasrec_tsv_parse.restype = i64
     for name in ("nasrec_gemm", "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm",
@@ -275,6 +289,8 @@ def load():
         if kind >= n or sizes[kind] != C.sizeof(cls):
             raise EngineError("struct layout mismatch for op kind %d: library %d bytes, binding %d bytes"
                               % (kind, sizes[kind] if kind < n else -1, C.sizeof(cls)))
+    if n <= 37 or sizes[37] != C.sizeof(PersistItem):
+        raise EngineError("struct layout mismatch for nasrec_persist_item_t: library %d bytes, binding %d bytes" % (sizes[37] if n > 37 else -1, C.sizeof(PersistItem)))
     _lib = lib
     return lib
 

@@ -58,6 +58,7 @@ static int dispatch(hipStream_t st, const void* desc) {
     case NASREC_OP_ACT_BWD: return launch_act_bwd(st, (const nasrec_act_bwd_desc_t*)desc);
     case NASREC_OP_STAGE_INPUTS: return launch_stage(st, (const nasrec_stage_desc_t*)desc);
     case NASREC_OP_CONST_I64: return launch_const_i64(st, (const nasrec_const_i64_desc_t*)desc);
+    case NASREC_OP_PERSIST: return launch_persist(st, (const nasrec_persist_desc_t*)desc);
     case NASREC_OP_SPLITK_EPILOGUES: return launch_splitk_epilogues(st, (const nasrec_splitk_epilogues_desc_t*)desc);
     case NASREC_OP_OPT_REDUCE: return launch_opt_reduce(st, (const nasrec_opt_reduce_desc_t*)desc);
     case NASREC_OP_OPT_APPLY: return launch_opt_apply(st, (const nasrec_opt_apply_desc_t*)desc);
@@ -243,6 +244,8 @@ int nasrec_desc_sizes(int32_t* out, int n) {
       (int32_t)sizeof(nasrec_dedup_ids_desc_t),     // 33
       (int32_t)sizeof(nasrec_opt_reduce2_desc_t),   // 34
       (int32_t)sizeof(nasrec_final_desc_t),         // 35
+      (int32_t)sizeof(nasrec_persist_desc_t),       // 36
+      (int32_t)sizeof(nasrec_persist_item_t),       // 37 (not an op: the item record of NASREC_OP_PERSIST, for the binding's layout check)
   };
   const int total = (int)(sizeof(sizes) / sizeof(sizes[0]));
   int w = 0;

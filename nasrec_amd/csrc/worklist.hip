@@ -8,6 +8,9 @@
 // in the level), so that a CU still holds 3-4 workgroups of different items next to each other.  Descriptors travel in the kernel
 // arguments (a 3.6 KB blob; GEMM descriptors truncated behind their last segment): no dependent global read before the operands.
 #include <stdlib.h>
+#include <string.h>
+
+#include <vector>
 
 #include "worklist_body.h"
 
@@ -154,18 +157,8 @@ static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, i
   return 0;
 }
 
-int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
-  if (w->n < 1 || w->n > NASREC_WL_MAX_ITEMS) return nasrec_set_error(-2, "worklist: n=%d outside [1,%d]", w->n, NASREC_WL_MAX_ITEMS);
-  nasrec_worklist_desc_t wl = *w;
-  static const bool force_big = getenv("NASREC_WL_BIG") != nullptr && atoi(getenv("NASREC_WL_BIG")) != 0;  // A/B knob
-  bool big = force_big;
-  int first = 0;
-  for (int k = 0; k < wl.n; ++k) {
-    nasrec_wl_item_t& it = wl.item[k];
-    if (it.off < 0 || (it.off & 15) || it.off >= NASREC_WL_BLOB_BYTES) return nasrec_set_error(-2, "worklist: item %d offset %d", k, it.off);
-    const char* blob = wl.blob + it.off;
-    const int left = NASREC_WL_BLOB_BYTES - it.off;
-    it.first = first;
+// geometry of ONE item (nblk, geom) from its descriptor at `blob` (`left` bytes up to the end of the blob); big: a Transformer backward
+static int wl_item_geometry(nasrec_wl_item_t& it, const char* blob, int left, int k, bool& big) {
     it.nblk = 0;
     it.geom[0] = it.geom[1] = it.geom[2] = 0;
 #define WL_NEED(T) if ((int)sizeof(T) > left) return nasrec_set_error(-2, "worklist: item %d runs past the blob", k)
@@ -257,6 +250,25 @@ int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
         return nasrec_set_error(-2, "worklist: item %d has kind %d, which has no body in the worklist kernel", k, it.kind);
     }
 #undef WL_NEED
+  return 0;
+}
+
+int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
+  if (w->n < 1 || w->n > NASREC_WL_MAX_ITEMS) return nasrec_set_error(-2, "worklist: n=%d outside [1,%d]", w->n, NASREC_WL_MAX_ITEMS);
+  nasrec_worklist_desc_t wl = *w;
+  static const bool force_big = getenv("NASREC_WL_BIG") != nullptr && atoi(getenv("NASREC_WL_BIG")) != 0;  // A/B knob
+  bool big = force_big;
+  int first = 0;
+  for (int k = 0; k < wl.n; ++k) {
+    nasrec_wl_item_t& it = wl.item[k];
+    if (it.off < 0 || (it.off & 15) || it.off >= NASREC_WL_BLOB_BYTES) return nasrec_set_error(-2, "worklist: item %d offset %d", k, it.off);
+    const char* blob = wl.blob + it.off;
+    const int left = NASREC_WL_BLOB_BYTES - it.off;
+    it.first = first;
+    {
+      const int rc = wl_item_geometry(it, blob, left, k, big);
+      if (rc) return rc;
+    }
     first += it.nblk;
   }
   wl.total_blocks = first;
@@ -290,4 +302,254 @@ int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
                        pf[5], pm[0], pm[1], pm[2], pm[3], pm[4], pm[5], wl);
   }
   return nasrec_check_launch("worklist");
+}
+
+// ======================================================================================================================================
+// NASREC_OP_PERSIST (include/nasrec_hip.h): the items of many levels in ONE launch, dependencies resolved in the kernel.
+// ======================================================================================================================================
+#define PS_SPIN_BUDGET_TICKS 1000000ull  // 10 ms of the 100 MHz wall clock: a wait that long is a bug (or a lost workgroup), not a slow producer
+
+template <bool BIG>
+__device__ __forceinline__ void ps_run_item(int it_kind, int it_part, int g0, int g1, int g2, unsigned long long blob, int vb, int nblk, int nwg) {
+  float* lds = wl_lds;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  switch (it_kind) {
+    case NASREC_OP_GEMM: {
+      if (it_part == 2) {  // (units of one element per thread: a workgroup walks vb, vb + nwg, ...)
+        for (int u = vb; u < nblk; u += nwg) wl_gemm_second_pass(blob, u, g0);
+        break;
+      }
+      const int cfg = g2;  // tile | binding pair << 2 | mask operand << 4
+      if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 3 && g1 == 0) wl_dense_small_dx(blob, vb, g0);
+      else if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 3) wl_dense_small(blob, vb, g0, g1);
+      else if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 1) wl_token_fwd(blob, vb, g0);
+      else if ((cfg & 3) == WL_TOKS) wl_token_dx(blob, vb, g0);
+      else if ((cfg >> 4) & 1) wl_gemm_bind<true>((cfg >> 2) & 3, cfg & 3, blob, vb, g0, g1);
+      else wl_gemm_bind<false>((cfg >> 2) & 3, cfg & 3, blob, vb, g0, g1);
+      break;
+    }
+    case NASREC_OP_MHA_FWD:
+      wl_mha_fwd(blob, vb);
+      break;
+    case NASREC_OP_MHA_BWD:
+      if (BIG) mha_bwd_sample<4>(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
+      break;
+    case NASREC_OP_FM_FWD: {
+      const nasrec_fm_desc_t& d = wl_ref<nasrec_fm_desc_t>(blob);
+      const int b = vb * 4 + wave;
+      if (b < d.B) fm_fwd_sample(d, b, lane);
+      break;
+    }
+    case NASREC_OP_FM_BWD: {
+      const nasrec_fm_desc_t& d = wl_ref<nasrec_fm_desc_t>(blob);
+      const int b = vb * 4 + wave;
+      if (b < d.B) fm_bwd_sample(d, b, lane);
+      break;
+    }
+    case NASREC_OP_DOT_TRI_FWD: {
+      const nasrec_dot_tri_desc_t& d = wl_ref<nasrec_dot_tri_desc_t>(blob);
+      const int b = vb * 4 + wave;
+      if (b < d.B) dot_tri_fwd_sample(d, b, lane, lds + wave * (d.k1 * TRI_LD));
+      break;
+    }
+    case NASREC_OP_DOT_TRI_BWD: {
+      const nasrec_dot_tri_desc_t& d = wl_ref<nasrec_dot_tri_desc_t>(blob);
+      const int b = vb * 4 + wave;
+      const int P4 = (d.k1 * (d.k1 - 1) / 2 + 3) & ~3;
+      if (b < d.B) dot_tri_bwd_sample(d, b, lane, lds + wave * (d.k1 * TRI_LD), lds + 4 * (d.k1 * TRI_LD) + wave * P4);
+      break;
+    }
+    case NASREC_OP_COPY_SEGS: {
+      const nasrec_copy_segs_desc_t& d = wl_ref<nasrec_copy_segs_desc_t>(blob);
+      const int W = g0;
+      const long t = (long)vb * 256 + tid;
+      if (t < (long)d.B * W) copy_segs_element(d, (int)(t / W), (int)(t % W));
+      break;
+    }
+    case NASREC_OP_GATE_BWD:
+      gate_bwd_element(wl_ref<nasrec_gate_bwd_desc_t>(blob), (long)vb * 256 + tid);
+      break;
+    case NASREC_OP_REDUCE_ROWS:
+      reduce_rows_block(wl_ref<nasrec_wl_reduce_t>(blob), vb, tid, lds);
+      break;
+    case NASREC_OP_DEDUP_IDS: {
+      const nasrec_dedup_ids_desc_t& d = wl_ref<nasrec_dedup_ids_desc_t>(blob);
+      dedup_ids_small_body(d, d.idx, d.B, d.Fs, __builtin_amdgcn_readfirstlane(vb), reinterpret_cast<int*>(lds), reinterpret_cast<int*>(lds) + 256);
+      break;
+    }
+    case NASREC_OP_FINAL_FWD:
+      final_fwd_block(wl_ref<nasrec_final_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), lds);
+      break;
+    case NASREC_OP_FINAL_FUSED:
+      final_fused_block(wl_ref<nasrec_final_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), lds);
+      break;
+    case NASREC_OP_FINAL_BWD:
+      for (int u = vb; u < nblk; u += nwg) {
+        final_bwd_block(wl_ref<nasrec_final_desc_t>(blob), g0, g1, g2, __builtin_amdgcn_readfirstlane(u), lds);
+        if (u + nwg < nblk) __syncthreads();  // (the next unit reuses the LDS buffer)
+      }
+      break;
+    default:
+      break;
+  }
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(256, BIG ? 3 : 4) void persist_kernel(const nasrec_persist_item_t* __restrict__ items, const char* __restrict__ blob0,
+                                                                    const uint16_t* __restrict__ chunk_item, unsigned long long* counters,
+                                                                    uint32_t* flags, uint32_t* err, int n, int shard_above, unsigned long long* trace) {
+  const int bid = blockIdx.x, tid = threadIdx.x;
+  if (trace && tid == 0) trace[4 * (size_t)bid] = wall_clock64();
+  // the workgroup's item: chunk index, then a short scan (the tables are written once per plan: scalar loads, warm after the first few workgroups)
+  int k = __builtin_amdgcn_readfirstlane((int)chunk_item[bid >> 4]);
+  {
+    const nasrec_persist_item_t* __restrict__ tab = items;
+#pragma unroll 1
+    while (k + 1 < n && bid >= wl_ref<nasrec_persist_item_t>((unsigned long long)(tab + k + 1)).first) ++k;
+  }
+  const nasrec_persist_item_t& it = wl_ref<nasrec_persist_item_t>((unsigned long long)(items + k));
+  const int it_first = it.first, it_nblk = it.nblk, it_kind = it.kind, it_part = it.part, it_off = it.off, ndeps = it.ndeps, nsucc = it._pad[0];
+  const int it_nwg = it._pad[1], desc_bytes = it._pad[2];
+  const int g0 = it.geom[0], g1 = it.geom[1], g2 = it.geom[2];
+  const int wg = bid - it_first;  // this workgroup's index in its item: it runs the units wg, wg + nwg, ... < nblk
+  const bool tracked = ndeps > 0 || nsucc > 0;
+  const unsigned long long blob = (unsigned long long)blob0 + (unsigned)it_off;
+  // arrival bookkeeping of this workgroup: shard of its item's counters, the shard's size
+  const int NS = it_nwg > shard_above ? NASREC_PS_SHARDS : 1;  // (one arrival counter up to shard_above workgroups: ~12 ns per add on one address)
+  const int shard = wg % NS;
+  const unsigned long long shard_n = (unsigned long long)((it_nwg - shard + NS - 1) / NS);
+  unsigned long long* const cnt = counters + (size_t)k * (NASREC_PS_SHARDS + 1) * NASREC_PS_COUNTER_STRIDE;
+  if (ndeps > 0) {
+    if (tid < 64) {
+      // the step's epoch: this item's shard counter only ever holds whole epochs plus the arrivals of THIS epoch, and this workgroup's own
+      // arrival is still to come — floor(counter / shard size) is the number of completed steps
+      const unsigned long long c = __hip_atomic_load(cnt + shard * NASREC_PS_COUNTER_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int dep = tid < ndeps ? items[k].deps[tid] : -1;  // lane i polls dependency i
+      const uint32_t* f = flags + ((size_t)(dep < 0 ? 0 : dep) * NASREC_PS_REPL + (bid % NASREC_PS_REPL)) * NASREC_PS_FLAG_STRIDE;
+      uint32_t seen = dep < 0 ? 0u : __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (in flight together with the counter)
+      wl_warm_blob(blob, desc_bytes);  // the body's descriptor through the scalar cache while the polls are in flight
+      const uint32_t want = (uint32_t)(c / shard_n) + 1u;
+      const unsigned long long t0 = wall_clock64();
+      for (;;) {
+        const bool ok = dep < 0 || seen == want;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > PS_SPIN_BUDGET_TICKS) {
+          if (!ok) {
+            atomicExch(err, 1u);
+            err[1] = (uint32_t)k;
+            err[2] = (uint32_t)dep;
+          }
+          break;
+        }
+        if (dep >= 0) seen = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // what the dependencies stored is in (uncached) memory; this CU's L1 may still hold older lines of the same addresses
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
+  if (trace && tid == 0) trace[4 * (size_t)bid + 1] = wall_clock64();
+  // (no loop around the switch: with the bodies inside a loop the register allocator keeps their hoisted descriptor reads live across
+  // ALL of them — 168 registers, 300 spilled, a step three times slower.  Only the two kinds whose units are one element per thread walk
+  // several units per workgroup, in loops of their own inside ps_run_item.)
+  ps_run_item<BIG>(it_kind, it_part, g0, g1, g2, blob, wg, it_nblk, it_nwg);
+  if (trace) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) trace[4 * (size_t)bid + 2] = wall_clock64();
+  }
+  if (tracked) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left
+    __syncthreads();
+    if (tid < 64) {
+      unsigned long long old = 0;
+      if (tid == 0) old = __hip_atomic_fetch_add(cnt + shard * NASREC_PS_COUNTER_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(old >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)old);
+      bool last = (old + 1) % shard_n == 0;
+      const uint32_t e1 = (uint32_t)(old / shard_n) + 1u;
+      if (last && NS > 1) {
+        unsigned long long o2 = 0;
+        if (tid == 0) o2 = __hip_atomic_fetch_add(cnt + NASREC_PS_SHARDS * NASREC_PS_COUNTER_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        o2 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(o2 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)o2);
+        last = (o2 + 1) % (unsigned long long)NS == 0;
+      }
+      if (last && nsucc > 0 && tid < NASREC_PS_REPL)
+        __hip_atomic_store(flags + ((size_t)k * NASREC_PS_REPL + tid) * NASREC_PS_FLAG_STRIDE, e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (trace && tid == 0) trace[4 * (size_t)bid + 3] = wall_clock64();
+}
+
+int nasrec_persist_prepare(nasrec_persist_desc_t* d) {
+  if (!d || d->kind != NASREC_OP_PERSIST) return nasrec_set_error(-1, "persist: wrong descriptor kind");
+  if (d->n < 1 || d->n > 65535) return nasrec_set_error(-2, "persist: n=%d items", d->n);
+  if (!d->host_items || !d->host_blob) return nasrec_set_error(-2, "persist: a host table pointer is null");
+  const bool dry = !d->items;  // geometry only (no device): the workgroup ranges are written back into host_items (CPU tests, tools)
+  if (!dry && (!d->blob || !d->chunk_item || !d->counters || !d->flags || !d->err)) return nasrec_set_error(-2, "persist: a device table pointer is null");
+  std::vector<nasrec_persist_item_t> tab(d->host_items, d->host_items + d->n);
+  bool big = false;
+  int first = 0;
+  for (int k = 0; k < d->n; ++k) {
+    nasrec_persist_item_t& p = tab[k];
+    if (p.off < 0 || (p.off & 15) || p.off >= d->blob_bytes) return nasrec_set_error(-2, "persist: item %d offset %d", k, p.off);
+    if (p.ndeps < 0 || p.ndeps > NASREC_PS_MAX_DEPS) return nasrec_set_error(-2, "persist: item %d has %d dependencies", k, p.ndeps);
+    for (int q = 0; q < p.ndeps; ++q)
+      if (p.deps[q] < 0 || p.deps[q] >= k) return nasrec_set_error(-2, "persist: item %d depends on item %d (not an earlier one)", k, p.deps[q]);
+    nasrec_wl_item_t w;
+    w.kind = p.kind, w.part = p.part, w.off = p.off;
+    const int rc = wl_item_geometry(w, d->host_blob + p.off, d->blob_bytes - p.off, k, big);
+    if (rc) return rc;
+    if (w.nblk < 1) return nasrec_set_error(-2, "persist: item %d (kind %d) has no workgroups; the caller drops empty operators", k, p.kind);
+    // units per workgroup: an item of thousands of one-element-per-thread units (split-K second passes, the final-logit backward) runs
+    // as at most max_wg workgroups that walk their units — the wait / acquire / arrival of the protocol is paid per WORKGROUP
+    static const int max_wg = getenv("NASREC_PS_MAX_WG") ? atoi(getenv("NASREC_PS_MAX_WG")) : 512;
+    const bool walks = (p.kind == NASREC_OP_GEMM && p.part == 2) || p.kind == NASREC_OP_FINAL_BWD;  // (ps_run_item: the kinds with a unit loop)
+    const int upw = walks ? (w.nblk + max_wg - 1) / (max_wg > 0 ? max_wg : 1) : 1;
+    const int nwg = (w.nblk + upw - 1) / upw;
+    p.first = first, p.nblk = w.nblk;
+    p.geom[0] = w.geom[0], p.geom[1] = w.geom[1], p.geom[2] = w.geom[2];
+    p._pad[1] = nwg;
+    p._pad[2] = ((k + 1 < d->n ? d->host_items[k + 1].off : d->blob_bytes) - p.off + 63) & ~63;  // bytes of the descriptor (rounded up to the warm-up's step)
+    first += nwg;
+  }
+  // successors: an item nobody waits for publishes nothing
+  for (int k = 0; k < d->n; ++k) tab[k]._pad[0] = 0;
+  for (int k = 0; k < d->n; ++k)
+    for (int q = 0; q < tab[k].ndeps; ++q) tab[tab[k].deps[q]]._pad[0] += 1;
+  const int chunks = (first + 15) / 16;
+  if (!dry && chunks > d->chunk_cap) return nasrec_set_error(-2, "persist: %d workgroups need %d chunk entries, the table holds %d", first, chunks, d->chunk_cap);
+  std::vector<uint16_t> ci(chunks);
+  for (int c = 0, k = 0; c < chunks; ++c) {
+    while (k + 1 < d->n && 16 * c >= tab[k + 1].first) ++k;
+    ci[c] = (uint16_t)k;
+  }
+  d->total_blocks = first;
+  d->big = big ? 1 : 0;
+  if (dry) {
+    memcpy(const_cast<nasrec_persist_item_t*>(d->host_items), tab.data(), sizeof(nasrec_persist_item_t) * d->n);
+    return 0;
+  }
+  hipError_t rc = hipMemcpy(d->items, tab.data(), sizeof(nasrec_persist_item_t) * d->n, hipMemcpyHostToDevice);
+  if (rc == hipSuccess) rc = hipMemcpy(d->blob, d->host_blob, d->blob_bytes, hipMemcpyHostToDevice);
+  if (rc == hipSuccess) rc = hipMemcpy(d->chunk_item, ci.data(), sizeof(uint16_t) * chunks, hipMemcpyHostToDevice);
+  if (rc == hipSuccess) rc = hipMemset(d->counters, 0, sizeof(unsigned long long) * (size_t)d->n * (NASREC_PS_SHARDS + 1) * NASREC_PS_COUNTER_STRIDE);
+  if (rc == hipSuccess) rc = hipMemset(d->flags, 0, sizeof(uint32_t) * (size_t)d->n * NASREC_PS_REPL * NASREC_PS_FLAG_STRIDE);
+  if (rc == hipSuccess) rc = hipMemset(d->err, 0, sizeof(uint32_t) * 4);
+  if (rc != hipSuccess) return nasrec_set_error((int)rc, "persist: table upload: %s", hipGetErrorString(rc));
+  return 0;
+}
+
+int launch_persist(hipStream_t st, const nasrec_persist_desc_t* d) {
+  if (d->total_blocks < 1) return nasrec_set_error(-2, "persist: the descriptor has not been through nasrec_persist_prepare");
+  static const int shard_above = getenv("NASREC_PS_SHARD_ABOVE") ? atoi(getenv("NASREC_PS_SHARD_ABOVE")) : 64;  // A/B knob
+  if (d->big) {
+    hipLaunchKernelGGL(persist_kernel<true>, dim3((unsigned)d->total_blocks), dim3(256), sizeof(float) * WL_LDS_BIG_FLOATS, st, d->items, d->blob, d->chunk_item,
+                       d->counters, d->flags, d->err, d->n, shard_above, d->trace);
+  } else {
+    hipLaunchKernelGGL(persist_kernel<false>, dim3((unsigned)d->total_blocks), dim3(256), sizeof(float) * WL_LDS_FLOATS, st, d->items, d->blob, d->chunk_item,
+                       d->counters, d->flags, d->err, d->n, shard_above, d->trace);
+  }
+  return nasrec_check_launch("persist");
 }

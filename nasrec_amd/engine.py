@@ -99,17 +99,20 @@ class ArenaRef:
 
 
 class _RawDeviceBytes:
-    """n bytes of device memory at ptr, as the CUDA array interface torch.as_tensor understands (zero-copy; the tensor keeps this object
-    alive).  The memory is the arena's: freed by Arena.__del__ through free()."""
+    """n bytes of device memory at ptr, as the CUDA array interface torch.as_tensor understands (zero-copy; the tensor's storage keeps this
+    object alive, and the memory is freed with it)."""
 
     def __init__(self, ptr, n):
         self.ptr, self.n = int(ptr), int(n)
         self.__cuda_array_interface__ = {"shape": (self.n,), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
 
-    def free(self):
-        if self.ptr:
-            L.load().nasrec_free_uncached(C.c_void_p(self.ptr))
-            self.ptr = 0
+    def __del__(self):  # (when the last tensor view of the memory is gone: torch keeps this object alive through the storage)
+        try:
+            if self.ptr:
+                L.load().nasrec_free_uncached(C.c_void_p(self.ptr))
+                self.ptr = 0
+        except Exception:
+            pass
 
 
 class Arena:
@@ -128,7 +131,6 @@ class Arena:
         self.chunks: List[torch.Tensor] = []
         self.base: List[int] = []
         self.cur, self.off = 0, 0
-        self._owned = []
 
     def reset(self):
         self.cur, self.off = 0, 0
@@ -139,9 +141,7 @@ class Arena:
             with torch.cuda.device(self.device):
                 ptr = C.c_void_p()
                 L.check(L.load().nasrec_alloc_uncached(n, C.byref(ptr)))
-            holder = _RawDeviceBytes(ptr.value, n)
-            self._owned.append(holder)
-            c = torch.as_tensor(holder, device=self.device)
+            c = torch.as_tensor(_RawDeviceBytes(ptr.value, n), device=self.device)
             assert c.data_ptr() == ptr.value and c.numel() == n and c.dtype == torch.uint8
         else:
             c = torch.empty(n, dtype=torch.uint8, device=self.device)
@@ -152,13 +152,6 @@ class Arena:
         """[(first byte, one past the last)] of the arena's chunks"""
         return [(b, b + c.numel()) for b, c in zip(self.base, self.chunks)]
 
-    def __del__(self):
-        try:
-            self.chunks = []
-            for h in self._owned:
-                h.free()
-        except Exception:
-            pass
 
     def alloc(self, numel: int, dtype=torch.float32) -> ArenaRef:
         numel = int(numel)
@@ -184,7 +177,11 @@ class Arena:
             self._grow(self.CHUNK)
 
 
-_UC_ARENA = os.environ.get("NASREC_UC_ARENA", "0") == "1"
+# The buffers of a level-scheduled training plan (fixed sub-network, batch <= 256) live in UNCACHED device memory: a step of ~27 dependent
+# launches hands every activation from one kernel to the next exactly once, and a store that goes through to memory leaves nothing for the
+# kernel boundary to write back — 0.2485 -> 0.2447 / 0.2458 ms per cfg-2 step in four A/B pairs (profiles/r06_ab_uc_arena.txt), bit-identical
+# results.  It is also what lets the persistent step (NASREC_OP_PERSIST) hand buffers over INSIDE a launch.  NASREC_UC_ARENA=0: torch's allocator.
+_UC_ARENA = os.environ.get("NASREC_UC_ARENA", "1") == "1"
 
 
 def _on_device(fn):
@@ -225,6 +222,11 @@ class SupernetEngine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.world_size = world_size
         self.stream = torch.cuda.Stream(device=self.device)
+        # the persistent step (NASREC_OP_PERSIST: the joint program's items in one launch, dependencies resolved in the kernel): built, bit-identical
+        # to the level launches, and SLOWER on the cfg-2 step (0.274 against 0.245 ms: workgroups are dispatched in index order, and the ones
+        # waiting for a dependency hold the chip's 768 slots against items that could run — DESIGN.md, profiles/r06_persist_*): opt-in
+        self.persist = S.PERSIST and os.environ.get("NASREC_PERSIST_DEFAULT", "0") == "1"
+        self._persist_errs = []
         self._last_plan = None
         # batch <= 256 (fixed sub-networks): operators that do not depend on each other share heterogeneous launches
         # (nasrec_amd/schedule.py); NASREC_WORKLIST=0 keeps one launch per operator (A/B runs, bit-identical results)
@@ -352,8 +354,9 @@ class SupernetEngine:
             self._last_plan = (fast, choice, self._plans[key])
             return self._plans[key]
         arena = None
-        if self.cfg.fixed and _UC_ARENA and B <= 256 and train:
-            arena = Arena(self.device, uncached=True)  # (A/B knob NASREC_UC_ARENA=1: the fixed plan's buffers in uncached memory)
+        persist = bool(self.persist and self.level_schedule and self.cfg.fixed and B <= 256 and train and local_optimizer)
+        if self.cfg.fixed and B <= 256 and train and self.level_schedule and (_UC_ARENA or persist):
+            arena = Arena(self.device, uncached=True)  # (see _UC_ARENA; the persistent step needs it whatever the knob says)
         if not self.cfg.fixed:
             # Sampled paths rarely repeat: a small cache of plan slots, each with its own arena.  Evicting a plan needs no device
             # synchronisation: its slot is reused by a plan whose kernels are enqueued, in stream order, behind the evicted one's
@@ -491,7 +494,20 @@ class SupernetEngine:
                     # (alloc: a forward product with several levels of slack may be re-cut into split-K items — only in the JOINT
                     # program, where the backward's latency-bound levels are there to hide it)
                     jf, jb = self._fuse_final(fwd_list, bwd_descs, fused) if _FUSE_FINAL else (fwd_list, bwd_descs)
-                    fb_descs, cp.fb_levels = S.pack(ids_in_program + jf + jb, alloc=ctx.alloc)
+                    fb_descs = None
+                    cp.persistent = False
+                    if persist:
+                        try:
+                            fb_descs, cp.fb_levels = S.pack_persistent(
+                                ids_in_program + jf + jb, lambda nb: torch.empty(max(int(nb), 16), dtype=torch.uint8, device=self.device),
+                                arena.ranges, alloc=ctx.alloc)
+                            cp.persistent = True
+                            self._persist_errs += [d.err_tensor for d in fb_descs if isinstance(d, L.PersistDesc)]
+                        except S.PersistRefused as e:
+                            import warnings
+                            warnings.warn("persistent step refused (%s): one launch per level instead" % (e,))
+                    if fb_descs is None:
+                        fb_descs, cp.fb_levels = S.pack(ids_in_program + jf + jb, alloc=ctx.alloc)
                     cp.fb = Program(fb_descs)
                     bwd_descs, cp.bwd_levels = S.pack(bwd_descs)
                 cp.bwd = Program(bwd_descs)
@@ -914,6 +930,10 @@ class SupernetEngine:
     def check_indices(self):
         """raise IndexError if any embedding id seen so far was out of range (torch raises at lookup time)"""
         torch.cuda.synchronize(self.device)
+        for t in self._persist_errs:
+            e = t.view(torch.int32)[:3].tolist()
+            if e[0] != 0:
+                raise RuntimeError("persistent step: a workgroup of item %d waited more than 10 ms for item %d (results of that step are invalid)" % (e[1], e[2]))
         flags = self.oob.tolist()
         if flags[0] != 0:
             raise IndexError("index out of range in embedding lookup")

@@ -472,7 +472,7 @@ RESPLIT = os.environ.get("NASREC_WL_RESPLIT", "0") == "1"
 RESPLIT_MIN_SLACK = 3
 
 
-def resplit_slack_solos(descs, alloc):
+def resplit_slack_solos(descs, alloc, min_slack=None):
     """A large forward product that runs as a launch of its own (csrc/gemm_kslice.hip: K split inside the workgroup) sits alone on the
     stream for 9-13 us.  When nothing waits for its result for several levels (in ea_criteo_kaggle_xlarge_best_1shot.json: all of
     block 5, which no later block selects — computed by the reference and thrown away), it is worth more as a worklist item beside a
@@ -492,7 +492,7 @@ def resplit_slack_solos(descs, alloc):
     out, changed = list(descs), False
     for i, nd in enumerate(nodes):
         d = nd.desc
-        if nd.part != "whole" or not isinstance(d, L.GemmDesc) or d.splitk > 1 or alap[i] - nd.level < RESPLIT_MIN_SLACK:
+        if nd.part != "whole" or not isinstance(d, L.GemmDesc) or d.splitk > 1 or alap[i] - nd.level < (RESPLIT_MIN_SLACK if min_slack is None else min_slack):
             continue
         if P.gemm_kernel_name(d) != "gemm_kslice_kernel":
             continue
@@ -696,6 +696,154 @@ def pack(descs, alloc=None):
             cur.n += 1
             cur.nodes.append(n)
             off += size
+    return out, nl
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the persistent form (round 6): the items of MANY levels in one NASREC_OP_PERSIST launch, dependencies resolved in the kernel
+# ----------------------------------------------------------------------------------------------------------------
+PERSIST = os.environ.get("NASREC_PERSIST", "1") != "0"
+_PS_ORDER = os.environ.get("NASREC_PERSIST_ORDER", "start")  # level: (level, longest first); start: estimated start time with slack (below)
+_PS_ALPHA = float(os.environ.get("NASREC_PERSIST_ALPHA", "0.5"))
+PERSIST_RESPLIT = os.environ.get("NASREC_PERSIST_RESPLIT", "off")  # off | slack | all: stand-alone products re-cut into items of the persistent launch
+
+
+class PersistRefused(Exception):
+    """the program cannot run in the persistent form (the caller falls back to one launch per level); str(e) says why"""
+
+
+def _inside(a: Acc, ranges) -> bool:
+    return any(lo <= a.ptr and a.end <= hi for lo, hi in ranges)
+
+
+def _visible_edge(later: Node, earlier: Node, uc_ranges):
+    """what `later` must SEE of `earlier` (read-after-write) or overwrite in order (write-after-write): every such footprint of
+    `earlier` has to lie in uncached memory — cached lines written by two workgroups of one launch on different XCDs are neither
+    visible to each other nor written back in order.  (Write-after-read needs ordering only.)  -> the first offending footprint or None"""
+    for w in earlier.writes:
+        if any(overlap(w, a) for a in later.reads) or any(overlap(w, a) for a in later.writes):
+            if not _inside(w, uc_ranges):
+                return w
+    return None
+
+
+def pack_persistent(descs, dev_alloc, uc_ranges, alloc=None):
+    """program -> scheduled program whose worklist-capable operators run as items of NASREC_OP_PERSIST launches: one launch per maximal
+    run of levels without a stand-alone kernel in between.  dev_alloc(nbytes) -> device tensor (tables, counters, flags; kept alive on
+    the descriptor); uc_ranges: [(lo, hi)] address ranges of the plan's uncached arena.  Returns (descriptor list, number of levels);
+    raises PersistRefused when a dependency edge runs through cached memory or an item has too many dependencies."""
+    # A product that would stand alone on the stream (csrc/gemm_kslice.hip: 1024-thread workgroups, no body in this kernel) cuts the persistent
+    # launch in two — a full drain and refill of the chip on either side of it.  Re-cut into split-K items it rides inside the launch:
+    # "slack" = only where nothing waits for it for several levels (the dead block's 256 x 768 x 1565 product: 13 us of the step that then
+    # overlap with the backward), "all" = every such product.  (A re-cut product sums its k-slices in another order than the one-pass kernel.)
+    if alloc is not None and PERSIST_RESPLIT != "off":
+        descs = resplit_slack_solos(descs, alloc, 0 if PERSIST_RESPLIT == "all" else RESPLIT_MIN_SLACK)
+    nodes = expand_for_worklists(descs)
+    nl = assign_levels(nodes)
+    if BALANCE:
+        balance_levels(nodes, nl)
+    n = len(nodes)
+    pred = [[j for j in range(i) if _depends(nodes[i], nodes[j])] for i in range(n)]
+    out = []
+    seg = []  # node indices of the current segment, in launch order
+
+    def flush():
+        if not seg:
+            return
+        if len(seg) == 1 and nodes[seg[0]].part == "whole":
+            out.append(nodes[seg[0]].desc)  # nothing to overlap with: the stand-alone kernel
+            seg.clear()
+            return
+        pos = {i: k for k, i in enumerate(seg)}
+        inseg = set(seg)
+        uc = uc_ranges() if callable(uc_ranges) else uc_ranges  # (now: the re-cut products' workspaces may have grown the arena)
+        items = (L.PersistItem * len(seg))()
+        blob = bytearray()
+        for k, i in enumerate(seg):
+            nd = nodes[i]
+            b = item_bytes(nd)
+            it = items[k]
+            it.kind, it.part, it.off = nd.desc.kind, _PART[nd.part], len(blob)
+            blob += b
+            blob += bytes((-len(blob)) % 16)
+            ps = [j for j in pred[i] if j in inseg]
+            # transitive reduction: a predecessor that another predecessor already waits for (directly or not) needs no edge of its own
+            anc = {}
+            def ancestors(j):
+                if j not in anc:
+                    a = set()
+                    for q in pred[j]:
+                        if q in inseg:
+                            a.add(q)
+                            a |= ancestors(q)
+                    anc[j] = a
+                return anc[j]
+            keep = [j for j in ps if not any(j in ancestors(q) for q in ps if q != j)]
+            if len(keep) > L.PS_MAX_DEPS:
+                raise PersistRefused("an operator waits for %d others (limit %d)" % (len(keep), L.PS_MAX_DEPS))
+            for j in ps:  # (visibility is checked on EVERY edge, reduced or not: the data of an indirect predecessor is read all the same)
+                bad = _visible_edge(nd, nodes[j], uc)
+                if bad is not None:
+                    raise PersistRefused("kind %d reads or overwrites [%#x, %#x) written by kind %d in the same launch, outside the uncached arena"
+                                         % (nd.desc.kind, bad.ptr, bad.end, nodes[j].desc.kind))
+            it.ndeps = len(keep)
+            for q, j in enumerate(sorted(keep, key=lambda j: pos[j])):
+                it.deps[q] = pos[j]
+        d = L.PersistDesc()
+        d.kind, d.n, d.blob_bytes = L.OP_PERSIST, len(seg), len(blob)
+        hb = C.create_string_buffer(bytes(blob), len(blob))
+        d.host_items, d.host_blob = C.addressof(items), C.addressof(hb)
+        d.nodes = [nodes[i] for i in seg]
+        d._host = (items, hb)
+        if dev_alloc is None:  # (descriptors and geometry only: CPU tests of the packing, tools)
+            L.check(L.load().nasrec_persist_prepare(C.addressof(d)))
+            out.append(d)
+            seg.clear()
+            return
+        cap = 4096  # chunk entries: 65 536 workgroups
+        t_items = dev_alloc(C.sizeof(L.PersistItem) * len(seg))
+        t_blob = dev_alloc(len(blob) + 64)  # (the descriptor warm-up reads whole 64-byte steps)
+        t_chunk = dev_alloc(2 * cap)
+        t_cnt = dev_alloc(8 * len(seg) * (L.PS_SHARDS + 1) * L.PS_COUNTER_STRIDE)
+        t_flags = dev_alloc(4 * len(seg) * L.PS_REPL * L.PS_FLAG_STRIDE)
+        t_err = dev_alloc(16)
+        d.items, d.blob, d.chunk_item, d.counters, d.flags, d.err = (t.data_ptr() for t in (t_items, t_blob, t_chunk, t_cnt, t_flags, t_err))
+        d.chunk_cap = cap
+        L.check(L.load().nasrec_persist_prepare(C.addressof(d)))
+        d._keep = (items, hb, t_items, t_blob, t_chunk, t_cnt, t_flags, t_err)
+        d.err_tensor = t_err
+        out.append(d)
+        seg.clear()
+
+    if _PS_ORDER == "level":
+        order = sorted(range(n), key=lambda i: (nodes[i].level, item_bytes(nodes[i]) is not None, -_cost(nodes[i])))
+    else:
+        # Workgroups are dispatched in index order, so the item order IS the priority order.  key = ASAP start + alpha * slack on a
+        # schedule without resource limits (durations: the cost model minus what a launch of its own would add): an item on the
+        # critical path (slack 0) sits at its earliest start; weight-gradient products and second passes nobody waits for slide towards
+        # their latest start and fill whatever the chain leaves idle, instead of queueing in front of it.  Any alpha in [0, 1] keeps
+        # the order topological (both the ASAP and the ALAP start of a successor exceed its predecessor's by the predecessor's duration).
+        dur = [max(_cost_r4(nodes[i]) - 2500, 1200) for i in range(n)]
+        asap = [0] * n
+        for i in range(n):
+            asap[i] = max([asap[j] + dur[j] for j in pred[i]] + [0])
+        end = max(asap[i] + dur[i] for i in range(n))
+        succ = [[] for _ in range(n)]
+        for i in range(n):
+            for j in pred[i]:
+                succ[j].append(i)
+        alap = [0] * n
+        for i in range(n - 1, -1, -1):
+            alap[i] = min([alap[k] for k in succ[i]] + [end]) - dur[i]
+        order = sorted(range(n), key=lambda i: (asap[i] + _PS_ALPHA * (alap[i] - asap[i]), i))
+    for i in order:
+        if item_bytes(nodes[i]) is None:
+            flush()
+            assert nodes[i].part == "whole"
+            out.append(nodes[i].desc)
+        else:
+            seg.append(i)
+    flush()
     return out, nl
 
 

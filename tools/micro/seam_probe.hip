@@ -18,6 +18,8 @@
 //   uc         as `fine` on UNCACHED device memory (hipExtMallocWithFlags(hipDeviceMallocUncached)): plain stores, plain loads behind
 //              the acquire — the form that would need no change to the operator bodies at all
 //   uc_sc1     uncached memory, plain stores, sc1 loads, no acquire
+//   uc_plain   uncached memory, plain stores, PLAIN loads and NO acquire: correct only if this memory type is not held in the CU's L1 either
+//              (the pre-read plants the lines: a stale hit shows as wrong bits)
 //   flags      coarse dependencies like `item` (wait for ALL of phase p-1) without any atomic: every finishing workgroup stores ITS flag,
 //              a waiting workgroup's wave 0 sweeps all G flags of the phase with 64-lane sc1 loads until every one carries the epoch
 // Every one-launch form PRE-READS its input tile with plain loads before it waits (values discarded): the tile then still holds the
@@ -34,7 +36,7 @@
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-enum { M_LAUNCHES = 0, M_LEVEL = 1, M_FINE = 2, M_FENCE = 3, M_ITEM = 4, M_INV = 5, M_UC = 6, M_UC_SC1 = 7, M_FLAGS = 8, M_COUNT = 9 };
+enum { M_LAUNCHES = 0, M_LEVEL = 1, M_FINE = 2, M_FENCE = 3, M_ITEM = 4, M_INV = 5, M_UC = 6, M_UC_SC1 = 7, M_FLAGS = 8, M_UC_PLAIN = 9, M_COUNT = 10 };
 #define REPL 32  // replica flags per phase in the `item` form, one 128-byte line each
 #define TM 32
 #define TK 128
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256, 3) void seam_kernel(const Args a) {
   constexpr bool SC1_LD = MODE == M_LEVEL || MODE == M_FINE || MODE == M_ITEM || MODE == M_UC_SC1 || MODE == M_FLAGS;
   constexpr bool SC1_ST = MODE == M_LEVEL || MODE == M_FINE || MODE == M_ITEM || MODE == M_INV || MODE == M_FLAGS;
   constexpr bool ACQ = MODE == M_FENCE || MODE == M_INV || MODE == M_UC;
-  constexpr bool PER_WG = MODE == M_FINE || MODE == M_INV || MODE == M_UC || MODE == M_UC_SC1;  // per-producer flags
+  constexpr bool PER_WG = MODE == M_FINE || MODE == M_INV || MODE == M_UC || MODE == M_UC_SC1 || MODE == M_UC_PLAIN;  // per-producer flags
   const int tid = threadIdx.x;
   const int G = a.G, nrb = G / 2;
   int p, w;
@@ -250,7 +252,7 @@ int main(int argc, char** argv) {
     printf("hipExtMallocWithFlags(hipDeviceMallocUncached) is refused on this box: the uc forms are skipped\n");
     Xu = nullptr;
     (void)hipGetLastError();
-    on[M_UC] = on[M_UC_SC1] = false;
+    on[M_UC] = on[M_UC_SC1] = on[M_UC_PLAIN] = false;
   }
   float* W;
   CK(hipMalloc(&W, TK * TN * 4));
@@ -273,12 +275,12 @@ int main(int argc, char** argv) {
   hipStream_t st;
   CK(hipStreamCreate(&st));
   std::vector<float> ref, got((size_t)rows * TK);
-  const char* names[M_COUNT] = {"launches", "level", "fine", "fence", "item", "inv", "uc", "uc_sc1", "flags"};
+  const char* names[M_COUNT] = {"launches", "level", "fine", "fence", "item", "inv", "uc", "uc_sc1", "flags", "uc_plain"};
   printf("seam probe: %d phases x %d workgroups of 256 threads, skew %d, %d timed runs each (one-launch forms pre-read their inputs)\n", P, G, skew, reps);
   unsigned epoch = 0;
   for (int mode = 0; mode < M_COUNT; ++mode) {
     if (!on[mode]) continue;
-    a.X = (mode == M_UC || mode == M_UC_SC1) ? Xu : Xc;
+    a.X = (mode == M_UC || mode == M_UC_SC1 || mode == M_UC_PLAIN) ? Xu : Xc;
     // poison everything but phase 0, so that a stale or early read shows
     CK(hipMemset(a.X, 0xff, xn * 4));
     CK(hipMemcpy(a.X, h0.data(), h0.size() * 4, hipMemcpyHostToDevice));
@@ -302,6 +304,7 @@ int main(int argc, char** argv) {
         case M_UC: us = run_once<M_UC>(a, st); break;
         case M_UC_SC1: us = run_once<M_UC_SC1>(a, st); break;
         case M_FLAGS: us = run_once<M_FLAGS>(a, st); break;
+        case M_UC_PLAIN: us = run_once<M_UC_PLAIN>(a, st); break;
         default: us = run_once<M_FENCE>(a, st); break;
       }
       if (r >= 5) {
