@@ -121,6 +121,8 @@ static int launch_gemm_t(hipStream_t st, const nasrec_gemm_desc_t* d) {
     return launch_gemm_kslice(st, d);  // batch-256 regime, one large forward product: K split inside the workgroup, single pass
   } else if (AM == NASREC_AM_KC && (BMODE == NASREC_AM_KC || BMODE == NASREC_AM_RC) && CM == NASREC_CM_PLAIN && gemm_skinny_n_eligible(d)) {
     return launch_gemm_skinny_n(st, d);  // large batch, N <= 16: a streaming read of x, K split inside the workgroup, single pass
+  } else if (AM == NASREC_AM_KC && (BMODE == NASREC_AM_KC || BMODE == NASREC_AM_RC) && CM == NASREC_CM_PLAIN && gemm_tinyk_eligible(d)) {
+    return launch_gemm_tinyk(st, d);  // large batch, K <= 16: a streaming write of y, weights in registers, no LDS
   } else if (AM == NASREC_AM_TOKK && token_dw_eligible(d)) {
     launch_token_dw(st, d, Mmax, Nmax);  // large batch: a wavefront per sample, operands straight to MFMA registers (token_linear.hip)
   } else if (CM == NASREC_CM_PLAIN && gemm_fast_eligible(d, Mmax, Nmax)) {

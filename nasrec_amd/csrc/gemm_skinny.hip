@@ -15,6 +15,8 @@
 //   * the NW partial 16 x 16 tiles are added through LDS in a fixed order, wave 0 runs the common epilogue (epilogue_store_col4:
 //     bias, activation, saved planes, accumulation — reads first, one wait, stores).
 // The summation order is a fixed function of (segment list, NW); NW depends on M alone.
+#include <stdlib.h>
+
 #include "gemm_tile.h"
 
 #define SKN_STEPS 8  // k-steps (of 16) fetched before their MFMAs
@@ -147,4 +149,128 @@ int launch_gemm_skinny_n(hipStream_t st, const nasrec_gemm_desc_t* d) {
     else hipLaunchKernelGGL((gemm_skinny_n_kernel<8, false>), dim3((unsigned)tiles), dim3(512), 0, st, *d);
   }
   return nasrec_check_launch("gemm_skinny_n");
+}
+
+// ======================================================================================================================================
+// The opposite corner (round 6): a WIDE output from a handful of inputs at large batch — y[M, N] = x[M, K] W^T with K <= 16 (the dense
+// projections of the raw dense features, modules.py:171 on supernet.py:1137-1145's 13 integer columns: 4096 x 1024 x 13), and the input
+// gradients dx = dy W of Linears with <= 16 outputs (KC / RC, one problem per k-segment of a zmode launch: 3 x 4096 x 1024 x 16).  These are
+// streaming WRITES (16.8 MB per problem, 0.1 GFLOP): on the 128 x 128 x 32 throughput tile they took 24 - 25 us (0.7 - 2 TB/s) — a k-tile
+// that is half padding, staged through LDS behind barriers, for an output that is one pass over memory.  Here a thread owns one column j
+// and eight rows: the K <= 16 weights of its column sit in registers (KC: W[j][0..K); RC: W[k][j], coalesced over the lanes), the rows'
+// K inputs are wave-uniform (scalar loads), 8 K FMAs, and two epilogue_store_col4 calls write 4 + 4 rows of the column — a wavefront's
+// store is 256 contiguous bytes per row.  No LDS, no barrier, no matrix pipe: 4 B of output per 2 K flops is far below any compute roof.
+// ======================================================================================================================================
+#define TK_MAXK 16
+#define TK_GROUPS 2
+#define TK_ROWS (8 * TK_GROUPS)
+template <bool BRC>
+__global__ __launch_bounds__(256) void gemm_tinyk_kernel(const nasrec_gemm_desc_t d) {
+  const int q = d.zmode ? (int)blockIdx.z : 0;
+  const nasrec_gemm_seg_t& sg = d.seg[q];
+  const int M = sg.M, N = sg.N, K = sg.K;
+  const int j = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  const int i0 = (int)blockIdx.y * TK_ROWS;
+  if (i0 >= M) return;
+  const int jc = min(j, N - 1);
+  float w[TK_MAXK];
+  if (sg.A != nullptr && K > 0) {
+#pragma unroll
+    for (int k = 0; k < TK_MAXK; ++k) w[k] = k < K ? (BRC ? sg.B[(long)k * sg.ldb + jc] : sg.B[(long)jc * sg.ldb + k]) : 0.f;
+  } else {
+#pragma unroll
+    for (int k = 0; k < TK_MAXK; ++k) w[k] = 0.f;
+  }
+  // the common epilogue's simple case, decided once: no residual, no gating operand, no accumulation, no prefix mask, bias along the columns
+  const bool simple = !d.pre_add && d.mul_nseg == 0 && !(d.zmode ? sg.accumulate : d.beta) && d.dims_in_use < 0 && !(d.bias && d.bias_on_rows);
+  const float bj = (simple && d.bias) ? d.bias[jc] : 0.f;
+  float* const zp = d.save_z;
+  float* const ap = d.save_act;
+  const int act = d.act;
+  // the rows' inputs, eight rows at a time: 8 x 16 floats for the whole wavefront in TWO vector loads (lane l holds
+  // x[i + l / 8][2 (l % 8) + {0, 1}]), handed to every lane through v_readlane (the operand of the FMA is then a scalar register).  Read per
+  // lane and element — 128 broadcast loads per thread for 8 stores — the kernel was bound by the issue rate of its vector-memory instructions
+  // (22 us for a 16.8 MB output).  TK_GROUPS groups of eight rows share the column's weights.
+  const int lane = (int)threadIdx.x & 63;
+  // (every group's inputs are loaded before the first store: vmcnt counts loads and stores in one in-order queue, so a load issued behind
+  // a group's stores would make the wave wait for those stores to be acknowledged — a store round trip per group)
+  float xa[TK_GROUPS], xb[TK_GROUPS];
+#pragma unroll
+  for (int gr = 0; gr < TK_GROUPS; ++gr) {
+    xa[gr] = xb[gr] = 0.f;
+    if (sg.A != nullptr && K > 0) {
+      const int ri = min(i0 + 8 * gr + (lane >> 3), M - 1), kc = 2 * (lane & 7);
+      const float* xr = sg.A + (long)ri * sg.lda;
+      if (kc < K) xa[gr] = xr[kc];
+      if (kc + 1 < K) xb[gr] = xr[kc + 1];
+    }
+  }
+#pragma unroll
+  for (int gr = 0; gr < TK_GROUPS; ++gr) {
+    const int ib = i0 + 8 * gr;
+    if (ib >= M) break;  // (uniform)
+    const float x0 = xa[gr], x1 = xb[gr];
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < TK_MAXK; ++k) {
+        const float xv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (k & 1) ? x1 : x0), r * 8 + (k >> 1)));
+        s = fmaf(xv, w[k], s);
+      }
+      acc[r] = s;
+    }
+    if (j < N) {
+      if (simple) {
+        // bias / activation / saved planes only: nothing to READ per element, so the eight rows' stores leave back to back (the general
+        // epilogue reads, waits for vmcnt(0) — which also waits for the previous group's stores — and only then stores: a store round trip
+        // per group of four rows, 8 groups per thread: that, not bandwidth, made the first version take 21 us for 16.8 MB)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          if (ib + r < M) {
+            const long o = (long)(ib + r) * sg.ldc + j;
+            float v = acc[r] + bj;
+            if (zp) zp[o] = v;
+            v = act_apply(v, act);
+            if (ap) ap[o] = v;
+            sg.C[o] = v;
+          }
+        }
+      } else {
+        const float va[4] = {acc[0], acc[1], acc[2], acc[3]}, vb[4] = {acc[4], acc[5], acc[6], acc[7]};
+        epilogue_store_col4<NASREC_CM_PLAIN>(d, sg, ib, j, M, va);
+        if (ib + 4 < M) epilogue_store_col4<NASREC_CM_PLAIN>(d, sg, ib + 4, j, M, vb);
+      }
+    }
+  }
+}
+
+bool gemm_tinyk_eligible(const nasrec_gemm_desc_t* d) {
+  static const bool on = getenv("NASREC_TINYK") == nullptr || atoi(getenv("NASREC_TINYK")) != 0;  // A/B knob
+  if (!on || d->amode != NASREC_AM_KC || (d->bmode != NASREC_AM_KC && d->bmode != NASREC_AM_RC) || d->cmode != NASREC_CM_PLAIN || d->splitk > 1) return false;
+  // (the input-gradient form — KC / RC, a problem per segment — measured 22 - 25 us against the throughput tile's 24: the kernel has it, the rule
+  // does not take it unless NASREC_TINYK=2)
+  static const bool rc_too = getenv("NASREC_TINYK") != nullptr && atoi(getenv("NASREC_TINYK")) == 2;
+  if (d->bmode == NASREC_AM_RC && !rc_too) return false;
+  if (!d->zmode && d->nseg != 1) return false;
+  for (int q = 0; q < d->nseg; ++q) {
+    const nasrec_gemm_seg_t& s = d->seg[q];
+    if (s.Aaux || s.Baux || s.ones_col || (s.Mvalid > 0 && s.Mvalid < s.M)) return false;
+    if (s.M < 1024 || s.N < 256 || s.K < 0 || s.K > TK_MAXK) return false;
+  }
+  return true;
+}
+
+int launch_gemm_tinyk(hipStream_t st, const nasrec_gemm_desc_t* d) {
+  int Mmax = 0, Nmax = 0;
+  const int nprob = d->zmode ? d->nseg : 1;
+  for (int q = 0; q < nprob; ++q) {
+    Mmax = max(Mmax, d->seg[q].M);
+    Nmax = max(Nmax, d->seg[q].N);
+  }
+  const dim3 grid((unsigned)((Nmax + 255) / 256), (unsigned)((Mmax + TK_ROWS - 1) / TK_ROWS), (unsigned)nprob);
+  if (d->bmode == NASREC_AM_RC) hipLaunchKernelGGL((gemm_tinyk_kernel<true>), grid, dim3(256), 0, st, *d);
+  else hipLaunchKernelGGL((gemm_tinyk_kernel<false>), grid, dim3(256), 0, st, *d);
+  return nasrec_check_launch("gemm_tinyk");
 }

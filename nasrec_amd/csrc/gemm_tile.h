@@ -33,6 +33,8 @@ bool gemm_kslice_eligible(const nasrec_gemm_desc_t* d);  // gemm_kslice.hip: lar
 int launch_gemm_kslice(hipStream_t st, const nasrec_gemm_desc_t* d);
 bool gemm_skinny_n_eligible(const nasrec_gemm_desc_t* d);  // gemm_skinny.hip: forward Linear with N <= 16 at large batch, x streamed once
 int launch_gemm_skinny_n(hipStream_t st, const nasrec_gemm_desc_t* d);
+bool gemm_tinyk_eligible(const nasrec_gemm_desc_t* d);  // gemm_skinny.hip: K <= 16 at large batch, the output streamed once
+int launch_gemm_tinyk(hipStream_t st, const nasrec_gemm_desc_t* d);
 bool token_linear_eligible(const nasrec_gemm_desc_t* d);  // token_linear.hip: token-axis Linear at large batch
 int launch_token_linear(hipStream_t st, const nasrec_gemm_desc_t* d);
 bool token_dw_eligible(const nasrec_gemm_desc_t* d);      // token-axis weight gradient at large batch (main pass; slabs -> gemm_splitk_epilogue)

@@ -324,8 +324,17 @@ __device__ __forceinline__ void ps_run_item(int it_kind, int it_part, int g0, in
       else if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 3) wl_dense_small(blob, vb, g0, g1);
       else if ((cfg & 3) == WL_TOKS && ((cfg >> 2) & 3) == 1) wl_token_fwd(blob, vb, g0);
       else if ((cfg & 3) == WL_TOKS) wl_token_dx(blob, vb, g0);
-      else if ((cfg >> 4) & 1) wl_gemm_bind<true>((cfg >> 2) & 3, cfg & 3, blob, vb, g0, g1);
-      else wl_gemm_bind<false>((cfg >> 2) & 3, cfg & 3, blob, vb, g0, g1);
+      else if ((cfg >> 4) & 1) {
+        for (int u = vb; u < nblk; u += nwg) {
+          wl_gemm_bind<true>((cfg >> 2) & 3, cfg & 3, blob, u, g0, g1);
+          if (u + nwg < nblk) __syncthreads();
+        }
+      } else {
+        for (int u = vb; u < nblk; u += nwg) {  // (tiles of a product: the bulk items walk several per workgroup)
+          wl_gemm_bind<false>((cfg >> 2) & 3, cfg & 3, blob, u, g0, g1);
+          if (u + nwg < nblk) __syncthreads();
+        }
+      }
       break;
     }
     case NASREC_OP_MHA_FWD:
@@ -505,8 +514,14 @@ int nasrec_persist_prepare(nasrec_persist_desc_t* d) {
     // units per workgroup: an item of thousands of one-element-per-thread units (split-K second passes, the final-logit backward) runs
     // as at most max_wg workgroups that walk their units — the wait / acquire / arrival of the protocol is paid per WORKGROUP
     static const int max_wg = getenv("NASREC_PS_MAX_WG") ? atoi(getenv("NASREC_PS_MAX_WG")) : 512;
-    const bool walks = (p.kind == NASREC_OP_GEMM && p.part == 2) || p.kind == NASREC_OP_FINAL_BWD;  // (ps_run_item: the kinds with a unit loop)
-    const int upw = walks ? (w.nblk + max_wg - 1) / (max_wg > 0 ? max_wg : 1) : 1;
+    // (ps_run_item: the kinds with a unit loop — second passes, the final-logit backward, the tile bodies of the products)
+    const bool tiles = p.kind == NASREC_OP_GEMM && p.part != 2 && (w.geom[2] & 3) != WL_TOKS;
+    const bool walks = (p.kind == NASREC_OP_GEMM && p.part == 2) || p.kind == NASREC_OP_FINAL_BWD || tiles;
+    // the caller's hint (item._pad[1] > 0): an operator nobody waits for soon runs on few workgroups, each walking many units, so that it
+    // cannot fill the chip's workgroup slots in front of the operators the step's critical chain is waiting for
+    const int hint = d->host_items[k]._pad[1];
+    const int cap = hint > 0 ? hint : (tiles ? 1 << 30 : max_wg);
+    const int upw = walks ? (w.nblk + cap - 1) / (cap > 0 ? cap : 1) : 1;
     const int nwg = (w.nblk + upw - 1) / upw;
     p.first = first, p.nblk = w.nblk;
     p.geom[0] = w.geom[0], p.geom[1] = w.geom[1], p.geom[2] = w.geom[2];

@@ -108,9 +108,10 @@ class _RawDeviceBytes:
 
     def __del__(self):  # (when the last tensor view of the memory is gone: torch keeps this object alive through the storage)
         try:
-            if self.ptr:
+            import sys
+            if self.ptr and not sys.is_finalizing():  # (at interpreter exit the HIP runtime may already be gone: the driver reclaims the memory)
                 L.load().nasrec_free_uncached(C.c_void_p(self.ptr))
-                self.ptr = 0
+            self.ptr = 0
         except Exception:
             pass
 

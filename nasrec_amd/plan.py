@@ -465,6 +465,27 @@ def _balanced_schedule_pays(segs, zmode):
     return (rounds - tiles / 512.0) * T * 3.8 >= BALANCED_MIN_SAVING_US
 
 
+_TINYK = _os.environ.get("NASREC_TINYK", "1") != "0"  # A/B knob (csrc/gemm_skinny.hip reads the same variable)
+_TINYK_RC = _os.environ.get("NASREC_TINYK", "1") == "2"  # the input-gradient form too (measured no faster than the throughput tile: off)
+
+
+def tinyk_eligible(d) -> bool:
+    """mirror of csrc/gemm_skinny.hip `gemm_tinyk_eligible`: K <= 16 at large batch with a wide output (a streaming write)"""
+    if not _TINYK or d.amode != L.AM_KC or d.bmode not in (L.AM_KC, L.AM_RC) or d.cmode != L.CM_PLAIN or d.splitk > 1:
+        return False
+    if d.bmode == L.AM_RC and not _TINYK_RC:
+        return False
+    if not d.zmode and d.nseg != 1:
+        return False
+    for q in range(d.nseg):
+        s = d.seg[q]
+        if s.Aaux or s.Baux or s.ones_col or (0 < s.Mvalid < s.M):
+            return False
+        if s.M < 1024 or s.N < 256 or s.K < 0 or s.K > 16:
+            return False
+    return True
+
+
 def gemm_kernel_name(d) -> str:
     """which kernel family launch_gemm picks for this descriptor (mirror of csrc/gemm.hip / gemm_fast.hip)"""
     segs = [dict(A=d.seg[q].A, Aaux=d.seg[q].Aaux, Baux=d.seg[q].Baux, M=d.seg[q].M, N=d.seg[q].N, K=d.seg[q].K) for q in range(d.nseg)]
@@ -475,6 +496,8 @@ def gemm_kernel_name(d) -> str:
     if d.splitk <= 1 and skinny_n_eligible(d.amode, d.bmode, d.cmode, [dict(sd, ones_col=d.seg[q].ones_col, Mvalid=d.seg[q].Mvalid, lda=d.seg[q].lda,
                                                                             ldb=d.seg[q].ldb) for q, sd in enumerate(segs)], d.zmode):
         return "gemm_skinny_n_kernel"
+    if tinyk_eligible(d):
+        return "gemm_tinyk_kernel"
     if (d.cmode == L.CM_TOKJ and d.bmode == L.AM_TOKR and d.amode in (L.AM_KC, L.AM_RC) and d.splitk <= 1 and not d.pre_add
             and not d.save_act and d.mul_nseg == 0 and all(sd["M"] <= 80 and sd["N"] >= 16 * 1024 and not sd["Aaux"] and not sd["Baux"] for sd in segs)):
         return "token_linear_kernel"  # (csrc/token_linear.hip `token_linear_eligible` has the complete rule)

@@ -705,7 +705,8 @@ def pack(descs, alloc=None):
 PERSIST = os.environ.get("NASREC_PERSIST", "1") != "0"
 _PS_ORDER = os.environ.get("NASREC_PERSIST_ORDER", "start")  # level: (level, longest first); start: estimated start time with slack (below)
 _PS_ALPHA = float(os.environ.get("NASREC_PERSIST_ALPHA", "0.5"))
-PERSIST_RESPLIT = os.environ.get("NASREC_PERSIST_RESPLIT", "off")  # off | slack | all: stand-alone products re-cut into items of the persistent launch
+PERSIST_RESPLIT = os.environ.get("NASREC_PERSIST_RESPLIT", "off")
+_PS_THROTTLE = float(os.environ.get("NASREC_PERSIST_THROTTLE", "0.5"))  # fraction of an operator's slack window its workgroups may take (0 = no throttling)  # off | slack | all: stand-alone products re-cut into items of the persistent launch
 
 
 class PersistRefused(Exception):
@@ -764,6 +765,10 @@ def pack_persistent(descs, dev_alloc, uc_ranges, alloc=None):
             b = item_bytes(nd)
             it = items[k]
             it.kind, it.part, it.off = nd.desc.kind, _PART[nd.part], len(blob)
+            if hint[i] < 0:
+                # units of this operator: unknown here (the launcher's geometry); the window travels as "workgroups that finish in it at 5 us per unit":
+                # resolved below by a dry geometry pass
+                it._pad[1] = hint[i]
             blob += b
             blob += bytes((-len(blob)) % 16)
             ps = [j for j in pred[i] if j in inseg]
@@ -793,6 +798,19 @@ def pack_persistent(descs, dev_alloc, uc_ranges, alloc=None):
         d.kind, d.n, d.blob_bytes = L.OP_PERSIST, len(seg), len(blob)
         hb = C.create_string_buffer(bytes(blob), len(blob))
         d.host_items, d.host_blob = C.addressof(items), C.addressof(hb)
+        if any(items[k]._pad[1] < 0 for k in range(len(seg))):
+            win = [items[k]._pad[1] for k in range(len(seg))]
+            for k in range(len(seg)):
+                items[k]._pad[1] = 0
+            dry = L.PersistDesc.from_buffer_copy(d)
+            L.check(L.load().nasrec_persist_prepare(C.addressof(dry)))  # (geometry only: fills items[k].nblk)
+            for k in range(len(seg)):
+                if win[k] < 0:
+                    units = items[k].nblk
+                    items[k]._pad[1] = max(32, min(units, -(-units * 5000 // -win[k])))
+                else:
+                    items[k]._pad[1] = 0
+                items[k].nblk = items[k].first = 0
         d.nodes = [nodes[i] for i in seg]
         d._host = (items, hb)
         if dev_alloc is None:  # (descriptors and geometry only: CPU tests of the packing, tools)
@@ -815,6 +833,7 @@ def pack_persistent(descs, dev_alloc, uc_ranges, alloc=None):
         out.append(d)
         seg.clear()
 
+    hint = [0] * n
     if _PS_ORDER == "level":
         order = sorted(range(n), key=lambda i: (nodes[i].level, item_bytes(nodes[i]) is not None, -_cost(nodes[i])))
     else:
@@ -836,6 +855,12 @@ def pack_persistent(descs, dev_alloc, uc_ranges, alloc=None):
         for i in range(n - 1, -1, -1):
             alap[i] = min([alap[k] for k in succ[i]] + [end]) - dur[i]
         order = sorted(range(n), key=lambda i: (asap[i] + _PS_ALPHA * (alap[i] - asap[i]), i))
+        if _PS_THROTTLE > 0:
+            # an operator with slack runs on as few workgroups as finish it inside a fraction of its window (units of ~5 us each)
+            for i in range(n):
+                slack = alap[i] - asap[i]
+                if slack >= 10000:
+                    hint[i] = -int(_PS_THROTTLE * slack)  # (negative: nanoseconds of window; turned into a workgroup count once the units are known)
     for i in order:
         if item_bytes(nodes[i]) is None:
             flush()

@@ -2,6 +2,7 @@
 GPU: the command line of the published recipe on TSV shards, the reference's log / checkpoint artefacts, and the fused
 engine step against the operator-by-operator torch route through the same loop."""
 import copy
+import json
 import os
 import pickle
 
@@ -257,3 +258,34 @@ def test_train_supernet_cli_with_row_sharded_tables(tmp_path, capsys):
     logs = TS.main(args)
     capsys.readouterr()
     assert len(logs[0]["test_loss"]) == 1 and np.isfinite(logs[0]["test_loss"][0]) and all(np.isfinite(v) for v in logs[0]["train_loss"])
+
+
+def test_eval_subnet_from_scratch_trains_sampled_subnetworks(tmp_path, capsys):
+    """nasrec/eval_subnet_from_scratch.py:195-245 on the engine: `--num_subnets` fixed sub-networks drawn by `fixed-path` from the seeded
+    global stream, each initialised with init_weights, trained for an epoch (the fused step: Adagrad, weight decay 0) and tested once at
+    its end; results.pickle holds one record per sub-network, distinct architectures, finite scores; a second run with the same seed
+    draws the same architectures."""
+    from nasrec_amd import eval_subnet_from_scratch as ES
+    from nasrec_amd.utils.config import DATASETS
+    from nasrec_amd.utils.io_utils import load_pickle_data
+    tables = [min(n, 1000) for n in DATASETS["kdd"]["tables"]]
+
+    def run(logdir):
+        args = ES.build_parser().parse_args([
+            "--dataset", "kdd", "--root_dir", "synthetic:steps=6,test_steps=2,seed=9,cap=1000", "--logging_dir", logdir, "--config", "autoctr",
+            "--num_blocks", "3", "--use_layernorm", "0", "--num_subnets", "2", "--random_seed", "7", "--learning_rate", "0.05",
+            "--train_batch_size", "32", "--test_batch_size", "32", "--train_limit", "192", "--gpu", "0"])
+        args.num_embeddings = tables
+        torch.manual_seed(1)
+        res = ES.main(args)
+        return res, load_pickle_data(os.path.join(logdir, "results.pickle"))
+
+    res, saved = run(str(tmp_path / "a"))
+    out = capsys.readouterr().out
+    assert "Evaluating 0 out of 2 subnetworks!" in out and "Trained model with the following choice..." in out and "FLOPS:" in out
+    assert len(res) == 2 and len(saved) == 2
+    assert all(np.isfinite(r["test_loss"]) and 0.0 <= r["test_auroc"] <= 1.0 for r in res)
+    assert json.dumps(res[0]["choice"], sort_keys=True, default=str) != json.dumps(res[1]["choice"], sort_keys=True, default=str)
+    res2, _ = run(str(tmp_path / "b"))
+    capsys.readouterr()
+    assert [json.dumps(r["choice"], sort_keys=True, default=str) for r in res2] == [json.dumps(r["choice"], sort_keys=True, default=str) for r in res]
