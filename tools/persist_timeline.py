@@ -54,11 +54,13 @@ for d in pds:
         rows.append(dict(k=k, kind=names.get(it.kind, "?") + ({0: "", 1: ":main", 2: ":epi"}[it.part] if it.kind == L.OP_GEMM else ""), nwg=nwg, nblk=it.nblk,
                          enter=sl[:, 0].min(), enter_last=sl[:, 0].max(), ready=sl[:, 1].max(), body_end=sl[:, 2].max(), done=sl[:, 3].max(),
                          deps=[it.deps[q] for q in range(it.ndeps)]))
+    if os.environ.get("NASREC_TIMELINE_JSON"):
+        json.dump([dict(r, node=d.nodes[r["k"]].index) for r in rows], open(os.environ["NASREC_TIMELINE_JSON"] + ".%d" % pds.index(d), "w"))
     print("persistent launch: %d items, %d workgroups, %.1f us from the first entry to the last arrival" % (d.n, d.total_blocks, t[:, 3].max()))
-    print("  k kind              wgs  enter(first..last)   ready   body_end   done | per dependency: producer done -> this ready (seam)")
+    print("  k kind              wgs units  enter(first..last)   ready   body_end   done | per dependency: producer done -> this ready (seam)")
     for r in rows:
         seams = ["%d:%+.1f" % (j, r["ready"] - rows[j]["done"]) for j in r["deps"]]
-        print("%3d %-16s %5d  %7.1f .. %7.1f  %7.1f  %8.1f %7.1f | %s" % (r["k"], r["kind"], r["nwg"], r["enter"], r["enter_last"], r["ready"], r["body_end"], r["done"], " ".join(seams)))
+        print("%3d %-16s %5d %5d  %7.1f .. %7.1f  %7.1f  %8.1f %7.1f | %s" % (r["k"], r["kind"], r["nwg"], r["nblk"], r["enter"], r["enter_last"], r["ready"], r["body_end"], r["done"], " ".join(seams)))
     # the chain that ends last
     k = max(range(d.n), key=lambda i: rows[i]["done"])
     chain = []
