@@ -639,7 +639,12 @@ def main():
                    "parallelism": parallelism,
                    "ids": "%s over each table; %d pre-generated id batches = %.0f MB of distinct-ish table rows per lap of the pool (Infinity Cache: 256 MB)"
                           % (args.ids, len(batches), len(batches) * B * Fs * 64 / 1e6),
-                   "embedding_update": "row-sparse clip+Adagrad (== dense reference update for weight_decay 0)", "table_sharding": args.table_sharding},
+                   "embedding_update": "row-sparse clip+Adagrad (== dense reference update for weight_decay 0)", "table_sharding": args.table_sharding,
+                   # round 6: where the step's buffers live and which form the joint forward + backward program takes (engine.py: _UC_ARENA, persist)
+                   "plan_buffers": ("uncached device memory (hipDeviceMallocUncached)" if (fixed and getattr(getattr(dp, "cp", None), "arena", None) is not None
+                                                                                             and getattr(dp.cp.arena, "uncached", False)) else "torch allocator"),
+                   "joint_program": ("persistent launch (in-kernel dependencies)" if getattr(getattr(dp, "cp", None), "persistent", False) else
+                                     "one launch per dependency level") if fixed else "one launch per operator"},
         "final_loss": loss,
     }
     if dry:

@@ -104,12 +104,14 @@ class _RawDeviceBytes:
 
     def __init__(self, ptr, n):
         self.ptr, self.n = int(ptr), int(n)
+        self.pid = os.getpid()  # (a forked child — multiprocessing.Manager() of a test, a DataLoader worker — inherits this object but not a usable HIP
+        #                         runtime: its garbage collector must not free the parent's memory.  Found as a segfault of a Manager server.)
         self.__cuda_array_interface__ = {"shape": (self.n,), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
 
     def __del__(self):  # (when the last tensor view of the memory is gone: torch keeps this object alive through the storage)
         try:
             import sys
-            if self.ptr and not sys.is_finalizing():  # (at interpreter exit the HIP runtime may already be gone: the driver reclaims the memory)
+            if self.ptr and not sys.is_finalizing() and os.getpid() == self.pid:  # (at interpreter exit the HIP runtime may already be gone: the driver reclaims the memory)
                 L.load().nasrec_free_uncached(C.c_void_p(self.ptr))
             self.ptr = 0
         except Exception:
@@ -183,6 +185,7 @@ class Arena:
 # kernel boundary to write back — 0.2485 -> 0.2447 / 0.2458 ms per cfg-2 step in four A/B pairs (profiles/r06_ab_uc_arena.txt), bit-identical
 # results.  It is also what lets the persistent step (NASREC_OP_PERSIST) hand buffers over INSIDE a launch.  NASREC_UC_ARENA=0: torch's allocator.
 _UC_ARENA = os.environ.get("NASREC_UC_ARENA", "1") == "1"
+_UC_FLAT = os.environ.get("NASREC_UC_FLAT", "g")
 
 
 def _on_device(fn):
@@ -251,9 +254,19 @@ class SupernetEngine:
             off += (numel + 3) // 4 * 4
         self.flat_numel = off
         with torch.cuda.stream(self.stream):
-            self.flat_p = torch.zeros(off, dtype=torch.float32, device=self.device)
-            self.flat_g = torch.zeros(off, dtype=torch.float32, device=self.device)
-            self.flat_s = torch.zeros(off, dtype=torch.float32, device=self.device)
+            # A fixed sub-network's gradient arena lives in uncached memory like its plan's buffers (_UC_ARENA): every gradient is written once
+            # by the backward and read once by the optimizer's launches — 0.2447 -> 0.2426 ms per cfg-2 step, three A/B pairs
+            # (profiles/r06_ab_uc_arena.txt).  NASREC_UC_FLAT = letters of the flat arenas to place there: g(radients), s(tate), p(arameters).
+            uc = _UC_FLAT if (cfg.fixed and off * 4 <= (64 << 20) and _UC_ARENA) else ""
+            self._uc_flat_arena = Arena(self.device, uncached=True) if uc else None
+
+            def flat(tag):
+                if tag in uc:
+                    t = self._uc_flat_arena.alloc(off).tensor()
+                    t.zero_()
+                    return t
+                return torch.zeros(off, dtype=torch.float32, device=self.device)
+            self.flat_p, self.flat_g, self.flat_s = flat("p"), flat("g"), flat("s")
             self.host_embedding = bool(host_embedding)
             if self.host_embedding:
                 self.tables = []
