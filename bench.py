@@ -629,6 +629,8 @@ def main():
     if not (loss == loss):
         raise SystemExit("loss is NaN")
 
+    cpx = getattr(dp, "cp", None)
+    cpx = getattr(cpx, "cp", cpx)  # (the exchange step's DPPlan wraps the engine's plan)
     result = {
         "metric": "supernet samples/sec at batch 256 (Criteo-shape), 1/2/4/8 MI355X",
         "value": B * world * steps / dt, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup, "setup_steps": n_settle,
@@ -641,9 +643,9 @@ def main():
                           % (args.ids, len(batches), len(batches) * B * Fs * 64 / 1e6),
                    "embedding_update": "row-sparse clip+Adagrad (== dense reference update for weight_decay 0)", "table_sharding": args.table_sharding,
                    # round 6: where the step's buffers live and which form the joint forward + backward program takes (engine.py: _UC_ARENA, persist)
-                   "plan_buffers": ("uncached device memory (hipDeviceMallocUncached)" if (fixed and getattr(getattr(dp, "cp", None), "arena", None) is not None
-                                                                                             and getattr(dp.cp.arena, "uncached", False)) else "torch allocator"),
-                   "joint_program": ("persistent launch (in-kernel dependencies)" if getattr(getattr(dp, "cp", None), "persistent", False) else
+                   "plan_buffers": ("uncached device memory (hipDeviceMallocUncached)" if (fixed and getattr(getattr(cpx, "arena", None), "uncached", False))
+                                    else "torch allocator"),
+                   "joint_program": ("persistent launch (in-kernel dependencies)" if getattr(cpx, "persistent", False) else
                                      "one launch per dependency level") if fixed else "one launch per operator"},
         "final_loss": loss,
     }

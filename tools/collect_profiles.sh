@@ -55,5 +55,18 @@ CONFIG=3 TOP=60 timeout 300 python3 $R/tools/supernet_step_table.py > $O/superne
 timeout 300 python3 $R/tools/gemm_vs_vendor.py > $O/gemm_vs_vendor.txt 2>> $O/log.txt < /dev/null
 timeout 300 python3 $R/tools/parser_bench.py > $O/parser_bench.txt 2>> $O/log.txt < /dev/null
 timeout 900 python3 $R/tools/e2e_tsv_run.py --rows 3000000 > $O/e2e_tsv_run.txt 2>> $O/log.txt < /dev/null
+# round 6: the search loop at its operating point, the persistent step against the level launches (+ its timeline), the uncached-arena A/B,
+# the seam and any-order probes (tools/micro/*.hip are built by the caller: hipcc -O3 --offload-arch=gfx950 -o X X.hip)
+timeout 600 python3 $R/tools/search_operating_point.py --candidates 3 2>> $O/log.txt < /dev/null | grep -E "candidate|checkpoint|steady|resident" > $O/search_operating_point.txt
+ab() { label=$1; shift; env "$@" python3 $R/bench.py --steps-only --no-cpu-baseline 2>> $O/log.txt < /dev/null | tail -1 | python3 -c "import sys,json; r=json.loads(sys.stdin.read()); print('$label:', round(r['value']), 'samples/s', round(r['ms_per_step'],4), 'ms mean', round(r['median_ms_per_step'],4), 'median;', r['config']['plan_buffers'], '/', r['config']['joint_program'])"; }
+for i in 1 2 3; do
+  ab "level launches, uncached plan buffers + gradient arena (default)" NASREC_PERSIST_DEFAULT=0 >> $O/ab_persist_uc.txt
+  ab "level launches, uncached plan buffers, cached gradient arena" NASREC_UC_FLAT= >> $O/ab_persist_uc.txt
+  ab "level launches, torch allocator" NASREC_UC_ARENA=0 >> $O/ab_persist_uc.txt
+  ab "persistent step (NASREC_PERSIST_DEFAULT=1)" NASREC_PERSIST_DEFAULT=1 >> $O/ab_persist_uc.txt
+done
+NASREC_PERSIST_THROTTLE=0 timeout 300 python3 $R/tools/persist_timeline.py > $O/persist_timeline.txt 2>> $O/log.txt < /dev/null
+[ -x $R/tools/micro/seam_probe ] && for sk in 1 3; do timeout 200 $R/tools/micro/seam_probe --skew $sk --groups 512 --reps 100 >> $O/seam_probe.txt 2>&1; done
+[ -x $R/tools/micro/anyorder_probe ] && timeout 60 $R/tools/micro/anyorder_probe >> $O/anyorder_probe.txt 2>&1
 (cd $R && timeout 2400 python3 -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/gpu_tests.txt)
 du -sh $O | tail -1

@@ -150,7 +150,10 @@ def install(O):
           ("bench_cfg2_driver_flags_result.json", TAG + "_bench_cfg2_driver_flags_result.json"),
           ("bench_cfg2_dp_path_real_result.json", TAG + "_bench_cfg2_dp_path_real_collectives_result.json"), ("ab_fuse_final.txt", TAG + "_ab_fuse_final.txt"),
           ("gpu_tests.txt", TAG + "_gpu_tests.txt"),
-          ("ab_graph_vs_launch.txt", TAG + "_ab_graph_vs_launch.txt"), ("launch_gaps.txt", TAG + "_launch_gaps.txt")]
+          ("ab_graph_vs_launch.txt", TAG + "_ab_graph_vs_launch.txt"), ("launch_gaps.txt", TAG + "_launch_gaps.txt"),
+          ("search_operating_point.txt", TAG + "_search_operating_point_final.txt"), ("ab_persist_uc.txt", TAG + "_ab_persist_uc_final.txt"),
+          ("persist_timeline.txt", TAG + "_persist_timeline_final.txt"), ("seam_probe.txt", TAG + "_seam_probe_final.txt"),
+          ("anyorder_probe.txt", TAG + "_anyorder_probe.txt")]
     for a, b in cp:
         src = os.path.join(O, a)
         if os.path.exists(src) and os.path.getsize(src) > 0:
