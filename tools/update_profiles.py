@@ -177,8 +177,8 @@ def install(O):
             if f is not None and w is not None:
                 big = r.get("roofline_largest_gemm", r["roofline"])
                 j = {"build_id": bid, "kernel": big["kernel"], "kernels_of_the_launch": "%s, grid size %s threads" % (d["kernel"], d["grid_size"]),
-                     "source": "tools/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python3 bench.py%s --steps 12 --warmup 3 --steps-only%s`; per-dispatch rows of this launch in profiles/" + TAG + "_dominant_launch_cfg%d_dispatches.json" % (
-                         "" if c == 2 else " --config %d" % c, " --no-graph" if c == 2 else "", c),
+                     "source": "tools/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python3 bench.py%s --steps 12 --warmup 3 --steps-only%s`; per-dispatch rows of this launch in profiles/%s_dominant_launch_cfg%d_dispatches.json" % (
+                         "" if c == 2 else " --config %d" % c, " --no-graph" if c == 2 else "", TAG, c),
                      "fetch_size_kb_raw": f, "fetch_correction": 2.0,
                      "fetch_correction_source": "MI355X_MICROARCH.md HBM section (gfx950 FETCH_SIZE tallies 128-B requests at 64 B); confirmed on known byte counts in round 1 (profiles/r01_pmc_fetch_calibration_loadrate.csv)",
                      "write_size_kb": w, "traffic_bytes_per_launch": int(round((2 * f + w) * 1024)),
