@@ -15,7 +15,10 @@
 // parameter gradients of the node over the sample's tokens: weight gradients as LDS outer products (lane = one
 // (row, column) entry of the wave's 4x16 slice), bias / LayerNorm gradients as wave reductions; per-sample
 // partials are summed across the batch in fixed order by NASREC_OP_REDUCE_ROWS (deterministic).
-#include "attention_body.h"
+#include "attention_tok.h"
+#ifndef MHA_TOK
+#define MHA_TOK 1  // token-major bodies (attention_tok.h) for the 4-wave launches; 0: the column-slice bodies of attention_body.h
+#endif
 
 template <int S>
 __global__ __launch_bounds__(1024 / S) void mha_fwd_kernel(const nasrec_mha_desc_t d) {
@@ -29,16 +32,30 @@ __global__ __launch_bounds__(1024 / S) __attribute__((amdgpu_waves_per_eu(3))) v
   mha_bwd_sample<S>(d, blockIdx.x, lds);
 }
 
+__global__ __launch_bounds__(256) void mha_fwd_tok_kernel(const nasrec_mha_desc_t d) {
+  __shared__ __attribute__((aligned(16))) float lds[MHA_TOK_FWD_LDS_FLOATS];
+  mha_fwd_tok(d, blockIdx.x, lds);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void mha_bwd_tok_kernel(const nasrec_mha_desc_t d) {
+  __shared__ __attribute__((aligned(16))) float lds[MHA_TOK_BWD_LDS_FLOATS];
+  mha_bwd_tok(d, blockIdx.x, lds);
+}
+
 int launch_mha(hipStream_t st, const nasrec_mha_desc_t* d) {
   if (d->N < 1 || d->N > MHA_N) return nasrec_set_error(-2, "mha: N=%d out of range [1,%d]", d->N, MHA_N);
   if (d->B == 0) return 0;
   if (d->kind == NASREC_OP_MHA_FWD) {
-    hipLaunchKernelGGL(mha_fwd_kernel<MHA_SLICE_FWD>, dim3(d->B), dim3(1024 / MHA_SLICE_FWD), 0, st, *d);
+    if (MHA_TOK)
+      hipLaunchKernelGGL(mha_fwd_tok_kernel, dim3(d->B), dim3(256), 0, st, *d);
+    else
+      hipLaunchKernelGGL(mha_fwd_kernel<MHA_SLICE_FWD>, dim3(d->B), dim3(1024 / MHA_SLICE_FWD), 0, st, *d);
   } else {
     if (d->saved == nullptr) return nasrec_set_error(-2, "mha backward needs the state saved by the forward launch (desc.saved)");
     // 8 waves per sample win where latency counts (batch 256: 23.5 against 26.7 us); at large batch the 4-wave form does the
     // same work with fewer wave-instructions per sample (B = 4096: 269 against 286 us)
-    if (d->B >= 1024 || d->bwd_form == 4)
+    if ((d->B >= 1024 || d->bwd_form == 4) && MHA_TOK)
+      hipLaunchKernelGGL(mha_bwd_tok_kernel, dim3(d->B), dim3(256), 0, st, *d);
+    else if (d->B >= 1024 || d->bwd_form == 4)
       hipLaunchKernelGGL(mha_bwd_kernel<4>, dim3(d->B), dim3(256), 0, st, *d);
     else
       hipLaunchKernelGGL(mha_bwd_kernel<MHA_SLICE_BWD>, dim3(d->B), dim3(1024 / MHA_SLICE_BWD), 0, st, *d);

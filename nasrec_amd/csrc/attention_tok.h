@@ -1,0 +1,398 @@
+// Token-major bodies of the fused Transformer (256 threads = 4 waves per sample), round 6.  Same arithmetic contract and the same saved-state
+// planes as attention_body.h (modules.py:648-686); different work assignment:
+//
+//   lane (r = lane & 15, g = lane >> 4) of wave w owns token 16 w + r and the columns 4 g .. 4 g + 3 of every 16-wide vector of that token
+//   (= heads 2 g and 2 g + 1 of the attention), in registers, from the first load to the last store.
+//
+// * Every per-token 16 x 16 product (in-projection x 3, out-projection, the two FFN layers, and their transposes in the backward) is FOUR
+//   v_mfma_f32_16x16x4_f32 of the wave on its own 16 tokens, computed transposed: D[o][token] = sum_k W[o][k] Y[token][k] with A = W and
+//   B = Y^T.  The k index of step s in lane group g is 4 g + s — which is exactly the column the lane holds in register s — and D leaves
+//   lane (r, g) with rows o = 4 g .. 4 g + 3 of token r: the output is in the input's layout.  One ds_read_b128 of the weights per product
+//   instead of sixteen broadcast reads and 64 FMAs; no LDS exchange of the vectors, no barrier between the stages.
+//   (The column-slice form of attention_body.h passes every intermediate vector through LDS and a workgroup barrier because each wave needs
+//   the other waves' columns: twelve barrier-separated stages whose latency, not their arithmetic, was 60 % of the backward at batch 256.)
+// * LayerNorm sums over a token's 16 columns = 4 in the lane + the 4 lanes (r, 0..3): v_permlane16_swap / v_permlane32_swap (gfx950), two
+//   instructions and two adds, every lane of the token gets the same bits.
+// * The attention loops are those of attention_body.h (two heads per packed-fp32 lane pair, keys / queries walked in LDS); the lane's
+//   K / V / Q / dO rows are read at its own column offset 4 g (four addresses per wave instruction instead of one).
+// * Sums over tokens (bias and LayerNorm-weight gradients): DPP reduction over the 16 lanes of a row, per-wave partials in LDS, summed
+//   over the four waves in fixed order.  16 x 16 weight gradients: one wave's MFMA chain over the 64 tokens per matrix (wgrad_mfma), after
+//   the loops, from planes parked in LDS.
+// Barriers: forward 2, backward 4.
+#pragma once
+#include "attention_body.h"
+
+__device__ __forceinline__ float tok_row16_sum(float v) {  // sum over the 16 lanes of a DPP row, in every lane of the row
+  v += dpp_mov<0xb1>(v);   // quad_perm:[1,0,3,2]
+  v += dpp_mov<0x4e>(v);   // quad_perm:[2,3,0,1]
+  v += dpp_mov<0x124>(v);  // row_ror:4
+  v += dpp_mov<0x128>(v);  // row_ror:8
+  return v;
+}
+__device__ __forceinline__ float tok_rows4_sum(float v) {  // sum over lanes r, r + 16, r + 32, r + 48, in each of them (same bits)
+  // (inline asm: handed the same value twice, the builtin is emitted with ONE register as both operands — a swap of the register with
+  // itself, rows exchanged in place — instead of a copy; two "+v" operands are two registers.  tools/micro/permlane_probe.hip.)
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));  // a = [row0, row0, row2, row2], b = [row1, row1, row3, row3]
+  a += b;
+  b = a;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));  // a = [lower, lower], b = [upper, upper]
+  return a + b;
+}
+// out[token r][4 g + i] = acc[i] + sum_k Wl[(4 g + i) * 16 + k] * y[token r][k]   (Wl: LDS, row = output; y: the lane's 4 columns)
+__device__ __forceinline__ f32x4 tok_mm(const float* Wl, int r, int c0, const f32x4 y, f32x4 acc) {
+  const f32x4 a = ld4(Wl + r * 16 + c0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], y[s], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ float sum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+__device__ __forceinline__ f32x4 pair_order(const f32x4 v) { return (f32x4){v[0], v[2], v[1], v[3]}; }  // (h0c0, h0c1, h1c0, h1c1) -> (h0c0, h1c0, h0c1, h1c1)
+__device__ __forceinline__ void tok_ln_stats(const f32x4 v, float& mu, float& rstd) {
+  mu = tok_rows4_sum(sum4(v)) * (1.f / 16.f);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) q += (v[e] - mu) * (v[e] - mu);
+  rstd = 1.f / sqrtf(tok_rows4_sum(q) * (1.f / 16.f) + 1e-5f);
+}
+
+#define MHA_TOK_FWD_LDS_FLOATS (NASREC_MHA_PARAMS + 2 * MHA_N * 16)
+__device__ __forceinline__ void mha_fwd_tok(const nasrec_mha_desc_t& d, const int b, float* lds) {
+  constexpr int NT = 256;
+  float* Wsh = lds;
+  float* Ks = Wsh + NASREC_MHA_PARAMS;
+  float* Vs = Ks + MHA_N * 16;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4, c0 = 4 * g, tok = 16 * w + r;
+  const int N = d.N;
+  const bool active = tok < N;
+  const bool saving = d.saved != nullptr;
+#ifdef MHA_STAMPS
+  unsigned mha_st[16];
+#endif
+  MHA_STAMP(0);
+  ParamPieces<NT> pp;
+  stage_params_load<NT>(d, tid, pp);
+  f32x4 x4 = ld4(d.x + (long)b * d.ldx + min(tok, N - 1) * 16 + c0);
+  stage_params_store<NT>(Wsh, tid, pp);
+  if (!active) x4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  MHA_STAMP(1);
+  // in-projection
+  f32x4 q4 = tok_mm(Wsh + OFF_WIN, r, c0, x4, ld4(Wsh + OFF_BIN + c0));
+  const f32x4 k4 = tok_mm(Wsh + OFF_WIN + 256, r, c0, x4, ld4(Wsh + OFF_BIN + 16 + c0));
+  const f32x4 v4 = tok_mm(Wsh + OFF_WIN + 512, r, c0, x4, ld4(Wsh + OFF_BIN + 32 + c0));
+  q4 *= MHA_SCALE;
+  *reinterpret_cast<f32x4*>(Ks + tok * 16 + c0) = pair_order(k4);
+  *reinterpret_cast<f32x4*>(Vs + tok * 16 + c0) = pair_order(v4);
+  const long po = (long)tok * 16 + c0;  // the lane's 16-byte piece of a [token][16] plane
+  if (saving && active) {
+    *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_Q) + po) = q4;
+    *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_K) + po) = k4;
+    *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_V) + po) = v4;
+  }
+  __syncthreads();
+  MHA_STAMP(2);
+  // attention: the lane's token as query, heads 2 g and 2 g + 1 as one packed-fp32 pair; scores in log2 units
+  constexpr float LOG2E = 1.44269504088896340736f;
+  const f32x2 qa = {q4[0] * LOG2E, q4[2] * LOG2E}, qb = {q4[1] * LOG2E, q4[3] * LOG2E};
+  f32x2 m2 = {-INFINITY, -INFINITY};
+#pragma unroll 8
+  for (int j = 0; j < N; ++j) {
+    const f32x4 kj = ld4(Ks + j * 16 + c0);
+    const f32x2 s2 = qa * (f32x2){kj[0], kj[1]} + qb * (f32x2){kj[2], kj[3]};
+    m2[0] = fmaxf(m2[0], s2[0]);
+    m2[1] = fmaxf(m2[1], s2[1]);
+  }
+  MHA_STAMP(3);
+  f32x2 l2 = {0.f, 0.f}, oa = {0.f, 0.f}, ob = {0.f, 0.f};
+#pragma unroll 8
+  for (int j = 0; j < N; ++j) {
+    const f32x4 kj = ld4(Ks + j * 16 + c0);
+    const f32x4 vj = ld4(Vs + j * 16 + c0);
+    const f32x2 t2 = qa * (f32x2){kj[0], kj[1]} + qb * (f32x2){kj[2], kj[3]} - m2;
+    const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+    l2 = l2 + p2;
+    oa = p2 * (f32x2){vj[0], vj[1]} + oa;
+    ob = p2 * (f32x2){vj[2], vj[3]} + ob;
+  }
+  const f32x2 mx = {m2[0] * (1.f / LOG2E), m2[1] * (1.f / LOG2E)};  // the backward works in natural units
+  const f32x2 li = {1.f / l2[0], 1.f / l2[1]};
+  const f32x4 o4 = {oa[0] * li[0], ob[0] * li[0], oa[1] * li[1], ob[1] * li[1]};
+  MHA_STAMP(4);
+  if (saving && active) {
+    *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_O) + po) = o4;
+    float* mp = sv_plane(d.saved, b, N, SV_M) + (long)tok * 16 + 2 * g;
+    *reinterpret_cast<f32x2*>(mp) = mx;
+    *reinterpret_cast<f32x2*>(mp + 8) = li;
+  }
+  MHA_STAMP(5);
+  // out-projection + residual + LayerNorm 1
+  f32x4 r1 = tok_mm(Wsh + OFF_WOUT, r, c0, o4, ld4(Wsh + OFF_BOUT + c0)) + x4;
+  float mu1, rstd1;
+  tok_ln_stats(r1, mu1, rstd1);
+  const f32x4 xh1 = (r1 - mu1) * rstd1;
+  const f32x4 h1 = xh1 * ld4(Wsh + OFF_L1W + c0) + ld4(Wsh + OFF_L1B + c0);
+  MHA_STAMP(6);
+  // FFN
+  f32x4 f1 = tok_mm(Wsh + OFF_W1, r, c0, h1, ld4(Wsh + OFF_C1 + c0));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) f1[e] = fmaxf(f1[e], 0.f);
+  const f32x4 r2 = tok_mm(Wsh + OFF_W2, r, c0, f1, ld4(Wsh + OFF_C2 + c0)) + h1;
+  MHA_STAMP(7);
+  float mu2, rstd2;
+  tok_ln_stats(r2, mu2, rstd2);
+  MHA_STAMP(8);
+  const f32x4 xh2 = (r2 - mu2) * rstd2;
+  f32x4 out = xh2 * ld4(Wsh + OFF_L2W + c0) + ld4(Wsh + OFF_L2B + c0);
+  if (d.dims_in_use >= 0 && tok >= d.dims_in_use) out = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    *reinterpret_cast<f32x4*>(d.out + (long)b * d.ldo + po) = out;
+    if (saving) {
+      *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_H1) + po) = h1;
+      *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_XH1) + po) = xh1;
+      *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_F1) + po) = f1;
+      *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_XH2) + po) = xh2;
+      if (g == 0) *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_RSTD) + tok * 4) = (f32x4){rstd1, rstd2, 0.f, 0.f};
+    }
+  }
+#ifdef MHA_STAMPS
+  MHA_STAMP(9);
+  __syncthreads();
+  if (tid == 0)
+    for (int i = 0; i < 10; ++i) d.out[(long)b * d.ldo + i] = __builtin_bit_cast(float, mha_st[i]);
+#endif
+}
+
+// ---- backward -------------------------------------------------------------------------------------------------------------------------------
+// LDS floats: transposed matrices 6 x 256 | LayerNorm weights 2 x 16 | K V Q dO rows 4 x 1024 | m' and D per (token, head) 2 x 512 |
+// five operand planes of the weight gradients 5 x 1024 | per-wave token sums 4 x 160
+#define MHA_TOK_WT 0
+#define MHA_TOK_LW (6 * 256)
+#define MHA_TOK_ROWS (MHA_TOK_LW + 32)
+#define MHA_TOK_MD (MHA_TOK_ROWS + 4 * MHA_N * 16)
+#define MHA_TOK_PL (MHA_TOK_MD + 2 * MHA_N * 8)
+#define MHA_TOK_BP (MHA_TOK_PL + 5 * MHA_N * 16)
+#define MHA_TOK_BWD_LDS_FLOATS (MHA_TOK_BP + 4 * 160)
+
+// transposed park of the six 16 x 16 matrices (Wt[m][i][o] = W_m[o][i]) and the two LayerNorm weight vectors; the other parameters are
+// not read by the backward
+template <int NT>
+__device__ __forceinline__ void stage_params_store_t(float* lds, int tid, const ParamPieces<NT>& pp) {
+#pragma unroll
+  for (int k = 0; k < ParamPieces<NT>::PER; ++k) {
+    const int piece = tid + k * NT;
+    if (piece >= ParamPieces<NT>::PIECES) continue;
+    const int off = 4 * piece;
+    int m = -1, base = 0;
+    if (off < OFF_BIN) {
+      m = off >> 8;
+      base = m << 8;
+    } else if (off >= OFF_WOUT && off < OFF_BOUT) {
+      m = 3;
+      base = OFF_WOUT;
+    } else if (off >= OFF_W1 && off < OFF_C1) {
+      m = 4;
+      base = OFF_W1;
+    } else if (off >= OFF_W2 && off < OFF_C2) {
+      m = 5;
+      base = OFF_W2;
+    }
+    if (m >= 0) {
+      const int o = (off - base) >> 4, i0 = (off - base) & 15;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lds[MHA_TOK_WT + m * 256 + (i0 + e) * 16 + o] = pp.v[k][e];
+    } else if (off >= OFF_L1W && off < OFF_L1B) {
+      *reinterpret_cast<f32x4*>(lds + MHA_TOK_LW + (off - OFF_L1W)) = pp.v[k];
+    } else if (off >= OFF_L2W && off < OFF_L2B) {
+      *reinterpret_cast<f32x4*>(lds + MHA_TOK_LW + 16 + (off - OFF_L2W)) = pp.v[k];
+    }
+  }
+}
+
+// per-wave sum over the wave's 16 tokens of the lane's 4 columns -> BP[w][vec][16]
+__device__ __forceinline__ void tok_bias_partial(float* bp, int vec, int r, int c0, const f32x4 v) {
+  f32x4 s;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s[e] = tok_row16_sum(v[e]);
+  if (r == 0) *reinterpret_cast<f32x4*>(bp + vec * 16 + c0) = s;
+}
+
+__device__ __forceinline__ void mha_bwd_tok(const nasrec_mha_desc_t& d, const int b, float* lds) {
+  constexpr int NT = 256;
+  float* Wt = lds + MHA_TOK_WT;
+  const float* LW = lds + MHA_TOK_LW;
+  float* Kb = lds + MHA_TOK_ROWS;
+  float* Vb = Kb + MHA_N * 16;
+  float* Qb = Vb + MHA_N * 16;
+  float* DOb = Qb + MHA_N * 16;
+  float* Mb = lds + MHA_TOK_MD;
+  float* Db = Mb + MHA_N * 8;
+  float* DR2p = lds + MHA_TOK_PL;
+  float* F1p = DR2p + MHA_N * 16;
+  float* DF1p = F1p + MHA_N * 16;
+  float* H1p = DF1p + MHA_N * 16;
+  float* DR1p = H1p + MHA_N * 16;
+  float* Op = Mb;  // after the attention loops (m' and D are dead: 2 x 512 floats = one plane)
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4, c0 = 4 * g, tok = 16 * w + r;
+  float* bp = lds + MHA_TOK_BP + w * 160;
+  const int N = d.N;
+  const bool active = tok < N;
+  float* gp = d.dparams_partial + (long)b * (d.partial_ld > 0 ? d.partial_ld : NASREC_MHA_PARAMS);
+#ifdef MHA_STAMPS
+  unsigned mha_st[16];
+#endif
+  MHA_STAMP(0);
+  // ---- everything the lane needs of its token, one round trip -----------------------------------------------------------------------
+  const int tl = min(tok, N - 1);
+  const long po = (long)tl * 16 + c0;
+  ParamPieces<NT> pp;
+  stage_params_load<NT>(d, tid, pp);
+  const f32x2 rs2 = *reinterpret_cast<const f32x2*>(sv_plane(d.saved, b, N, SV_RSTD) + tl * 4);
+  const float* mp = sv_plane(d.saved, b, N, SV_M) + (long)tl * 16 + 2 * g;
+  const f32x2 mx = *reinterpret_cast<const f32x2*>(mp), li = *reinterpret_cast<const f32x2*>(mp + 8);
+  f32x4 dout = ld4(d.dout + (long)b * d.ldo + po);
+  f32x4 x4 = ld4(d.x + (long)b * d.ldx + po);
+  f32x4 q4 = ld4(sv_plane(d.saved, b, N, SV_Q) + po), k4 = ld4(sv_plane(d.saved, b, N, SV_K) + po), v4 = ld4(sv_plane(d.saved, b, N, SV_V) + po);
+  f32x4 o4 = ld4(sv_plane(d.saved, b, N, SV_O) + po), h1 = ld4(sv_plane(d.saved, b, N, SV_H1) + po), f1 = ld4(sv_plane(d.saved, b, N, SV_F1) + po);
+  f32x4 xh1 = ld4(sv_plane(d.saved, b, N, SV_XH1) + po), xh2 = ld4(sv_plane(d.saved, b, N, SV_XH2) + po);
+  stage_params_store_t<NT>(lds, tid, pp);
+  constexpr float LOG2E = 1.44269504088896340736f;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  float rstd1 = rs2[0], rstd2 = rs2[1];
+  f32x2 mq = {(mx[0] - __logf(li[0])) * LOG2E, (mx[1] - __logf(li[1])) * LOG2E};  // m' = (max + ln sum) log2 e per (token, head)
+  if (!active) {
+    x4 = q4 = k4 = v4 = o4 = h1 = f1 = xh1 = xh2 = dout = z4;
+    rstd1 = rstd2 = 1.f;
+    mq = (f32x2){0.f, 0.f};
+  }
+  if (d.dims_in_use >= 0 && tok >= d.dims_in_use) dout = z4;
+  // rows of the attention loops in pair order (h0c0, h1c0, h0c1, h1c1); q and k keep that order in registers too
+  q4 = pair_order(q4);
+  k4 = pair_order(k4);
+  v4 = pair_order(v4);
+  *reinterpret_cast<f32x4*>(Qb + tok * 16 + c0) = q4;
+  *reinterpret_cast<f32x4*>(Kb + tok * 16 + c0) = k4;
+  *reinterpret_cast<f32x4*>(Vb + tok * 16 + c0) = v4;
+  *reinterpret_cast<f32x2*>(Mb + tok * 8 + 2 * g) = mq;
+  *reinterpret_cast<f32x4*>(F1p + tok * 16 + c0) = f1;
+  *reinterpret_cast<f32x4*>(H1p + tok * 16 + c0) = h1;
+  __syncthreads();  // the transposed matrices are parked
+  MHA_STAMP(1);
+  MHA_STAMP(2);
+  // ---- LayerNorm 2 ----
+  tok_bias_partial(bp, 0, r, c0, dout * xh2);
+  tok_bias_partial(bp, 1, r, c0, dout);
+  f32x4 gw = dout * ld4(LW + 16 + c0);
+  float ca = tok_rows4_sum(sum4(gw)) * (1.f / 16.f), cb = tok_rows4_sum(sum4(gw * xh2)) * (1.f / 16.f);
+  const f32x4 dr2 = (gw - ca - xh2 * cb) * rstd2;
+  *reinterpret_cast<f32x4*>(DR2p + tok * 16 + c0) = dr2;
+  tok_bias_partial(bp, 2, r, c0, dr2);
+  MHA_STAMP(3);
+  // ---- FFN 2, FFN 1 ----
+  f32x4 df1 = tok_mm(Wt + 5 * 256, r, c0, dr2, z4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) df1[e] = f1[e] > 0.f ? df1[e] : 0.f;
+  *reinterpret_cast<f32x4*>(DF1p + tok * 16 + c0) = df1;
+  tok_bias_partial(bp, 3, r, c0, df1);
+  MHA_STAMP(4);
+  const f32x4 dh1 = tok_mm(Wt + 4 * 256, r, c0, df1, dr2);
+  MHA_STAMP(5);
+  // ---- LayerNorm 1 ----
+  tok_bias_partial(bp, 4, r, c0, dh1 * xh1);
+  tok_bias_partial(bp, 5, r, c0, dh1);
+  gw = dh1 * ld4(LW + c0);
+  ca = tok_rows4_sum(sum4(gw)) * (1.f / 16.f);
+  cb = tok_rows4_sum(sum4(gw * xh1)) * (1.f / 16.f);
+  const f32x4 dr1 = (gw - ca - xh1 * cb) * rstd1;
+  *reinterpret_cast<f32x4*>(DR1p + tok * 16 + c0) = dr1;
+  tok_bias_partial(bp, 6, r, c0, dr1);
+  MHA_STAMP(6);
+  // ---- out-projection ----
+  const f32x4 dO = tok_mm(Wt + 3 * 256, r, c0, dr1, z4);
+  const f32x2 dd2 = {fmaf(dO[0], o4[0], dO[1] * o4[1]), fmaf(dO[2], o4[2], dO[3] * o4[3])};
+  *reinterpret_cast<f32x2*>(Db + tok * 8 + 2 * g) = dd2;
+  *reinterpret_cast<f32x4*>(DOb + tok * 16 + c0) = pair_order(dO);
+  __syncthreads();  // every token's K / V / Q / dO rows, m' and D are in LDS
+  MHA_STAMP(7);
+  // ---- attention backward: the loops of attention_body.h (same operations per element, same order) ----
+  f32x4 dq, dk, dv;
+  {
+    const f32x2 qa = {q4[0] * LOG2E, q4[1] * LOG2E}, qb = {q4[2] * LOG2E, q4[3] * LOG2E}, doa = {dO[0], dO[2]}, dob = {dO[1], dO[3]};
+    f32x2 dqa = {0.f, 0.f}, dqb = {0.f, 0.f};  // phase A: the lane's token as query
+#pragma unroll 4
+    for (int j = 0; j < N; ++j) {
+      const f32x4 kj = ld4(Kb + j * 16 + c0), vj = ld4(Vb + j * 16 + c0);
+      const f32x2 ka = {kj[0], kj[1]}, kb = {kj[2], kj[3]}, va = {vj[0], vj[1]}, vb = {vj[2], vj[3]};
+      const f32x2 t = __builtin_elementwise_fma(qa, ka, qb * kb) - mq;
+      const f32x2 p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+      const f32x2 ds = p * (__builtin_elementwise_fma(doa, va, dob * vb) - dd2);
+      dqa = __builtin_elementwise_fma(ds, ka, dqa);
+      dqb = __builtin_elementwise_fma(ds, kb, dqb);
+    }
+    dq = (f32x4){dqa[0] * MHA_SCALE, dqb[0] * MHA_SCALE, dqa[1] * MHA_SCALE, dqb[1] * MHA_SCALE};
+    MHA_STAMP(8);
+    const f32x2 ka = {k4[0] * LOG2E, k4[1] * LOG2E}, kb = {k4[2] * LOG2E, k4[3] * LOG2E}, va = {v4[0], v4[1]}, vb = {v4[2], v4[3]};
+    f32x2 dka = {0.f, 0.f}, dkb = {0.f, 0.f}, dva = {0.f, 0.f}, dvb = {0.f, 0.f};  // phase B: the lane's token as key
+#pragma unroll 4
+    for (int i = 0; i < N; ++i) {
+      const f32x4 qi = ld4(Qb + i * 16 + c0), doi = ld4(DOb + i * 16 + c0);
+      const f32x2 qia = {qi[0], qi[1]}, qib = {qi[2], qi[3]}, da = {doi[0], doi[1]}, db = {doi[2], doi[3]};
+      const f32x2 mi = *reinterpret_cast<const f32x2*>(Mb + i * 8 + 2 * g), di = *reinterpret_cast<const f32x2*>(Db + i * 8 + 2 * g);
+      const f32x2 t = __builtin_elementwise_fma(qia, ka, qib * kb) - mi;
+      const f32x2 p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+      dva = __builtin_elementwise_fma(p, da, dva);
+      dvb = __builtin_elementwise_fma(p, db, dvb);
+      const f32x2 ds = p * (__builtin_elementwise_fma(da, va, db * vb) - di);
+      dka = __builtin_elementwise_fma(ds, qia, dka);
+      dkb = __builtin_elementwise_fma(ds, qib, dkb);
+    }
+    dk = (f32x4){dka[0], dkb[0], dka[1], dkb[1]};
+    dv = (f32x4){dva[0], dvb[0], dva[1], dvb[1]};
+  }
+  MHA_STAMP(9);
+  if (!active) dq = dk = dv = z4;
+  tok_bias_partial(bp, 7, r, c0, dq);
+  tok_bias_partial(bp, 8, r, c0, dk);
+  tok_bias_partial(bp, 9, r, c0, dv);
+  __syncthreads();  // every wave is done with the K / V / Q / dO rows, m' and D
+  *reinterpret_cast<f32x4*>(Qb + tok * 16 + c0) = dq;
+  *reinterpret_cast<f32x4*>(Kb + tok * 16 + c0) = dk;
+  *reinterpret_cast<f32x4*>(Vb + tok * 16 + c0) = dv;
+  *reinterpret_cast<f32x4*>(DOb + tok * 16 + c0) = x4;
+  *reinterpret_cast<f32x4*>(Op + tok * 16 + c0) = o4;
+  MHA_STAMP(10);
+  // ---- dx = dr1 + Win^T [dq; dk; dv] ----
+  f32x4 dx = tok_mm(Wt, r, c0, dq, dr1);
+  dx = tok_mm(Wt + 256, r, c0, dk, dx);
+  dx = tok_mm(Wt + 512, r, c0, dv, dx);
+  if (active) *reinterpret_cast<f32x4*>(d.dx + (long)b * d.ldx + (long)tok * 16 + c0) = dx;
+  __syncthreads();  // the operand planes of the weight gradients and the per-wave token sums are complete
+  MHA_STAMP(11);
+  // ---- parameter gradients of the sample: six 16 x 16 matrices as MFMA chains over the tokens, the ten 16-vectors from the wave partials ----
+  if (w == 0) {
+    wgrad_mfma(Qb, DOb, lane, N, gp + OFF_WIN);
+    wgrad_mfma(DR2p, F1p, lane, N, gp + OFF_W2);
+  } else if (w == 1) {
+    wgrad_mfma(Kb, DOb, lane, N, gp + OFF_WIN + 256);
+    wgrad_mfma(DF1p, H1p, lane, N, gp + OFF_W1);
+  } else if (w == 2) {
+    wgrad_mfma(Vb, DOb, lane, N, gp + OFF_WIN + 512);
+  } else {
+    wgrad_mfma(DR1p, Op, lane, N, gp + OFF_WOUT);
+  }
+  if (w >= 2) {
+    const float* BP = lds + MHA_TOK_BP;
+    for (int t = tid - 128; t < 160; t += 128) {
+      const int vec = t >> 4;
+      const int dst = vec == 0 ? OFF_L2W : vec == 1 ? OFF_L2B : vec == 2 ? OFF_C2 : vec == 3 ? OFF_C1 : vec == 4 ? OFF_L1W : vec == 5 ? OFF_L1B
+                      : vec == 6 ? OFF_BOUT : OFF_BIN + 16 * (vec - 7);
+      gp[dst + (t & 15)] = (BP[t] + BP[160 + t]) + (BP[320 + t] + BP[480 + t]);
+    }
+  }
+#ifdef MHA_STAMPS
+  MHA_STAMP(12);
+  __syncthreads();
+  if (tid == 0)
+    for (int i = 0; i < 13; ++i) gp[i] = __builtin_bit_cast(float, mha_st[i]);
+#endif
+}

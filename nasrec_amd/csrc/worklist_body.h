@@ -1,6 +1,9 @@
 // Device side of NASREC_OP_WORKLIST (see worklist.hip): the kernel and its item bodies.
 #pragma once
-#include "attention_body.h"
+#include "attention_tok.h"
+#ifndef MHA_TOK
+#define MHA_TOK 1
+#endif
 #include "gemm_rt.h"
 #include "final_bodies.h"
 #include "interact_bodies.h"
@@ -360,7 +363,8 @@ __device__ __forceinline__ void wl_gemm_second_pass(unsigned long long blob, int
 }
 
 __device__ __forceinline__ void wl_mha_fwd(unsigned long long blob, int vb) {
-  mha_fwd_sample<4>(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
+  if (MHA_TOK) mha_fwd_tok(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
+  else mha_fwd_sample<4>(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
 }
 
 // BIG: the variant that also carries the Transformer backward (164 registers, 52 KB of LDS: three workgroups per CU instead of four /
@@ -425,7 +429,8 @@ __global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(unsigned f01
       wl_mha_fwd(blob, vb);
       break;
     case NASREC_OP_MHA_BWD:
-      if (BIG) mha_bwd_sample<4>(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
+      if (BIG && MHA_TOK) mha_bwd_tok(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
+      else if (BIG) mha_bwd_sample<4>(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
       break;
     case NASREC_OP_FM_FWD: {
       const nasrec_fm_desc_t& d = wl_ref<nasrec_fm_desc_t>(blob);
