@@ -33,7 +33,7 @@ extern "C" {
 #define NASREC_MAX_TABLES 32
 #define NASREC_EMB_DIM 16
 #define NASREC_MHA_PARAMS 1696 /* floats of parameter gradient produced per Transformer node */
-#define NASREC_MHA_SAVED 148   /* floats of forward state kept per token for the Transformer backward */
+#define NASREC_MHA_SAVED 36    /* floats of forward state kept per token for the Transformer backward (rounds 1-5: 148) */
 
 /* operand addressing modes of the GEMM family (see DESIGN.md "One GEMM, six bindings") */
 enum {
@@ -230,15 +230,14 @@ typedef struct nasrec_mha_desc {
   float* dx;            /* overwritten */
   float* dparams_partial; /* [B, NASREC_MHA_PARAMS] */
   const float* params[12];
-  float* saved;         /* optional [B, N, NASREC_MHA_SAVED]: forward intermediates per token (scaled q, k, v, attention
-                           output, softmax max / 1/sum per head, both LayerNorm x-hats and 1/std, FFN hidden) written by the
-                           forward launch and read by the backward launch instead of recomputing the forward */
+  float* saved;         /* optional [B, N * NASREC_MHA_SAVED]: per sample the planes [N][16] attention output, [N][16] softmax max /
+                           1/sum per head, [N][4] 1/std and mean of both LayerNorms, written by the forward launch; the backward
+                           launch reads them and recomputes q, k, v, the x-hats and the FFN hidden layer from x (six 16 x 16
+                           products per token on the matrix cores) instead of reading 112 more floats per token */
   int32_t partial_ld;   /* bwd: row stride of dparams_partial in floats (0 = NASREC_MHA_PARAMS); lets several Transformer nodes
                            share one partial buffer [B, n * NASREC_MHA_PARAMS] that ONE NASREC_OP_REDUCE_ROWS launch sums */
-  int32_t bwd_form;     /* bwd: 0 = the launcher picks (8 waves per sample below batch 1024, 4 waves above); 4 = the 4-wave form
-                           whatever the batch — the form a worklist launch runs, so that a level-scheduled plan gives the same
-                           bits whether its Transformer backward rides in a worklist or stands alone (the two forms differ in
-                           the summation order of the weight gradients over the tokens) */
+  int32_t bwd_form;     /* ignored since ABI 16 (one backward form: 4 waves per sample, token-major; rounds 3-5: 0 = the launcher
+                           picks 8 or 4 waves per sample by the batch, 4 = the form a worklist launch runs) */
 } nasrec_mha_desc_t;
 
 /* out[c] = sum_r in[r*ld + c], r < R, c < C, fixed order.  Optionally scattered to up to NASREC_REDUCE_MAX_DST destination

@@ -20,7 +20,7 @@ MAX_SEGS = 8
 MAX_TABLES = 32
 EMB_DIM = 16
 MHA_PARAMS = 1696
-MHA_SAVED = 148
+MHA_SAVED = 36
 REDUCE_MAX_DST = 48
 
 AM_KC, AM_RC, AM_TOKR, AM_TOKK = 0, 1, 2, 3
@@ -281,8 +281,8 @@ def load():
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
                  "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_worklist", "nasrec_dedup_ids", "nasrec_opt_reduce2", "nasrec_final_fused"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 15:
-        raise EngineError("ABI version mismatch: library %d, binding 15" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 16:
+        raise EngineError("ABI version mismatch: library %d, binding 16" % lib.nasrec_abi_version())
     sizes = (i32 * 40)()
     n = lib.nasrec_desc_sizes(sizes, 40)
     for kind, cls in DESC_BY_KIND.items():

@@ -18,6 +18,9 @@
 // * Sums over tokens (bias and LayerNorm-weight gradients): DPP reduction over the 16 lanes of a row, per-wave partials in LDS, summed
 //   over the four waves in fixed order.  16 x 16 weight gradients: one wave's MFMA chain over the 64 tokens per matrix (wgrad_mfma), after
 //   the loops, from planes parked in LDS.
+// * The backward rebuilds q, k, v, both LayerNorm x-hats, the LayerNorm-1 output and the FFN hidden layer from x, the saved attention
+//   output and the saved LayerNorm statistics: six more products per token (24 MFMAs, the same instructions on the same operands as the
+//   forward: the same bits) instead of 112 more floats per token through HBM in both directions.
 // Barriers: forward 2, backward 4.
 #pragma once
 #include "attention_body.h"
@@ -40,12 +43,17 @@ __device__ __forceinline__ float tok_rows4_sum(float v) {  // sum over lanes r, 
   return a + b;
 }
 // out[token r][4 g + i] = acc[i] + sum_k Wl[(4 g + i) * 16 + k] * y[token r][k]   (Wl: LDS, row = output; y: the lane's 4 columns)
-__device__ __forceinline__ f32x4 tok_mm(const float* Wl, int r, int c0, const f32x4 y, f32x4 acc) {
-  const f32x4 a = ld4(Wl + r * 16 + c0);
-#pragma unroll
-  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], y[s], acc, 0, 0, 0);
-  return acc;
+// (two accumulators — k = 4 g + {0, 1} on top of `acc`, {2, 3} from zero — so that a product is two dependent MFMAs and an add deep instead
+// of four: these products sit in dependent chains of three to five per body; forward and recomputation share this one function)
+__device__ __forceinline__ f32x4 tok_mma(const f32x4 a, const f32x4 y, f32x4 acc) {  // the lane's piece of the matrix in registers
+  f32x4 hi = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], y[0], acc, 0, 0, 0);
+  hi = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], y[2], hi, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], y[1], acc, 0, 0, 0);
+  hi = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], y[3], hi, 0, 0, 0);
+  return acc + hi;
 }
+__device__ __forceinline__ f32x4 tok_mm(const float* Wl, int r, int c0, const f32x4 y, f32x4 acc) { return tok_mma(ld4(Wl + r * 16 + c0), y, acc); }
 __device__ __forceinline__ float sum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 __device__ __forceinline__ f32x4 pair_order(const f32x4 v) { return (f32x4){v[0], v[2], v[1], v[3]}; }  // (h0c0, h0c1, h1c0, h1c1) -> (h0c0, h1c0, h0c1, h1c1)
 __device__ __forceinline__ void tok_ln_stats(const f32x4 v, float& mu, float& rstd) {
@@ -57,14 +65,18 @@ __device__ __forceinline__ void tok_ln_stats(const f32x4 v, float& mu, float& rs
 }
 
 #define MHA_TOK_FWD_LDS_FLOATS (NASREC_MHA_PARAMS + 2 * MHA_N * 16)
+// Which block of 16 tokens wave w of sample b owns: rotated by the sample index, so that with N <= 48 the waves WITHOUT tokens (they only
+// help park the parameters and meet the barriers) are not the same wave slot — hence the same SIMD — in every workgroup of the launch.
+__device__ __forceinline__ int tok_block(int w, int b) { return (w + b) & 3; }
+
 __device__ __forceinline__ void mha_fwd_tok(const nasrec_mha_desc_t& d, const int b, float* lds) {
   constexpr int NT = 256;
   float* Wsh = lds;
   float* Ks = Wsh + NASREC_MHA_PARAMS;
   float* Vs = Ks + MHA_N * 16;
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4, c0 = 4 * g, tok = 16 * w + r;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4, c0 = 4 * g, tok = 16 * tok_block(w, b) + r;
   const int N = d.N;
-  const bool active = tok < N;
+  const bool active = tok < N, wave_active = tok - r < N;  // (wave-uniform: the wave's block holds tokens)
   const bool saving = d.saved != nullptr;
 #ifdef MHA_STAMPS
   unsigned mha_st[16];
@@ -72,110 +84,108 @@ __device__ __forceinline__ void mha_fwd_tok(const nasrec_mha_desc_t& d, const in
   MHA_STAMP(0);
   ParamPieces<NT> pp;
   stage_params_load<NT>(d, tid, pp);
-  f32x4 x4 = ld4(d.x + (long)b * d.ldx + min(tok, N - 1) * 16 + c0);
+  f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
+  if (wave_active) x4 = ld4(d.x + (long)b * d.ldx + min(tok, N - 1) * 16 + c0);
   stage_params_store<NT>(Wsh, tid, pp);
   if (!active) x4 = (f32x4){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   MHA_STAMP(1);
   // in-projection
-  f32x4 q4 = tok_mm(Wsh + OFF_WIN, r, c0, x4, ld4(Wsh + OFF_BIN + c0));
-  const f32x4 k4 = tok_mm(Wsh + OFF_WIN + 256, r, c0, x4, ld4(Wsh + OFF_BIN + 16 + c0));
-  const f32x4 v4 = tok_mm(Wsh + OFF_WIN + 512, r, c0, x4, ld4(Wsh + OFF_BIN + 32 + c0));
-  q4 *= MHA_SCALE;
-  *reinterpret_cast<f32x4*>(Ks + tok * 16 + c0) = pair_order(k4);
-  *reinterpret_cast<f32x4*>(Vs + tok * 16 + c0) = pair_order(v4);
-  const long po = (long)tok * 16 + c0;  // the lane's 16-byte piece of a [token][16] plane
-  if (saving && active) {
-    *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_Q) + po) = q4;
-    *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_K) + po) = k4;
-    *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_V) + po) = v4;
+  f32x4 q4 = x4;
+  if (wave_active) {
+    q4 = tok_mm(Wsh + OFF_WIN, r, c0, x4, ld4(Wsh + OFF_BIN + c0)) * MHA_SCALE;
+    const f32x4 k4 = tok_mm(Wsh + OFF_WIN + 256, r, c0, x4, ld4(Wsh + OFF_BIN + 16 + c0));
+    const f32x4 v4 = tok_mm(Wsh + OFF_WIN + 512, r, c0, x4, ld4(Wsh + OFF_BIN + 32 + c0));
+    *reinterpret_cast<f32x4*>(Ks + tok * 16 + c0) = pair_order(k4);
+    *reinterpret_cast<f32x4*>(Vs + tok * 16 + c0) = pair_order(v4);
   }
   __syncthreads();
   MHA_STAMP(2);
-  // attention: the lane's token as query, heads 2 g and 2 g + 1 as one packed-fp32 pair; scores in log2 units
-  constexpr float LOG2E = 1.44269504088896340736f;
-  const f32x2 qa = {q4[0] * LOG2E, q4[2] * LOG2E}, qb = {q4[1] * LOG2E, q4[3] * LOG2E};
-  f32x2 m2 = {-INFINITY, -INFINITY};
+  if (wave_active) {
+    const long po = (long)tok * 16 + c0;  // the lane's 16-byte piece of a [token][16] plane
+    // attention: the lane's token as query, heads 2 g and 2 g + 1 as one packed-fp32 pair; scores in log2 units
+    constexpr float LOG2E = 1.44269504088896340736f;
+    const f32x2 qa = {q4[0] * LOG2E, q4[2] * LOG2E}, qb = {q4[1] * LOG2E, q4[3] * LOG2E};
+    f32x2 m2 = {-INFINITY, -INFINITY};
 #pragma unroll 8
-  for (int j = 0; j < N; ++j) {
-    const f32x4 kj = ld4(Ks + j * 16 + c0);
-    const f32x2 s2 = qa * (f32x2){kj[0], kj[1]} + qb * (f32x2){kj[2], kj[3]};
-    m2[0] = fmaxf(m2[0], s2[0]);
-    m2[1] = fmaxf(m2[1], s2[1]);
-  }
-  MHA_STAMP(3);
-  f32x2 l2 = {0.f, 0.f}, oa = {0.f, 0.f}, ob = {0.f, 0.f};
+    for (int j = 0; j < N; ++j) {
+      const f32x4 kj = ld4(Ks + j * 16 + c0);
+      const f32x2 s2 = qa * (f32x2){kj[0], kj[1]} + qb * (f32x2){kj[2], kj[3]};
+      m2[0] = fmaxf(m2[0], s2[0]);
+      m2[1] = fmaxf(m2[1], s2[1]);
+    }
+    MHA_STAMP(3);
+    f32x2 l2 = {0.f, 0.f}, oa = {0.f, 0.f}, ob = {0.f, 0.f};
 #pragma unroll 8
-  for (int j = 0; j < N; ++j) {
-    const f32x4 kj = ld4(Ks + j * 16 + c0);
-    const f32x4 vj = ld4(Vs + j * 16 + c0);
-    const f32x2 t2 = qa * (f32x2){kj[0], kj[1]} + qb * (f32x2){kj[2], kj[3]} - m2;
-    const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
-    l2 = l2 + p2;
-    oa = p2 * (f32x2){vj[0], vj[1]} + oa;
-    ob = p2 * (f32x2){vj[2], vj[3]} + ob;
-  }
-  const f32x2 mx = {m2[0] * (1.f / LOG2E), m2[1] * (1.f / LOG2E)};  // the backward works in natural units
-  const f32x2 li = {1.f / l2[0], 1.f / l2[1]};
-  const f32x4 o4 = {oa[0] * li[0], ob[0] * li[0], oa[1] * li[1], ob[1] * li[1]};
-  MHA_STAMP(4);
-  if (saving && active) {
-    *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_O) + po) = o4;
-    float* mp = sv_plane(d.saved, b, N, SV_M) + (long)tok * 16 + 2 * g;
-    *reinterpret_cast<f32x2*>(mp) = mx;
-    *reinterpret_cast<f32x2*>(mp + 8) = li;
-  }
-  MHA_STAMP(5);
-  // out-projection + residual + LayerNorm 1
-  f32x4 r1 = tok_mm(Wsh + OFF_WOUT, r, c0, o4, ld4(Wsh + OFF_BOUT + c0)) + x4;
-  float mu1, rstd1;
-  tok_ln_stats(r1, mu1, rstd1);
-  const f32x4 xh1 = (r1 - mu1) * rstd1;
-  const f32x4 h1 = xh1 * ld4(Wsh + OFF_L1W + c0) + ld4(Wsh + OFF_L1B + c0);
-  MHA_STAMP(6);
-  // FFN
-  f32x4 f1 = tok_mm(Wsh + OFF_W1, r, c0, h1, ld4(Wsh + OFF_C1 + c0));
+    for (int j = 0; j < N; ++j) {
+      const f32x4 kj = ld4(Ks + j * 16 + c0);
+      const f32x4 vj = ld4(Vs + j * 16 + c0);
+      const f32x2 t2 = qa * (f32x2){kj[0], kj[1]} + qb * (f32x2){kj[2], kj[3]} - m2;
+      const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+      l2 = l2 + p2;
+      oa = p2 * (f32x2){vj[0], vj[1]} + oa;
+      ob = p2 * (f32x2){vj[2], vj[3]} + ob;
+    }
+    const f32x2 mx = {m2[0] * (1.f / LOG2E), m2[1] * (1.f / LOG2E)};  // the backward works in natural units
+    const f32x2 li = {1.f / l2[0], 1.f / l2[1]};
+    const f32x4 o4 = {oa[0] * li[0], ob[0] * li[0], oa[1] * li[1], ob[1] * li[1]};
+    MHA_STAMP(4);
+    if (saving && active) {
+      *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_O) + po) = o4;
+      float* mp = sv_plane(d.saved, b, N, SV_M) + (long)tok * 16 + 2 * g;
+      *reinterpret_cast<f32x2*>(mp) = mx;
+      *reinterpret_cast<f32x2*>(mp + 8) = li;
+    }
+    MHA_STAMP(5);
+    // out-projection + residual + LayerNorm 1
+    const f32x4 r1 = tok_mm(Wsh + OFF_WOUT, r, c0, o4, ld4(Wsh + OFF_BOUT + c0)) + x4;
+    float mu1, rstd1;
+    tok_ln_stats(r1, mu1, rstd1);
+    const f32x4 xh1 = (r1 - mu1) * rstd1;
+    const f32x4 h1 = xh1 * ld4(Wsh + OFF_L1W + c0) + ld4(Wsh + OFF_L1B + c0);
+    MHA_STAMP(6);
+    // FFN
+    f32x4 f1 = tok_mm(Wsh + OFF_W1, r, c0, h1, ld4(Wsh + OFF_C1 + c0));
 #pragma unroll
-  for (int e = 0; e < 4; ++e) f1[e] = fmaxf(f1[e], 0.f);
-  const f32x4 r2 = tok_mm(Wsh + OFF_W2, r, c0, f1, ld4(Wsh + OFF_C2 + c0)) + h1;
-  MHA_STAMP(7);
-  float mu2, rstd2;
-  tok_ln_stats(r2, mu2, rstd2);
-  MHA_STAMP(8);
-  const f32x4 xh2 = (r2 - mu2) * rstd2;
-  f32x4 out = xh2 * ld4(Wsh + OFF_L2W + c0) + ld4(Wsh + OFF_L2B + c0);
-  if (d.dims_in_use >= 0 && tok >= d.dims_in_use) out = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (active) {
-    *reinterpret_cast<f32x4*>(d.out + (long)b * d.ldo + po) = out;
-    if (saving) {
-      *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_H1) + po) = h1;
-      *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_XH1) + po) = xh1;
-      *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_F1) + po) = f1;
-      *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_XH2) + po) = xh2;
-      if (g == 0) *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_RSTD) + tok * 4) = (f32x4){rstd1, rstd2, 0.f, 0.f};
+    for (int e = 0; e < 4; ++e) f1[e] = fmaxf(f1[e], 0.f);
+    const f32x4 r2 = tok_mm(Wsh + OFF_W2, r, c0, f1, ld4(Wsh + OFF_C2 + c0)) + h1;
+    MHA_STAMP(7);
+    float mu2, rstd2;
+    tok_ln_stats(r2, mu2, rstd2);
+    MHA_STAMP(8);
+    const f32x4 xh2 = (r2 - mu2) * rstd2;
+    f32x4 out = xh2 * ld4(Wsh + OFF_L2W + c0) + ld4(Wsh + OFF_L2B + c0);
+    if (d.dims_in_use >= 0 && tok >= d.dims_in_use) out = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      *reinterpret_cast<f32x4*>(d.out + (long)b * d.ldo + po) = out;
+      if (saving && g == 0) *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_STAT) + tok * 4) = (f32x4){rstd1, rstd2, mu1, mu2};
     }
   }
 #ifdef MHA_STAMPS
   MHA_STAMP(9);
   __syncthreads();
-  if (tid == 0)
+  if (tid == 0)  // (wave 0 owns block b & 3: tools/mha_stamps.py reads the samples where that block holds tokens)
     for (int i = 0; i < 10; ++i) d.out[(long)b * d.ldo + i] = __builtin_bit_cast(float, mha_st[i]);
 #endif
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------------------------------
-// LDS floats: transposed matrices 6 x 256 | LayerNorm weights 2 x 16 | K V Q dO rows 4 x 1024 | m' and D per (token, head) 2 x 512 |
-// five operand planes of the weight gradients 5 x 1024 | per-wave token sums 4 x 160
+// LDS floats: transposed matrices 6 x 16 rows of 20 | the twelve-minus-matrices parameter vectors 160 | K V Q dO rows 4 x 1024 | m' and D per (token, head) 2 x 512 |
+// 1024 spare | per-wave weight-gradient operand planes 4 x 2 x 256 | per-wave token sums 4 x 160
 #define MHA_TOK_WT 0
-#define MHA_TOK_LW (6 * 256)
-#define MHA_TOK_ROWS (MHA_TOK_LW + 32)
+#define MHA_TOK_WLD 20   // row stride of a parked matrix: rows 16 banks apart for the column reads, 16-byte aligned for the row reads
+#define MHA_TOK_WSZ (16 * MHA_TOK_WLD)
+#define MHA_TOK_VEC (6 * MHA_TOK_WSZ)  // bin 48 | bout 16 | l1w 16 | l1b 16 | c1 16 | c2 16 | l2w 16 | l2b 16
+#define MHA_TOK_ROWS (MHA_TOK_VEC + 160)
 #define MHA_TOK_MD (MHA_TOK_ROWS + 4 * MHA_N * 16)
-#define MHA_TOK_PL (MHA_TOK_MD + 2 * MHA_N * 8)
-#define MHA_TOK_BP (MHA_TOK_PL + 5 * MHA_N * 16)
+#define MHA_TOK_EX (MHA_TOK_MD + 2 * MHA_N * 8)   // (rows + m' / D + these 1024 floats = the 4 x 6 x 256 per-wave weight-gradient partials, after the loops)
+#define MHA_TOK_SCR (MHA_TOK_EX + 1024)          // per wave: two operand planes [16 tokens][16] of its weight-gradient products
+#define MHA_TOK_BP (MHA_TOK_SCR + 4 * 512)
 #define MHA_TOK_BWD_LDS_FLOATS (MHA_TOK_BP + 4 * 160)
 
-// transposed park of the six 16 x 16 matrices (Wt[m][i][o] = W_m[o][i]) and the two LayerNorm weight vectors; the other parameters are
-// not read by the backward
+// The six 16 x 16 matrices parked TRANSPOSED (Wt[m][i][o] = W_m[o][i], rows of MHA_TOK_WLD floats): a product with W^T reads the
+// lane's operand as one 16-byte row piece (tok_mm), a product with W as four dwords down a column (tok_mm_col) — 16 consecutive floats
+// per lane group, the groups 16 banks apart: conflict-free both ways, as is this store.  The vectors go to their own 160 floats.
 template <int NT>
 __device__ __forceinline__ void stage_params_store_t(float* lds, int tid, const ParamPieces<NT>& pp) {
 #pragma unroll
@@ -183,30 +193,44 @@ __device__ __forceinline__ void stage_params_store_t(float* lds, int tid, const 
     const int piece = tid + k * NT;
     if (piece >= ParamPieces<NT>::PIECES) continue;
     const int off = 4 * piece;
-    int m = -1, base = 0;
+    int m = -1, base = 0, vec = -1;
     if (off < OFF_BIN) {
       m = off >> 8;
       base = m << 8;
-    } else if (off >= OFF_WOUT && off < OFF_BOUT) {
+    } else if (off < OFF_WOUT) {
+      vec = off - OFF_BIN;
+    } else if (off < OFF_BOUT) {
       m = 3;
       base = OFF_WOUT;
-    } else if (off >= OFF_W1 && off < OFF_C1) {
+    } else if (off < OFF_W1) {
+      vec = 48 + (off - OFF_BOUT);  // bout, l1w, l1b
+    } else if (off < OFF_C1) {
       m = 4;
       base = OFF_W1;
-    } else if (off >= OFF_W2 && off < OFF_C2) {
+    } else if (off < OFF_W2) {
+      vec = 96 + (off - OFF_C1);  // c1
+    } else if (off < OFF_C2) {
       m = 5;
       base = OFF_W2;
+    } else {
+      vec = 112 + (off - OFF_C2);  // c2, l2w, l2b
     }
     if (m >= 0) {
       const int o = (off - base) >> 4, i0 = (off - base) & 15;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) lds[MHA_TOK_WT + m * 256 + (i0 + e) * 16 + o] = pp.v[k][e];
-    } else if (off >= OFF_L1W && off < OFF_L1B) {
-      *reinterpret_cast<f32x4*>(lds + MHA_TOK_LW + (off - OFF_L1W)) = pp.v[k];
-    } else if (off >= OFF_L2W && off < OFF_L2B) {
-      *reinterpret_cast<f32x4*>(lds + MHA_TOK_LW + 16 + (off - OFF_L2W)) = pp.v[k];
+      for (int e = 0; e < 4; ++e) lds[MHA_TOK_WT + m * MHA_TOK_WSZ + (i0 + e) * MHA_TOK_WLD + o] = pp.v[k][e];
+    } else {
+      *reinterpret_cast<f32x4*>(lds + MHA_TOK_VEC + vec) = pp.v[k];
     }
   }
+}
+// products against a parked matrix: with W^T (the backward's) and with W (the recomputed forward)
+__device__ __forceinline__ f32x4 tok_mm_t(const float* Wt, int r, int c0, const f32x4 y, f32x4 acc) {
+  return tok_mma(ld4(Wt + r * MHA_TOK_WLD + c0), y, acc);
+}
+__device__ __forceinline__ f32x4 tok_mm_col(const float* Wt, int r, int c0, const f32x4 y, f32x4 acc) {
+  const float* p = Wt + c0 * MHA_TOK_WLD + r;
+  return tok_mma((f32x4){p[0], p[MHA_TOK_WLD], p[2 * MHA_TOK_WLD], p[3 * MHA_TOK_WLD]}, y, acc);
 }
 
 // per-wave sum over the wave's 16 tokens of the lane's 4 columns -> BP[w][vec][16]
@@ -217,106 +241,130 @@ __device__ __forceinline__ void tok_bias_partial(float* bp, int vec, int r, int 
   if (r == 0) *reinterpret_cast<f32x4*>(bp + vec * 16 + c0) = s;
 }
 
+// The wave's share of a weight gradient dW[o][i] = sum_tok G[tok][o] V[tok][i]: its own 16 tokens, 4 MFMAs with k = token.  The lane's
+// pieces of G and V (token r, columns 4 g ..) go to the wave's two scratch planes and come back transposed — lane (r, g) feeds
+// A(o = r, k = 4 s + g) = G[4 s + g][r] and B(k, i = r) = V[4 s + g][r]: 16 consecutive floats per lane group, the groups 16 banks apart.
+// LDS operations of one wave execute in order: no barrier.  Result: D[o = 4 g + e][i = r] in register e.  Rows of tokens >= N are zero
+// in G (every gradient of an inactive lane is zero), so they add nothing.
+__device__ __forceinline__ f32x4 tok_wgrad(float* Gs, float* Vs, int r, int g, const f32x4 gv, const f32x4 vv, bool write_v) {
+  *reinterpret_cast<f32x4*>(Gs + r * 16 + 4 * g) = gv;
+  if (write_v) *reinterpret_cast<f32x4*>(Vs + r * 16 + 4 * g) = vv;
+  f32x4 a, b;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    a[s] = Gs[(4 * s + g) * 16 + r];
+    b[s] = Vs[(4 * s + g) * 16 + r];
+  }
+  return tok_mma(a, b, (f32x4){0.f, 0.f, 0.f, 0.f});
+}
+
 __device__ __forceinline__ void mha_bwd_tok(const nasrec_mha_desc_t& d, const int b, float* lds) {
   constexpr int NT = 256;
   float* Wt = lds + MHA_TOK_WT;
-  const float* LW = lds + MHA_TOK_LW;
   float* Kb = lds + MHA_TOK_ROWS;
   float* Vb = Kb + MHA_N * 16;
   float* Qb = Vb + MHA_N * 16;
   float* DOb = Qb + MHA_N * 16;
   float* Mb = lds + MHA_TOK_MD;
   float* Db = Mb + MHA_N * 8;
-  float* DR2p = lds + MHA_TOK_PL;
-  float* F1p = DR2p + MHA_N * 16;
-  float* DF1p = F1p + MHA_N * 16;
-  float* H1p = DF1p + MHA_N * 16;
-  float* DR1p = H1p + MHA_N * 16;
-  float* Op = Mb;  // after the attention loops (m' and D are dead: 2 x 512 floats = one plane)
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4, c0 = 4 * g, tok = 16 * w + r;
-  float* bp = lds + MHA_TOK_BP + w * 160;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4, c0 = 4 * g, blk = tok_block(w, b), tok = 16 * blk + r;
+  float* bp = lds + MHA_TOK_BP + blk * 160;   // per-BLOCK partials (summed in block order below: the same bits whatever the rotation)
+  float* Gs = lds + MHA_TOK_SCR + w * 512;    // the wave's operand planes of its weight-gradient products
+  float* Vs = Gs + 256;
   const int N = d.N;
-  const bool active = tok < N;
+  const bool active = tok < N, wave_active = 16 * blk < N;
   float* gp = d.dparams_partial + (long)b * (d.partial_ld > 0 ? d.partial_ld : NASREC_MHA_PARAMS);
 #ifdef MHA_STAMPS
   unsigned mha_st[16];
 #endif
   MHA_STAMP(0);
-  // ---- everything the lane needs of its token, one round trip -----------------------------------------------------------------------
+  // ---- everything the lane needs of its token, one round trip: x, dout, attention output and statistics (and its share of the parameters) ----
   const int tl = min(tok, N - 1);
   const long po = (long)tl * 16 + c0;
-  ParamPieces<NT> pp;
-  stage_params_load<NT>(d, tid, pp);
-  const f32x2 rs2 = *reinterpret_cast<const f32x2*>(sv_plane(d.saved, b, N, SV_RSTD) + tl * 4);
-  const float* mp = sv_plane(d.saved, b, N, SV_M) + (long)tl * 16 + 2 * g;
-  const f32x2 mx = *reinterpret_cast<const f32x2*>(mp), li = *reinterpret_cast<const f32x2*>(mp + 8);
-  f32x4 dout = ld4(d.dout + (long)b * d.ldo + po);
-  f32x4 x4 = ld4(d.x + (long)b * d.ldx + po);
-  f32x4 q4 = ld4(sv_plane(d.saved, b, N, SV_Q) + po), k4 = ld4(sv_plane(d.saved, b, N, SV_K) + po), v4 = ld4(sv_plane(d.saved, b, N, SV_V) + po);
-  f32x4 o4 = ld4(sv_plane(d.saved, b, N, SV_O) + po), h1 = ld4(sv_plane(d.saved, b, N, SV_H1) + po), f1 = ld4(sv_plane(d.saved, b, N, SV_F1) + po);
-  f32x4 xh1 = ld4(sv_plane(d.saved, b, N, SV_XH1) + po), xh2 = ld4(sv_plane(d.saved, b, N, SV_XH2) + po);
-  stage_params_store_t<NT>(lds, tid, pp);
   constexpr float LOG2E = 1.44269504088896340736f;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  float rstd1 = rs2[0], rstd2 = rs2[1];
-  f32x2 mq = {(mx[0] - __logf(li[0])) * LOG2E, (mx[1] - __logf(li[1])) * LOG2E};  // m' = (max + ln sum) log2 e per (token, head)
-  if (!active) {
-    x4 = q4 = k4 = v4 = o4 = h1 = f1 = xh1 = xh2 = dout = z4;
-    rstd1 = rstd2 = 1.f;
-    mq = (f32x2){0.f, 0.f};
+  ParamPieces<NT> pp;
+  stage_params_load<NT>(d, tid, pp);
+  f32x4 st4 = z4, dout = z4, x4 = z4, o4 = z4;
+  f32x2 mq = {0.f, 0.f};
+  if (wave_active) {
+    st4 = ld4(sv_plane(d.saved, b, N, SV_STAT) + tl * 4);
+    const float* mp = sv_plane(d.saved, b, N, SV_M) + (long)tl * 16 + 2 * g;
+    const f32x2 mx = *reinterpret_cast<const f32x2*>(mp), li = *reinterpret_cast<const f32x2*>(mp + 8);
+    dout = ld4(d.dout + (long)b * d.ldo + po);
+    x4 = ld4(d.x + (long)b * d.ldx + po);
+    o4 = ld4(sv_plane(d.saved, b, N, SV_O) + po);
+    mq = (f32x2){(mx[0] - __logf(li[0])) * LOG2E, (mx[1] - __logf(li[1])) * LOG2E};  // m' = (max + ln sum) log2 e per (token, head)
   }
+  stage_params_store_t<NT>(lds, tid, pp);
+  if (!active) x4 = o4 = dout = z4;
   if (d.dims_in_use >= 0 && tok >= d.dims_in_use) dout = z4;
-  // rows of the attention loops in pair order (h0c0, h1c0, h0c1, h1c1); q and k keep that order in registers too
-  q4 = pair_order(q4);
-  k4 = pair_order(k4);
-  v4 = pair_order(v4);
-  *reinterpret_cast<f32x4*>(Qb + tok * 16 + c0) = q4;
-  *reinterpret_cast<f32x4*>(Kb + tok * 16 + c0) = k4;
-  *reinterpret_cast<f32x4*>(Vb + tok * 16 + c0) = v4;
-  *reinterpret_cast<f32x2*>(Mb + tok * 8 + 2 * g) = mq;
-  *reinterpret_cast<f32x4*>(F1p + tok * 16 + c0) = f1;
-  *reinterpret_cast<f32x4*>(H1p + tok * 16 + c0) = h1;
-  __syncthreads();  // the transposed matrices are parked
+  if (wave_active) *reinterpret_cast<f32x2*>(Mb + tok * 8 + 2 * g) = mq;
+  __syncthreads();  // the parameters are parked
   MHA_STAMP(1);
-  MHA_STAMP(2);
-  // ---- LayerNorm 2 ----
-  tok_bias_partial(bp, 0, r, c0, dout * xh2);
-  tok_bias_partial(bp, 1, r, c0, dout);
-  f32x4 gw = dout * ld4(LW + 16 + c0);
-  float ca = tok_rows4_sum(sum4(gw)) * (1.f / 16.f), cb = tok_rows4_sum(sum4(gw * xh2)) * (1.f / 16.f);
-  const f32x4 dr2 = (gw - ca - xh2 * cb) * rstd2;
-  *reinterpret_cast<f32x4*>(DR2p + tok * 16 + c0) = dr2;
-  tok_bias_partial(bp, 2, r, c0, dr2);
-  MHA_STAMP(3);
-  // ---- FFN 2, FFN 1 ----
-  f32x4 df1 = tok_mm(Wt + 5 * 256, r, c0, dr2, z4);
+  f32x4 q4 = z4, k4 = z4, v4 = z4, dr1 = z4, dO = z4, gW2 = z4, gW1 = z4, gWo = z4, gWq = z4, gWk = z4, gWv = z4;
+  f32x2 dd2 = {0.f, 0.f};
+  if (wave_active) {
+    // ---- the forward again, from x and o (mha_fwd_tok's instructions on the same operands) ----
+    const float* VEC = lds + MHA_TOK_VEC;
+    const float rstd1 = st4[0], rstd2 = st4[1];
+    const f32x4 l1w = ld4(VEC + 64 + c0), l2w = ld4(VEC + 128 + c0);
+    q4 = tok_mm_col(Wt, r, c0, x4, ld4(VEC + c0)) * MHA_SCALE;
+    k4 = tok_mm_col(Wt + MHA_TOK_WSZ, r, c0, x4, ld4(VEC + 16 + c0));
+    v4 = tok_mm_col(Wt + 2 * MHA_TOK_WSZ, r, c0, x4, ld4(VEC + 32 + c0));
+    const f32x4 xh1 = (tok_mm_col(Wt + 3 * MHA_TOK_WSZ, r, c0, o4, ld4(VEC + 48 + c0)) + x4 - st4[2]) * rstd1;
+    const f32x4 h1 = xh1 * l1w + ld4(VEC + 80 + c0);
+    f32x4 f1 = tok_mm_col(Wt + 4 * MHA_TOK_WSZ, r, c0, h1, ld4(VEC + 96 + c0));
 #pragma unroll
-  for (int e = 0; e < 4; ++e) df1[e] = f1[e] > 0.f ? df1[e] : 0.f;
-  *reinterpret_cast<f32x4*>(DF1p + tok * 16 + c0) = df1;
-  tok_bias_partial(bp, 3, r, c0, df1);
-  MHA_STAMP(4);
-  const f32x4 dh1 = tok_mm(Wt + 4 * 256, r, c0, df1, dr2);
-  MHA_STAMP(5);
-  // ---- LayerNorm 1 ----
-  tok_bias_partial(bp, 4, r, c0, dh1 * xh1);
-  tok_bias_partial(bp, 5, r, c0, dh1);
-  gw = dh1 * ld4(LW + c0);
-  ca = tok_rows4_sum(sum4(gw)) * (1.f / 16.f);
-  cb = tok_rows4_sum(sum4(gw * xh1)) * (1.f / 16.f);
-  const f32x4 dr1 = (gw - ca - xh1 * cb) * rstd1;
-  *reinterpret_cast<f32x4*>(DR1p + tok * 16 + c0) = dr1;
-  tok_bias_partial(bp, 6, r, c0, dr1);
-  MHA_STAMP(6);
-  // ---- out-projection ----
-  const f32x4 dO = tok_mm(Wt + 3 * 256, r, c0, dr1, z4);
-  const f32x2 dd2 = {fmaf(dO[0], o4[0], dO[1] * o4[1]), fmaf(dO[2], o4[2], dO[3] * o4[3])};
-  *reinterpret_cast<f32x2*>(Db + tok * 8 + 2 * g) = dd2;
-  *reinterpret_cast<f32x4*>(DOb + tok * 16 + c0) = pair_order(dO);
+    for (int e = 0; e < 4; ++e) f1[e] = fmaxf(f1[e], 0.f);
+    const f32x4 xh2 = (tok_mm_col(Wt + 5 * MHA_TOK_WSZ, r, c0, f1, ld4(VEC + 112 + c0)) + h1 - st4[3]) * rstd2;
+    // rows of the attention loops in pair order (h0c0, h1c0, h0c1, h1c1); q, k, v keep that order in registers too
+    q4 = pair_order(q4);
+    k4 = pair_order(k4);
+    v4 = pair_order(v4);
+    *reinterpret_cast<f32x4*>(Qb + tok * 16 + c0) = q4;
+    *reinterpret_cast<f32x4*>(Kb + tok * 16 + c0) = k4;
+    *reinterpret_cast<f32x4*>(Vb + tok * 16 + c0) = v4;
+    MHA_STAMP(2);
+    // ---- LayerNorm 2 ----
+    tok_bias_partial(bp, 0, r, c0, dout * xh2);
+    tok_bias_partial(bp, 1, r, c0, dout);
+    f32x4 gw = dout * l2w;
+    float ca = tok_rows4_sum(sum4(gw)) * (1.f / 16.f), cb = tok_rows4_sum(sum4(gw * xh2)) * (1.f / 16.f);
+    const f32x4 dr2 = (gw - ca - xh2 * cb) * rstd2;
+    gW2 = tok_wgrad(Gs, Vs, r, g, dr2, f1, true);
+    tok_bias_partial(bp, 2, r, c0, dr2);
+    MHA_STAMP(3);
+    // ---- FFN 2, FFN 1 ----
+    f32x4 df1 = tok_mm_t(Wt + 5 * MHA_TOK_WSZ, r, c0, dr2, z4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) df1[e] = f1[e] > 0.f ? df1[e] : 0.f;
+    gW1 = tok_wgrad(Gs, Vs, r, g, df1, h1, true);
+    tok_bias_partial(bp, 3, r, c0, df1);
+    MHA_STAMP(4);
+    const f32x4 dh1 = tok_mm_t(Wt + 4 * MHA_TOK_WSZ, r, c0, df1, dr2);
+    MHA_STAMP(5);
+    // ---- LayerNorm 1 ----
+    tok_bias_partial(bp, 4, r, c0, dh1 * xh1);
+    tok_bias_partial(bp, 5, r, c0, dh1);
+    gw = dh1 * l1w;
+    ca = tok_rows4_sum(sum4(gw)) * (1.f / 16.f);
+    cb = tok_rows4_sum(sum4(gw * xh1)) * (1.f / 16.f);
+    dr1 = (gw - ca - xh1 * cb) * rstd1;
+    gWo = tok_wgrad(Gs, Vs, r, g, dr1, o4, true);
+    tok_bias_partial(bp, 6, r, c0, dr1);
+    MHA_STAMP(6);
+    // ---- out-projection ----
+    dO = tok_mm_t(Wt + 3 * MHA_TOK_WSZ, r, c0, dr1, z4);
+    dd2 = (f32x2){fmaf(dO[0], o4[0], dO[1] * o4[1]), fmaf(dO[2], o4[2], dO[3] * o4[3])};
+    *reinterpret_cast<f32x2*>(Db + tok * 8 + 2 * g) = dd2;
+    *reinterpret_cast<f32x4*>(DOb + tok * 16 + c0) = pair_order(dO);
+  }
   __syncthreads();  // every token's K / V / Q / dO rows, m' and D are in LDS
   MHA_STAMP(7);
-  // ---- attention backward: the loops of attention_body.h (same operations per element, same order) ----
-  f32x4 dq, dk, dv;
-  {
+  if (wave_active) {
+    // ---- attention backward: two heads per packed-fp32 lane pair, one exponential per probability (exp2(s' - m')) ----
+    f32x4 dq, dk, dv;
     const f32x2 qa = {q4[0] * LOG2E, q4[1] * LOG2E}, qb = {q4[2] * LOG2E, q4[3] * LOG2E}, doa = {dO[0], dO[2]}, dob = {dO[1], dO[3]};
     f32x2 dqa = {0.f, 0.f}, dqb = {0.f, 0.f};  // phase A: the lane's token as query
 #pragma unroll 4
@@ -348,45 +396,59 @@ __device__ __forceinline__ void mha_bwd_tok(const nasrec_mha_desc_t& d, const in
     }
     dk = (f32x4){dka[0], dkb[0], dka[1], dkb[1]};
     dv = (f32x4){dva[0], dvb[0], dva[1], dvb[1]};
+    MHA_STAMP(9);
+    if (!active) dq = dk = dv = z4;
+    tok_bias_partial(bp, 7, r, c0, dq);
+    tok_bias_partial(bp, 8, r, c0, dk);
+    tok_bias_partial(bp, 9, r, c0, dv);
+    // ---- in-projection: weight gradients (the wave's tokens), dx = dr1 + Win^T [dq; dk; dv] ----
+    gWq = tok_wgrad(Gs, Vs, r, g, dq, x4, true);
+    gWk = tok_wgrad(Gs, Vs, r, g, dk, x4, false);
+    gWv = tok_wgrad(Gs, Vs, r, g, dv, x4, false);
+    const f32x4 dx = (tok_mm_t(Wt, r, c0, dq, dr1) + tok_mm_t(Wt + MHA_TOK_WSZ, r, c0, dk, z4)) + tok_mm_t(Wt + 2 * MHA_TOK_WSZ, r, c0, dv, z4);
+    if (active) *reinterpret_cast<f32x4*>(d.dx + (long)b * d.ldx + (long)tok * 16 + c0) = dx;
   }
-  MHA_STAMP(9);
-  if (!active) dq = dk = dv = z4;
-  tok_bias_partial(bp, 7, r, c0, dq);
-  tok_bias_partial(bp, 8, r, c0, dk);
-  tok_bias_partial(bp, 9, r, c0, dv);
-  __syncthreads();  // every wave is done with the K / V / Q / dO rows, m' and D
-  *reinterpret_cast<f32x4*>(Qb + tok * 16 + c0) = dq;
-  *reinterpret_cast<f32x4*>(Kb + tok * 16 + c0) = dk;
-  *reinterpret_cast<f32x4*>(Vb + tok * 16 + c0) = dv;
-  *reinterpret_cast<f32x4*>(DOb + tok * 16 + c0) = x4;
-  *reinterpret_cast<f32x4*>(Op + tok * 16 + c0) = o4;
   MHA_STAMP(10);
-  // ---- dx = dr1 + Win^T [dq; dk; dv] ----
-  f32x4 dx = tok_mm(Wt, r, c0, dq, dr1);
-  dx = tok_mm(Wt + 256, r, c0, dk, dx);
-  dx = tok_mm(Wt + 512, r, c0, dv, dx);
-  if (active) *reinterpret_cast<f32x4*>(d.dx + (long)b * d.ldx + (long)tok * 16 + c0) = dx;
-  __syncthreads();  // the operand planes of the weight gradients and the per-wave token sums are complete
-  MHA_STAMP(11);
-  // ---- parameter gradients of the sample: six 16 x 16 matrices as MFMA chains over the tokens, the ten 16-vectors from the wave partials ----
-  if (w == 0) {
-    wgrad_mfma(Qb, DOb, lane, N, gp + OFF_WIN);
-    wgrad_mfma(DR2p, F1p, lane, N, gp + OFF_W2);
-  } else if (w == 1) {
-    wgrad_mfma(Kb, DOb, lane, N, gp + OFF_WIN + 256);
-    wgrad_mfma(DF1p, H1p, lane, N, gp + OFF_W1);
-  } else if (w == 2) {
-    wgrad_mfma(Vb, DOb, lane, N, gp + OFF_WIN + 512);
-  } else {
-    wgrad_mfma(DR1p, Op, lane, N, gp + OFF_WOUT);
+  __syncthreads();  // every wave is done with the K / V / Q / dO rows, m' and D: their LDS takes the per-block partials [block][matrix][i][o]
+  if (wave_active) {
+    float* P = lds + MHA_TOK_ROWS + blk * 1536 + r * 16 + c0;
+    *reinterpret_cast<f32x4*>(P) = gWq;
+    *reinterpret_cast<f32x4*>(P + 256) = gWk;
+    *reinterpret_cast<f32x4*>(P + 512) = gWv;
+    *reinterpret_cast<f32x4*>(P + 768) = gWo;
+    *reinterpret_cast<f32x4*>(P + 1024) = gW1;
+    *reinterpret_cast<f32x4*>(P + 1280) = gW2;
   }
-  if (w >= 2) {
-    const float* BP = lds + MHA_TOK_BP;
-    for (int t = tid - 128; t < 160; t += 128) {
-      const int vec = t >> 4;
+  __syncthreads();
+  MHA_STAMP(11);
+  // ---- the sample's parameter gradients: the blocks' partials in block order; thread t owns entry (o = t / 16, i = t % 16) of every matrix ----
+  {
+    const float* P = lds + MHA_TOK_ROWS + (tid & 15) * 16 + (tid >> 4);
+    const int nb = (N + 15) >> 4;  // blocks that hold tokens (the others parked nothing): every read of a block in flight at once
+    const float* BP = lds + MHA_TOK_BP + min(tid, 159);
+    float v[6][4], bs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int m = 0; m < 6; ++m) v[m][k] = 0.f;
+      bs[k] = 0.f;
+      if (k < nb) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) v[m][k] = P[k * 1536 + m * 256];
+        bs[k] = BP[k * 160];
+      }
+    }
+    const float b0 = bs[0], b1 = bs[1], b2 = bs[2], b3 = bs[3];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      const int dst = m < 3 ? OFF_WIN + 256 * m : m == 3 ? OFF_WOUT : m == 4 ? OFF_W1 : OFF_W2;
+      gp[dst + tid] = (v[m][0] + v[m][1]) + (v[m][2] + v[m][3]);
+    }
+    if (tid < 160) {
+      const int vec = tid >> 4;
       const int dst = vec == 0 ? OFF_L2W : vec == 1 ? OFF_L2B : vec == 2 ? OFF_C2 : vec == 3 ? OFF_C1 : vec == 4 ? OFF_L1W : vec == 5 ? OFF_L1B
                       : vec == 6 ? OFF_BOUT : OFF_BIN + 16 * (vec - 7);
-      gp[dst + (t & 15)] = (BP[t] + BP[160 + t]) + (BP[320 + t] + BP[480 + t]);
+      gp[dst + (tid & 15)] = (b0 + b1) + (b2 + b3);
     }
   }
 #ifdef MHA_STAMPS

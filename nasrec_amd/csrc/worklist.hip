@@ -341,8 +341,7 @@ __device__ __forceinline__ void ps_run_item(int it_kind, int it_part, int g0, in
       wl_mha_fwd(blob, vb);
       break;
     case NASREC_OP_MHA_BWD:
-      if (BIG && MHA_TOK) mha_bwd_tok(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
-      else if (BIG) mha_bwd_sample<4>(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
+      if (BIG) mha_bwd_tok(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
       break;
     case NASREC_OP_FM_FWD: {
       const nasrec_fm_desc_t& d = wl_ref<nasrec_fm_desc_t>(blob);

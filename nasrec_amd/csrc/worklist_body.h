@@ -1,16 +1,14 @@
 // Device side of NASREC_OP_WORKLIST (see worklist.hip): the kernel and its item bodies.
 #pragma once
 #include "attention_tok.h"
-#ifndef MHA_TOK
-#define MHA_TOK 1
-#endif
 #include "gemm_rt.h"
 #include "final_bodies.h"
 #include "interact_bodies.h"
 #include "dedup_bodies.h"
 
-#define WL_LDS_BIG_FLOATS MHA_BWD_LDS_FLOATS(4)  // 12960 floats = 52 KB
-#define WL_LDS_FLOATS MHA_FWD_LDS_FLOATS(4)  // 7840 floats = 31 KB (5 workgroups per CU): the Transformer forward; a 64x16x64 GEMM tile needs 5568
+#define WL_LDS_BIG_FLOATS 12960  // 52 KB, 3 workgroups per CU: the Transformer backward (MHA_TOK_BWD_LDS_FLOATS = 12416)
+#define WL_LDS_FLOATS 7840  // 31 KB (5 workgroups per CU): the DotProduct cores up to k1 = 48; a 64x16x64 GEMM tile needs 5568, the Transformer forward 3744
+static_assert(MHA_TOK_BWD_LDS_FLOATS <= WL_LDS_BIG_FLOATS && MHA_TOK_FWD_LDS_FLOATS <= WL_LDS_FLOATS, "Transformer bodies fit the worklist launches");
 
 #define WL_TK 64  // staged k depth of every GEMM item (a product with K <= 32 pads its one tile with zeros: same sums, bit for bit)
 // tile configurations of GEMM items: geom[2] = tile | binding pair << 2 | mask operand << 4
@@ -363,8 +361,7 @@ __device__ __forceinline__ void wl_gemm_second_pass(unsigned long long blob, int
 }
 
 __device__ __forceinline__ void wl_mha_fwd(unsigned long long blob, int vb) {
-  if (MHA_TOK) mha_fwd_tok(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
-  else mha_fwd_sample<4>(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
+  mha_fwd_tok(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
 }
 
 // BIG: the variant that also carries the Transformer backward (164 registers, 52 KB of LDS: three workgroups per CU instead of four /
@@ -429,8 +426,7 @@ __global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(unsigned f01
       wl_mha_fwd(blob, vb);
       break;
     case NASREC_OP_MHA_BWD:
-      if (BIG && MHA_TOK) mha_bwd_tok(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
-      else if (BIG) mha_bwd_sample<4>(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
+      if (BIG) mha_bwd_tok(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
       break;
     case NASREC_OP_FM_FWD: {
       const nasrec_fm_desc_t& d = wl_ref<nasrec_fm_desc_t>(blob);

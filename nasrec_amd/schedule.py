@@ -358,6 +358,8 @@ def _work_ns(node):
     c = _BAL_COST(node)
     if isinstance(node.desc, L.GemmDesc):
         return max(c - _LATENCY_NS, 0) if node.part != "epi" else 400
+    if node.desc.kind in (L.OP_MHA_FWD, L.OP_MHA_BWD):
+        return c // _MHA_NS[4 if node.desc.kind == L.OP_MHA_FWD else 5]
     return c // 4
 
 
@@ -604,6 +606,14 @@ _ITEM_NS = {L.OP_MHA_BWD: 18000, L.OP_MHA_FWD: 11000, L.OP_DOT_TRI_BWD: 10000, L
 _ITEM_NS_R4 = {L.OP_MHA_BWD: 18500, L.OP_MHA_FWD: 10500, L.OP_REDUCE_ROWS: 6000, L.OP_FM_BWD: 7000, L.OP_FM_FWD: 3500, L.OP_FINAL_BWD: 7000,
                L.OP_FINAL_FWD: 3400, L.OP_GATE_BWD: 3500, L.OP_DEDUP_IDS: 8000, L.OP_FINAL_FUSED: 4500}
 _COST_MODEL = os.environ.get("NASREC_WL_COST", "time")
+# round 6: the token-major Transformer bodies (csrc/attention_tok.h), stand-alone launches of tools/mha_bench.py at batch 256: forward
+# 4.3 / 8.2 / 9.7 us, backward 7.25 / 11.4 / 13.2 us for N = 8 / 48 / 64 tokens -> base + slope * N (ns); the third pair of numbers is the
+# divisor of the body's duration that counts as chip occupancy when it shares a level (forward, backward)
+_MHA_NS = [int(v) for v in os.environ.get("NASREC_WL_MHA_NS", "10500,0,18500,0,4,4").split(",")]
+
+
+def _mha_ns(d):
+    return _MHA_NS[0] + _MHA_NS[1] * d.N if d.kind == L.OP_MHA_FWD else _MHA_NS[2] + _MHA_NS[3] * d.N
 
 
 def _cost(node):
@@ -622,6 +632,8 @@ def _cost(node):
         return 5000 + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in range(d.nseg) if d.seg[q].A) // 20000
     if d.kind == L.OP_FINAL_BWD and d.dseg_done:
         return 5000
+    if d.kind in (L.OP_MHA_FWD, L.OP_MHA_BWD):
+        return _mha_ns(d)
     return _ITEM_NS.get(d.kind, 3000)
 
 
@@ -641,6 +653,8 @@ def _cost_r4(node):
         return 3000 + int(0.2 * d.k1 * d.k1)
     if d.kind == L.OP_FINAL_BWD and d.dseg_done:
         return 5000
+    if d.kind in (L.OP_MHA_FWD, L.OP_MHA_BWD):
+        return _mha_ns(d)
     return _ITEM_NS_R4.get(d.kind, 3000)
 
 

@@ -590,8 +590,8 @@ def _mha_ref(x, p, dims):
 @pytest.mark.parametrize("N,dims,B,form", [(16, -1, 13, 0), (64, -1, 13, 0), (48, 32, 13, 0), (7, -1, 13, 0), (64, 40, 1030, 0), (26, -1, 1024, 0),
                                            (64, -1, 13, 4), (48, 32, 9, 4), (7, -1, 5, 4), (17, 16, 6, 4), (1, -1, 3, 4), (33, -1, 258, 4)])
 def test_mha_ffn(lib, N, dims, use_saved, B, form):
-    """the forward runs with or without saving its per-token state; the backward always consumes a saved state.  Batches >= 1024 and
-    `bwd_form` 4 (what the batch-256 step's worklist launches run) take the 4-wave token-major backward, smaller ones the 8-wave form"""
+    """the forward runs with or without saving its per-token state (36 floats per token: attention output, softmax and LayerNorm
+    statistics); the backward always consumes a saved state and recomputes the rest (`bwd_form` is ignored since ABI 16)"""
     torch.manual_seed(7 + N)
     shapes = [(48, 16), (48,), (16, 16), (16,), (16,), (16,), (16, 16), (16,), (16, 16), (16,), (16,), (16,)]
     p = [torch.randn(s) * (0.3 if len(s) == 2 else 0.1) for s in shapes]

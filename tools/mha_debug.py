@@ -48,13 +48,13 @@ plane = lambda i: sv[:, i * N * 16:(i + 1) * N * 16].reshape(B, N, 16)
 def rep(name, a, b):
     print("  %-8s max err %.3e (scale %.2e)" % (name, float((a - b).abs().max()), float(b.abs().max())))
 print("forward B=%d N=%d dims=%d" % (B, N, dims))
-rep("q", plane(0), q.detach() / math.sqrt(2)); rep("k", plane(1), k.detach()); rep("v", plane(2), v.detach()); rep("o", plane(3), o.detach())
-rep("h1", plane(4), h1.detach()); rep("xh1", plane(5), xh1.detach()); rep("f1", plane(6), f1.detach()); rep("xh2", plane(7), xh2.detach())
-m = plane(8)
+rep("o", plane(0), o.detach())
+m = plane(1)
 smax = s.detach().max(-1).values.permute(0, 2, 1); ssum = torch.exp(s.detach() - s.detach().max(-1, keepdim=True).values).sum(-1).permute(0, 2, 1)
 rep("max", m[..., :8], smax); rep("1/sum", m[..., 8:], 1 / ssum)
-rs = sv[:, 9 * N * 16:9 * N * 16 + N * 4].reshape(B, N, 4)
+rs = sv[:, 2 * N * 16:2 * N * 16 + N * 4].reshape(B, N, 4)
 rep("rstd1", rs[..., 0], (1 / torch.sqrt(var1 + 1e-5)).detach()[..., 0]); rep("rstd2", rs[..., 1], (1 / torch.sqrt(var2 + 1e-5)).detach()[..., 0])
+rep("mu1", rs[..., 2], mu1.detach()[..., 0]); rep("mu2", rs[..., 3], mu2.detach()[..., 0])
 rep("out", gout.cpu().double(), out.detach())
 dout = torch.randn(B, N, 16)
 out.backward(dout.double())

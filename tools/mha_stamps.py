@@ -34,17 +34,17 @@ for _ in range(3):
     eng.train_step(bx[0], bx[1], bx[2], 1e-3, choice=choice)
 torch.cuda.synchronize()
 cp = eng.compile(choice, B, train=True)
-names = ["loads + first barrier", "LDS -> registers", "LayerNorm 2", "FFN 2", "FFN 1", "LayerNorm 1", "out-projection", "attention A (dq)",
-         "attention B (dk, dv)", "barrier + store + barrier", "in-projection weight/bias gradients", "dx"]
-fnames = ["loads + first barrier", "in-projection, k / v parked, q / k / v saved", "attention: row maxima", "attention: softmax and P V",
-          "o parked + barrier (+ saved)", "out-projection, LayerNorm 1, h1 parked", "FFN", "LayerNorm 2", "output + saved planes"]
+names = ["loads, parameters parked, barrier", "forward recomputed, q / k / v rows parked", "LayerNorm 2 (+ dW2 partial)", "FFN 2 (+ dW1 partial)", "FFN 1", "LayerNorm 1 (+ dWout partial)",
+         "out-projection, dO rows parked, barrier", "attention A (dq)", "attention B (dk, dv)", "token sums, dWin partials, dx", "barrier, partials parked, barrier", "sums over the blocks, stores"]
+fnames = ["loads, parameters parked, barrier", "in-projection, k / v rows parked, barrier", "attention: row maxima", "attention: softmax and P V",
+          "o and softmax statistics saved", "out-projection, LayerNorm 1", "FFN", "LayerNorm 2", "output + LayerNorm statistics stored"]
 mha = []
 for d in cp.fwd.descs:
     mha += [n.desc for n in d.nodes] if isinstance(d, L.WorklistDesc) else [d]
 for d in mha:
     if d.kind != L.OP_MHA_FWD:
         continue
-    raw = torch.as_tensor(_Raw(d.out, B * d.ldo), device=dev).cpu().numpy().astype(np.int64).reshape(B, d.ldo)[:, :10] & 0xffffffff
+    raw = torch.as_tensor(_Raw(d.out, B * d.ldo), device=dev).cpu().numpy().astype(np.int64).reshape(B, d.ldo)[::4, :10] & 0xffffffff  # (samples whose wave 0 owns token block 0)
     dt = ((raw[:, 1:] - raw[:, :-1]) & 0xffffffff) / 100.0
     print("MHA_FWD N=%d: whole body median %.2f (x100 shader clocks)" % (d.N, np.median(((raw[:, 9] - raw[:, 0]) & 0xffffffff) / 100.0)))
     for i, n in enumerate(fnames):
@@ -57,7 +57,7 @@ for n in nodes:
     if d.kind != L.OP_MHA_BWD:
         continue
     ld = d.partial_ld if d.partial_ld > 0 else L.MHA_PARAMS
-    raw = torch.as_tensor(_Raw(d.dparams_partial, B * ld), device=dev).cpu().numpy().astype(np.int64).reshape(B, ld)[:, :13] & 0xffffffff
+    raw = torch.as_tensor(_Raw(d.dparams_partial, B * ld), device=dev).cpu().numpy().astype(np.int64).reshape(B, ld)[::4, :13] & 0xffffffff
     dt = ((raw[:, 1:] - raw[:, :-1]) & 0xffffffff) / 100.0
     print("MHA_BWD N=%d: whole body median %.2f (max %.2f) (x100 shader clocks)" % (d.N, np.median(((raw[:, 12] - raw[:, 0]) & 0xffffffff) / 100.0), np.max(((raw[:, 12] - raw[:, 0]) & 0xffffffff) / 100.0)))
     for i, nm in enumerate(names):
@@ -73,6 +73,6 @@ for n in nodes:
     with torch.cuda.stream(eng.stream):
         us = bench.time_desc(lib, L, sp, one, iters=3) * 1e3
     torch.cuda.synchronize()
-    raw = torch.as_tensor(_Raw(d.dparams_partial, B * ld), device=dev).cpu().numpy().astype(np.int64).reshape(B, ld)[:, :13] & 0xffffffff
+    raw = torch.as_tensor(_Raw(d.dparams_partial, B * ld), device=dev).cpu().numpy().astype(np.int64).reshape(B, ld)[::4, :13] & 0xffffffff
     dt = ((raw[:, 1:] - raw[:, :-1]) & 0xffffffff) / 100.0
     print("   back to back on its own (%.2f us per launch): whole body %.2f, loads + first barrier %.2f" % (us, np.median(((raw[:, 12] - raw[:, 0]) & 0xffffffff) / 100.0), np.median(dt[:, 0])))
