@@ -646,7 +646,9 @@ def main():
                    "plan_buffers": ("uncached device memory (hipDeviceMallocUncached)" if (fixed and getattr(getattr(cpx, "arena", None), "uncached", False))
                                     else "torch allocator"),
                    "joint_program": ("persistent launch (in-kernel dependencies)" if getattr(cpx, "persistent", False) else
-                                     "one launch per dependency level") if fixed else "one launch per operator"},
+                                     "one launch per dependency level") if fixed else "one launch per operator",
+                   # the level schedule the plan's compile-time tuner kept (engine._tune_levels): outside the timed region, same bits whatever it picks
+                   "level_schedule_tuning": getattr(cpx, "level_tuning", None)},
         "final_loss": loss,
     }
     if dry:

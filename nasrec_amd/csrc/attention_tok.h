@@ -171,15 +171,16 @@ __device__ __forceinline__ void mha_fwd_tok(const nasrec_mha_desc_t& d, const in
 
 // ---- backward -------------------------------------------------------------------------------------------------------------------------------
 // LDS floats: transposed matrices 6 x 16 rows of 20 | the twelve-minus-matrices parameter vectors 160 | K V Q dO rows 4 x 1024 | m' and D per (token, head) 2 x 512 |
-// 1024 spare | per-wave weight-gradient operand planes 4 x 2 x 256 | per-wave token sums 4 x 160
+// per-wave weight-gradient operand planes 4 x 2 x 256 | per-block token sums 4 x 160
 #define MHA_TOK_WT 0
 #define MHA_TOK_WLD 20   // row stride of a parked matrix: rows 16 banks apart for the column reads, 16-byte aligned for the row reads
 #define MHA_TOK_WSZ (16 * MHA_TOK_WLD)
 #define MHA_TOK_VEC (6 * MHA_TOK_WSZ)  // bin 48 | bout 16 | l1w 16 | l1b 16 | c1 16 | c2 16 | l2w 16 | l2b 16
 #define MHA_TOK_ROWS (MHA_TOK_VEC + 160)
 #define MHA_TOK_MD (MHA_TOK_ROWS + 4 * MHA_N * 16)
-#define MHA_TOK_EX (MHA_TOK_MD + 2 * MHA_N * 8)   // (rows + m' / D + these 1024 floats = the 4 x 6 x 256 per-wave weight-gradient partials, after the loops)
-#define MHA_TOK_SCR (MHA_TOK_EX + 1024)          // per wave: two operand planes [16 tokens][16] of its weight-gradient products
+#define MHA_TOK_SCR (MHA_TOK_MD + 2 * MHA_N * 8)  // per wave: two operand planes [16 tokens][16] of its weight-gradient products
+// (after the loops, rows + m' / D + the first half of these planes = the 4 x 6 x 256 per-block weight-gradient partials; 39.5 KB in all:
+// four workgroups per CU)
 #define MHA_TOK_BP (MHA_TOK_SCR + 4 * 512)
 #define MHA_TOK_BWD_LDS_FLOATS (MHA_TOK_BP + 4 * 160)
 

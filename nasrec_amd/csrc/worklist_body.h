@@ -6,7 +6,7 @@
 #include "interact_bodies.h"
 #include "dedup_bodies.h"
 
-#define WL_LDS_BIG_FLOATS 12960  // 52 KB, 3 workgroups per CU: the Transformer backward (MHA_TOK_BWD_LDS_FLOATS = 12416)
+#define WL_LDS_BIG_FLOATS 9888  // 39.5 KB, 4 workgroups per CU: the Transformer backward (MHA_TOK_BWD_LDS_FLOATS)
 #define WL_LDS_FLOATS 7840  // 31 KB (5 workgroups per CU): the DotProduct cores up to k1 = 48; a 64x16x64 GEMM tile needs 5568, the Transformer forward 3744
 static_assert(MHA_TOK_BWD_LDS_FLOATS <= WL_LDS_BIG_FLOATS && MHA_TOK_FWD_LDS_FLOATS <= WL_LDS_FLOATS, "Transformer bodies fit the worklist launches");
 
@@ -375,7 +375,7 @@ __device__ __forceinline__ void wl_mha_fwd(unsigned long long blob, int vb) {
 #define WL_PACKED_NONE 0xffffffffu
 #define WL_HEAD_BYTES 48  // the twelve scalars in front of the descriptor in the argument segment
 template <bool BIG>
-__global__ __launch_bounds__(256, BIG ? 3 : 4) void worklist_kernel(unsigned f01, unsigned f23, unsigned f45, unsigned f67, unsigned f89, unsigned fab,
+__global__ __launch_bounds__(256, 4) void worklist_kernel(unsigned f01, unsigned f23, unsigned f45, unsigned f67, unsigned f89, unsigned fab,
                                                                     unsigned m01, unsigned m23, unsigned m45, unsigned m67, unsigned m89, unsigned mab,
                                                                     const nasrec_worklist_desc_t wl) {
   float* lds = wl_lds;

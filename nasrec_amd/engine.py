@@ -24,6 +24,8 @@ E = 16
 DEDUP_SPLIT_MAX_B = min(int(os.environ.get("NASREC_DEDUP_SPLIT_MAX_B", "2048")), L.DEDUP_IDS_MAX_B)
 # the id half of a level-scheduled step (B <= 256) as an ITEM of the joint forward + backward program (A/B knob: 0 = on the staging launch)
 _IDS_AS_ITEM = os.environ.get("NASREC_IDS_AS_ITEM", "1") != "0"
+_WL_TUNE = os.environ.get("NASREC_WL_TUNE", "1") != "0"  # time a handful of level schedules of a fixed batch-256 training plan at compile time (_tune_levels)
+_WL_TUNE_MARGIN = float(os.environ.get("NASREC_WL_TUNE_MARGIN", "0.004"))
 _FUSE_FINAL = os.environ.get("NASREC_FUSE_FINAL", "1") != "0"  # joint program: final logit + the per-sample part of its backward as one operator
 # clip + Adagrad of a fixed sub-network over the ranges of the parameters its backward reaches, not the whole arena (A/B knob)
 _FIXED_OPT_TABLE = os.environ.get("NASREC_FIXED_OPT_TABLE", "1") != "0"
@@ -510,6 +512,7 @@ class SupernetEngine:
                     jf, jb = self._fuse_final(fwd_list, bwd_descs, fused) if _FUSE_FINAL else (fwd_list, bwd_descs)
                     fb_descs = None
                     cp.persistent = False
+                    cp.level_tuning = None
                     if persist:
                         try:
                             fb_descs, cp.fb_levels = S.pack_persistent(
@@ -522,6 +525,8 @@ class SupernetEngine:
                             warnings.warn("persistent step refused (%s): one launch per level instead" % (e,))
                     if fb_descs is None:
                         fb_descs, cp.fb_levels = S.pack(ids_in_program + jf + jb, alloc=ctx.alloc)
+                        if _WL_TUNE and S.BALANCE:
+                            fb_descs, cp.level_tuning = self._tune_levels(ids_in_program + jf + jb, ctx.alloc, fb_descs)
                     cp.fb = Program(fb_descs)
                     bwd_descs, cp.bwd_levels = S.pack(bwd_descs)
                 cp.bwd = Program(bwd_descs)
@@ -546,6 +551,57 @@ class SupernetEngine:
         self._plans[key] = cp
         self._last_plan = (fast, choice, cp)
         return cp
+
+    def _tune_levels(self, prog_in, alloc, default_descs):
+        """The balancing pass of schedule.pack places slack operators by a duration MODEL whose least certain entries are the Transformer
+        bodies (one workgroup per sample: how much of their time other items can share depends on what those items are).  A fixed
+        sub-network's batch-256 plan is compiled once and run for an epoch, so the model's Transformer durations are treated as knobs:
+        the joint program is packed for a handful of settings (schedule.TUNE_MHA_NS), every distinct schedule is replayed on the plan's
+        own (zero-filled) buffers, and the fastest one wins if it beats the default by more than the timing noise.  Any schedule gives
+        the same bits (same bodies, same operands, dependencies respected: tests/test_parity_gpu.py), so this only moves time.
+        Returns (descriptors, report)."""
+        sp = self.stream.cuda_stream
+
+        def sig(descs):
+            return hash(b"".join(bytes(d) for d in descs))
+
+        def run_ms(prog, reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
+            for _ in range(reps):
+                prog.run(sp)
+            e1.record(self.stream)
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        keep = list(S._MHA_NS)
+        cands = [("default", default_descs)]
+        seen = {sig(default_descs)}
+        try:
+            for ns in S.TUNE_MHA_NS:
+                S._MHA_NS[:] = list(ns) + keep[len(ns):]
+                descs, _ = S.pack(prog_in, alloc=alloc)
+                h = sig(descs)
+                if h not in seen:
+                    seen.add(h)
+                    cands.append((",".join(str(v) for v in ns), descs))
+        finally:
+            S._MHA_NS[:] = keep
+        if len(cands) == 1:
+            return default_descs, {"candidates": 1, "chosen": "default"}
+        progs = [(name, descs, Program(descs)) for name, descs in cands]
+        for _, _, pg in progs:
+            run_ms(pg, 5)  # descriptors and code warm
+        times = {name: [] for name, _, _ in progs}
+        for _ in range(5):  # interleaved rounds: clock and cache drift hits every candidate alike
+            for name, _, pg in progs:
+                times[name].append(run_ms(pg, 20))
+        med = {name: sorted(v)[len(v) // 2] for name, v in times.items()}
+        best = min(med, key=med.get)
+        if med[best] > med["default"] * (1.0 - _WL_TUNE_MARGIN):
+            best = "default"
+        chosen = next(descs for name, descs, _ in progs if name == best)
+        return chosen, {"candidates": len(progs), "chosen": best, "ms": {k: round(v, 5) for k, v in med.items()}}
 
     def _build_training_tail(self, cp, ctx, w, bptr, fsegs, B, K, grad_scale):
         """BCE descriptor, the final-logit backward closure, the backward program (ctx.bwd) and, for a supernet, the path's chunk

@@ -612,6 +612,10 @@ _COST_MODEL = os.environ.get("NASREC_WL_COST", "time")
 _MHA_NS = [int(v) for v in os.environ.get("NASREC_WL_MHA_NS", "10500,0,18500,0,4,4").split(",")]
 
 
+# settings the engine's compile-time tuner tries besides the default (engine._tune_levels): (forward base, slope, backward base, slope)
+TUNE_MHA_NS = [(f, 0, b, 0) for f in (8000, 10500) for b in (12000, 14000, 16000, 18500, 21000, 24000)] + [(6000, 0, 24000, 0), (3500, 95, 6400, 105)]
+
+
 def _mha_ns(d):
     return _MHA_NS[0] + _MHA_NS[1] * d.N if d.kind == L.OP_MHA_FWD else _MHA_NS[2] + _MHA_NS[3] * d.N
 
