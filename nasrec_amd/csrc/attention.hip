@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void mha_fwd_tok_kernel(const nasrec_mha_desc_
   __shared__ __attribute__((aligned(16))) float lds[MHA_TOK_FWD_LDS_FLOATS];
   mha_fwd_tok(d, blockIdx.x, lds);
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void mha_bwd_tok_kernel(const nasrec_mha_desc_t d) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void mha_bwd_tok_kernel(const nasrec_mha_desc_t d) {
   __shared__ __attribute__((aligned(16))) float lds[MHA_TOK_BWD_LDS_FLOATS];
   mha_bwd_tok(d, blockIdx.x, lds);
 }

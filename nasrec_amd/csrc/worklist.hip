@@ -124,7 +124,7 @@ static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, i
       it.geom[0] = TU;
       it.geom[1] = 0;
       it.geom[2] = WL_TOKS | (2 << 2);
-      it.nblk = ((Nmax >> 4) * TU + 3) / 4;
+      it.nblk = std::min(((Nmax >> 4) * TU + 3) / 4, WL_TOK_MAX_WG);
       return 0;
     }
   }

@@ -291,16 +291,22 @@ __device__ __forceinline__ void wl_dense_small_dx(unsigned long long blob, int v
 // rows); lane (r, g) of MFMA j of step s needs W[16 s + 4 g + j][r] (four dwords, a row of W apart), lane (e, g) needs
 // dy[b][16 s + 4 g + j][e].  K = the Linear's output rows (16 .. 64): one to four steps, all loads issued up front.
 #define WL_TOKDX_STEPS 4
+// (A cap on the workgroups of this item with a wave walking several units — WL_TOK_MAX_WG = 256 — was measured: the three-segment product's
+// 704 workgroups take 8.6 us capped or not, with or without its loads and stores (tools/step_table.py ITEMS=1), two-segment items got
+// slower (4.9 -> 6.3 us), the step 0.2283 -> 0.2315 ms.  The loop stays, the cap does not bind.)
+#define WL_TOK_MAX_WG (1 << 20)
+__device__ __forceinline__ void wl_token_dx_unit(const nasrec_gemm_desc_t& g, int unit, int TU, int e, int fg);
 __device__ __forceinline__ void wl_token_dx(unsigned long long blob, int vb_, int TU_) {
   const nasrec_gemm_desc_t& g = wl_ref<nasrec_gemm_desc_t>(blob);
   const int vb = __builtin_amdgcn_readfirstlane(vb_), TU = __builtin_amdgcn_readfirstlane(TU_);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int e = lane & 15, fg = lane >> 4;
   wl_warm_blob(blob, (int)offsetof(nasrec_gemm_desc_t, seg) + g.nseg * (int)sizeof(nasrec_gemm_seg_t));  // (the segment walk below reads every segment's fields)
-  const int unit = vb * 4 + wave;
+  const int total = (g.seg[0].N >> 4) * TU, stride = 4 * min((total + 3) >> 2, WL_TOK_MAX_WG);
+  for (int unit = vb * 4 + wave; unit < total; unit += stride) wl_token_dx_unit(g, unit, TU, lane & 15, lane >> 4);
+}
+__device__ __forceinline__ void wl_token_dx_unit(const nasrec_gemm_desc_t& g, int unit, int TU, int e, int fg) {
   const int b = unit / TU;
   int t = unit - b * TU, q = 0;
-  if (b >= (g.seg[0].N >> 4)) return;
   while (q < g.nseg && t >= ((g.seg[q].M + 15) >> 4)) t -= (g.seg[q].M + 15) >> 4, ++q;  // (segment, row block) of this unit
   const nasrec_gemm_seg_t& sg = g.seg[q];
   const int M = sg.M, K = sg.K;
