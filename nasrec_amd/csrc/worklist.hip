@@ -110,9 +110,12 @@ static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, i
       return 0;
     }
   }
-  // token-axis Linear input gradients (W^T dy per input segment, binding RC / TOKR / TOKJ, zmode), unsplit, no mask operands, at most
-  // 64 output rows of the Linear: a wavefront per (sample, segment, 16 token rows) (wl_token_dx)
-  if (tok_body && it.part == 0 && g->zmode && !aux && g->amode == NASREC_AM_RC && g->bmode == NASREC_AM_TOKR && g->cmode == NASREC_CM_TOKJ && (Nmax & 15) == 0) {
+  // token-axis Linear input gradients (W^T dy per input segment, binding RC / TOKR / TOKJ, zmode), unsplit, no mask on the weights (one on
+  // dy — the fused ReLU backward — is applied as the operand is loaded), at most 64 output rows of the Linear: a wavefront per (sample,
+  // segment, 16 token rows) (wl_token_dx)
+  bool aux_a = false;
+  for (int q = 0; q < g->nseg; ++q) aux_a = aux_a || g->seg[q].Aaux;
+  if (tok_body && it.part == 0 && g->zmode && !aux_a && g->amode == NASREC_AM_RC && g->bmode == NASREC_AM_TOKR && g->cmode == NASREC_CM_TOKJ && (Nmax & 15) == 0) {
     bool plain = true;
     int TU = 0;
     for (int q = 0; q < g->nseg; ++q) {

@@ -332,6 +332,18 @@ __device__ __forceinline__ void wl_token_dx_unit(const nasrec_gemm_desc_t& g, in
       fa[s][j] = wp[(long)k * sg.lda];
       fb[s][j] = yb[k * 16];
     }
+  if (sg.Baux) {  // fused ReLU backward: B(j, k) counts as 0 where Baux(j, k) <= 0 (same binding as B); the mask loads ride with the operands
+    const float* xb = sg.Baux + (long)b * sg.ldb + e;
+    float fx[WL_TOKDX_STEPS][4];
+#pragma unroll
+    for (int s = 0; s < WL_TOKDX_STEPS; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fx[s][j] = xb[min(16 * s + 4 * fg + j, K - 1) * 16];
+#pragma unroll
+    for (int s = 0; s < WL_TOKDX_STEPS; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[s][j] = fx[s][j] > 0.f ? fb[s][j] : 0.f;
+  }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < WL_TOKDX_STEPS; ++s) {

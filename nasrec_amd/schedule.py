@@ -676,6 +676,25 @@ def expand_for_worklists(descs) -> List[Node]:
     return nodes
 
 
+_SOLO_ITEMS = os.environ.get("NASREC_WL_SOLO_ITEMS", "1") != "0"  # (A/B knob)
+
+
+def _item_beats_kernel(d):
+    """a level's only operator normally runs as its stand-alone kernel; the token-axis input gradients (W^T dy per input segment, K <= 64
+    rows of the Linear, mask on dy allowed) are the exception: the worklist's wavefront-per-tile body (csrc/worklist_body.h wl_token_dx)
+    takes 3.6 - 5 us where the general template takes 5.5 - 8.9 (tools/step_table.py ITEMS=1; the conditions of csrc/worklist.hip)"""
+    if not (_SOLO_ITEMS and isinstance(d, L.GemmDesc) and d.zmode and d.splitk <= 1):
+        return False
+    if (d.amode, d.bmode, d.cmode) != (L.AM_RC, L.AM_TOKR, L.CM_TOKJ):
+        return False
+    n0 = d.seg[0].N
+    for q in range(d.nseg):
+        sg = d.seg[q]
+        if sg.Aaux or sg.ones_col or (0 < sg.Mvalid < sg.M) or sg.N != n0 or sg.K > 64 or sg.M <= 0:
+            return False
+    return n0 % 16 == 0
+
+
 def pack(descs, alloc=None):
     """program -> scheduled program: per level, the operators the worklist kernel has bodies for share NASREC_OP_WORKLIST launches
     (as many as their descriptors need blobs), the others stay launches of their own.  Returns (new descriptor list, number of
@@ -696,7 +715,7 @@ def pack(descs, alloc=None):
         for n, _ in solo:
             assert n.part == "whole"
             out.append(n.desc)
-        if len(items) == 1 and items[0][0].part == "whole":
+        if len(items) == 1 and items[0][0].part == "whole" and not _item_beats_kernel(items[0][0].desc):
             out.append(items[0][0].desc)  # nothing to share a launch with: the stand-alone kernel
             continue
         cur, off = None, 0
