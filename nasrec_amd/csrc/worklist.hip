@@ -77,7 +77,9 @@ static int wl_gemm_geometry(const nasrec_gemm_desc_t* g, nasrec_wl_item_t& it, i
   }
   // small dense input gradients (dy W per problem, binding KC / RC / plain, zmode), unsplit, no mask operands, K <= 16 WL_DENSE_STEPS:
   // a wavefront per 16 x 16 tile of one problem (wl_dense_small_dx; geom[1] = 0 tells the two bodies apart)
-  if (dense_body && it.part == 0 && g->zmode && !aux && g->amode == NASREC_AM_KC && g->bmode == NASREC_AM_RC && g->cmode == NASREC_CM_PLAIN) {
+  bool aux_b = false;  // (a mask on dy — the fused ReLU backward — is applied as the operand is loaded; one on the weights has no body here)
+  for (int q = 0; q < g->nseg; ++q) aux_b = aux_b || g->seg[q].Baux;
+  if (dense_body && it.part == 0 && g->zmode && !aux_b && g->amode == NASREC_AM_KC && g->bmode == NASREC_AM_RC && g->cmode == NASREC_CM_PLAIN) {
     bool plain = true;
     int TU = 0;
     for (int q = 0; q < g->nseg; ++q) {

@@ -269,6 +269,16 @@ __device__ __forceinline__ void wl_dense_small_dx(unsigned long long blob, int v
 #pragma unroll
     for (int j = 0; j < 4; ++j) fb[s][j] = wp[(long)min(16 * s + 4 * fg + j, K - 1) * sg.ldb];  // (clamped, masked below)
   }
+  if (sg.Aaux) {  // fused ReLU backward: A(r, k) counts as 0 where Aaux(r, k) <= 0 (same binding as A); the mask loads ride with the operands
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.Aaux), 0, (int)(4 * ((long)(M - 1) * sg.lda + K)), 0x00020000);
+    f32x4 fx[WL_DENSE_STEPS];
+#pragma unroll
+    for (int s = 0; s < WL_DENSE_STEPS; ++s) fx[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, 4 * (row * sg.lda + 16 * s + 4 * fg), 0, 0));
+#pragma unroll
+    for (int s = 0; s < WL_DENSE_STEPS; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fa[s][j] = fx[s][j] > 0.f ? fa[s][j] : 0.f;
+  }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < WL_DENSE_STEPS; ++s) {
