@@ -55,7 +55,30 @@ __device__ __forceinline__ f32x4 tok_mma(const f32x4 a, const f32x4 y, f32x4 acc
 }
 __device__ __forceinline__ f32x4 tok_mm(const float* Wl, int r, int c0, const f32x4 y, f32x4 acc) { return tok_mma(ld4(Wl + r * 16 + c0), y, acc); }
 __device__ __forceinline__ float sum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
-__device__ __forceinline__ f32x4 pair_order(const f32x4 v) { return (f32x4){v[0], v[2], v[1], v[3]}; }  // (h0c0, h0c1, h1c0, h1c1) -> (h0c0, h1c0, h0c1, h1c1)
+// The attention loops run on PAIRS OF TOKENS: the two lanes (r, g), (r ^ 1, g) own tokens t0 = r & ~1, t1 = t0 + 1 and heads 2 g, 2 g + 1;
+// inside the loops lane r & 1 = hs takes head 2 g + hs of BOTH tokens — one packed-fp32 pair per component — so that a key (or query) row
+// costs the lane 8 bytes of LDS instead of 16 for the same two (token, head) products.  With the row of both heads per lane the loops
+// ran at the LDS port's 128 bytes per clock (four waves x 64 lanes x 16 or 32 bytes per key: 40 / 69 clocks per key measured in the two
+// forward passes against 16 / 56 of vector issue).  Exchange = one quad_perm DPP move per float, in and out.
+struct TokPairs { f32x2 c0, c1; };  // components 0 and 1 of one head, tokens (t0, t1)
+__device__ __forceinline__ TokPairs tok_to_pairs(const f32x4 v, bool hs) {  // v: (h0c0, h0c1, h1c0, h1c1) of the lane's own token
+  const float k0 = hs ? v[2] : v[0], k1 = hs ? v[3] : v[1];  // own token, head hs
+  const float r0 = dpp_mov<0xb1>(hs ? v[0] : v[2]), r1 = dpp_mov<0xb1>(hs ? v[1] : v[3]);  // the partner's token, head hs
+  TokPairs p;
+  p.c0 = hs ? (f32x2){r0, k0} : (f32x2){k0, r0};
+  p.c1 = hs ? (f32x2){r1, k1} : (f32x2){k1, r1};
+  return p;
+}
+__device__ __forceinline__ f32x4 tok_from_pairs(const f32x2 c0, const f32x2 c1, bool hs) {  // back: both heads of the lane's own token
+  const float k0 = hs ? c0[1] : c0[0], k1 = hs ? c1[1] : c1[0];
+  const float r0 = dpp_mov<0xb1>(hs ? c0[0] : c0[1]), r1 = dpp_mov<0xb1>(hs ? c1[0] : c1[1]);
+  return hs ? (f32x4){r0, r1, k0, k1} : (f32x4){k0, k1, r0, r1};
+}
+__device__ __forceinline__ f32x2 tok_swap_pair(const f32x2 v, bool hs) {  // (head 2 g, head 2 g + 1) of the own token <-> (t0, t1) of head hs: an involution
+  const float k = hs ? v[1] : v[0], r = dpp_mov<0xb1>(hs ? v[0] : v[1]);
+  return hs ? (f32x2){r, k} : (f32x2){k, r};
+}
+
 __device__ __forceinline__ void tok_ln_stats(const f32x4 v, float& mu, float& rstd) {
   mu = tok_rows4_sum(sum4(v)) * (1.f / 16.f);
   float q = 0.f;
@@ -96,21 +119,23 @@ __device__ __forceinline__ void mha_fwd_tok(const nasrec_mha_desc_t& d, const in
     q4 = tok_mm(Wsh + OFF_WIN, r, c0, x4, ld4(Wsh + OFF_BIN + c0)) * MHA_SCALE;
     const f32x4 k4 = tok_mm(Wsh + OFF_WIN + 256, r, c0, x4, ld4(Wsh + OFF_BIN + 16 + c0));
     const f32x4 v4 = tok_mm(Wsh + OFF_WIN + 512, r, c0, x4, ld4(Wsh + OFF_BIN + 32 + c0));
-    *reinterpret_cast<f32x4*>(Ks + tok * 16 + c0) = pair_order(k4);
-    *reinterpret_cast<f32x4*>(Vs + tok * 16 + c0) = pair_order(v4);
+    *reinterpret_cast<f32x4*>(Ks + tok * 16 + c0) = k4;
+    *reinterpret_cast<f32x4*>(Vs + tok * 16 + c0) = v4;
   }
   __syncthreads();
   MHA_STAMP(2);
   if (wave_active) {
     const long po = (long)tok * 16 + c0;  // the lane's 16-byte piece of a [token][16] plane
-    // attention: the lane's token as query, heads 2 g and 2 g + 1 as one packed-fp32 pair; scores in log2 units
+    // attention: head 2 g + hs of the lane pair's two tokens as queries (see TokPairs); scores in log2 units
     constexpr float LOG2E = 1.44269504088896340736f;
-    const f32x2 qa = {q4[0] * LOG2E, q4[2] * LOG2E}, qb = {q4[1] * LOG2E, q4[3] * LOG2E};
+    const bool hs = r & 1;
+    const int h2 = c0 + 2 * (r & 1);  // the head's two columns in a row
+    const TokPairs Q = tok_to_pairs(q4 * LOG2E, hs);
     f32x2 m2 = {-INFINITY, -INFINITY};
 #pragma unroll 8
     for (int j = 0; j < N; ++j) {
-      const f32x4 kj = ld4(Ks + j * 16 + c0);
-      const f32x2 s2 = qa * (f32x2){kj[0], kj[1]} + qb * (f32x2){kj[2], kj[3]};
+      const f32x2 kj = *reinterpret_cast<const f32x2*>(Ks + j * 16 + h2);
+      const f32x2 s2 = Q.c0 * kj[0] + Q.c1 * kj[1];
       m2[0] = fmaxf(m2[0], s2[0]);
       m2[1] = fmaxf(m2[1], s2[1]);
     }
@@ -118,17 +143,17 @@ __device__ __forceinline__ void mha_fwd_tok(const nasrec_mha_desc_t& d, const in
     f32x2 l2 = {0.f, 0.f}, oa = {0.f, 0.f}, ob = {0.f, 0.f};
 #pragma unroll 8
     for (int j = 0; j < N; ++j) {
-      const f32x4 kj = ld4(Ks + j * 16 + c0);
-      const f32x4 vj = ld4(Vs + j * 16 + c0);
-      const f32x2 t2 = qa * (f32x2){kj[0], kj[1]} + qb * (f32x2){kj[2], kj[3]} - m2;
+      const f32x2 kj = *reinterpret_cast<const f32x2*>(Ks + j * 16 + h2);
+      const f32x2 vj = *reinterpret_cast<const f32x2*>(Vs + j * 16 + h2);
+      const f32x2 t2 = Q.c0 * kj[0] + Q.c1 * kj[1] - m2;
       const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
       l2 = l2 + p2;
-      oa = p2 * (f32x2){vj[0], vj[1]} + oa;
-      ob = p2 * (f32x2){vj[2], vj[3]} + ob;
+      oa = p2 * vj[0] + oa;
+      ob = p2 * vj[1] + ob;
     }
-    const f32x2 mx = {m2[0] * (1.f / LOG2E), m2[1] * (1.f / LOG2E)};  // the backward works in natural units
-    const f32x2 li = {1.f / l2[0], 1.f / l2[1]};
-    const f32x4 o4 = {oa[0] * li[0], ob[0] * li[0], oa[1] * li[1], ob[1] * li[1]};
+    const f32x2 lip = {1.f / l2[0], 1.f / l2[1]};
+    const f32x2 mx = tok_swap_pair(m2 * (1.f / LOG2E), hs), li = tok_swap_pair(lip, hs);  // per head of the own token; the backward works in natural units
+    const f32x4 o4 = tok_from_pairs(oa * lip, ob * lip, hs);
     MHA_STAMP(4);
     if (saving && active) {
       *reinterpret_cast<f32x4*>(sv_plane(d.saved, b, N, SV_O) + po) = o4;
@@ -266,8 +291,7 @@ __device__ __forceinline__ void mha_bwd_tok(const nasrec_mha_desc_t& d, const in
   float* Vb = Kb + MHA_N * 16;
   float* Qb = Vb + MHA_N * 16;
   float* DOb = Qb + MHA_N * 16;
-  float* Mb = lds + MHA_TOK_MD;
-  float* Db = Mb + MHA_N * 8;
+  float* MDb = lds + MHA_TOK_MD;  // [token][16]: (m', D) of head h at columns 2 h, 2 h + 1
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4, c0 = 4 * g, blk = tok_block(w, b), tok = 16 * blk + r;
   float* bp = lds + MHA_TOK_BP + blk * 160;   // per-BLOCK partials (summed in block order below: the same bits whatever the rotation)
   float* Gs = lds + MHA_TOK_SCR + w * 512;    // the wave's operand planes of its weight-gradient products
@@ -300,7 +324,6 @@ __device__ __forceinline__ void mha_bwd_tok(const nasrec_mha_desc_t& d, const in
   stage_params_store_t<NT>(lds, tid, pp);
   if (!active) x4 = o4 = dout = z4;
   if (d.dims_in_use >= 0 && tok >= d.dims_in_use) dout = z4;
-  if (wave_active) *reinterpret_cast<f32x2*>(Mb + tok * 8 + 2 * g) = mq;
   __syncthreads();  // the parameters are parked
   MHA_STAMP(1);
   f32x4 q4 = z4, k4 = z4, v4 = z4, dr1 = z4, dO = z4, gW2 = z4, gW1 = z4, gWo = z4, gWq = z4, gWk = z4, gWv = z4;
@@ -319,10 +342,6 @@ __device__ __forceinline__ void mha_bwd_tok(const nasrec_mha_desc_t& d, const in
 #pragma unroll
     for (int e = 0; e < 4; ++e) f1[e] = fmaxf(f1[e], 0.f);
     const f32x4 xh2 = (tok_mm_col(Wt + 5 * MHA_TOK_WSZ, r, c0, f1, ld4(VEC + 112 + c0)) + h1 - st4[3]) * rstd2;
-    // rows of the attention loops in pair order (h0c0, h1c0, h0c1, h1c1); q, k, v keep that order in registers too
-    q4 = pair_order(q4);
-    k4 = pair_order(k4);
-    v4 = pair_order(v4);
     *reinterpret_cast<f32x4*>(Qb + tok * 16 + c0) = q4;
     *reinterpret_cast<f32x4*>(Kb + tok * 16 + c0) = k4;
     *reinterpret_cast<f32x4*>(Vb + tok * 16 + c0) = v4;
@@ -358,45 +377,50 @@ __device__ __forceinline__ void mha_bwd_tok(const nasrec_mha_desc_t& d, const in
     // ---- out-projection ----
     dO = tok_mm_t(Wt + 3 * MHA_TOK_WSZ, r, c0, dr1, z4);
     dd2 = (f32x2){fmaf(dO[0], o4[0], dO[1] * o4[1]), fmaf(dO[2], o4[2], dO[3] * o4[3])};
-    *reinterpret_cast<f32x2*>(Db + tok * 8 + 2 * g) = dd2;
-    *reinterpret_cast<f32x4*>(DOb + tok * 16 + c0) = pair_order(dO);
+    *reinterpret_cast<f32x4*>(MDb + tok * 16 + c0) = (f32x4){mq[0], dd2[0], mq[1], dd2[1]};  // (m', D) per head
+    *reinterpret_cast<f32x4*>(DOb + tok * 16 + c0) = dO;
   }
   __syncthreads();  // every token's K / V / Q / dO rows, m' and D are in LDS
   MHA_STAMP(7);
   if (wave_active) {
-    // ---- attention backward: two heads per packed-fp32 lane pair, one exponential per probability (exp2(s' - m')) ----
+    // ---- attention backward on token pairs (see TokPairs): head 2 g + hs of tokens t0, t1; one exponential per probability (exp2(s' - m')) ----
     f32x4 dq, dk, dv;
-    const f32x2 qa = {q4[0] * LOG2E, q4[1] * LOG2E}, qb = {q4[2] * LOG2E, q4[3] * LOG2E}, doa = {dO[0], dO[2]}, dob = {dO[1], dO[3]};
-    f32x2 dqa = {0.f, 0.f}, dqb = {0.f, 0.f};  // phase A: the lane's token as query
+    const bool hs = r & 1;
+    const int h2 = c0 + 2 * (r & 1);
+    {
+      const TokPairs Q = tok_to_pairs(q4 * LOG2E, hs), DO = tok_to_pairs(dO, hs);
+      const f32x2 M2 = tok_swap_pair(mq, hs), DD = tok_swap_pair(dd2, hs);
+      f32x2 dq0 = {0.f, 0.f}, dq1 = {0.f, 0.f};  // phase A: the pair's tokens as queries
 #pragma unroll 4
-    for (int j = 0; j < N; ++j) {
-      const f32x4 kj = ld4(Kb + j * 16 + c0), vj = ld4(Vb + j * 16 + c0);
-      const f32x2 ka = {kj[0], kj[1]}, kb = {kj[2], kj[3]}, va = {vj[0], vj[1]}, vb = {vj[2], vj[3]};
-      const f32x2 t = __builtin_elementwise_fma(qa, ka, qb * kb) - mq;
-      const f32x2 p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-      const f32x2 ds = p * (__builtin_elementwise_fma(doa, va, dob * vb) - dd2);
-      dqa = __builtin_elementwise_fma(ds, ka, dqa);
-      dqb = __builtin_elementwise_fma(ds, kb, dqb);
+      for (int j = 0; j < N; ++j) {
+        const f32x2 kj = *reinterpret_cast<const f32x2*>(Kb + j * 16 + h2), vj = *reinterpret_cast<const f32x2*>(Vb + j * 16 + h2);
+        const f32x2 t = Q.c0 * kj[0] + Q.c1 * kj[1] - M2;
+        const f32x2 p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        const f32x2 ds = p * (DO.c0 * vj[0] + DO.c1 * vj[1] - DD);
+        dq0 = ds * kj[0] + dq0;
+        dq1 = ds * kj[1] + dq1;
+      }
+      dq = tok_from_pairs(dq0 * MHA_SCALE, dq1 * MHA_SCALE, hs);
     }
-    dq = (f32x4){dqa[0] * MHA_SCALE, dqb[0] * MHA_SCALE, dqa[1] * MHA_SCALE, dqb[1] * MHA_SCALE};
     MHA_STAMP(8);
-    const f32x2 ka = {k4[0] * LOG2E, k4[1] * LOG2E}, kb = {k4[2] * LOG2E, k4[3] * LOG2E}, va = {v4[0], v4[1]}, vb = {v4[2], v4[3]};
-    f32x2 dka = {0.f, 0.f}, dkb = {0.f, 0.f}, dva = {0.f, 0.f}, dvb = {0.f, 0.f};  // phase B: the lane's token as key
+    {
+      const TokPairs K = tok_to_pairs(k4 * LOG2E, hs), V = tok_to_pairs(v4, hs);
+      f32x2 dk0 = {0.f, 0.f}, dk1 = {0.f, 0.f}, dv0 = {0.f, 0.f}, dv1 = {0.f, 0.f};  // phase B: the pair's tokens as keys
 #pragma unroll 4
-    for (int i = 0; i < N; ++i) {
-      const f32x4 qi = ld4(Qb + i * 16 + c0), doi = ld4(DOb + i * 16 + c0);
-      const f32x2 qia = {qi[0], qi[1]}, qib = {qi[2], qi[3]}, da = {doi[0], doi[1]}, db = {doi[2], doi[3]};
-      const f32x2 mi = *reinterpret_cast<const f32x2*>(Mb + i * 8 + 2 * g), di = *reinterpret_cast<const f32x2*>(Db + i * 8 + 2 * g);
-      const f32x2 t = __builtin_elementwise_fma(qia, ka, qib * kb) - mi;
-      const f32x2 p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-      dva = __builtin_elementwise_fma(p, da, dva);
-      dvb = __builtin_elementwise_fma(p, db, dvb);
-      const f32x2 ds = p * (__builtin_elementwise_fma(da, va, db * vb) - di);
-      dka = __builtin_elementwise_fma(ds, qia, dka);
-      dkb = __builtin_elementwise_fma(ds, qib, dkb);
+      for (int i = 0; i < N; ++i) {
+        const f32x2 qi = *reinterpret_cast<const f32x2*>(Qb + i * 16 + h2), doi = *reinterpret_cast<const f32x2*>(DOb + i * 16 + h2);
+        const f32x2 md = *reinterpret_cast<const f32x2*>(MDb + i * 16 + h2);
+        const f32x2 t = K.c0 * qi[0] + K.c1 * qi[1] - md[0];
+        const f32x2 p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        dv0 = p * doi[0] + dv0;
+        dv1 = p * doi[1] + dv1;
+        const f32x2 ds = p * (V.c0 * doi[0] + V.c1 * doi[1] - md[1]);
+        dk0 = ds * qi[0] + dk0;
+        dk1 = ds * qi[1] + dk1;
+      }
+      dk = tok_from_pairs(dk0, dk1, hs);
+      dv = tok_from_pairs(dv0, dv1, hs);
     }
-    dk = (f32x4){dka[0], dkb[0], dka[1], dkb[1]};
-    dv = (f32x4){dva[0], dvb[0], dva[1], dvb[1]};
     MHA_STAMP(9);
     if (!active) dq = dk = dv = z4;
     tok_bias_partial(bp, 7, r, c0, dq);
