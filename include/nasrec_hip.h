@@ -212,12 +212,14 @@ typedef struct nasrec_fm_desc {
 /* ------------------------------------------------------------------------------------------------
  * Transformer body after the token projection (modules.py:664-686): nn.MultiheadAttention(16, 8 heads,
  * head_dim 2) + residual + LN + FC(16,16)+ReLU+FC(16,16) + residual + LN, optional token prefix mask on
- * the output.  One wavefront per sample; everything between x and out stays in registers/LDS.
- * `params` points to 10 parameter tensors in this order: in_proj_weight[48,16], in_proj_bias[48],
+ * the output.  One workgroup of four wavefronts per sample, lane = (token, 4 columns); everything between x and
+ * out stays in registers / LDS, the per-token 16 x 16 products run on the matrix cores (csrc/attention_tok.h).
+ * `params` points to the 12 parameter tensors in this order: in_proj_weight[48,16], in_proj_bias[48],
  * out_proj.weight[16,16], out_proj.bias[16], attn_ln.weight[16], attn_ln.bias[16], fc1.weight[16,16],
  * fc1.bias[16], fc2.weight[16,16], fc2.bias[16], fc_ln.weight[16], fc_ln.bias[16]  (12 pointers).
- * Backward recomputes the forward from x, writes dx and per-sample parameter-gradient partials
- * [B, NASREC_MHA_PARAMS] that NASREC_OP_REDUCE_ROWS sums in fixed order (deterministic).
+ * Backward: reads the state the forward launch saved (`saved`), recomputes the rest of the forward from x, writes dx
+ * and per-sample parameter-gradient partials [B, NASREC_MHA_PARAMS] that NASREC_OP_REDUCE_ROWS sums in fixed order
+ * (deterministic).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct nasrec_mha_desc {
   int32_t kind; /* NASREC_OP_MHA_FWD / _BWD */
