@@ -125,10 +125,10 @@ def time_desc(lib, L, stream_ptr, desc, iters=200):
     L.check(lib.nasrec_event_create(C.byref(e0)))
     L.check(lib.nasrec_event_create(C.byref(e1)))
     for _ in range(10):
-        L.check(lib.nasrec_launch(stream_ptr, C.addressof(desc)))
+        L.check(lib.nasrec_launch(stream_ptr, C.addressof(getattr(desc, "launch_as", desc))))  # (the form the step launches: a resident worklist descriptor if the plan has one)
     L.check(lib.nasrec_event_record(e0, stream_ptr))
     for _ in range(iters):
-        L.check(lib.nasrec_launch(stream_ptr, C.addressof(desc)))
+        L.check(lib.nasrec_launch(stream_ptr, C.addressof(getattr(desc, "launch_as", desc))))  # (the form the step launches: a resident worklist descriptor if the plan has one)
     L.check(lib.nasrec_event_record(e1, stream_ptr))
     ms = C.c_float()
     L.check(lib.nasrec_event_elapsed_ms(e0, e1, C.byref(ms)))
@@ -223,7 +223,7 @@ def launch_table_in_step(lib, L, sp, descs, reps, blocker, warm=None):
             warm()
         L.check(lib.nasrec_event_record(evs[0], sp))
         for i, d in enumerate(descs):
-            L.check(lib.nasrec_launch(sp, C.addressof(d)))
+            L.check(lib.nasrec_launch(sp, C.addressof(getattr(d, "launch_as", d))))
             L.check(lib.nasrec_event_record(evs[i + 1], sp))
         for i in range(n):
             L.check(lib.nasrec_event_elapsed_ms(evs[i], evs[i + 1], C.byref(ms)))
@@ -233,7 +233,7 @@ def launch_table_in_step(lib, L, sp, descs, reps, blocker, warm=None):
             warm()
         L.check(lib.nasrec_event_record(evs[0], sp))
         for d in descs:
-            L.check(lib.nasrec_launch(sp, C.addressof(d)))
+            L.check(lib.nasrec_launch(sp, C.addressof(getattr(d, "launch_as", d))))
         L.check(lib.nasrec_event_record(evs[1], sp))
         L.check(lib.nasrec_event_elapsed_ms(evs[0], evs[1], C.byref(ms)))
         seq += ms.value
@@ -791,7 +791,7 @@ def main():
 
             def warm_step():
                 for dsc in step_descs:
-                    L.check(lib.nasrec_launch(sp, C.addressof(dsc)))
+                    L.check(lib.nasrec_launch(sp, C.addressof(getattr(dsc, "launch_as", dsc))))
             us_in, us_raw, seq_us = launch_table_in_step(lib, L, sp, step_descs, 30 if fixed else 5, blocker, warm_step)
             for r, u, w_ in zip(rows, us_in, us_raw):
                 r["us_isolated"], r["us"], r["us_event_interval"] = r["us"], float(u), float(w_)

@@ -83,7 +83,8 @@ enum {
   NASREC_OP_DEDUP_IDS = 33,
   NASREC_OP_OPT_REDUCE2 = 34,
   NASREC_OP_FINAL_FUSED = 35,
-  NASREC_OP_PERSIST = 36
+  NASREC_OP_PERSIST = 36,
+  NASREC_OP_WORKLIST_DEV = 38 /* (37 is taken by a layout-check slot of nasrec_desc_sizes) */
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -622,6 +623,23 @@ typedef struct nasrec_worklist_desc {
   nasrec_wl_item_t item[NASREC_WL_MAX_ITEMS];
   char blob[NASREC_WL_BLOB_BYTES] __attribute__((aligned(16)));
 } nasrec_worklist_desc_t;
+
+/* NASREC_OP_WORKLIST with the descriptor RESIDENT IN DEVICE MEMORY (ABI 17).  A worklist launch passes its 4 KB descriptor by value: a fresh
+ * copy in the runtime's kernel-argument ring per launch, whose lines are cold when the workgroups read their item's descriptor from it —
+ * 0.75 - 1.6 us per launch against a buffer that was uploaded once and is read again every step (tools/micro/kernarg_probe.hip), on each of
+ * the ~21 dependent launches of a batch-256 step.  nasrec_worklist_prepare computes the items' geometry ONCE (the launcher does it per launch
+ * otherwise), copies the completed descriptor to `dev_buf` (sizeof(nasrec_worklist_desc_t) bytes of device memory the caller owns and keeps
+ * alive and unchanged; synchronous copy) and fills `out`, which then launches like any descriptor (nasrec_launch / nasrec_program_run /
+ * nasrec_graph_create).  The descriptors inside the blob are frozen at that point: for plans whose operand pointers never change. */
+typedef struct nasrec_worklist_dev_desc {
+  int32_t kind;          /* NASREC_OP_WORKLIST_DEV */
+  int32_t total_blocks;
+  int32_t big;           /* the launch carries a Transformer backward (LDS size) */
+  int32_t _pad;
+  uint32_t pf[6], pm[6]; /* the packed item table (first workgroups / kind, part, offset), passed as preloaded scalar arguments */
+  const nasrec_worklist_desc_t* dev;
+} nasrec_worklist_dev_desc_t;
+int nasrec_worklist_prepare(const nasrec_worklist_desc_t* w, void* dev_buf, nasrec_worklist_dev_desc_t* out);
 
 /* ------------------------------------------------------------------------------------------------
  * Persistent step (batch <= 256, round 6): the worklist items of MANY levels in ONE launch, ordered topologically, with the

@@ -34,6 +34,7 @@ ACT_BY_NAME = {"identity": ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU}
  OP_ADAGRAD_DENSE, OP_ADAGRAD_ROWS, OP_MEMSET, OP_LAYERNORM_FWD, OP_LAYERNORM_BWD, OP_ADD_SEGS, OP_SCALE,
  OP_ACT_BWD, OP_STAGE_INPUTS, OP_OPT_REDUCE, OP_OPT_APPLY, OP_WORKLIST, OP_CONST_I64, OP_SPLITK_EPILOGUES, OP_DEDUP_IDS,
  OP_OPT_REDUCE2, OP_FINAL_FUSED, OP_PERSIST) = range(1, 37)
+OP_WORKLIST_DEV = 38  # (37: a layout-check slot of nasrec_desc_sizes)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -208,6 +209,11 @@ class WorklistDesc(C.Structure):
                 ("blob", C.c_char * WL_BLOB_BYTES)]
 
 
+class WorklistDevDesc(C.Structure):
+    """NASREC_OP_WORKLIST with its descriptor resident in device memory (nasrec_worklist_prepare, ABI 17)"""
+    _fields_ = [("kind", i32), ("total_blocks", i32), ("big", i32), ("_pad", i32), ("pf", C.c_uint32 * 6), ("pm", C.c_uint32 * 6), ("dev", vp)]
+
+
 PS_MAX_DEPS, PS_REPL, PS_SHARDS, PS_COUNTER_STRIDE, PS_FLAG_STRIDE = 8, 16, 8, 16, 32  # NASREC_PS_*
 
 
@@ -229,7 +235,7 @@ DESC_BY_KIND = {
     OP_ADAGRAD_ROWS: AdagradRowsDesc, OP_MEMSET: MemsetDesc, OP_LAYERNORM_FWD: LayerNormDesc, OP_LAYERNORM_BWD: LayerNormDesc,
     OP_SCALE: ScaleDesc, OP_ACT_BWD: ActBwdDesc, OP_STAGE_INPUTS: StageDesc, OP_OPT_REDUCE: OptReduceDesc, OP_OPT_APPLY: OptApplyDesc,
     OP_WORKLIST: WorklistDesc, OP_CONST_I64: ConstI64Desc, OP_SPLITK_EPILOGUES: SplitkEpiloguesDesc, OP_DEDUP_IDS: DedupIdsDesc,
-    OP_OPT_REDUCE2: OptReduce2Desc, OP_FINAL_FUSED: FinalDesc, OP_PERSIST: PersistDesc,
+    OP_OPT_REDUCE2: OptReduce2Desc, OP_FINAL_FUSED: FinalDesc, OP_PERSIST: PersistDesc, OP_WORKLIST_DEV: WorklistDevDesc,
 }
 
 # every symbol include/nasrec_hip.h declares
@@ -239,7 +245,7 @@ SYMBOLS = [
     "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense", "nasrec_adagrad_rows", "nasrec_opt_reduce",
     "nasrec_opt_apply", "nasrec_worklist", "nasrec_dedup_ids", "nasrec_opt_reduce2", "nasrec_final_fused", "nasrec_event_create",
     "nasrec_event_record", "nasrec_event_elapsed_ms", "nasrec_event_destroy", "nasrec_last_error", "nasrec_abi_version",
-    "nasrec_desc_sizes", "nasrec_tsv_parse", "nasrec_alloc_uncached", "nasrec_free_uncached", "nasrec_persist_prepare",
+    "nasrec_desc_sizes", "nasrec_tsv_parse", "nasrec_alloc_uncached", "nasrec_free_uncached", "nasrec_persist_prepare", "nasrec_worklist_prepare",
 ]
 
 _lib = None
@@ -275,14 +281,15 @@ def load():
     lib.nasrec_alloc_uncached.argtypes = [i64, C.POINTER(vp)]
     lib.nasrec_free_uncached.argtypes = [vp]
     lib.nasrec_persist_prepare.argtypes = [vp]
+    lib.nasrec_worklist_prepare.argtypes = [vp, vp, vp]
     lib.nasrec_tsv_parse.argtypes = [vp, i64, i32, i32, vp, i64, vp, vp, vp, C.POINTER(i64), C.POINTER(i32)]
     lib.nasrec_tsv_parse.restype = i64
     for name in ("nasrec_gemm", "nasrec_embedding_gather", "nasrec_embedding_dedup", "nasrec_dot_tri", "nasrec_fm",
                  "nasrec_mha_ffn", "nasrec_layernorm", "nasrec_final_logit", "nasrec_bce_logits", "nasrec_adagrad_dense",
                  "nasrec_adagrad_rows", "nasrec_opt_reduce", "nasrec_opt_apply", "nasrec_worklist", "nasrec_dedup_ids", "nasrec_opt_reduce2", "nasrec_final_fused"):
         getattr(lib, name).argtypes = [vp, vp]
-    if lib.nasrec_abi_version() != 16:
-        raise EngineError("ABI version mismatch: library %d, binding 16" % lib.nasrec_abi_version())
+    if lib.nasrec_abi_version() != 17:
+        raise EngineError("ABI version mismatch: library %d, binding 17" % lib.nasrec_abi_version())
     sizes = (i32 * 40)()
     n = lib.nasrec_desc_sizes(sizes, 40)
     for kind, cls in DESC_BY_KIND.items():

@@ -63,6 +63,7 @@ static int dispatch(hipStream_t st, const void* desc) {
     case NASREC_OP_OPT_REDUCE: return launch_opt_reduce(st, (const nasrec_opt_reduce_desc_t*)desc);
     case NASREC_OP_OPT_APPLY: return launch_opt_apply(st, (const nasrec_opt_apply_desc_t*)desc);
     case NASREC_OP_WORKLIST: return launch_worklist(st, (const nasrec_worklist_desc_t*)desc);
+    case NASREC_OP_WORKLIST_DEV: return launch_worklist_dev(st, (const nasrec_worklist_dev_desc_t*)desc);
     case NASREC_OP_DEDUP_IDS: return launch_dedup_ids(st, (const nasrec_dedup_ids_desc_t*)desc);
     case NASREC_OP_OPT_REDUCE2: return launch_opt_reduce2(st, (const nasrec_opt_reduce2_desc_t*)desc);
     default: return nasrec_set_error(-1, "unknown op kind %d", kind);
@@ -204,7 +205,7 @@ int nasrec_event_destroy(void* ev) {
 
 const char* nasrec_last_error(void) { return g_err; }
 
-int nasrec_abi_version(void) { return 16; }
+int nasrec_abi_version(void) { return 17; }
 
 int nasrec_desc_sizes(int32_t* out, int n) {
   static const int32_t sizes[] = {
@@ -246,6 +247,7 @@ int nasrec_desc_sizes(int32_t* out, int n) {
       (int32_t)sizeof(nasrec_final_desc_t),         // 35
       (int32_t)sizeof(nasrec_persist_desc_t),       // 36
       (int32_t)sizeof(nasrec_persist_item_t),       // 37 (not an op: the item record of NASREC_OP_PERSIST, for the binding's layout check)
+      (int32_t)sizeof(nasrec_worklist_dev_desc_t),  // 38
   };
   const int total = (int)(sizeof(sizes) / sizeof(sizes[0]));
   int w = 0;

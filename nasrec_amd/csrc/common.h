@@ -134,6 +134,7 @@ int launch_memset_flat(hipStream_t s, const nasrec_memset_desc_t* d);
 int launch_const_i64(hipStream_t s, const nasrec_const_i64_desc_t* d);
 int launch_splitk_epilogues(hipStream_t s, const nasrec_splitk_epilogues_desc_t* d);
 int launch_worklist(hipStream_t s, const nasrec_worklist_desc_t* d);
+int launch_worklist_dev(hipStream_t s, const nasrec_worklist_dev_desc_t* d);
 int launch_dedup_ids(hipStream_t s, const nasrec_dedup_ids_desc_t* d);
 int launch_opt_reduce2(hipStream_t s, const nasrec_opt_reduce2_desc_t* d);
 int launch_persist(hipStream_t s, const nasrec_persist_desc_t* d);

@@ -258,11 +258,11 @@ static int wl_item_geometry(nasrec_wl_item_t& it, const char* blob, int left, in
   return 0;
 }
 
-int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
-  if (w->n < 1 || w->n > NASREC_WL_MAX_ITEMS) return nasrec_set_error(-2, "worklist: n=%d outside [1,%d]", w->n, NASREC_WL_MAX_ITEMS);
-  nasrec_worklist_desc_t wl = *w;
+// geometry of every item, the workgroup ranges and the packed item table of a launch (wl is completed in place)
+static int wl_finalize(nasrec_worklist_desc_t& wl, bool& big, unsigned (&pf)[6], unsigned (&pm)[6]) {
+  if (wl.n < 1 || wl.n > NASREC_WL_MAX_ITEMS) return nasrec_set_error(-2, "worklist: n=%d outside [1,%d]", wl.n, NASREC_WL_MAX_ITEMS);
   static const bool force_big = getenv("NASREC_WL_BIG") != nullptr && atoi(getenv("NASREC_WL_BIG")) != 0;  // A/B knob
-  bool big = force_big;
+  big = force_big;
   int first = 0;
   for (int k = 0; k < wl.n; ++k) {
     nasrec_wl_item_t& it = wl.item[k];
@@ -277,10 +277,8 @@ int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
     first += it.nblk;
   }
   wl.total_blocks = first;
-  if (first < 1) return 0;
   // the item table packed into the twelve leading scalar arguments (worklist_body.h: they are preloaded into SGPRs)
   static_assert(NASREC_WL_MAX_ITEMS == 12 && NASREC_WL_BLOB_BYTES <= 256 * 16 && offsetof(nasrec_worklist_desc_t, blob) % 16 == 0, "packed item table");
-  unsigned pf[6], pm[6];
   bool packed = first < 0xffff;
   for (int q = 0; q < 6; ++q) {
     unsigned f2[2], m2[2];
@@ -299,6 +297,17 @@ int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
     pm[q] = m2[0] | (m2[1] << 16);
   }
   if (!packed) pf[0] = WL_PACKED_NONE;
+  return 0;
+}
+
+int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
+  nasrec_worklist_desc_t wl = *w;
+  bool big;
+  unsigned pf[6], pm[6];
+  const int rc = wl_finalize(wl, big, pf, pm);
+  if (rc) return rc;
+  const int first = wl.total_blocks;
+  if (first < 1) return 0;
   if (big) {
     hipLaunchKernelGGL(worklist_kernel<true>, dim3((unsigned)first), dim3(256), sizeof(float) * WL_LDS_BIG_FLOATS, st, pf[0], pf[1], pf[2], pf[3], pf[4],
                        pf[5], pm[0], pm[1], pm[2], pm[3], pm[4], pm[5], wl);
@@ -307,6 +316,37 @@ int launch_worklist(hipStream_t st, const nasrec_worklist_desc_t* w) {
                        pf[5], pm[0], pm[1], pm[2], pm[3], pm[4], pm[5], wl);
   }
   return nasrec_check_launch("worklist");
+}
+
+// ABI 17: the same launch with the completed descriptor resident in device memory (include/nasrec_hip.h nasrec_worklist_dev_desc_t)
+extern "C" int nasrec_worklist_prepare(const nasrec_worklist_desc_t* w, void* dev_buf, nasrec_worklist_dev_desc_t* out) {
+  if (!w || w->kind != NASREC_OP_WORKLIST || !dev_buf || !out) return nasrec_set_error(-1, "worklist_prepare: wrong descriptor / null buffer");
+  nasrec_worklist_desc_t wl = *w;
+  bool big;
+  const int rc = wl_finalize(wl, big, out->pf, out->pm);
+  if (rc) return rc;
+  if (hipMemcpy(dev_buf, &wl, sizeof(wl), hipMemcpyHostToDevice) != hipSuccess) return nasrec_set_error(-3, "worklist_prepare: copy to the device buffer failed");
+  out->kind = NASREC_OP_WORKLIST_DEV;
+  out->total_blocks = wl.total_blocks;
+  out->big = big ? 1 : 0;
+  out->_pad = 0;
+  out->dev = reinterpret_cast<const nasrec_worklist_desc_t*>(dev_buf);
+  return 0;
+}
+
+int launch_worklist_dev(hipStream_t st, const nasrec_worklist_dev_desc_t* d) {
+  if (!d->dev) return nasrec_set_error(-2, "worklist (device-resident): not prepared");
+  if (d->total_blocks < 1) return 0;
+  const unsigned* pf = d->pf;
+  const unsigned* pm = d->pm;
+  if (d->big) {
+    hipLaunchKernelGGL(worklist_dev_kernel<true>, dim3((unsigned)d->total_blocks), dim3(256), sizeof(float) * WL_LDS_BIG_FLOATS, st, pf[0], pf[1], pf[2], pf[3],
+                       pf[4], pf[5], pm[0], pm[1], pm[2], pm[3], pm[4], pm[5], d->dev);
+  } else {
+    hipLaunchKernelGGL(worklist_dev_kernel<false>, dim3((unsigned)d->total_blocks), dim3(256), sizeof(float) * WL_LDS_FLOATS, st, pf[0], pf[1], pf[2], pf[3],
+                       pf[4], pf[5], pm[0], pm[1], pm[2], pm[3], pm[4], pm[5], d->dev);
+  }
+  return nasrec_check_launch("worklist (device-resident)");
 }
 
 // ======================================================================================================================================

@@ -402,10 +402,12 @@ __device__ __forceinline__ void wl_mha_fwd(unsigned long long blob, int vb) {
 // stand-alone kernel).  WL_PACKED_NONE in f01: the table did not fit 16 bits per entry, use the copy in memory.
 #define WL_PACKED_NONE 0xffffffffu
 #define WL_HEAD_BYTES 48  // the twelve scalars in front of the descriptor in the argument segment
+// `base`: address of the launch's nasrec_worklist_desc_t — in the kernel-argument segment (passed by value) or in device memory (ABI 17:
+// uploaded once per plan; warm lines instead of a fresh copy per launch)
 template <bool BIG>
-__global__ __launch_bounds__(256, 4) void worklist_kernel(unsigned f01, unsigned f23, unsigned f45, unsigned f67, unsigned f89, unsigned fab,
-                                                                    unsigned m01, unsigned m23, unsigned m45, unsigned m67, unsigned m89, unsigned mab,
-                                                                    const nasrec_worklist_desc_t wl) {
+__device__ __forceinline__ void wl_run(unsigned f01, unsigned f23, unsigned f45, unsigned f67, unsigned f89, unsigned fab, unsigned m01, unsigned m23,
+                                       unsigned m45, unsigned m67, unsigned m89, unsigned mab, const unsigned long long base) {
+  const nasrec_worklist_desc_t& wl = wl_ref<nasrec_worklist_desc_t>(base);
   float* lds = wl_lds;
   const int bid = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int k = 0, it_first = 0, it_kind, it_part, it_off;
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256, 4) void worklist_kernel(unsigned f01, unsigned
   }
   const nasrec_wl_item_t& it = wl.item[k];  // (geometry only below)
   const int vb = bid - it_first;
-  const unsigned long long blob = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + WL_HEAD_BYTES + offsetof(nasrec_worklist_desc_t, blob) + it_off;
+  const unsigned long long blob = base + offsetof(nasrec_worklist_desc_t, blob) + it_off;
   switch (it_kind) {
     case NASREC_OP_GEMM: {
       if (it_part == 2) {
@@ -513,3 +515,15 @@ __global__ __launch_bounds__(256, 4) void worklist_kernel(unsigned f01, unsigned
   }
 }
 
+template <bool BIG>
+__global__ __launch_bounds__(256, 4) void worklist_kernel(unsigned f01, unsigned f23, unsigned f45, unsigned f67, unsigned f89, unsigned fab,
+                                                                    unsigned m01, unsigned m23, unsigned m45, unsigned m67, unsigned m89, unsigned mab,
+                                                                    const nasrec_worklist_desc_t wl) {
+  wl_run<BIG>(f01, f23, f45, f67, f89, fab, m01, m23, m45, m67, m89, mab, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + WL_HEAD_BYTES);
+}
+template <bool BIG>
+__global__ __launch_bounds__(256, 4) void worklist_dev_kernel(unsigned f01, unsigned f23, unsigned f45, unsigned f67, unsigned f89, unsigned fab,
+                                                                        unsigned m01, unsigned m23, unsigned m45, unsigned m67, unsigned m89, unsigned mab,
+                                                                        const nasrec_worklist_desc_t* wl) {
+  wl_run<BIG>(f01, f23, f45, f67, f89, fab, m01, m23, m45, m67, m89, mab, (unsigned long long)wl);
+}

@@ -29,6 +29,9 @@ _IDS_AS_ITEM = os.environ.get("NASREC_IDS_AS_ITEM", "1") != "0"
 # write the engine-wide gradient arena — a compile() in the middle of a step sequence must not do that.
 _WL_TUNE = os.environ.get("NASREC_WL_TUNE", "0") == "1"
 _WL_TUNE_MARGIN = float(os.environ.get("NASREC_WL_TUNE_MARGIN", "0.004"))
+# the worklist descriptors of a fixed batch-256 plan live in device memory, uploaded once (ABI 17, nasrec_worklist_prepare): a launch that passes
+# its 4 KB descriptor by value reads it from a fresh, cold copy in the kernel-argument ring (tools/micro/kernarg_probe.hip: + 0.75 - 1.6 us)
+_WL_RESIDENT = os.environ.get("NASREC_WL_RESIDENT", "1") != "0"
 _FUSE_FINAL = os.environ.get("NASREC_FUSE_FINAL", "1") != "0"  # joint program: final logit + the per-sample part of its backward as one operator
 # clip + Adagrad of a fixed sub-network over the ranges of the parameters its backward reaches, not the whole arena (A/B knob)
 _FIXED_OPT_TABLE = os.environ.get("NASREC_FIXED_OPT_TABLE", "1") != "0"
@@ -37,7 +40,7 @@ _FIXED_OPT_TABLE = os.environ.get("NASREC_FIXED_OPT_TABLE", "1") != "0"
 def _ptr_array(descs):
     arr = (C.c_void_p * len(descs))()
     for i, d in enumerate(descs):
-        arr[i] = C.addressof(d)
+        arr[i] = C.addressof(getattr(d, "launch_as", d))  # (a worklist whose descriptor lives in device memory: _resident_worklists)
     return arr
 
 
@@ -473,6 +476,7 @@ class SupernetEngine:
                 fwd_list, cp.dead_forward = S.eliminate_dead_forward(fwd_list, ctx.bwd if train else [])
             if scheduled:
                 fwd_descs, cp.fwd_levels = S.pack(fwd_list)
+                self._resident_worklists(cp, fwd_descs)
             else:
                 fwd_descs = fwd_list
             cp.fwd = Program(fwd_descs)
@@ -530,8 +534,10 @@ class SupernetEngine:
                         fb_descs, cp.fb_levels = S.pack(ids_in_program + jf + jb, alloc=ctx.alloc)
                         if _WL_TUNE and S.BALANCE:
                             fb_descs, cp.level_tuning = self._tune_levels(ids_in_program + jf + jb, ctx.alloc, fb_descs)
+                    self._resident_worklists(cp, fb_descs)
                     cp.fb = Program(fb_descs)
                     bwd_descs, cp.bwd_levels = S.pack(bwd_descs)
+                    self._resident_worklists(cp, bwd_descs)
                 cp.bwd = Program(bwd_descs)
                 cp.bwd_tail_start = len(pre) - 1 + ctx.bwd_tail_start  # cp.bwd.descs[this:] = the parked weight-gradient products
                 cp.bwd_marks = [(b, len(pre) - 1 + idx) for b, idx in ctx.block_marks]  # block b's gradients complete after cp.bwd.descs[:idx]
@@ -554,6 +560,27 @@ class SupernetEngine:
         self._plans[key] = cp
         self._last_plan = (fast, choice, cp)
         return cp
+
+    def _resident_worklists(self, cp, descs):
+        """nasrec_worklist_prepare for every worklist launch of `descs` (a fixed plan: the pointers inside the items never change): the
+        descriptor objects stay what they are (reports, tests, the data-parallel readiness model read them), a Program launches their
+        `launch_as` — the device-resident form — instead"""
+        if not _WL_RESIDENT:
+            return
+        lists = [d for d in descs if isinstance(d, L.WorklistDesc) and not hasattr(d, "launch_as")]
+        if not lists:
+            return
+        lib = L.load()
+        sz = (C.sizeof(L.WorklistDesc) + 255) & ~255
+        buf = torch.empty(sz * len(lists), dtype=torch.uint8, device=self.device)
+        if not hasattr(cp, "_wl_resident"):
+            cp._wl_resident = []
+        cp._wl_resident.append(buf)  # (owned by the plan)
+        self.stream.synchronize()  # (the copies below are synchronous on the null stream)
+        for i, d in enumerate(lists):
+            dv = L.WorklistDevDesc()
+            L.check(lib.nasrec_worklist_prepare(C.addressof(d), buf.data_ptr() + i * sz, C.addressof(dv)))
+            d.launch_as = dv
 
     def _tune_levels(self, prog_in, alloc, default_descs):
         """The balancing pass of schedule.pack places slack operators by a duration MODEL whose least certain entries are the Transformer

@@ -71,7 +71,7 @@ def test_c_abi_exports_every_declared_symbol_and_struct_layouts():
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.nasrec_abi_version() == 16
+    assert lib.nasrec_abi_version() == 17
     assert lib.nasrec_launch(None, None) != 0  # null descriptor: error code + message, no crash
     assert b"null descriptor" in lib.nasrec_last_error()
 
