@@ -142,7 +142,8 @@ def launch_kernel_name(L, P, d):
     if isinstance(d, L.PersistDesc):
         return "persist_kernel<%s>" % ("true" if d.big else "false")
     if isinstance(d, L.WorklistDesc):
-        return "worklist_kernel<%s>" % ("true" if any(n.desc.kind == L.OP_MHA_BWD for n in d.nodes) else "false")  # csrc/worklist.hip:143-146
+        # (csrc/worklist.hip wl_finalize: `big`; the descriptor-resident form of a fixed plan — engine._resident_worklists — is a kernel of its own name)
+        return "%s<%s>" % ("worklist_dev_kernel" if hasattr(d, "launch_as") else "worklist_kernel", "true" if any(n.desc.kind == L.OP_MHA_BWD for n in d.nodes) else "false")
     if isinstance(d, L.GemmDesc):
         return P.gemm_kernel_name(d)
     names = {getattr(L, n): n[3:].lower() for n in dir(L) if n.startswith("OP_")}
