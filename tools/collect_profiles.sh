@@ -68,5 +68,6 @@ done
 NASREC_PERSIST_THROTTLE=0 timeout 300 python3 $R/tools/persist_timeline.py > $O/persist_timeline.txt 2>> $O/log.txt < /dev/null
 [ -x $R/tools/micro/seam_probe ] && for sk in 1 3; do timeout 200 $R/tools/micro/seam_probe --skew $sk --groups 512 --reps 100 >> $O/seam_probe.txt 2>&1; done
 [ -x $R/tools/micro/anyorder_probe ] && timeout 60 $R/tools/micro/anyorder_probe >> $O/anyorder_probe.txt 2>&1
+rm -rf /tmp/nasrec_tsv_* /tmp/nasrec_search_point /tmp/nasrec_search_ckpt* 2>/dev/null  # (the suite writes ~25 GB of checkpoints itself: one box ran out of disk behind the runs above)
 (cd $R && timeout 2400 python3 -m pytest tests -q -m gpu 2>&1 | grep -v "^\[Gloo\]" | tail -6 > $O/gpu_tests.txt)
 du -sh $O | tail -1
