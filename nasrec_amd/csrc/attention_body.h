@@ -85,33 +85,3 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 #else
 #define MHA_STAMP(i)
 #endif
-
-// Weight gradient of one product y = W v (W [16,16]): dW[o][i] = sum_tok G[tok][o] * V[tok][i]; G, V are LDS rows [token][16].
-// The whole 16 x 16 matrix by ONE wave on the matrix cores: dW = G^T V is a [16, N] x [N, 16] product, i.e.
-// ceil(N / 4) v_mfma_f32_16x16x4_f32 with k = token.  Lane (r = lane & 15, g = lane >> 4) feeds A(o = r, k = 4 step + g) =
-// G[4 step + g][r] and B(k, i = r) = V[4 step + g][r]: both are 64 consecutive LDS floats per step (rows 4 step .. 4 step + 3),
-// conflict-free; tokens >= N contribute zeros (exact fp32 FMA chains, tokens in ascending order).
-__device__ __forceinline__ void wgrad_mfma(const float* G, const float* V, int lane, int N, float* out) {
-  const int r = lane & 15, g = lane >> 4;
-  // every LDS read of the product is issued before the first MFMA (a loop of read, wait, multiply was 16 dependent LDS round trips
-  // on one wave: tools/mha_stamps.py); one accumulator.
-  float a[MHA_N / 4], b[MHA_N / 4];
-#pragma unroll
-  for (int s = 0; s < MHA_N / 4; ++s) {
-    const int t = 4 * s + g;
-    const int tt = t < N ? t : 0;
-    a[s] = G[tt * 16 + r];
-    b[s] = V[tt * 16 + r];
-  }
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int s = 0; s < MHA_N / 4; ++s) {
-    if (4 * s < N) {  // (uniform)
-      const bool ok = 4 * s + g < N;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? a[s] : 0.f, ok ? b[s] : 0.f, acc, 0, 0, 0);
-    }
-  }
-  // D: row o = 4 * (lane >> 4) + reg, column i = lane & 15
-#pragma unroll
-  for (int q = 0; q < 4; ++q) out[(4 * g + q) * 16 + r] = acc[q];
-}

@@ -1,27 +1,28 @@
-// Token-major bodies of the fused Transformer (256 threads = 4 waves per sample), round 6.  Same arithmetic contract and the same saved-state
-// planes as attention_body.h (modules.py:648-686); different work assignment:
+// Token-major bodies of the fused Transformer (256 threads = 4 waves per sample), round 6 (modules.py:648-686):
 //
-//   lane (r = lane & 15, g = lane >> 4) of wave w owns token 16 w + r and the columns 4 g .. 4 g + 3 of every 16-wide vector of that token
-//   (= heads 2 g and 2 g + 1 of the attention), in registers, from the first load to the last store.
+//   lane (r = lane & 15, g = lane >> 4) of wave w owns ONE token — 16 blk + r, blk = the wave's block of 16 tokens — and the columns
+//   4 g .. 4 g + 3 of every 16-wide vector of that token (= heads 2 g and 2 g + 1 of the attention), in registers, from the first load to
+//   the last store.
 //
-// * Every per-token 16 x 16 product (in-projection x 3, out-projection, the two FFN layers, and their transposes in the backward) is FOUR
+// * Every per-token 16 x 16 product (in-projection x 3, out-projection, the two FFN layers, their transposes in the backward) is FOUR
 //   v_mfma_f32_16x16x4_f32 of the wave on its own 16 tokens, computed transposed: D[o][token] = sum_k W[o][k] Y[token][k] with A = W and
-//   B = Y^T.  The k index of step s in lane group g is 4 g + s — which is exactly the column the lane holds in register s — and D leaves
-//   lane (r, g) with rows o = 4 g .. 4 g + 3 of token r: the output is in the input's layout.  One ds_read_b128 of the weights per product
-//   instead of sixteen broadcast reads and 64 FMAs; no LDS exchange of the vectors, no barrier between the stages.
-//   (The column-slice form of attention_body.h passes every intermediate vector through LDS and a workgroup barrier because each wave needs
-//   the other waves' columns: twelve barrier-separated stages whose latency, not their arithmetic, was 60 % of the backward at batch 256.)
+//   B = Y^T.  The k index of step s in lane group g is 4 g + s — exactly the column the lane holds in register s — and D leaves lane
+//   (r, g) with rows o = 4 g .. 4 g + 3 of token r: the output is in the input's layout.  One LDS read of the weights per product instead
+//   of sixteen broadcast reads and 64 FMAs; no LDS exchange of the vectors, no barrier between the stages.
+//   (Rounds 3 - 5 ran a column-slice mapping — lane = token, wave = 2 or 4 columns of every vector — that passed every intermediate
+//   vector through LDS and a workgroup barrier because each wave needed the other waves' columns: twelve barrier-separated stages whose
+//   latency, not their arithmetic, was 60 % of the backward at batch 256.)
 // * LayerNorm sums over a token's 16 columns = 4 in the lane + the 4 lanes (r, 0..3): v_permlane16_swap / v_permlane32_swap (gfx950), two
 //   instructions and two adds, every lane of the token gets the same bits.
-// * The attention loops are those of attention_body.h (two heads per packed-fp32 lane pair, keys / queries walked in LDS); the lane's
-//   K / V / Q / dO rows are read at its own column offset 4 g (four addresses per wave instruction instead of one).
-// * Sums over tokens (bias and LayerNorm-weight gradients): DPP reduction over the 16 lanes of a row, per-wave partials in LDS, summed
-//   over the four waves in fixed order.  16 x 16 weight gradients: one wave's MFMA chain over the 64 tokens per matrix (wgrad_mfma), after
-//   the loops, from planes parked in LDS.
-// * The backward rebuilds q, k, v, both LayerNorm x-hats, the LayerNorm-1 output and the FFN hidden layer from x, the saved attention
-//   output and the saved LayerNorm statistics: six more products per token (24 MFMAs, the same instructions on the same operands as the
-//   forward: the same bits) instead of 112 more floats per token through HBM in both directions.
-// Barriers: forward 2, backward 4.
+// * Attention (head_dim 2: nothing for the matrix cores): K / V rows (backward: Q, dO, (m', D) too) in LDS in natural order; inside the
+//   loops a lane pair (r, r ^ 1) trades heads so that each lane runs ONE head of TWO tokens as packed fp32 (TokPairs).
+// * Backward: q, k, v, both LayerNorm x-hats, the LayerNorm-1 output and the FFN hidden layer are rebuilt from x, the saved attention
+//   output and the saved LayerNorm statistics — six more products per token, the forward's own instructions on the same operands (the
+//   same bits) instead of 112 more floats per token through HBM in both directions.  Weight gradients: 4 MFMAs per matrix with k = the
+//   wave's own tokens (tok_wgrad), bias-like gradients: DPP sums over the 16 lanes of a row; per-BLOCK partials in LDS, summed in block
+//   order at the end (deterministic whatever the rotation of blocks over waves).
+// * A wave whose block holds no token (N <= 48) skips everything but the parameter staging and the barriers.
+// Barriers: forward 2, backward 4.  LDS: forward 15 KB, backward 39.5 KB.
 #pragma once
 #include "attention_body.h"
 

@@ -4,9 +4,10 @@
 // backward, fixed-order row reductions — so results are bit-identical to the separate launches; what disappears is a kernel
 // boundary (~5 us of cold-L2 start at batch 256) per operator that has an independent neighbour.
 //
-// One LDS buffer is shared by all bodies (the largest wins: 35 KB for a 64x64x64 GEMM tile, 52 KB when a Transformer backward is
-// in the level), so that a CU still holds 3-4 workgroups of different items next to each other.  Descriptors travel in the kernel
-// arguments (a 3.6 KB blob; GEMM descriptors truncated behind their last segment): no dependent global read before the operands.
+// One LDS buffer is shared by all bodies (the largest wins: 31 KB, 39.5 KB when a Transformer backward is in the level), so that a CU
+// holds four workgroups of different items next to each other.  Descriptors travel in the kernel arguments (a 3.6 KB blob; GEMM
+// descriptors truncated behind their last segment) or, for plans whose pointers never change, sit in device memory (ABI 17:
+// nasrec_worklist_prepare below — geometry once per plan, warm lines instead of a fresh copy per launch).
 #include <stdlib.h>
 #include <string.h>
 

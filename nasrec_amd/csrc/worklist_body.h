@@ -17,7 +17,7 @@ static_assert(MHA_TOK_BWD_LDS_FLOATS <= WL_LDS_BIG_FLOATS && MHA_TOK_FWD_LDS_FLO
 #endif
 enum { WL_TOKS = 0, WL_T32x32 = 1, WL_T64x16 = 2, WL_T16x64 = 3 };  // WL_TOKS: wl_token_fwd (a wavefront per sample)
 
-// All bodies share the launch's DYNAMIC LDS buffer (sized by the launcher: 35 KB, or 52 KB when a Transformer backward is in the level).
+// All bodies share the launch's DYNAMIC LDS buffer (sized by the launcher: 31 KB, or 39.5 KB when a Transformer backward is in the level).
 extern __shared__ __attribute__((aligned(16))) float wl_lds[];
 
 // Taking the address of the by-value kernel argument (`wl.blob + off` bound to a reference through a cast) makes clang copy all 4 KB of
@@ -392,8 +392,8 @@ __device__ __forceinline__ void wl_mha_fwd(unsigned long long blob, int vb) {
   mha_fwd_tok(wl_ref<nasrec_mha_desc_t>(blob), __builtin_amdgcn_readfirstlane(vb), wl_lds);
 }
 
-// BIG: the variant that also carries the Transformer backward (164 registers, 52 KB of LDS: three workgroups per CU instead of four /
-// five) — used for the levels that contain one, so that the level's other items run beside it instead of before it
+// BIG: the variant that also carries the Transformer backward (39.5 KB of LDS instead of 31; 127 registers and four workgroups per CU
+// either way since round 6 — rounds 3 - 5: 164 registers, 52 KB, three per CU) — used for the levels that contain one
 // The item table once more as twelve leading scalar kernel arguments: the build passes -amdgpu-kernarg-preload-count=12, so on gfx950
 // they arrive in SGPRs with the wavefront (no memory access): f = first workgroup of item k (16 bits each, 0xffff behind the last
 // item), m = kind | part << 6 | (blob offset / 16) << 8.  The search for the workgroup's item, its kind and the address of its
