@@ -342,7 +342,8 @@ def assign_levels(nodes: List[Node]) -> int:
 # ----------------------------------------------------------------------------------------------------------------
 BALANCE = os.environ.get("NASREC_WL_BALANCE", "1") != "0"
 _PUSH = os.environ.get("NASREC_WL_PUSH", "1") != "0"  # (A/B knob: 0 = a node only moves inside the window its successors leave as they stand)
-_LATENCY_NS = 5000  # what a level costs however little it does (launch, descriptor + operand first touch on cold caches, drain)
+_LATENCY_NS = int(os.environ.get("NASREC_WL_LAT_NS", "5000"))  # what a level costs however little it does (launch, descriptor + operand first touch on cold caches, drain)
+_GEMM_DIV = int(os.environ.get("NASREC_WL_GEMM_DIV", "20000"))  # M N K per ns of a product on the worklist tile (A/B knob of the balancing model)
 
 
 _BAL_R4 = os.environ.get("NASREC_WL_BAL_COST", "r4") == "r4"  # (A/B knob)
@@ -651,7 +652,7 @@ def _cost_r4(node):
             return 4000
         live = [q for q in range(d.nseg) if d.seg[q].A]
         extra = 0 if d.zmode else 900 * max(len(live) - 1, 0)
-        return 5200 + extra + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in live) // 20000
+        return 5200 + extra + sum(d.seg[q].M * d.seg[q].N * max(d.seg[q].K, 1) for q in live) // _GEMM_DIV
     if d.kind == L.OP_DOT_TRI_BWD:
         return 3500 + int(2.3 * d.k1 * d.k1)
     if d.kind == L.OP_DOT_TRI_FWD:
