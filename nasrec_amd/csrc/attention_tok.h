@@ -101,6 +101,10 @@ __device__ __forceinline__ void mha_fwd_tok(const nasrec_mha_desc_t& d, const in
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4, c0 = 4 * g, tok = 16 * tok_block(w, b) + r;
   const int N = d.N;
   const bool active = tok < N, wave_active = tok - r < N;  // (wave-uniform: the wave's block holds tokens)
+  // supernet token mask (modules.py:678-686): output tokens >= dims_in_use are zero.  They still act as KEYS (their k / v rows come from
+  // whatever x holds there), but nothing of them as queries survives: a wave whose whole block is masked parks its k / v rows and stores zeros
+  const int qn = d.dims_in_use >= 0 ? min(N, d.dims_in_use) : N;
+  const bool q_active = tok - r < qn;
   const bool saving = d.saved != nullptr;
 #ifdef MHA_STAMPS
   unsigned mha_st[16];
@@ -125,7 +129,9 @@ __device__ __forceinline__ void mha_fwd_tok(const nasrec_mha_desc_t& d, const in
   }
   __syncthreads();
   MHA_STAMP(2);
-  if (wave_active) {
+  if (wave_active && !q_active) {
+    if (active) *reinterpret_cast<f32x4*>(d.out + (long)b * d.ldo + (long)tok * 16 + c0) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  } else if (wave_active) {
     const long po = (long)tok * 16 + c0;  // the lane's 16-byte piece of a [token][16] plane
     // attention: head 2 g + hs of the lane pair's two tokens as queries (see TokPairs); scores in log2 units
     constexpr float LOG2E = 1.44269504088896340736f;
@@ -299,6 +305,11 @@ __device__ __forceinline__ void mha_bwd_tok(const nasrec_mha_desc_t& d, const in
   float* Vs = Gs + 256;
   const int N = d.N;
   const bool active = tok < N, wave_active = 16 * blk < N;
+  // supernet token mask: d out is zero for tokens >= dims_in_use, hence every gradient of theirs AS QUERIES is exactly zero (d r2, d f1, d h1,
+  // d r1, d O, D, d q); as KEYS they still receive d k / d v from the unmasked queries.  A wave whose whole block is masked recomputes its k / v
+  // rows, runs the key-side loop only, and that loop walks the unmasked queries only (the others would add p * 0).
+  const int qn = d.dims_in_use >= 0 ? min(N, d.dims_in_use) : N;
+  const bool q_active = 16 * blk < qn;
   float* gp = d.dparams_partial + (long)b * (d.partial_ld > 0 ? d.partial_ld : NASREC_MHA_PARAMS);
 #ifdef MHA_STAMPS
   unsigned mha_st[16];
@@ -313,7 +324,8 @@ __device__ __forceinline__ void mha_bwd_tok(const nasrec_mha_desc_t& d, const in
   stage_params_load<NT>(d, tid, pp);
   f32x4 st4 = z4, dout = z4, x4 = z4, o4 = z4;
   f32x2 mq = {0.f, 0.f};
-  if (wave_active) {
+  if (wave_active && !q_active) x4 = ld4(d.x + (long)b * d.ldx + po);
+  if (q_active) {
     st4 = ld4(sv_plane(d.saved, b, N, SV_STAT) + tl * 4);
     const float* mp = sv_plane(d.saved, b, N, SV_M) + (long)tl * 16 + 2 * g;
     const f32x2 mx = *reinterpret_cast<const f32x2*>(mp), li = *reinterpret_cast<const f32x2*>(mp + 8);
@@ -329,7 +341,17 @@ __device__ __forceinline__ void mha_bwd_tok(const nasrec_mha_desc_t& d, const in
   MHA_STAMP(1);
   f32x4 q4 = z4, k4 = z4, v4 = z4, dr1 = z4, dO = z4, gW2 = z4, gW1 = z4, gWo = z4, gWq = z4, gWk = z4, gWv = z4;
   f32x2 dd2 = {0.f, 0.f};
-  if (wave_active) {
+  if (wave_active && !q_active) {  // a masked block: its k / v rows (it is a set of keys), nothing else
+    const float* VEC = lds + MHA_TOK_VEC;
+    k4 = tok_mm_col(Wt + MHA_TOK_WSZ, r, c0, x4, ld4(VEC + 16 + c0));
+    v4 = tok_mm_col(Wt + 2 * MHA_TOK_WSZ, r, c0, x4, ld4(VEC + 32 + c0));
+    *reinterpret_cast<f32x4*>(Kb + tok * 16 + c0) = k4;
+    *reinterpret_cast<f32x4*>(Vb + tok * 16 + c0) = v4;
+#pragma unroll
+    for (int vec = 0; vec < 7; ++vec)
+      if (r == 0) *reinterpret_cast<f32x4*>(bp + vec * 16 + c0) = z4;  // (the block's token sums of everything but d q / d k / d v: zeros)
+  }
+  if (q_active) {
     // ---- the forward again, from x and o (mha_fwd_tok's instructions on the same operands) ----
     const float* VEC = lds + MHA_TOK_VEC;
     const float rstd1 = st4[0], rstd2 = st4[1];
@@ -385,10 +407,10 @@ __device__ __forceinline__ void mha_bwd_tok(const nasrec_mha_desc_t& d, const in
   MHA_STAMP(7);
   if (wave_active) {
     // ---- attention backward on token pairs (see TokPairs): head 2 g + hs of tokens t0, t1; one exponential per probability (exp2(s' - m')) ----
-    f32x4 dq, dk, dv;
+    f32x4 dq = z4, dk, dv;
     const bool hs = r & 1;
     const int h2 = c0 + 2 * (r & 1);
-    {
+    if (q_active) {
       const TokPairs Q = tok_to_pairs(q4 * LOG2E, hs), DO = tok_to_pairs(dO, hs);
       const f32x2 M2 = tok_swap_pair(mq, hs), DD = tok_swap_pair(dd2, hs);
       f32x2 dq0 = {0.f, 0.f}, dq1 = {0.f, 0.f};  // phase A: the pair's tokens as queries
@@ -408,7 +430,7 @@ __device__ __forceinline__ void mha_bwd_tok(const nasrec_mha_desc_t& d, const in
       const TokPairs K = tok_to_pairs(k4 * LOG2E, hs), V = tok_to_pairs(v4, hs);
       f32x2 dk0 = {0.f, 0.f}, dk1 = {0.f, 0.f}, dv0 = {0.f, 0.f}, dv1 = {0.f, 0.f};  // phase B: the pair's tokens as keys
 #pragma unroll 4
-      for (int i = 0; i < N; ++i) {
+      for (int i = 0; i < qn; ++i) {  // (queries behind the token mask have d O = D = 0: they would add nothing)
         const f32x2 qi = *reinterpret_cast<const f32x2*>(Qb + i * 16 + h2), doi = *reinterpret_cast<const f32x2*>(DOb + i * 16 + h2);
         const f32x2 md = *reinterpret_cast<const f32x2*>(MDb + i * 16 + h2);
         const f32x2 t = K.c0 * qi[0] + K.c1 * qi[1] - md[0];

@@ -588,7 +588,9 @@ def _mha_ref(x, p, dims):
 
 @pytest.mark.parametrize("use_saved", [False, True])
 @pytest.mark.parametrize("N,dims,B,form", [(16, -1, 13, 0), (64, -1, 13, 0), (48, 32, 13, 0), (7, -1, 13, 0), (64, 40, 1030, 0), (26, -1, 1024, 0),
-                                           (64, -1, 13, 4), (48, 32, 9, 4), (7, -1, 5, 4), (17, 16, 6, 4), (1, -1, 3, 4), (33, -1, 258, 4)])
+                                           (64, -1, 13, 4), (48, 32, 9, 4), (7, -1, 5, 4), (17, 16, 6, 4), (1, -1, 3, 4), (33, -1, 258, 4),
+                                           # whole blocks of 16 tokens behind the token mask (they act as keys only): round 6
+                                           (64, 16, 7, 4), (64, 33, 5, 4), (48, 0, 3, 4), (64, 48, 1027, 0)])
 def test_mha_ffn(lib, N, dims, use_saved, B, form):
     """the forward runs with or without saving its per-token state (36 floats per token: attention output, softmax and LayerNorm
     statistics); the backward always consumes a saved state and recomputes the rest (`bwd_form` is ignored since ABI 16)"""

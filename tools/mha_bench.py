@@ -19,14 +19,16 @@ def launch(d):
 
 
 shapes = [(48, 16), (48,), (16, 16), (16,), (16,), (16,), (16, 16), (16,), (16, 16), (16,), (16,), (16,)]
-for B, N in ((256, 64), (256, 48), (256, 8), (4096, 64), (4096, 26), (8192, 10)):
+for B, N, dims in ((256, 64, -1), (256, 48, -1), (256, 8, -1), (4096, 64, -1), (4096, 64, 48), (4096, 64, 32), (4096, 64, 16), (4096, 26, -1), (8192, 10, -1)):
     torch.manual_seed(0)
     p = [(torch.randn(s) * (0.3 if len(s) == 2 else 0.1)).to(dev) for s in shapes]
     x, out, dout = torch.randn(B, N, 16, device=dev), torch.zeros(B, N, 16, device=dev), torch.randn(B, N, 16, device=dev)
+    if dims >= 0:
+        x[:, dims:] = 0  # (the supernet zeroes masked tokens in front of the attention: modules.py:653-662)
     dx, part, saved = torch.zeros(B, N, 16, device=dev), torch.zeros(B, L.MHA_PARAMS, device=dev), torch.zeros(B * N * L.MHA_SAVED, device=dev)
     f, b = L.MhaDesc(), L.MhaDesc()
     for d, kind in ((f, L.OP_MHA_FWD), (b, L.OP_MHA_BWD)):
-        d.kind, d.B, d.N, d.ldx, d.ldo, d.dims_in_use = kind, B, N, N * 16, N * 16, -1
+        d.kind, d.B, d.N, d.ldx, d.ldo, d.dims_in_use = kind, B, N, N * 16, N * 16, dims
         d.x, d.out, d.dout, d.dx, d.dparams_partial, d.saved = x.data_ptr(), out.data_ptr(), dout.data_ptr(), dx.data_ptr(), part.data_ptr(), saved.data_ptr()
         d.bwd_form = 4
         for q in range(12):
@@ -44,4 +46,4 @@ for B, N in ((256, 64), (256, 48), (256, 8), (4096, 64), (4096, 26), (8192, 10))
         e1.record()
         torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) * 1e3 / reps)
-    print("B=%5d N=%2d: forward %7.2f us   backward %7.2f us   (checksums %.6e %.6e %.6e)" % (B, N, res[0], res[1], float(out.double().sum()), float(dx.double().sum()), float(part.double().sum())))
+    print("B=%5d N=%2d dims=%2d: forward %7.2f us   backward %7.2f us   (checksums %.6e %.6e %.6e)" % (B, N, dims, res[0], res[1], float(out.double().sum()), float(dx.double().sum()), float(part.double().sum())))
